@@ -1,0 +1,111 @@
+/* librsis_hip.so -- C ABI of the MI355X (gfx950) RSIS hot path.
+ *
+ * The reference (imatge-upc/rsis) has no FFI: its hot path sits behind PyTorch nn.Modules
+ * (src/modules/clstm.py, model.py, vision.py) that dispatch to cuDNN/THCUNN.  This header is the drop-in
+ * boundary one level below that module surface: every entry point replaces the torch op(s) cited next to
+ * it, on caller-owned device buffers, and is what the Python binding in rsis_amd/_lib.py (ctypes) loads.
+ *
+ * Conventions
+ *   - every pointer is a device pointer to a caller-owned, contiguous fp32 NCHW tensor unless stated;
+ *   - no hidden allocation, no host synchronisation, graph-capture safe; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream);
+ *   - return value: 0 = OK, nonzero = error code (rsis_error_string); nothing throws across the ABI;
+ *   - thread-safe / re-entrant per stream.
+ *   - "packed" weights are a private MFMA-friendly copy ([K][Cout_pad], K = (segment, ci, r, s) with each
+ *     channel-concat segment padded to a multiple of 16 rows; ConvLSTM rows gate-interleaved 4*j+gate);
+ *     they are rebuilt from the reference-layout weight ([Cout][Cin][k][k], gate order i,f,o,g) and never
+ *     serialised.
+ */
+#ifndef RSIS_HIP_H
+#define RSIS_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSIS_ABI_VERSION 1
+
+int rsis_version(void);
+const char* rsis_error_string(int code);
+
+/* ---- weight repacking (private cache of nn.Conv2d.weight; clstm.py:17, model.py:43-47,109, torchvision trunk) ---- */
+/* number of floats of the packed forward copy for a conv whose input is the channel concat of nseg tensors */
+long rsis_conv_packed_floats_fwd(int Cout, int ks, int nseg, const int* Cseg);
+/* number of floats of the packed dgrad copy producing input channels [c_lo, c_hi) */
+long rsis_conv_packed_floats_dgrad(int Cout, int ks, int c_count);
+/* lstm_hid > 0: rows of W are [i|f|o|g] x hid (clstm.py:47) and are interleaved to 4*j+gate */
+int rsis_conv_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int nseg, const int* Cseg, int lstm_hid,
+                       void* stream);
+int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int c_lo, int c_hi, int lstm_hid,
+                         void* stream);
+
+/* ---- nn.Conv2d forward (model.py:59-63 skip convs, :167 conv_out, vision.py:12-19 trunk convs) ----
+ * out[B][Cout][Ho][Wo] = conv(cat(src[0..nsrc-1], dim=1), W, stride, pad) + bias (+ addend, same shape as out).
+ * torch.cat (model.py:153) is folded in: up to 3 sources.  tile = 0 lets the library choose the MFMA tiling. */
+int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const float* Wp, int Cout,
+                    int ks, int stride, int pad, const float* bias, const float* addend, float* out, int Ho, int Wo,
+                    int tile, void* stream);
+
+/* ---- nn.Conv2d backward-data (autograd of the above): dx for input channels [c_lo,c_hi) of the conv input, written
+ * to ndst tensors dx[i] = [B][Cdx[i]][Hx][Wx] (the inverse of the channel concat). dy = [B][Cout][Hy][Wy].
+ * Cin_packed = c_hi - c_lo given to rsis_conv_pack_dgrad; sum(Cdx) <= Cin_packed (leading channels are produced). ---- */
+int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const float* Wd, int Cin_packed, int ks, int stride,
+                      int pad, float* const* dx, const int* Cdx, int ndst, int Hx, int Wx, int tile, void* stream);
+
+/* ---- nn.Conv2d backward-weight: dW[Cout][Ctot][ks][ks] (reference layout) += corr(x, dy) for the source tensor
+ * x = [B][Cs][H][W] that occupies input channels [c_off, c_off+Cs).  ACCUMULATES (fp32 atomics): zero dW first.
+ * lstm_hid > 0: dy rows are gate-interleaved (4*j+gate) and are mapped back to reference rows. ---- */
+int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs, int H, int W, int Cout, int Ho, int Wo,
+                      int ks, int stride, int pad, int Ctot, int c_off, int lstm_hid, void* stream);
+
+/* ---- conv bias gradient: db[Cout] += sum_{b,h,w} dy  (ACCUMULATES; lstm_hid as above) ---- */
+int rsis_bias_grad(const float* dy, float* db, int B, int C, int HW, int lstm_hid, void* stream);
+
+/* ---- ConvLSTMCell.forward (clstm.py:19-62): cat(x.., h_prev) -> Gates conv -> chunk -> sigmoid/tanh -> c,h in ONE
+ * kernel.  src = the x tensor(s) followed by h_prev (omit h_prev and pass c_prev = NULL for the zero state of
+ * clstm.py:26-37).  bias_packed / act_out / addend use interleaved rows.  act_out (post-nonlinearity i,f,o,g, needed
+ * by the backward) may be NULL for inference. addend: optional precomputed time-invariant gate contribution. ---- */
+int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const float* Wp,
+                      const float* bias_packed, const float* addend, const float* c_prev, float* h_out, float* c_out,
+                      float* act_out, int hid, int ks, int pad, int tile, void* stream);
+
+/* ---- ConvLSTMCell pointwise backward: (dh, dc_next, saved act, c_prev, c) -> da (gate pre-activation grads,
+ * interleaved rows) and dc_prev.  dh / dc_next / c_prev / dc_prev / da_sum may be NULL. da_sum += da if given. ---- */
+int rsis_convlstm_bwd_gates(const float* dh, const float* dc_next, const float* act, const float* c_prev, const float* c,
+                            float* da, float* dc_prev, float* da_sum, int B, int hid, int HW, void* stream);
+
+/* ---- nn.UpsamplingBilinear2d(size) = bilinear, align_corners=True (model.py:149,163; train.py:96; test.py:39) ---- */
+int rsis_upsample_bilinear_ac_fwd(const float* x, float* y, long BC, int Hi, int Wi, int Ho, int Wo, void* stream);
+int rsis_upsample_bilinear_ac_bwd(const float* dy, float* dx, long BC, int Hi, int Wi, int Ho, int Wo, void* stream);
+
+/* ---- nn.MaxPool2d(full map) side features (model.py:143): y[BC], argmax[BC] (int32 flat index) ---- */
+int rsis_global_maxpool_fwd(const float* x, float* y, int* argmax, long BC, int HW, void* stream);
+int rsis_global_maxpool_bwd(const float* dy, const int* argmax, float* dx, long BC, int HW, void* stream);
+
+/* ---- nn.BatchNorm2d (+ residual add + ReLU of the bottleneck) (model.py:50-54,59-63; torchvision trunk) ----
+ * train != 0: batch statistics, running-stat update (momentum, unbiased var), saves mean / rstd for the backward.
+ * stats: scratch of 2*C doubles. res may be NULL. */
+int rsis_bn_fwd(const float* x, const float* res, float* y, double* stats, const float* gamma, const float* beta,
+                float* running_mean, float* running_var, float* save_mean, float* save_rstd, int B, int C, int HW,
+                float eps, float momentum, int relu, int train, void* stream);
+/* train-mode backward. y (the forward output) is only read when relu != 0. dres (grad of the residual input = masked
+ * dy) may be NULL. */
+int rsis_bn_bwd(const float* dy, const float* x, const float* y, const float* save_mean, const float* save_rstd,
+                const float* gamma, double* stats, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C,
+                int HW, int relu, void* stream);
+
+/* ---- nn.MaxPool2d(3, stride 2, padding 1) of the ResNet stem (vision.py:15) ---- */
+int rsis_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* argmax, long BC, int H, int W, int Ho, int Wo,
+                          void* stream);
+int rsis_maxpool3x3s2_bwd(const float* dy, const unsigned char* argmax, float* dx, long BC, int H, int W, int Ho, int Wo,
+                          void* stream);
+
+/* ---- torch.optim.Adam step on a flat parameter range (utils/utils.py:83-84; train.py:185-187); g is scaled by gscale
+ * (1/world_size after the RCCL sum all-reduce) before the L2 weight-decay term is added. ---- */
+int rsis_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float gscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSIS_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of librsis_hip.so (C ABI in include/rsis_hip.h).
+
+The library is the product: there is NO fallback.  If it has not been built (or cannot be loaded) every op
+raises -- build it with `python -c "import __graft_entry__ as g; g.build()"` (hipcc, gfx950).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librsis_hip.so")
+
+_vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+_ip = ctypes.POINTER(ctypes.c_int)
+_vpp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); must list every symbol declared in include/rsis_hip.h
+SIGNATURES = {
+    "rsis_version": (_i, []),
+    "rsis_error_string": (ctypes.c_char_p, [_i]),
+    "rsis_conv_packed_floats_fwd": (_l, [_i, _i, _i, _ip]),
+    "rsis_conv_packed_floats_dgrad": (_l, [_i, _i, _i]),
+    "rsis_conv_pack_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _ip, _i, _vp]),
+    "rsis_conv_pack_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsis_conv2d_fwd": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "rsis_conv2d_dgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vpp, _ip, _i, _i, _i, _i, _vp]),
+    "rsis_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsis_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsis_convlstm_fwd": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsis_convlstm_bwd_gates": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "rsis_upsample_bilinear_ac_fwd": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
+    "rsis_upsample_bilinear_ac_bwd": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
+    "rsis_global_maxpool_fwd": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
+    "rsis_global_maxpool_bwd": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
+    "rsis_bn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp]),
+    "rsis_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsis_maxpool3x3s2_fwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
+    "rsis_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
+    "rsis_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp]),
+}
+
+_LIB = None
+
+
+class RsisHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load librsis_hip.so once; raise loudly if it is missing (no CPU / eager fallback exists)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RsisHipError("%s is missing: the HIP library is the product path and has no fallback; build it with "
+                               "`python -c \"import __graft_entry__ as g; g.build()\"`" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RsisHipError("%s failed: %s (code %d)" % (what, lib().rsis_error_string(rc).decode(), rc))
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def int_array(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def require_cuda_f32(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RsisHipError("rsis_amd ops run on the GPU only (got a %s tensor); there is no CPU path" % t.device)
+        if t.dtype != torch.float32:
+            raise RsisHipError("rsis_amd ops are fp32 (got %s)" % t.dtype)

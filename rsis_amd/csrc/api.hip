@@ -1,0 +1,199 @@
+// extern "C" entry points of librsis_hip.so (declared in include/rsis_hip.h).  Argument validation + dispatch only.
+#include "common.h"
+#include "../../include/rsis_hip.h"
+
+// launchers implemented in the other translation units
+int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_tile, hipStream_t st);
+int rsis_launch_conv_wgrad(WgradArgs& a, int ks, hipStream_t st);
+int rsis_l_pack_fwd(const float*, float*, int, int, int, int, const int*, int, int, int, hipStream_t);
+int rsis_l_pack_dgrad(const float*, float*, int, int, int, int, int, int, int, int, hipStream_t);
+int rsis_l_lstm_bwd(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
+                    hipStream_t);
+int rsis_l_upsample_fwd(const float*, float*, long, int, int, int, int, hipStream_t);
+int rsis_l_upsample_bwd(const float*, float*, long, int, int, int, int, hipStream_t);
+int rsis_l_gmax_fwd(const float*, float*, int*, long, int, hipStream_t);
+int rsis_l_gmax_bwd(const float*, const int*, float*, long, int, hipStream_t);
+int rsis_l_bn_fwd(const float*, const float*, float*, double*, const float*, const float*, float*, float*, float*, float*, int,
+                  int, int, float, float, int, int, hipStream_t);
+int rsis_l_bn_bwd(const float*, const float*, const float*, const float*, const float*, const float*, double*, float*, float*,
+                  float*, float*, int, int, int, int, hipStream_t);
+int rsis_l_maxpool_fwd(const float*, float*, unsigned char*, long, int, int, int, int, hipStream_t);
+int rsis_l_maxpool_bwd(const float*, const unsigned char*, float*, long, int, int, int, int, hipStream_t);
+int rsis_l_channel_sum(const float*, float*, int, int, int, int, hipStream_t);
+int rsis_l_adam(float*, const float*, float*, float*, long, float, float, float, float, float, int, float, hipStream_t);
+
+static inline int ktiles_of(int C, int ks) { return (C * ks * ks + RSIS_BK - 1) / RSIS_BK; }
+static inline int log2i(int s) { int l = 0; while ((1 << l) < s) ++l; return l; }
+
+extern "C" {
+
+int rsis_version(void) { return RSIS_ABI_VERSION; }
+
+const char* rsis_error_string(int code) {
+  switch (code) {
+    case RSIS_OK: return "ok";
+    case RSIS_ERR_ARG: return "invalid argument";
+    case RSIS_ERR_LAUNCH: return "HIP launch failed";
+    case RSIS_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown error";
+  }
+}
+
+long rsis_conv_packed_floats_fwd(int Cout, int ks, int nseg, const int* Cseg) {
+  if (nseg < 1 || nseg > RSIS_MAX_SRC || !Cseg) return -1;
+  long kt = 0;
+  for (int s = 0; s < nseg; ++s) kt += ktiles_of(Cseg[s], ks);
+  return kt * RSIS_BK * (long)rsis_roundup(Cout, RSIS_LDW_ALIGN);
+}
+
+long rsis_conv_packed_floats_dgrad(int Cout, int ks, int c_count) {
+  return (long)ktiles_of(Cout, ks) * RSIS_BK * (long)rsis_roundup(c_count, RSIS_LDW_ALIGN);
+}
+
+int rsis_conv_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int nseg, const int* Cseg, int lstm_hid,
+                       void* stream) {
+  if (!W || !Wp || nseg < 1 || nseg > RSIS_MAX_SRC) return RSIS_ERR_ARG;
+  int csum = 0, kt = 0;
+  for (int s = 0; s < nseg; ++s) { csum += Cseg[s]; kt += ktiles_of(Cseg[s], ks); }
+  if (csum != Ctot) return RSIS_ERR_ARG;
+  if (lstm_hid > 0 && Cout != 4 * lstm_hid) return RSIS_ERR_ARG;
+  return rsis_l_pack_fwd(W, Wp, Cout, Ctot, ks, nseg, Cseg, rsis_roundup(Cout, RSIS_LDW_ALIGN), kt * RSIS_BK, lstm_hid,
+                         (hipStream_t)stream);
+}
+
+int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int c_lo, int c_hi, int lstm_hid,
+                         void* stream) {
+  if (!W || !Wd || c_lo < 0 || c_hi > Ctot || c_lo >= c_hi) return RSIS_ERR_ARG;
+  if (lstm_hid > 0 && Cout != 4 * lstm_hid) return RSIS_ERR_ARG;
+  return rsis_l_pack_dgrad(W, Wd, Cout, Ctot, ks, c_lo, c_hi, rsis_roundup(c_hi - c_lo, RSIS_LDW_ALIGN),
+                           ktiles_of(Cout, ks) * RSIS_BK, lstm_hid, (hipStream_t)stream);
+}
+
+static int fill_sources(ConvArgs& a, const float* const* src, const int* Csrc, int nsrc, int ks) {
+  if (nsrc < 1 || nsrc > RSIS_MAX_SRC || !src || !Csrc) return RSIS_ERR_ARG;
+  a.nsrc = nsrc;
+  for (int s = 0; s < RSIS_MAX_SRC; ++s) { a.src[s] = nullptr; a.C[s] = 0; a.ktiles[s] = 0; }
+  for (int s = 0; s < nsrc; ++s) {
+    if (!src[s] || Csrc[s] < 1) return RSIS_ERR_ARG;
+    a.src[s] = src[s]; a.C[s] = Csrc[s]; a.ktiles[s] = ktiles_of(Csrc[s], ks);
+  }
+  return RSIS_OK;
+}
+
+int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const float* Wp, int Cout,
+                    int ks, int stride, int pad, const float* bias, const float* addend, float* out, int Ho, int Wo,
+                    int tile, void* stream) {
+  ConvArgs a = {};
+  int rc = fill_sources(a, src, Csrc, nsrc, ks);
+  if (rc) return rc;
+  if (!Wp || !out || B < 1 || stride < 1) return RSIS_ERR_ARG;
+  if (Ho != (H + 2 * pad - ks) / stride + 1 || Wo != (W + 2 * pad - ks) / stride + 1) return RSIS_ERR_ARG;
+  a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = pad; a.sshift = 0;
+  a.wp = Wp; a.ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN); a.Cout = Cout; a.bias = bias; a.addend = addend;
+  a.dst[0] = out; a.Cd[0] = Cout; a.ndst = 1;
+  return rsis_launch_conv_igemm(a, ks, false, 0, tile, (hipStream_t)stream);
+}
+
+int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const float* Wd, int Cin_packed, int ks, int stride,
+                      int pad, float* const* dx, const int* Cdx, int ndst, int Hx, int Wx, int tile, void* stream) {
+  if (!dy || !Wd || !dx || !Cdx || ndst < 1 || ndst > RSIS_MAX_SRC) return RSIS_ERR_ARG;
+  if (stride != 1 && stride != 2 && stride != 4) return RSIS_ERR_UNSUPPORTED;
+  ConvArgs a = {};
+  const float* srcs[1] = {dy};
+  const int cs[1] = {Cout};
+  int rc = fill_sources(a, srcs, cs, 1, ks);
+  if (rc) return rc;
+  int ctot = 0;
+  for (int i = 0; i < ndst; ++i) { if (!dx[i] || Cdx[i] < 1) return RSIS_ERR_ARG; a.dst[i] = dx[i]; a.Cd[i] = Cdx[i]; ctot += Cdx[i]; }
+  a.ndst = ndst;
+  a.B = B; a.H = Hy; a.W = Wy; a.Ho = Hx; a.Wo = Wx; a.stride = stride; a.pad = pad; a.sshift = log2i(stride);
+  if (ctot > Cin_packed) return RSIS_ERR_ARG;
+  a.wp = Wd; a.ldw = rsis_roundup(Cin_packed, RSIS_LDW_ALIGN); a.Cout = ctot; a.bias = nullptr; a.addend = nullptr;
+  return rsis_launch_conv_igemm(a, ks, true, 0, tile, (hipStream_t)stream);
+}
+
+int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs, int H, int W, int Cout, int Ho, int Wo,
+                      int ks, int stride, int pad, int Ctot, int c_off, int lstm_hid, void* stream) {
+  if (!dy || !x || !dW || c_off < 0 || c_off + Cs > Ctot) return RSIS_ERR_ARG;
+  WgradArgs a = {};
+  a.dy = dy; a.x = x; a.dw = dW; a.B = B; a.Cs = Cs; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+  a.stride = stride; a.pad = pad; a.ldo = Ctot * ks * ks; a.n_off = c_off * ks * ks; a.interleave_hid = lstm_hid;
+  return rsis_launch_conv_wgrad(a, ks, (hipStream_t)stream);
+}
+
+int rsis_bias_grad(const float* dy, float* db, int B, int C, int HW, int lstm_hid, void* stream) {
+  if (!dy || !db) return RSIS_ERR_ARG;
+  return rsis_l_channel_sum(dy, db, B, C, HW, lstm_hid, (hipStream_t)stream);
+}
+
+int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const float* Wp,
+                      const float* bias_packed, const float* addend, const float* c_prev, float* h_out, float* c_out,
+                      float* act_out, int hid, int ks, int pad, int tile, void* stream) {
+  ConvArgs a = {};
+  int rc = fill_sources(a, src, Csrc, nsrc, ks);
+  if (rc) return rc;
+  if (!Wp || !h_out || !c_out || hid < 1) return RSIS_ERR_ARG;
+  if (2 * pad != ks - 1) return RSIS_ERR_UNSUPPORTED;   // "same" conv only (the state keeps its size)
+  a.B = B; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.stride = 1; a.pad = pad; a.sshift = 0;
+  a.wp = Wp; a.ldw = rsis_roundup(4 * hid, RSIS_LDW_ALIGN); a.Cout = 4 * hid; a.bias = bias_packed; a.addend = addend;
+  a.ndst = 1; a.dst[0] = nullptr; a.Cd[0] = 4 * hid;
+  a.hid = hid; a.c_prev = c_prev; a.h_out = h_out; a.c_out = c_out; a.act_out = act_out;
+  return rsis_launch_conv_igemm(a, ks, false, 1, tile, (hipStream_t)stream);
+}
+
+int rsis_convlstm_bwd_gates(const float* dh, const float* dc_next, const float* act, const float* c_prev, const float* c,
+                            float* da, float* dc_prev, float* da_sum, int B, int hid, int HW, void* stream) {
+  if (!act || !c || !da) return RSIS_ERR_ARG;
+  return rsis_l_lstm_bwd(dh, dc_next, act, c_prev, c, da, dc_prev, da_sum, B, hid, HW, (hipStream_t)stream);
+}
+
+int rsis_upsample_bilinear_ac_fwd(const float* x, float* y, long BC, int Hi, int Wi, int Ho, int Wo, void* stream) {
+  if (!x || !y) return RSIS_ERR_ARG;
+  return rsis_l_upsample_fwd(x, y, BC, Hi, Wi, Ho, Wo, (hipStream_t)stream);
+}
+int rsis_upsample_bilinear_ac_bwd(const float* dy, float* dx, long BC, int Hi, int Wi, int Ho, int Wo, void* stream) {
+  if (!dy || !dx) return RSIS_ERR_ARG;
+  return rsis_l_upsample_bwd(dy, dx, BC, Hi, Wi, Ho, Wo, (hipStream_t)stream);
+}
+int rsis_global_maxpool_fwd(const float* x, float* y, int* argmax, long BC, int HW, void* stream) {
+  if (!x || !y || !argmax) return RSIS_ERR_ARG;
+  return rsis_l_gmax_fwd(x, y, argmax, BC, HW, (hipStream_t)stream);
+}
+int rsis_global_maxpool_bwd(const float* dy, const int* argmax, float* dx, long BC, int HW, void* stream) {
+  if (!dy || !dx || !argmax) return RSIS_ERR_ARG;
+  return rsis_l_gmax_bwd(dy, argmax, dx, BC, HW, (hipStream_t)stream);
+}
+int rsis_bn_fwd(const float* x, const float* res, float* y, double* stats, const float* gamma, const float* beta,
+                float* running_mean, float* running_var, float* save_mean, float* save_rstd, int B, int C, int HW,
+                float eps, float momentum, int relu, int train, void* stream) {
+  if (!x || !y || !gamma || !beta || !running_mean || !running_var) return RSIS_ERR_ARG;
+  if (train && (!stats || !save_mean || !save_rstd)) return RSIS_ERR_ARG;
+  return rsis_l_bn_fwd(x, res, y, stats, gamma, beta, running_mean, running_var, save_mean, save_rstd, B, C, HW, eps,
+                       momentum, relu, train, (hipStream_t)stream);
+}
+int rsis_bn_bwd(const float* dy, const float* x, const float* y, const float* save_mean, const float* save_rstd,
+                const float* gamma, double* stats, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C,
+                int HW, int relu, void* stream) {
+  if (!dy || !x || !save_mean || !save_rstd || !gamma || !stats || !dx || !dgamma || !dbeta) return RSIS_ERR_ARG;
+  if (relu && !y) return RSIS_ERR_ARG;
+  return rsis_l_bn_bwd(dy, x, y, save_mean, save_rstd, gamma, stats, dx, dres, dgamma, dbeta, B, C, HW, relu,
+                       (hipStream_t)stream);
+}
+int rsis_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* argmax, long BC, int H, int W, int Ho, int Wo,
+                          void* stream) {
+  if (!x || !y || !argmax) return RSIS_ERR_ARG;
+  return rsis_l_maxpool_fwd(x, y, argmax, BC, H, W, Ho, Wo, (hipStream_t)stream);
+}
+int rsis_maxpool3x3s2_bwd(const float* dy, const unsigned char* argmax, float* dx, long BC, int H, int W, int Ho, int Wo,
+                          void* stream) {
+  if (!dy || !dx || !argmax) return RSIS_ERR_ARG;
+  return rsis_l_maxpool_bwd(dy, argmax, dx, BC, H, W, Ho, Wo, (hipStream_t)stream);
+}
+int rsis_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float gscale, void* stream) {
+  if (!p || !g || !m || !v || n < 0 || step < 1) return RSIS_ERR_ARG;
+  if (n == 0) return RSIS_OK;
+  return rsis_l_adam(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, gscale, (hipStream_t)stream);
+}
+
+}  // extern "C"

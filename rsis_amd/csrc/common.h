@@ -1,0 +1,66 @@
+// Internal helpers shared by the HIP translation units of librsis_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RSIS_OK 0
+#define RSIS_ERR_ARG 1
+#define RSIS_ERR_LAUNCH 2
+#define RSIS_ERR_UNSUPPORTED 3
+
+#define RSIS_BK 16          // K-tile depth of the implicit-GEMM kernels (fwd / dgrad)
+#define RSIS_LDW_ALIGN 128  // packed-weight row stride is a multiple of this many floats
+#define RSIS_MAX_SRC 3      // channel-concatenated sources / split destinations per conv
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int rsis_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? RSIS_OK : RSIS_ERR_LAUNCH;
+}
+
+static inline int rsis_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int rsis_roundup(int a, int b) { return ((a + b - 1) / b) * b; }
+
+__device__ __forceinline__ float rsis_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Arguments of the implicit-GEMM convolution kernels (NCHW fp32).
+// GEMM view:  D[co][px] = sum_k  Wp[k][co] * Xcol[k][px],   px = (b, ho, wo),  k = (segment, ci, r, s).
+struct ConvArgs {
+  const float* src[RSIS_MAX_SRC];  // gathered tensors, each [B][C[s]][H][W]
+  int C[RSIS_MAX_SRC];
+  int ktiles[RSIS_MAX_SRC];        // K-tiles per source segment (= ceil(C*ks*ks / BK))
+  int nsrc;
+  int B, H, W;                     // gathered-tensor geometry
+  int Ho, Wo;                      // output geometry
+  int stride, pad, sshift;         // sshift = log2(stride) (dgrad mode)
+  const float* wp;                 // packed weights [sum(ktiles)*BK][ldw]
+  int ldw;
+  int Cout;                        // real number of output rows
+  const float* bias;               // [Cout] (packed row order) or null
+  const float* addend;             // optional, same layout as dst[0] (single destination only)
+  float* dst[RSIS_MAX_SRC];        // output tensors, rows split by Cd[]; each [B][Cd[i]][Ho][Wo]
+  int Cd[RSIS_MAX_SRC];
+  int ndst;
+  int n_co_tiles, n_px_tiles;
+  // ConvLSTM epilogue (EPI_LSTM): rows are gate-interleaved, row = 4*j + gate, gate in (i,f,o,g)
+  int hid;
+  const float* c_prev;             // [B][hid][Ho][Wo] or null (zero state)
+  float* h_out;                    // [B][hid][Ho][Wo]
+  float* c_out;                    // [B][hid][Ho][Wo]
+  float* act_out;                  // [B][4*hid][Ho][Wo] post-nonlinearity gates (interleaved rows) or null
+};
+
+// Arguments of the split-K weight-gradient kernel (conv_wgrad.hip).
+struct WgradArgs {
+  const float* dy;   // [B][CoutDy][Ho][Wo]   (for ConvLSTM: the gate pre-activation grads, interleaved rows)
+  const float* x;    // [B][Cs][H][W]
+  float* dw;         // [Cout][ldo]  reference layout, ldo = Ctot*ks*ks
+  int B, Cs, H, W, Ho, Wo, Cout;
+  int stride, pad;
+  int ldo, n_off;    // row stride of dW, column offset of this source (= channel offset * ks*ks)
+  int interleave_hid;  // >0: dy rows are 4*j+gate -> dW row gate*hid + j
+  int chunk;         // px per split (multiple of BKW)
+  int n_co_tiles, n_n_tiles;
+};

@@ -1,0 +1,278 @@
+// Implicit-GEMM convolution for gfx950 (CDNA4), NCHW fp32, exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Replaces, on the RSIS hot path, every nn.Conv2d the reference dispatches to cuDNN:
+//   * ConvLSTMCell.Gates + cat + chunk + sigmoid/tanh + cell update  (reference src/modules/clstm.py:43-58)  -> EPI_LSTM
+//   * skip convs, conv_out, ResNet-101 trunk convs                     (src/modules/model.py:43-47,109; vision.py:12-19) -> EPI_PLAIN
+//   * the data-gradient of all of them (DGRAD gather mode)
+//
+// GEMM view:  D[co][px] = sum_k Wp[k][co] * Xcol[k][px]
+//   MFMA "A" operand = packed weights (rows = output channels), "B" operand = gathered pixels, so that the
+//   accumulator tile is [co][px] with px = lane&31: stores are coalesced along W in NCHW, and (with
+//   gate-interleaved weight rows 4*j+gate) one lane holds i,f,o,g of the same hidden channel/pixel in
+//   acc[4*r4 .. 4*r4+3], so the whole LSTM cell update happens in registers.
+//   Channel concat (torch.cat at clstm.py:43 / model.py:153) is "by pointer": up to 3 source tensors, each owning
+//   a BK-aligned segment of the packed K axis.
+//   LDS tiles are k-major ([BK][BM] / [BK][BN]) so every ds_read_b32 of an MFMA operand is conflict-free.
+#include "common.h"
+
+#define BK RSIS_BK
+
+enum { EPI_PLAIN = 0, EPI_LSTM = 1 };
+
+template <int BM, int BN, int WGM, int WGN, int KS, bool DGRAD, int EPI>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+  constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+  constexpr int KK = KS * KS;
+  constexpr int B_ROWS = 256 / BN;       // k rows covered by one load pass of the pixel operand
+  constexpr int B_LOADS = BK / B_ROWS;   // dword loads per thread per K-tile
+  constexpr int A_F4 = BK * BM / 4;      // float4 per weight tile
+  constexpr int A_LOADS = (A_F4 + 255) / 256;
+  static_assert(WGM * WGN == 4, "4 waves per block");
+  static_assert(BN == 64 || BN == 128 || BN == 256, "BN");
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (BM + BN)];
+  float* As0 = lds;                 // [2][BK][BM]
+  float* Bs0 = lds + 2 * BK * BM;   // [2][BK][BN]
+
+  // ---- block -> (co tile, px tile); blocks b, b+8, ... share an XCD (L2): keep a pixel tile's co tiles there ----
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = bid >> 3;
+  const int co_t = q % p.n_co_tiles;
+  const int px_t = (q / p.n_co_tiles) * 8 + xcd;
+  if (px_t >= p.n_px_tiles) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  const int HoWo = p.Ho * p.Wo, HW = p.H * p.W;
+  const int Npx = p.B * HoWo;
+
+  // ---- per-thread pixel of the gathered operand (fixed for the whole K loop) ----
+  const int px_local = tid % BN;
+  const int krow0 = __builtin_amdgcn_readfirstlane(tid / BN);
+  int px = px_t * BN + px_local;
+  const bool pxv = px < Npx;
+  if (!pxv) px = 0;
+  const int pb = px / HoWo;
+  const int psp = px - pb * HoWo;
+  const int pho = psp / p.Wo, pwo = psp - pho * p.Wo;
+  int hi0, wi0;
+  if (!DGRAD) { hi0 = pho * p.stride - p.pad; wi0 = pwo * p.stride - p.pad; }
+  else        { hi0 = pho + p.pad;            wi0 = pwo + p.pad; }
+  const int smask = (1 << p.sshift) - 1;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float rb[B_LOADS];
+  f32x4 ra[A_LOADS];
+
+  int ntiles = 0;
+  for (int s = 0; s < p.nsrc; ++s) ntiles += p.ktiles[s];
+
+  int seg = 0, lt = 0;  // scalar K-tile cursor: source segment / tile within the segment
+
+  auto load_tile = [&](int gt) {
+    const float* __restrict__ src = p.src[seg];
+    const int Cs = p.C[seg];
+    const int k0 = lt * BK + krow0;
+    const int bbase = pb * Cs * HW;
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const int kl = k0 + i * B_ROWS;  // wave-uniform
+      const int ci = kl / KK;
+      const int rs = kl - ci * KK;
+      const int r = rs / KS, s = rs - r * KS;
+      bool ok = pxv && (ci < Cs);
+      int ih, iw;
+      if (!DGRAD) {
+        ih = hi0 + r; iw = wi0 + s;
+        ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+      } else {
+        const int th = hi0 - r, tw = wi0 - s;
+        ok = ok && (th >= 0) && (tw >= 0) && (((th | tw) & smask) == 0);
+        ih = th >> p.sshift; iw = tw >> p.sshift;
+        ok = ok && (ih < p.H) && (iw < p.W);
+      }
+      const int off = bbase + ci * HW + ih * p.W + iw;
+      rb[i] = ok ? src[off] : 0.f;
+    }
+    const float* __restrict__ wrow = p.wp + (size_t)gt * BK * p.ldw + co_t * BM;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int idx = tid + i * 256;
+      if (A_F4 % 256 == 0 || idx < A_F4) {
+        const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+        ra[i] = *reinterpret_cast<const f32x4*>(wrow + (size_t)row * p.ldw + c4 * 4);
+      }
+    }
+    // advance the cursor
+    if (++lt == p.ktiles[seg]) { lt = 0; ++seg; }
+  };
+
+  auto store_tile = [&](int buf) {
+    float* As = As0 + buf * BK * BM;
+    float* Bs = Bs0 + buf * BK * BN;
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) Bs[(krow0 + i * B_ROWS) * BN + px_local] = rb[i];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int idx = tid + i * 256;
+      if (A_F4 % 256 == 0 || idx < A_F4) {
+        const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+        *reinterpret_cast<f32x4*>(As + row * BM + c4 * 4) = ra[i];
+      }
+    }
+  };
+
+  auto compute = [&](int buf) {
+    const float* As = As0 + buf * BK * BM + wm * TM * 32 + l31;
+    const float* Bs = Bs0 + buf * BK * BN + wn * TN * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int krow = kk * 2 + hi;
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[krow * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[krow * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- software pipeline: global->regs for tile t+1 overlaps MFMA on tile t; one barrier per tile ----
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) load_tile(t + 1);
+    compute(cur);
+    if (t + 1 < ntiles) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const int co_base = co_t * BM + wm * TM * 32;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int opx = px_t * BN + wn * TN * 32 + j * 32 + l31;
+    if (opx >= Npx) continue;
+    const int ob = opx / HoWo;
+    const int osp = opx - ob * HoWo;
+    if (EPI == EPI_PLAIN) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (co >= p.Cout) continue;
+          float v = acc[i][j][r];
+          if (p.bias) v += p.bias[co];
+          int cl = co, d = 0;
+          if (p.ndst > 1 && cl >= p.Cd[0]) { cl -= p.Cd[0]; d = 1; if (p.ndst > 2 && cl >= p.Cd[1]) { cl -= p.Cd[1]; d = 2; } }
+          const size_t idx = ((size_t)ob * p.Cd[d] + cl) * HoWo + osp;
+          if (p.addend) v += p.addend[idx];
+          p.dst[d][idx] = v;
+        }
+      }
+    } else {
+      const int hid = p.hid;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int jh = ((co_base + i * 32) >> 2) + 2 * r4 + hi;   // hidden channel
+          if (jh >= hid) continue;
+          const int cop = jh * 4;                                      // packed gate row of gate i
+          float ai = acc[i][j][4 * r4 + 0], af = acc[i][j][4 * r4 + 1];
+          float ao = acc[i][j][4 * r4 + 2], ag = acc[i][j][4 * r4 + 3];
+          if (p.bias) { ai += p.bias[cop]; af += p.bias[cop + 1]; ao += p.bias[cop + 2]; ag += p.bias[cop + 3]; }
+          const size_t gidx = ((size_t)ob * 4 * hid + cop) * HoWo + osp;
+          if (p.addend) {
+            ai += p.addend[gidx]; af += p.addend[gidx + HoWo];
+            ao += p.addend[gidx + 2 * (size_t)HoWo]; ag += p.addend[gidx + 3 * (size_t)HoWo];
+          }
+          const float gi = rsis_sigmoid(ai), gf = rsis_sigmoid(af), go = rsis_sigmoid(ao), gg = tanhf(ag);
+          const size_t sidx = ((size_t)ob * hid + jh) * HoWo + osp;
+          const float cp = p.c_prev ? p.c_prev[sidx] : 0.f;
+          const float c = gf * cp + gi * gg;       // clstm.py:57
+          const float h = go * tanhf(c);           // clstm.py:58
+          p.c_out[sidx] = c;
+          p.h_out[sidx] = h;
+          if (p.act_out) {
+            p.act_out[gidx] = gi; p.act_out[gidx + HoWo] = gf;
+            p.act_out[gidx + 2 * (size_t)HoWo] = go; p.act_out[gidx + 3 * (size_t)HoWo] = gg;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, int KS, bool DGRAD, int EPI>
+static int launch_cfg(ConvArgs& a, hipStream_t st) {
+  const long Npx = (long)a.B * a.Ho * a.Wo;
+  a.n_co_tiles = rsis_cdiv(a.Cout, BM);
+  a.n_px_tiles = rsis_cdiv(Npx, BN);
+  const int grid = a.n_co_tiles * 8 * rsis_cdiv(a.n_px_tiles, 8);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, KS, DGRAD, EPI>), dim3(grid), dim3(256), 0, st, a);
+  return rsis_check_launch();
+}
+
+// Tile selection: the widest co tile the layer fills, then the px tile that still gives >= ~1 block per CU.
+template <int KS, bool DGRAD, int EPI>
+static int launch_ks(ConvArgs& a, hipStream_t st, int force_tile) {
+  const long Npx = (long)a.B * a.Ho * a.Wo;
+  int tile = force_tile;
+  if (tile <= 0) {
+    if (a.Cout <= 32) tile = (Npx >= 256L * 256) ? 1 : 2;                 // 32x256 / 32x128
+    else if (a.Cout <= 64) tile = 3;                                      // 64x128
+    else {
+      const long b128 = (long)rsis_cdiv(a.Cout, 128) * rsis_cdiv(Npx, 128);
+      tile = (b128 >= 200) ? 4 : 5;                                       // 128x128 / 64x64
+    }
+  }
+  switch (tile) {
+    case 1: return launch_cfg<32, 256, 1, 4, KS, DGRAD, EPI>(a, st);
+    case 2: return launch_cfg<32, 128, 1, 4, KS, DGRAD, EPI>(a, st);
+    case 3: return launch_cfg<64, 128, 2, 2, KS, DGRAD, EPI>(a, st);
+    case 4: return launch_cfg<128, 128, 2, 2, KS, DGRAD, EPI>(a, st);
+    case 5: return launch_cfg<64, 64, 2, 2, KS, DGRAD, EPI>(a, st);
+    default: return RSIS_ERR_ARG;
+  }
+}
+
+int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_tile, hipStream_t st) {
+  if (a.nsrc < 1 || a.nsrc > RSIS_MAX_SRC) return RSIS_ERR_ARG;
+  if (epi == EPI_LSTM) {
+    if (dgrad) return RSIS_ERR_UNSUPPORTED;
+    if (ks == 3) return launch_ks<3, false, EPI_LSTM>(a, st, force_tile);
+    if (ks == 1) return launch_ks<1, false, EPI_LSTM>(a, st, force_tile);
+    return RSIS_ERR_UNSUPPORTED;
+  }
+  if (!dgrad) {
+    if (ks == 1) return launch_ks<1, false, EPI_PLAIN>(a, st, force_tile);
+    if (ks == 3) return launch_ks<3, false, EPI_PLAIN>(a, st, force_tile);
+    if (ks == 7) return launch_ks<7, false, EPI_PLAIN>(a, st, force_tile);
+  } else {
+    if (ks == 1) return launch_ks<1, true, EPI_PLAIN>(a, st, force_tile);
+    if (ks == 3) return launch_ks<3, true, EPI_PLAIN>(a, st, force_tile);
+    if (ks == 7) return launch_ks<7, true, EPI_PLAIN>(a, st, force_tile);
+  }
+  return RSIS_ERR_UNSUPPORTED;
+}

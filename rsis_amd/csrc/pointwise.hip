@@ -1,0 +1,470 @@
+// Bandwidth-bound kernels of the RSIS hot path for gfx950 (NCHW fp32): ConvLSTM pointwise backward, bilinear
+// align-corners upsample fwd/bwd, global max-pool fwd/bwd, train/eval BatchNorm(+residual)(+ReLU) fwd/bwd,
+// 3x3/2 max-pool fwd/bwd, per-channel bias-grad reduction, weight repacking and the flat fused Adam step.
+// All are HBM-roofline kernels: coalesced along W, grid-stride, float4 where the row length allows it.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// weight repacking (private layouts; never serialised)
+// ------------------------------------------------------------------------------------------------
+// FWD:   Wp[kbase_s + ci_l*KK + rs][co_p] = W[ref(co_p)][c0_s + ci_l][rs]     (zero in K / Cout padding)
+// DGRAD: Wd[co_p*KK + rs][ci - c_lo]      = W[ref(co_p)][ci][rs]
+// ref(co_p) = (co_p&3)*hid + (co_p>>2) for gate-interleaved ConvLSTM rows, identity otherwise.
+__global__ void pack_fwd_kernel(const float* __restrict__ W, float* __restrict__ Wp, int Cout, int Ctot, int KK,
+                                int nseg, int c0, int c1, int c2, int ldw, int krows, int hid) {
+  const long total = (long)krows * ldw;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / ldw), cop = (int)(e - (long)k * ldw);
+    float v = 0.f;
+    if (cop < Cout) {
+      const int Cs[3] = {c0, c1, c2};
+      int kb = 0, cb = 0;
+      for (int s = 0; s < nseg; ++s) {
+        const int kt = ((Cs[s] * KK + RSIS_BK - 1) / RSIS_BK) * RSIS_BK;
+        if (k < kb + kt) {
+          const int kl = k - kb;
+          if (kl < Cs[s] * KK) {
+            const int ci = kl / KK, rs = kl - ci * KK;
+            const int co = hid > 0 ? (cop & 3) * hid + (cop >> 2) : cop;
+            v = W[((long)co * Ctot + cb + ci) * KK + rs];
+          }
+          break;
+        }
+        kb += kt; cb += Cs[s];
+      }
+    }
+    Wp[e] = v;
+  }
+}
+
+__global__ void pack_dgrad_kernel(const float* __restrict__ W, float* __restrict__ Wd, int Cout, int Ctot, int KK,
+                                  int c_lo, int c_hi, int ldw, int krows, int hid) {
+  const long total = (long)krows * ldw;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / ldw), cl = (int)(e - (long)k * ldw);
+    float v = 0.f;
+    const int cop = k / KK, rs = k - cop * KK;
+    if (cop < Cout && cl < c_hi - c_lo) {
+      const int co = hid > 0 ? (cop & 3) * hid + (cop >> 2) : cop;
+      v = W[((long)co * Ctot + c_lo + cl) * KK + rs];
+    }
+    Wd[e] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ConvLSTM pointwise backward (derivative of reference clstm.py:47-58; formulas in SURVEY.md 8(a))
+//   do = dh*tanh(c); dc = dc_next + dh*o*(1-tanh(c)^2); di = dc*g; dg = dc*i; df = dc*c_prev; dc_prev = dc*f
+//   da_i = di*i(1-i), da_f = df*f(1-f), da_o = do*o(1-o), da_g = dg*(1-g^2)
+// act / da use gate-interleaved rows (4*j+gate).  Optionally accumulates da into da_sum (for the hoisted,
+// time-invariant skip channels: sum_t da_t feeds ONE dgrad/wgrad per iteration).
+// ------------------------------------------------------------------------------------------------
+__global__ void lstm_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc_next,
+                                const float* __restrict__ act, const float* __restrict__ c_prev,
+                                const float* __restrict__ c, float* __restrict__ da, float* __restrict__ dc_prev,
+                                float* __restrict__ da_sum, int hid, int HW, long total) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long bj = e / HW;               // b*hid + j
+    const int sp = (int)(e - bj * HW);
+    const long g0 = bj * 4 * HW + sp;     // (b*4*hid + 4*j)*HW + sp
+    const float gi = act[g0], gf = act[g0 + HW], go = act[g0 + 2L * HW], gg = act[g0 + 3L * HW];
+    const float tc = tanhf(c[e]);
+    const float dhv = dh ? dh[e] : 0.f;
+    float dcv = dhv * go * (1.f - tc * tc);
+    if (dc_next) dcv += dc_next[e];
+    const float cp = c_prev ? c_prev[e] : 0.f;
+    const float dai = dcv * gg * gi * (1.f - gi);
+    const float daf = dcv * cp * gf * (1.f - gf);
+    const float dao = dhv * tc * go * (1.f - go);
+    const float dag = dcv * gi * (1.f - gg * gg);
+    da[g0] = dai; da[g0 + HW] = daf; da[g0 + 2L * HW] = dao; da[g0 + 3L * HW] = dag;
+    if (da_sum) { da_sum[g0] += dai; da_sum[g0 + HW] += daf; da_sum[g0 + 2L * HW] += dao; da_sum[g0 + 3L * HW] += dag; }
+    if (dc_prev) dc_prev[e] = dcv * gf;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear upsample, align_corners=True  (nn.UpsamplingBilinear2d: model.py:149,163; train.py:96; test.py:39)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ac_coord(int o, float scale, int in, int& i0, int& i1, float& l1) {
+  const float src = scale * o;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - i0;
+}
+
+__global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int Hi, int Wi, int Ho, int Wo,
+                                    float sh, float sw, long total) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int wo = (int)(e % Wo);
+    const long t = e / Wo;
+    const int ho = (int)(t % Ho);
+    const long bc = t / Ho;
+    int h0, h1, w0, w1; float lh, lw;
+    ac_coord(ho, sh, Hi, h0, h1, lh);
+    ac_coord(wo, sw, Wi, w0, w1, lw);
+    const float* xb = x + bc * Hi * Wi;
+    const float v00 = xb[h0 * Wi + w0], v01 = xb[h0 * Wi + w1], v10 = xb[h1 * Wi + w0], v11 = xb[h1 * Wi + w1];
+    y[e] = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+  }
+}
+
+// dx must be zero-filled by the caller (the C entry point does it)
+__global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Hi, int Wi, int Ho, int Wo,
+                                    float sh, float sw, long total) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int wo = (int)(e % Wo);
+    const long t = e / Wo;
+    const int ho = (int)(t % Ho);
+    const long bc = t / Ho;
+    int h0, h1, w0, w1; float lh, lw;
+    ac_coord(ho, sh, Hi, h0, h1, lh);
+    ac_coord(wo, sw, Wi, w0, w1, lw);
+    const float g = dy[e];
+    float* xb = dx + bc * Hi * Wi;
+    atomicAdd(xb + h0 * Wi + w0, (1.f - lh) * (1.f - lw) * g);
+    atomicAdd(xb + h0 * Wi + w1, (1.f - lh) * lw * g);
+    atomicAdd(xb + h1 * Wi + w0, lh * (1.f - lw) * g);
+    atomicAdd(xb + h1 * Wi + w1, lh * lw * g);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// global spatial max-pool (nn.MaxPool2d(full map): model.py:143) + its backward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void global_maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 int* __restrict__ arg, int HW) {
+  const long bc = blockIdx.x;
+  const float* xb = x + bc * HW;
+  float best = -INFINITY; int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float v = xb[i];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+  __shared__ float sv[256]; __shared__ int si[256];
+  sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float v = sv[threadIdx.x + s]; const int i = si[threadIdx.x + s];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = i; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { y[bc] = sv[0]; arg[bc] = si[0] == 0x7fffffff ? 0 : si[0]; }
+}
+
+__global__ void global_maxpool_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ arg, float* __restrict__ dx,
+                                          int HW, long total) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long bc = e / HW;
+    const int sp = (int)(e - bc * HW);
+    dx[e] = (sp == arg[bc]) ? dy[bc] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm2d (stock semantics: eps, momentum, biased var for normalisation, unbiased for running_var)
+//   fused with the optional residual add and ReLU of the ResNet bottleneck.
+// stats[c] = {sum, sumsq} (train) or {sum g, sum g*xhat} (backward) accumulated in fp64.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_reduce2_atomic(double a, double b, double* dst) {
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
+  __shared__ double sa[4], sb[4];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sa[w] = a; sb[w] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(dst, sa[0] + sa[1] + sa[2] + sa[3]);
+    atomicAdd(dst + 1, sb[0] + sb[1] + sb[2] + sb[3]);
+  }
+}
+
+// grid (C, S): block (c, s) reduces elements e = s*256+tid, stride S*256, of channel c (e over B*HW)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int C, int HW,
+                                                       long N) {
+  const int c = blockIdx.x;
+  double s = 0.0, ss = 0.0;
+  for (long e = blockIdx.y * 256L + threadIdx.x; e < N; e += gridDim.y * 256L) {
+    const long b = e / HW; const int sp = (int)(e - b * HW);
+    const float v = x[(b * C + c) * HW + sp];
+    s += v; ss += (double)v * v;
+  }
+  block_reduce2_atomic(s, ss, stats + 2 * c);
+}
+
+// mode 0: train (batch stats from `stats`, updates running stats, saves mean/rstd); mode 1: eval (running stats)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                       float* __restrict__ y, const double* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                       float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                       int C, int HW, long N, float eps, float momentum, int relu, int mode) {
+  const int c = blockIdx.x;
+  float mean, rstd;
+  if (mode == 0) {
+    const double m = stats[2 * c] / (double)N;
+    double var = stats[2 * c + 1] / (double)N - m * m;
+    if (var < 0) var = 0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+      save_mean[c] = mean; save_rstd[c] = rstd;
+      const double unb = N > 1 ? var * (double)N / (double)(N - 1) : var;
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+  } else {
+    mean = run_mean[c];
+    rstd = 1.0f / sqrtf(run_var[c] + eps);
+  }
+  const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
+  for (long e = blockIdx.y * 256L + threadIdx.x; e < N; e += gridDim.y * 256L) {
+    const long b = e / HW; const int sp = (int)(e - b * HW);
+    const long idx = (b * C + c) * HW + sp;
+    float v = x[idx] * sc + sh;
+    if (res) v += res[idx];
+    if (relu) v = fmaxf(v, 0.f);
+    y[idx] = v;
+  }
+}
+
+// backward pass 1: stats[c] = {sum g, sum g*xhat},  g = dy * (y > 0 if relu)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, double* __restrict__ stats,
+                                                            int C, int HW, long N, int relu) {
+  const int c = blockIdx.x;
+  const float m = mean[c], r = rstd[c];
+  double s1 = 0.0, s2 = 0.0;
+  for (long e = blockIdx.y * 256L + threadIdx.x; e < N; e += gridDim.y * 256L) {
+    const long b = e / HW; const int sp = (int)(e - b * HW);
+    const long idx = (b * C + c) * HW + sp;
+    float g = dy[idx];
+    if (relu && !(y[idx] > 0.f)) g = 0.f;
+    s1 += g; s2 += (double)g * ((x[idx] - m) * r);
+  }
+  block_reduce2_atomic(s1, s2, stats + 2 * c);
+}
+
+// backward pass 2: dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)); dres = g; dgamma/dbeta from the sums
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const double* __restrict__ stats, float* __restrict__ dx,
+                                                           float* __restrict__ dres, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int C, int HW, long N, int relu) {
+  const int c = blockIdx.x;
+  const float m = mean[c], r = rstd[c];
+  const float mg = (float)(stats[2 * c] / (double)N), mgx = (float)(stats[2 * c + 1] / (double)N);
+  const float k = gamma[c] * r;
+  if (blockIdx.y == 0 && threadIdx.x == 0) { dgamma[c] = (float)stats[2 * c + 1]; dbeta[c] = (float)stats[2 * c]; }
+  for (long e = blockIdx.y * 256L + threadIdx.x; e < N; e += gridDim.y * 256L) {
+    const long b = e / HW; const int sp = (int)(e - b * HW);
+    const long idx = (b * C + c) * HW + sp;
+    float g = dy[idx];
+    if (relu && !(y[idx] > 0.f)) g = 0.f;
+    const float xh = (x[idx] - m) * r;
+    dx[idx] = k * (g - mg - xh * mgx);
+    if (dres) dres[idx] = g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(3, stride 2, pad 1) of the ResNet stem (torchvision; reference vision.py:15)
+// ------------------------------------------------------------------------------------------------
+__global__ void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ arg,
+                                        int H, int W, int Ho, int Wo, long total) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int wo = (int)(e % Wo);
+    const long t = e / Wo;
+    const int ho = (int)(t % Ho);
+    const long bc = t / Ho;
+    const float* xb = x + bc * H * W;
+    float best = -INFINITY; int bi = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int h = ho * 2 - 1 + r, w = wo * 2 - 1 + s;
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+          const float v = xb[h * W + w];
+          if (v > best || v != v) { best = v; bi = r * 3 + s; }
+        }
+      }
+    y[e] = best; arg[e] = (unsigned char)bi;
+  }
+}
+
+__global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                        float* __restrict__ dx, int H, int W, int Ho, int Wo, long total) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(e % W);
+    const long t = e / W;
+    const int h = (int)(t % H);
+    const long bc = t / H;
+    float g = 0.f;
+    const int ho_lo = h >> 1, wo_lo = w >> 1;            // windows (2*ho-1 .. 2*ho+1) containing h: ho in {h/2, (h+1)/2}
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ho = ho_lo + a;
+      const int r = h - (ho * 2 - 1);
+      if (ho >= Ho || r < 0 || r > 2) continue;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int wo = wo_lo + b;
+        const int s = w - (wo * 2 - 1);
+        if (wo >= Wo || s < 0 || s > 2) continue;
+        const long o = (bc * Ho + ho) * Wo + wo;
+        if (arg[o] == r * 3 + s) g += dy[o];
+      }
+    }
+    dx[e] = g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-channel sum over (B, HW): conv bias gradient.  hid>0: interleaved rows -> reference rows. Accumulates.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dy, float* __restrict__ db, int C, int HW,
+                                                          long N, int hid) {
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (long e = blockIdx.y * 256L + threadIdx.x; e < N; e += gridDim.y * 256L) {
+    const long b = e / HW; const int sp = (int)(e - b * HW);
+    s += dy[(b * C + c) * HW + sp];
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  __shared__ double sa[4];
+  if ((threadIdx.x & 63) == 0) sa[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int row = hid > 0 ? (c & 3) * hid + (c >> 2) : c;
+    atomicAdd(db + row, (float)(sa[0] + sa[1] + sa[2] + sa[3]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// flat fused Adam (torch.optim.Adam semantics incl. L2 weight decay: reference utils/utils.py:83-84)
+// ------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    float gv = g[e] * gscale + wd * p[e];
+    const float mv = b1 * m[e] + (1.f - b1) * gv;
+    const float vv = b2 * v[e] + (1.f - b2) * gv * gv;
+    m[e] = mv; v[e] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[e] -= (lr / bc1) * (mv / denom);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (called from api.hip)
+// ------------------------------------------------------------------------------------------------
+static inline int ew_grid(long total) {
+  long g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+static inline int chan_splits(int C, long N) {
+  long s = (2048 + C - 1) / C;
+  const long maxs = (N + 1023) / 1024;
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+int rsis_l_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int nseg, const int* Cseg, int ldw, int krows,
+                    int hid, hipStream_t st) {
+  const long total = (long)krows * ldw;
+  hipLaunchKernelGGL(pack_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, W, Wp, Cout, Ctot, ks * ks, nseg, Cseg[0],
+                     nseg > 1 ? Cseg[1] : 0, nseg > 2 ? Cseg[2] : 0, ldw, krows, hid);
+  return rsis_check_launch();
+}
+int rsis_l_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int c_lo, int c_hi, int ldw, int krows, int hid,
+                      hipStream_t st) {
+  const long total = (long)krows * ldw;
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, st, W, Wd, Cout, Ctot, ks * ks, c_lo, c_hi, ldw,
+                     krows, hid);
+  return rsis_check_launch();
+}
+int rsis_l_lstm_bwd(const float* dh, const float* dc_next, const float* act, const float* c_prev, const float* c, float* da,
+                    float* dc_prev, float* da_sum, int B, int hid, int HW, hipStream_t st) {
+  const long total = (long)B * hid * HW;
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dh, dc_next, act, c_prev, c, da, dc_prev, da_sum,
+                     hid, HW, total);
+  return rsis_check_launch();
+}
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+int rsis_l_upsample_fwd(const float* x, float* y, long BC, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
+  const long total = BC * Ho * Wo;
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, Hi, Wi, Ho, Wo, ac_scale(Hi, Ho),
+                     ac_scale(Wi, Wo), total);
+  return rsis_check_launch();
+}
+int rsis_l_upsample_bwd(const float* dy, float* dx, long BC, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
+  if (hipMemsetAsync(dx, 0, sizeof(float) * BC * Hi * Wi, st) != hipSuccess) return RSIS_ERR_LAUNCH;
+  const long total = BC * Ho * Wo;
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, ac_scale(Hi, Ho),
+                     ac_scale(Wi, Wo), total);
+  return rsis_check_launch();
+}
+int rsis_l_gmax_fwd(const float* x, float* y, int* arg, long BC, int HW, hipStream_t st) {
+  hipLaunchKernelGGL(global_maxpool_fwd_kernel, dim3((unsigned)BC), dim3(256), 0, st, x, y, arg, HW);
+  return rsis_check_launch();
+}
+int rsis_l_gmax_bwd(const float* dy, const int* arg, float* dx, long BC, int HW, hipStream_t st) {
+  const long total = BC * HW;
+  hipLaunchKernelGGL(global_maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, arg, dx, HW, total);
+  return rsis_check_launch();
+}
+int rsis_l_bn_fwd(const float* x, const float* res, float* y, double* stats, const float* gamma, const float* beta,
+                  float* run_mean, float* run_var, float* save_mean, float* save_rstd, int B, int C, int HW, float eps,
+                  float momentum, int relu, int train, hipStream_t st) {
+  const long N = (long)B * HW;
+  const int S = chan_splits(C, N);
+  if (train) {
+    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, st) != hipSuccess) return RSIS_ERR_LAUNCH;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, S), dim3(256), 0, st, x, stats, C, HW, N);
+  }
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(C, S), dim3(256), 0, st, x, res, y, stats, gamma, beta, run_mean, run_var, save_mean,
+                     save_rstd, C, HW, N, eps, momentum, relu, train ? 0 : 1);
+  return rsis_check_launch();
+}
+int rsis_l_bn_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, const float* gamma,
+                  double* stats, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C, int HW, int relu,
+                  hipStream_t st) {
+  const long N = (long)B * HW;
+  const int S = chan_splits(C, N);
+  if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, st) != hipSuccess) return RSIS_ERR_LAUNCH;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, mean, rstd, stats, C, HW, N, relu);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, mean, rstd, gamma, stats, dx, dres, dgamma,
+                     dbeta, C, HW, N, relu);
+  return rsis_check_launch();
+}
+int rsis_l_maxpool_fwd(const float* x, float* y, unsigned char* arg, long BC, int H, int W, int Ho, int Wo, hipStream_t st) {
+  const long total = BC * Ho * Wo;
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, arg, H, W, Ho, Wo, total);
+  return rsis_check_launch();
+}
+int rsis_l_maxpool_bwd(const float* dy, const unsigned char* arg, float* dx, long BC, int H, int W, int Ho, int Wo,
+                       hipStream_t st) {
+  const long total = BC * H * W;
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, arg, dx, H, W, Ho, Wo, total);
+  return rsis_check_launch();
+}
+int rsis_l_channel_sum(const float* dy, float* db, int B, int C, int HW, int hid, hipStream_t st) {
+  const long N = (long)B * HW;
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, chan_splits(C, N)), dim3(256), 0, st, dy, db, C, HW, N, hid);
+  return rsis_check_launch();
+}
+int rsis_l_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
+                int step, float gscale, hipStream_t st) {
+  const float bc1 = 1.f - powf(b1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(b2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, gscale);
+  return rsis_check_launch();
+}

@@ -1,0 +1,129 @@
+"""FeatureExtractor + RSIS decoder -- drop-in for reference src/modules/model.py on MI355X.
+
+Same class names, constructor argument (`args` namespace), forward signatures / return values, child-module names
+and state_dict keys; every conv / BN / ConvLSTM / upsample / max-pool runs in librsis_hip.so.
+Differences that are deliberate: no network download in the constructor (weights come from
+load_state_dict or random init), python-3 integer division for the channel pyramid, no modules constructed inside
+forward.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from ..utils.utils import get_skip_dims
+from .clstm import ConvLSTMCell
+from .vision import HipBatchNorm2d, HipConv2d, ResNet101
+
+
+class FeatureExtractor(nn.Module):
+    """Returns base network to extract visual features from image (reference model.py:15-70)."""
+
+    def __init__(self, args):
+        super().__init__()
+        skip_dims_in = get_skip_dims(args.base_model)
+        if args.base_model == "resnet101":
+            self.base = ResNet101()   # model.py:29-31; pretrained weights are loaded by the caller (no download here)
+        else:
+            raise Exception("The base model you chose is not supported !")   # model.py:37 (resnet34/50/vgg16 out of scope)
+        self.hidden_size = int(args.hidden_size)
+        self.kernel_size = int(args.kernel_size)
+        self.padding = 0 if self.kernel_size == 1 else 1
+        hs, k, p = self.hidden_size, self.kernel_size, self.padding
+        self.sk5 = HipConv2d(skip_dims_in[0], hs, k, padding=p)        # model.py:43-47
+        self.sk4 = HipConv2d(skip_dims_in[1], hs, k, padding=p)
+        self.sk3 = HipConv2d(skip_dims_in[2], hs // 2, k, padding=p)
+        self.sk2 = HipConv2d(skip_dims_in[3], hs // 4, k, padding=p)
+        self.sk1 = HipConv2d(skip_dims_in[4], hs // 8, k, padding=p)
+        self.bn5 = HipBatchNorm2d(hs)                                   # model.py:50-54
+        self.bn4 = HipBatchNorm2d(hs)
+        self.bn3 = HipBatchNorm2d(hs // 2)
+        self.bn2 = HipBatchNorm2d(hs // 4)
+        self.bn1 = HipBatchNorm2d(hs // 8)
+
+    def forward(self, x, semseg=False, raw=False):
+        x5, x4, x3, x2, x1 = self.base(x)            # model.py:57
+        if semseg:
+            return x5
+        if raw:
+            return x5, x4, x3, x2, x1
+        x5_skip = self.bn5(self.sk5(x5))             # model.py:59-63 (BN, no ReLU)
+        x4_skip = self.bn4(self.sk4(x4))
+        x3_skip = self.bn3(self.sk3(x3))
+        x2_skip = self.bn2(self.sk2(x2))
+        x1_skip = self.bn1(self.sk1(x1))
+        return x5_skip, x4_skip, x3_skip, x2_skip, x1_skip
+
+
+class RSIS(nn.Module):
+    """The recurrent decoder (reference model.py:72-184)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.hidden_size = int(args.hidden_size)
+        self.num_classes = args.num_classes
+        self.kernel_size = int(args.kernel_size)
+        padding = 0 if self.kernel_size == 1 else 1
+        self.padding = padding
+        self.dropout = args.dropout
+        self.dropout_stop = args.dropout_stop
+        self.dropout_cls = args.dropout_cls
+        self.skip_mode = args.skip_mode
+        hs = self.hidden_size
+        skip_dims_out = [hs, hs // 2, hs // 4, hs // 8, hs // 16]       # model.py:91-93
+        self.clstm_list = nn.ModuleList()
+        for i in range(len(skip_dims_out)):                              # model.py:98-106
+            if i == 0:
+                clstm_in_dim = hs
+            else:
+                clstm_in_dim = skip_dims_out[i - 1]
+                if self.skip_mode == "concat":
+                    clstm_in_dim *= 2
+            self.clstm_list.append(ConvLSTMCell(args, clstm_in_dim, skip_dims_out[i], self.kernel_size, padding=padding))
+        self.conv_out = HipConv2d(skip_dims_out[-1], 1, self.kernel_size, padding=padding)   # model.py:109
+        fc_dim = sum(skip_dims_out)                                      # model.py:115-117
+        self.fc_class = nn.Linear(fc_dim, self.num_classes)              # model.py:119
+        self.fc_stop = nn.Linear(fc_dim, 1)                              # model.py:120
+
+    def forward(self, skip_feats, prev_hidden_list):
+        clstm_in = [skip_feats[0]]                                       # model.py:124
+        skip_feats = skip_feats[1:]
+        side_feats = []
+        hidden_list = []
+        for i in range(len(skip_feats) + 1):                             # model.py:129
+            state = self.clstm_list[i].forward_multi(clstm_in, None if prev_hidden_list is None else prev_hidden_list[i])
+            hidden_list.append(state)                                    # model.py:137 (pre-dropout state recurs)
+            hidden = state[0]
+            if self.dropout > 0:
+                hidden = nn.functional.dropout2d(hidden, self.dropout, training=True)   # model.py:141
+            side_feats.append(ops.global_maxpool(hidden))                # model.py:143
+            if i < len(skip_feats):
+                skip_vec = skip_feats[i]
+                hidden = ops.upsample_bilinear_ac(hidden, skip_vec.shape[-2:])          # model.py:149-150
+                if self.skip_mode == "concat":
+                    clstm_in = [hidden, skip_vec]                        # model.py:153 (concat by pointer)
+                elif self.skip_mode == "sum":
+                    clstm_in = [hidden + skip_vec]
+                elif self.skip_mode == "mul":
+                    clstm_in = [hidden * skip_vec]
+                elif self.skip_mode == "none":
+                    clstm_in = [hidden]
+                else:
+                    raise Exception("Skip connection mode not supported !")
+            else:
+                hidden = ops.upsample_bilinear_ac(hidden, (hidden.shape[-2] * 2, hidden.shape[-1] * 2))   # model.py:163-164
+                clstm_in = [hidden]
+        out_mask = self.conv_out(clstm_in[0])                            # model.py:167
+        side_feats = torch.cat(side_feats, 1).squeeze()                  # model.py:169 (drops the batch dim at B == 1)
+        if self.dropout_cls > 0:
+            class_feats = nn.functional.dropout(side_feats, self.dropout_cls, training=True)
+        else:
+            class_feats = side_feats
+        class_feats = self.fc_class(class_feats)                         # model.py:174
+        if self.dropout_stop > 0:
+            stop_feats = nn.functional.dropout(side_feats, self.dropout_stop, training=True)
+        else:
+            stop_feats = side_feats
+        stop_probs = self.fc_stop(stop_feats)                            # model.py:179 (a logit)
+        # model.py:182: implicit-dim nn.Softmax() -> dim 1 for 2-D input (dim 0 for the 1-D B == 1 quirk)
+        class_probs = torch.softmax(class_feats, dim=1 if class_feats.dim() == 2 else 0)
+        return out_mask, class_probs, stop_probs, hidden_list            # model.py:184

@@ -1,0 +1,118 @@
+"""ResNet-101 feature pyramid -- drop-in for reference src/modules/vision.py:6-21 on MI355X.
+
+The reference subclasses torchvision's ResNet(Bottleneck, [3,4,23,3]) (un-vendored third party); this module owns the
+same module tree / state_dict keys (conv1, bn1, layer1..4.{j}.{conv1,bn1,conv2,bn2,conv3,bn3,downsample.{0,1}}, fc)
+and runs every conv / BN / ReLU / residual add / max-pool in librsis_hip.so.  Stride sits on the 3x3 conv
+(torchvision), max-pool is 3x3/2 pad 1.  `avgpool`/`fc` are never called by the reference (vision.py:11-21); `fc` is
+kept only for checkpoint-key compatibility.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import ops
+
+
+class HipConv2d(nn.Module):
+    """nn.Conv2d parameters (reference layout) + the gfx950 implicit-GEMM forward/backward."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = int(cin), int(cout)
+        self.kernel_size, self.stride, self.padding = int(kernel_size), int(stride), int(padding)
+        self.weight = nn.Parameter(torch.empty(self.out_channels, self.in_channels, self.kernel_size, self.kernel_size))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(self.out_channels))
+            bound = 1.0 / math.sqrt(self.in_channels * self.kernel_size ** 2)
+            nn.init.uniform_(self.bias, -bound, bound)
+        else:
+            self.register_parameter("bias", None)
+        self._pack = ops.PackedConv(self.kernel_size, [self.in_channels])
+
+    def forward(self, x):
+        return ops.conv2d([x], self.weight, self.bias, self.stride, self.padding, self._pack)
+
+
+class HipBatchNorm2d(nn.Module):
+    """nn.BatchNorm2d state (weight, bias, running_mean, running_var, num_batches_tracked) + fused HIP kernels.
+    forward(x, res=None, relu=False) computes act(bn(x) + res)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = int(num_features), eps, momentum
+        self.weight = nn.Parameter(torch.ones(self.num_features))
+        self.bias = nn.Parameter(torch.zeros(self.num_features))
+        self.register_buffer("running_mean", torch.zeros(self.num_features))
+        self.register_buffer("running_var", torch.ones(self.num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        # torch-0.2 era checkpoints (the reference's) have no num_batches_tracked
+        key = prefix + "num_batches_tracked"
+        if key not in state_dict:
+            state_dict[key] = torch.tensor(0, dtype=torch.long)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
+    def forward(self, x, res=None, relu=False):
+        if self.training:
+            self.num_batches_tracked += 1
+        return ops.batchnorm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu=relu, res=res,
+                             eps=self.eps, momentum=self.momentum)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = HipConv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = HipBatchNorm2d(planes)
+        self.conv2 = HipConv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = HipBatchNorm2d(planes)
+        self.conv3 = HipConv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = HipBatchNorm2d(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        residual = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
+        return self.bn3(self.conv3(out), res=residual, relu=True)
+
+
+class ResNet101(nn.Module):
+    """Returns intermediate features (x5,x4,x3,x2,x1) -- reference vision.py:11-21."""
+
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = HipConv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = HipBatchNorm2d(64)
+        self.layer1 = self._make_layer(64, 3)
+        self.layer2 = self._make_layer(128, 4, stride=2)
+        self.layer3 = self._make_layer(256, 23, stride=2)
+        self.layer4 = self._make_layer(512, 3, stride=2)
+        self.fc = nn.Linear(2048, 1000)  # present in reference checkpoints, never used in forward (vision.py:11-21)
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(HipConv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
+                                       HipBatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x1 = self.bn1(self.conv1(x), relu=True)   # vision.py:12-14 (x1 is the post-ReLU stem)
+        x = ops.maxpool3x3s2(x1)                  # :15
+        x2 = self.layer1(x)
+        x3 = self.layer2(x2)
+        x4 = self.layer3(x3)
+        x5 = self.layer4(x4)
+        return x5, x4, x3, x2, x1

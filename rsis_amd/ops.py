@@ -1,0 +1,374 @@
+"""torch.autograd.Function wrappers over the C ABI of librsis_hip.so (include/rsis_hip.h).
+
+PyTorch is plumbing here (device memory, streams, the autograd tape); every arithmetic op of the hot path runs in
+the hand-written gfx950 kernels.  There is no CPU/eager fallback: the ops raise if the library is missing or a
+tensor is not a CUDA fp32 tensor.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, int_array, lib, ptr, ptr_array, require_cuda_f32, stream
+
+# Bumped whenever parameters are modified behind autograd's back (the flat HIP Adam step, load_state_dict):
+# invalidates every packed-weight cache.
+_WEIGHT_EPOCH = [0]
+
+
+# Test hook: force the MFMA tile configuration of the implicit-GEMM kernels (0 = library heuristic).
+FORCE_TILE = [0]
+
+
+def bump_weight_epoch():
+    _WEIGHT_EPOCH[0] += 1
+
+
+class PackedConv(object):
+    """Private MFMA-friendly copies of one nn.Conv2d weight (never serialised; rebuilt when the weight changes).
+
+    segs: channel counts of the tensors whose concat forms the conv input (torch.cat folded into the kernel).
+    lstm_hid > 0: ConvLSTM `Gates` conv -- rows [i|f|o|g] are interleaved to 4*j+gate (clstm.py:47).
+    """
+
+    def __init__(self, ks, segs, lstm_hid=0):
+        self.ks = int(ks)
+        self.segs = [int(s) for s in segs]
+        self.lstm_hid = int(lstm_hid)
+        self._key_f = None
+        self._key_d = None
+        self.wp = None
+        self.wd = None
+        self.bias_p = None
+
+    def _key(self, w):
+        return (_WEIGHT_EPOCH[0], w._version, w.data_ptr())
+
+    def fwd(self, w, bias=None):
+        key = self._key(w) + ((bias._version, bias.data_ptr()) if bias is not None else ())
+        if self._key_f != key:
+            L = lib()
+            Cout, Ctot = w.shape[0], w.shape[1]
+            segs = int_array(self.segs)
+            n = L.rsis_conv_packed_floats_fwd(Cout, self.ks, len(self.segs), segs)
+            if self.wp is None or self.wp.numel() != n:
+                self.wp = torch.empty(n, dtype=torch.float32, device=w.device)
+            wd = w.detach()
+            check(L.rsis_conv_pack_fwd(ptr(wd), ptr(self.wp), Cout, Ctot, self.ks, len(self.segs), segs, self.lstm_hid,
+                                       stream()), "rsis_conv_pack_fwd")
+            if bias is not None and self.lstm_hid > 0:
+                self.bias_p = bias.detach().view(4, self.lstm_hid).t().contiguous().view(-1)
+            self._key_f = key
+        return self.wp
+
+    def dgrad(self, w):
+        key = self._key(w)
+        if self._key_d != key:
+            L = lib()
+            Cout, Ctot = w.shape[0], w.shape[1]
+            n = L.rsis_conv_packed_floats_dgrad(Cout, self.ks, Ctot)
+            if self.wd is None or self.wd.numel() != n:
+                self.wd = torch.empty(n, dtype=torch.float32, device=w.device)
+            check(L.rsis_conv_pack_dgrad(ptr(w.detach()), ptr(self.wd), Cout, Ctot, self.ks, 0, Ctot, self.lstm_hid, stream()),
+                  "rsis_conv_pack_dgrad")
+            self._key_d = key
+        return self.wd
+
+
+def _contig(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _conv_out_size(n, ks, stride, pad):
+    return (n + 2 * pad - ks) // stride + 1
+
+
+def _dgrad_all(L, dy, wd, cin_packed, ks, stride, pad, srcs, Hx, Wx):
+    """One dgrad launch producing the gradient of every concat source."""
+    B, Cout, Hy, Wy = dy.shape
+    dxs = [torch.empty_like(s) for s in srcs]
+    check(L.rsis_conv2d_dgrad(ptr(dy), B, Cout, Hy, Wy, ptr(wd), cin_packed, ks, stride, pad, ptr_array(dxs),
+                              int_array([s.shape[1] for s in srcs]), len(srcs), Hx, Wx, FORCE_TILE[0], stream()), "rsis_conv2d_dgrad")
+    return dxs
+
+
+def _wgrad_all(L, dy, srcs, w_shape, ks, stride, pad, lstm_hid):
+    B, Cout, Ho, Wo = dy.shape
+    Ctot = w_shape[1]
+    dW = torch.zeros(w_shape, dtype=torch.float32, device=dy.device)
+    c_off = 0
+    for s in srcs:
+        _, Cs, H, W = s.shape
+        check(L.rsis_conv2d_wgrad(ptr(dy), ptr(s), ptr(dW), B, Cs, H, W, Cout, Ho, Wo, ks, stride, pad, Ctot, c_off, lstm_hid,
+                                  stream()), "rsis_conv2d_wgrad")
+        c_off += Cs
+    return dW
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pack, stride, pad, nsrc, *tensors):
+        srcs = [_contig(t) for t in tensors[:nsrc]]
+        weight, bias = tensors[nsrc], tensors[nsrc + 1]
+        require_cuda_f32(weight, bias, *srcs)
+        L = lib()
+        B, _, H, W = srcs[0].shape
+        Cout, ks = weight.shape[0], weight.shape[2]
+        Ho, Wo = _conv_out_size(H, ks, stride, pad), _conv_out_size(W, ks, stride, pad)
+        wp = pack.fwd(weight)
+        out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=weight.device)
+        check(L.rsis_conv2d_fwd(ptr_array(srcs), int_array([s.shape[1] for s in srcs]), nsrc, B, H, W, ptr(wp), Cout, ks, stride,
+                                pad, ptr(bias.detach() if bias is not None else None), None, ptr(out), Ho, Wo, FORCE_TILE[0], stream()),
+              "rsis_conv2d_fwd")
+        ctx.pack, ctx.stride, ctx.pad, ctx.nsrc = pack, stride, pad, nsrc
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(weight, *srcs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight = ctx.saved_tensors[0]
+        srcs = list(ctx.saved_tensors[1:])
+        dy = _contig(dy)
+        L = lib()
+        ks = weight.shape[2]
+        nsrc = ctx.nsrc
+        grads = [None] * (nsrc + 2)
+        if any(ctx.needs_input_grad[4:4 + nsrc]):
+            wd = ctx.pack.dgrad(weight)
+            dxs = _dgrad_all(L, dy, wd, weight.shape[1], ks, ctx.stride, ctx.pad, srcs, srcs[0].shape[2], srcs[0].shape[3])
+            for i in range(nsrc):
+                if ctx.needs_input_grad[4 + i]:
+                    grads[i] = dxs[i]
+        if ctx.needs_input_grad[4 + nsrc]:
+            grads[nsrc] = _wgrad_all(L, dy, srcs, tuple(weight.shape), ks, ctx.stride, ctx.pad, 0)
+        if ctx.has_bias and ctx.needs_input_grad[5 + nsrc]:
+            db = torch.zeros(weight.shape[0], dtype=torch.float32, device=dy.device)
+            check(L.rsis_bias_grad(ptr(dy), ptr(db), dy.shape[0], dy.shape[1], dy.shape[2] * dy.shape[3], 0, stream()),
+                  "rsis_bias_grad")
+            grads[nsrc + 1] = db
+        return (None, None, None, None) + tuple(grads)
+
+
+def conv2d(srcs, weight, bias, stride, pad, pack):
+    """nn.Conv2d over the channel concat of `srcs` (list of NCHW tensors)."""
+    return _Conv2dFn.apply(pack, int(stride), int(pad), len(srcs), *srcs, weight, bias)
+
+
+class _ConvLSTMFn(torch.autograd.Function):
+    """ConvLSTMCell.forward (reference clstm.py:19-62) as one fused kernel; returns (h, c)."""
+
+    @staticmethod
+    def forward(ctx, pack, pad, nx, has_state, *tensors):
+        xs = [_contig(t) for t in tensors[:nx]]
+        h_prev, c_prev, weight, bias = tensors[nx], tensors[nx + 1], tensors[nx + 2], tensors[nx + 3]
+        require_cuda_f32(weight, bias, h_prev, c_prev, *xs)
+        L = lib()
+        B, _, H, W = xs[0].shape
+        hid, ks = weight.shape[0] // 4, weight.shape[2]
+        srcs = list(xs)
+        if has_state:
+            h_prev, c_prev = _contig(h_prev), _contig(c_prev)
+            srcs.append(h_prev)
+        wp = pack.fwd(weight, bias)
+        need_grad = any(ctx.needs_input_grad)  # (grad mode is off inside Function.forward)
+        h = torch.empty((B, hid, H, W), dtype=torch.float32, device=weight.device)
+        c = torch.empty_like(h)
+        act = torch.empty((B, 4 * hid, H, W), dtype=torch.float32, device=weight.device) if need_grad else None
+        # zero state (clstm.py:26-37): the h_prev segment is the LAST segment of the packed K axis, so it is skipped
+        # simply by passing the x sources only (the kernel walks the K-tiles of the sources it is given).
+        segs = [s.shape[1] for s in srcs]
+        check(L.rsis_convlstm_fwd(ptr_array(srcs), int_array(segs), len(srcs), B, H, W, ptr(wp), ptr(pack.bias_p), None,
+                                  ptr(c_prev) if has_state else None, ptr(h), ptr(c), ptr(act), hid, ks, pad, FORCE_TILE[0], stream()),
+              "rsis_convlstm_fwd")
+        ctx.pack, ctx.pad, ctx.nx, ctx.has_state = pack, pad, nx, has_state
+        if need_grad:
+            ctx.save_for_backward(weight, act, c, c_prev if has_state else None, *srcs)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        weight, act, c, c_prev = ctx.saved_tensors[:4]
+        srcs = list(ctx.saved_tensors[4:])
+        L = lib()
+        nx, has_state = ctx.nx, ctx.has_state
+        B, hid, H, W = c.shape
+        ks = weight.shape[2]
+        dh = _contig(dh) if dh is not None else None
+        dc = _contig(dc) if dc is not None else None
+        da = torch.empty_like(act)
+        dc_prev = torch.empty_like(c) if has_state else None
+        check(L.rsis_convlstm_bwd_gates(ptr(dh), ptr(dc), ptr(act), ptr(c_prev), ptr(c), ptr(da), ptr(dc_prev), None, B, hid, H * W,
+                                        stream()), "rsis_convlstm_bwd_gates")
+        grads = [None] * (nx + 4)
+        need_src = list(ctx.needs_input_grad[4:4 + nx]) + ([ctx.needs_input_grad[4 + nx]] if has_state else [])
+        if any(need_src):
+            wd = ctx.pack.dgrad(weight)
+            dxs = _dgrad_all(L, da, wd, weight.shape[1], ks, 1, ctx.pad, srcs, H, W)
+            for i in range(nx):
+                if need_src[i]:
+                    grads[i] = dxs[i]
+            if has_state and need_src[nx]:
+                grads[nx] = dxs[nx]
+        if has_state:
+            grads[nx + 1] = dc_prev
+        if ctx.needs_input_grad[4 + nx + 2]:
+            # zero state: the h_prev channels of dW get no contribution (h_prev == 0)
+            grads[nx + 2] = _wgrad_all(L, da, srcs, tuple(weight.shape), ks, 1, ctx.pad, hid)
+        if ctx.needs_input_grad[4 + nx + 3]:
+            db = torch.zeros(4 * hid, dtype=torch.float32, device=da.device)
+            check(L.rsis_bias_grad(ptr(da), ptr(db), B, 4 * hid, H * W, hid, stream()), "rsis_bias_grad")
+            grads[nx + 3] = db
+        return (None, None, None, None) + tuple(grads)
+
+
+def convlstm(xs, state, weight, bias, pad, pack):
+    """xs: list of NCHW tensors whose channel concat is the cell input; state: None or (h, c)."""
+    has_state = state is not None
+    h_prev, c_prev = (state[0], state[1]) if has_state else (None, None)
+    return _ConvLSTMFn.apply(pack, int(pad), len(xs), has_state, *xs, h_prev, c_prev, weight, bias)
+
+
+class _UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        x = _contig(x)
+        require_cuda_f32(x)
+        B, C, Hi, Wi = x.shape
+        y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        check(lib().rsis_upsample_bilinear_ac_fwd(ptr(x), ptr(y), B * C, Hi, Wi, Ho, Wo, stream()), "rsis_upsample_fwd")
+        ctx.dims = (B, C, Hi, Wi, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, Hi, Wi, Ho, Wo = ctx.dims
+        dy = _contig(dy)
+        dx = torch.empty((B, C, Hi, Wi), dtype=torch.float32, device=dy.device)
+        check(lib().rsis_upsample_bilinear_ac_bwd(ptr(dy), ptr(dx), B * C, Hi, Wi, Ho, Wo, stream()), "rsis_upsample_bwd")
+        return dx, None, None
+
+
+def upsample_bilinear_ac(x, size):
+    """nn.UpsamplingBilinear2d(size=size) (align_corners=True)."""
+    Ho, Wo = int(size[0]), int(size[1])
+    if x.shape[2] == Ho and x.shape[3] == Wo:
+        return x  # align_corners resize to the same size is the identity
+    return _UpsampleFn.apply(x, Ho, Wo)
+
+
+class _GlobalMaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(x)
+        require_cuda_f32(x)
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, 1, 1), dtype=torch.float32, device=x.device)
+        arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
+        check(lib().rsis_global_maxpool_fwd(ptr(x), ptr(y), ptr(arg), B * C, H * W, stream()), "rsis_global_maxpool_fwd")
+        ctx.save_for_backward(arg)
+        ctx.dims = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        B, C, H, W = ctx.dims
+        dy = _contig(dy)
+        dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dy.device)
+        check(lib().rsis_global_maxpool_bwd(ptr(dy), ptr(arg), ptr(dx), B * C, H * W, stream()), "rsis_global_maxpool_bwd")
+        return dx
+
+
+def global_maxpool(x):
+    """nn.MaxPool2d(kernel = full map) -> (B, C, 1, 1)."""
+    return _GlobalMaxPoolFn.apply(x)
+
+
+class _BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, train, relu, eps, momentum):
+        x = _contig(x)
+        res = _contig(res) if res is not None else None
+        require_cuda_f32(x, res, gamma, beta, running_mean, running_var)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        if train:
+            stats = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            rstd = torch.empty_like(mean)
+        else:
+            stats = mean = rstd = None
+        check(lib().rsis_bn_fwd(ptr(x), ptr(res), ptr(y), ptr(stats), ptr(gamma.detach()), ptr(beta.detach()), ptr(running_mean),
+                                ptr(running_var), ptr(mean), ptr(rstd), B, C, H * W, float(eps), float(momentum), int(relu),
+                                int(train), stream()), "rsis_bn_fwd")
+        ctx.train, ctx.relu, ctx.has_res, ctx.eps = train, relu, res is not None, eps
+        if train:
+            ctx.save_for_backward(x, y if relu else None, gamma, mean, rstd)
+        else:
+            ctx.save_for_backward(x, y if relu else None, gamma, running_mean, running_var)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, rstd = ctx.saved_tensors
+        dy = _contig(dy)
+        B, C, H, W = x.shape
+        if not ctx.train:
+            # eval-mode BN is an affine map: dx = g * gamma / sqrt(running_var + eps)
+            g = dy * (y > 0).to(dy.dtype) if ctx.relu else dy
+            scale = gamma.detach() / torch.sqrt(rstd + ctx.eps)  # here `rstd` holds running_var
+            dx = g * scale.view(1, C, 1, 1)
+            xh = (x - mean.view(1, C, 1, 1)) / torch.sqrt(rstd + ctx.eps).view(1, C, 1, 1)
+            return dx, (g if ctx.has_res else None), (g * xh).sum((0, 2, 3)), g.sum((0, 2, 3)), None, None, None, None, None, None
+        stats = torch.empty(2 * C, dtype=torch.float64, device=dy.device)
+        dx = torch.empty_like(x)
+        need_dres = ctx.has_res and ctx.relu
+        dres = torch.empty_like(x) if need_dres else None
+        dgamma = torch.empty(C, dtype=torch.float32, device=dy.device)
+        dbeta = torch.empty_like(dgamma)
+        check(lib().rsis_bn_bwd(ptr(dy), ptr(x), ptr(y), ptr(mean), ptr(rstd), ptr(gamma.detach()), ptr(stats), ptr(dx), ptr(dres),
+                                ptr(dgamma), ptr(dbeta), B, C, H * W, int(ctx.relu), stream()), "rsis_bn_bwd")
+        if ctx.has_res and not need_dres:
+            dres = dy
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batchnorm(x, gamma, beta, running_mean, running_var, train, relu=False, res=None, eps=1e-5, momentum=0.1):
+    """nn.BatchNorm2d (+ residual add) (+ ReLU): y = act(bn(x) + res)."""
+    return _BatchNormFn.apply(x, res, gamma, beta, running_mean, running_var, bool(train), bool(relu), eps, momentum)
+
+
+class _MaxPool3x3s2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(x)
+        require_cuda_f32(x)
+        B, C, H, W = x.shape
+        Ho, Wo = _conv_out_size(H, 3, 2, 1), _conv_out_size(W, 3, 2, 1)
+        y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        arg = torch.empty((B, C, Ho, Wo), dtype=torch.uint8, device=x.device)
+        check(lib().rsis_maxpool3x3s2_fwd(ptr(x), ptr(y), ptr(arg), B * C, H, W, Ho, Wo, stream()), "rsis_maxpool3x3s2_fwd")
+        ctx.save_for_backward(arg)
+        ctx.dims = (B, C, H, W, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        B, C, H, W, Ho, Wo = ctx.dims
+        dy = _contig(dy)
+        dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dy.device)
+        check(lib().rsis_maxpool3x3s2_bwd(ptr(dy), ptr(arg), ptr(dx), B * C, H, W, Ho, Wo, stream()), "rsis_maxpool3x3s2_bwd")
+        return dx
+
+
+def maxpool3x3s2(x):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1)."""
+    return _MaxPool3x3s2Fn.apply(x)
+
+
+def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gscale=1.0):
+    """torch.optim.Adam step on flat fp32 buffers (in place; bumps the packed-weight epoch)."""
+    require_cuda_f32(p, g, m, v)
+    check(lib().rsis_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                               float(weight_decay), int(step), float(gscale), stream()), "rsis_adam_step")
+    bump_weight_epoch()

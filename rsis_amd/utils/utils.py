@@ -1,0 +1,122 @@
+"""Host-side glue mirroring reference src/utils/utils.py (names, argument meaning and behaviour)."""
+import os
+import pickle
+from collections import OrderedDict
+
+import torch
+
+
+def make_dir(dir):
+    if not os.path.exists(dir):
+        os.mkdir(dir)
+
+
+def get_skip_dims(model_name):
+    """reference utils/utils.py:129-137"""
+    if model_name == "resnet50" or model_name == "resnet101":
+        return [2048, 1024, 512, 256, 64]
+    elif model_name == "resnet34":
+        return [512, 256, 128, 64, 64]
+    elif model_name == "vgg16":
+        return [512, 512, 256, 128, 64]
+    raise Exception("The base model you chose is not supported !")
+
+
+def check_parallel(encoder_dict, decoder_dict):
+    """reference utils/utils.py:12-32: strip the `module.` prefix of DataParallel-trained checkpoints (the reference
+    inspects only the first encoder key)."""
+    trained_parallel = False
+    for k, _v in encoder_dict.items():
+        if k[:7] == "module.":
+            trained_parallel = True
+        break
+    if trained_parallel:
+        encoder_dict = OrderedDict((k[7:], v) for k, v in encoder_dict.items())
+        decoder_dict = OrderedDict((k[7:], v) for k, v in decoder_dict.items())
+    return encoder_dict, decoder_dict
+
+
+def get_base_params(args, model):
+    """reference utils/utils.py:34-52.  The reference walks b[i].modules() and yields j.parameters() for EVERY nested
+    module, so tensors are yielded 1-4 times; here each trunk tensor is yielded once --
+    use `base_param_multiplicity` to reproduce the reference's effective 1x/3x/4x encoder learning rate."""
+    seen = set()
+    for m in (model.base.conv1, model.base.bn1, model.base.layer1, model.base.layer2, model.base.layer3, model.base.layer4):
+        for p in m.parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                yield p
+
+
+def base_param_multiplicity(model):
+    """How many times the reference's get_base_params generator yields each trunk tensor (stem x1, bottleneck
+    conv/bn params x3, downsample params x4): {param: count}."""
+    counts = {}
+    for top in (model.base.conv1, model.base.bn1, model.base.layer1, model.base.layer2, model.base.layer3, model.base.layer4):
+        for j in top.modules():
+            for k in j.parameters():
+                counts[k] = counts.get(k, 0) + 1
+    return counts
+
+
+def get_skip_params(model):
+    """reference utils/utils.py:54-71"""
+    for m in (model.sk1, model.sk2, model.sk3, model.sk4, model.sk5, model.bn1, model.bn2, model.bn3, model.bn4, model.bn5):
+        for p in m.parameters():
+            yield p
+
+
+def merge_params(params):
+    for j in range(len(params)):
+        for i in params[j]:
+            yield i
+
+
+def get_optimizer(optim_name, lr, parameters, weight_decay=0, momentum=0.9):
+    """reference utils/utils.py:78-87 (stock torch optimizers; the fused flat HIP Adam lives in rsis_amd.optim)."""
+    params = [p for p in parameters if p.requires_grad]
+    if optim_name == "sgd":
+        return torch.optim.SGD(params, lr=lr, weight_decay=weight_decay, momentum=momentum)
+    elif optim_name == "adam":
+        return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)
+    elif optim_name == "rmsprop":
+        return torch.optim.RMSprop(params, lr=lr, weight_decay=weight_decay)
+    raise Exception("unknown optimizer %s" % optim_name)
+
+
+def save_checkpoint(args, encoder, decoder, enc_opt, dec_opt, root="../models"):
+    """reference utils/utils.py:89-95 (same five files)."""
+    d = os.path.join(root, args.model_name)
+    os.makedirs(d, exist_ok=True)
+    torch.save(encoder.state_dict(), os.path.join(d, "encoder.pt"))
+    torch.save(decoder.state_dict(), os.path.join(d, "decoder.pt"))
+    torch.save(enc_opt.state_dict(), os.path.join(d, "enc_opt.pt"))
+    torch.save(dec_opt.state_dict(), os.path.join(d, "dec_opt.pt"))
+    pickle.dump(args, open(os.path.join(d, "args.pkl"), "wb"))
+
+
+def load_checkpoint(model_name, use_gpu=True, root="../models"):
+    """reference utils/utils.py:97-111 (python-2 pickles of the reference load with encoding='latin1')."""
+    d = os.path.join(root, model_name)
+    ml = None if use_gpu else (lambda storage, location: storage)
+    dicts = [torch.load(os.path.join(d, f), map_location=ml, weights_only=False)
+             for f in ("encoder.pt", "decoder.pt", "enc_opt.pt", "dec_opt.pt")]
+    with open(os.path.join(d, "args.pkl"), "rb") as f:
+        try:
+            args = pickle.load(f)
+        except UnicodeDecodeError:
+            f.seek(0)
+            args = pickle.load(f, encoding="latin1")
+    return dicts[0], dicts[1], dicts[2], dicts[3], args
+
+
+def batch_to_var(args, inputs, targets):
+    """reference utils/utils.py:113-127: split the [B, gt_T, H*W+3] target tensor."""
+    x = inputs
+    y_mask = targets[:, :, :-3].float()
+    y_class = targets[:, :, -3].long()
+    sw_mask = targets[:, :, -2]
+    sw_class = targets[:, :, -1]
+    if args.use_gpu:
+        return x.cuda(), y_mask.cuda(), y_class.cuda(), sw_mask.cuda(), sw_class.cuda()
+    return x, y_mask, y_class, sw_mask, sw_class

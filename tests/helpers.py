@@ -1,0 +1,40 @@
+"""Shared test helpers (oracle = CPU checker; the product runs on cuda:0 through librsis_hip.so)."""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def mk_args(hidden_size=128, num_classes=21, maxseqlen=10, **kw):
+    a = argparse.Namespace(use_gpu=True, base_model="resnet101", hidden_size=hidden_size, kernel_size=3,
+                           num_classes=num_classes, dropout=0.0, dropout_stop=0.0, dropout_cls=0.0, skip_mode="concat",
+                           maxseqlen=maxseqlen, gt_maxseqlen=20, iou_weight=1.0, class_weight=0.1, stop_weight=0.5,
+                           stop_balance_weight=0.5, use_class_loss=True, use_stop_loss=True, curriculum_learning=False,
+                           update_encoder=True)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def assert_close(what, got, want, atol, rtol=0.0):
+    got = torch.as_tensor(got).detach().double().cpu()
+    want = torch.as_tensor(np.asarray(want) if not torch.is_tensor(want) else want).detach().double().cpu()
+    assert got.shape == want.shape, "%s: shape %s vs %s" % (what, tuple(got.shape), tuple(want.shape))
+    if got.numel() == 0:
+        return
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    if bad.any() or torch.isnan(got).any():
+        i = int(torch.argmax(err - tol))
+        idx = np.unravel_index(i, got.shape) if got.dim() else ()
+        raise AssertionError("%s: max abs err %.3e (tol %.1e + %.1e*|ref|) at %s: got %.6g want %.6g; %d/%d bad; |ref|max %.3g"
+                             % (what, float(err.max()), atol, rtol, idx, float(got.reshape(-1)[i]), float(want.reshape(-1)[i]),
+                                int(bad.sum()), got.numel(), float(want.abs().max())))

@@ -1,0 +1,175 @@
+"""GPU parity tests, module level: the product modules (rsis_amd.modules, HIP path) against the committed golden
+vectors (outputs of the unmodified reference) and against the CPU oracle run live on the same seeded inputs.
+Bar (BASELINE.json north_star): per-timestep mask / class / stop outputs within 1e-4 (fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, gold, mk_args
+
+pytestmark = pytest.mark.gpu
+
+
+def _loaded_native():
+    """fail loudly if the HIP library is not the thing that ran"""
+    maps = open("/proc/self/maps").read()
+    assert "librsis_hip.so" in maps, "librsis_hip.so is not loaded: the HIP path did not run"
+
+
+@pytest.mark.parametrize("name", ["cell_small", "cell_l4like", "cell_wide"])
+def test_cell_golden(name):
+    from oracle import filler
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules import ConvLSTMCell
+    g = gold(name)
+    B, Cin, hid, H, W = [int(v) for v in g["shape"]]
+    ocell = filler.fill_module(O.ConvLSTMCell(mk_args(), Cin, hid, 3, 1), seed=11)
+    cell = ConvLSTMCell(mk_args(), Cin, hid, 3, 1).cuda()
+    cell.load_state_dict(ocell.state_dict())
+    x0 = filler.tensor(11, name + ".x0", (B, Cin, H, W)).cuda().requires_grad_()
+    x1 = filler.tensor(11, name + ".x1", (B, Cin, H, W)).cuda().requires_grad_()
+    gh = filler.tensor(11, name + ".gh", (B, hid, H, W)).cuda()
+    gc = filler.tensor(11, name + ".gc", (B, hid, H, W)).cuda()
+    h0, c0 = cell(x0, None)
+    h1, c1 = cell(x1, (h0, c0))
+    ((h1 * gh).sum() + (c1 * gc).sum()).backward()
+    got = dict(h0=h0, c0=c0, h1=h1, c1=c1, dx0=x0.grad, dx1=x1.grad, dW=cell.Gates.weight.grad, db=cell.Gates.bias.grad)
+    for k, v in got.items():
+        ref = g[k]
+        assert_close(name + "." + k, v, ref, 1e-4 * max(1.0, float(np.abs(ref).max())), 1e-4)
+    _loaded_native()
+
+
+@pytest.mark.parametrize("name", ["dec_pow2", "dec_odd"])
+def test_decoder_golden(name):
+    from oracle import filler
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules import RSIS
+    g = gold(name)
+    hs, B, T = int(g["hidden_size"]), int(g["B"]), int(g["T"])
+    sizes = [tuple(int(v) for v in s) for s in g["sizes"]]
+    odec = filler.fill_module(O.RSIS(mk_args(hidden_size=hs)), seed=22)
+    dec = RSIS(mk_args(hidden_size=hs)).cuda()
+    dec.load_state_dict(odec.state_dict())
+    chans = [hs, hs, hs // 2, hs // 4, hs // 8]
+    feats = [filler.tensor(22, "%s.f%d" % (name, i), (B, chans[i]) + sizes[i]).cuda().requires_grad_() for i in range(5)]
+    hidden, loss = None, 0.0
+    for t in range(T):
+        m, c, s, hidden = dec(feats, hidden)
+        assert_close("%s.mask%d" % (name, t), m, g["mask%d" % t], 1e-4)
+        assert_close("%s.class%d" % (name, t), c, g["class%d" % t], 1e-5)
+        assert_close("%s.stop%d" % (name, t), s, g["stop%d" % t], 1e-4)
+        loss = loss + (m * filler.tensor(22, "%s.gm%d" % (name, t), m.shape).cuda()).sum() \
+            + (c * filler.tensor(22, "%s.gc%d" % (name, t), c.shape).cuda()).sum() \
+            + (s * filler.tensor(22, "%s.gs%d" % (name, t), s.shape).cuda()).sum()
+    for i, (h, c) in enumerate(hidden):
+        assert_close("%s.h%d" % (name, i), h, g["h%d" % i], 1e-4)
+        assert_close("%s.c%d" % (name, i), c, g["c%d" % i], 1e-4)
+    loss.backward()
+    for i, f in enumerate(feats):
+        ref = g["dfeat%d" % i]
+        assert_close("%s.dfeat%d" % (name, i), f.grad, ref, 2e-4 * max(1.0, float(np.abs(ref).max())), 1e-4)
+    for k, p in dec.named_parameters():
+        ref = g["grad." + k]
+        assert_close("%s.grad.%s" % (name, k), p.grad, ref, 2e-4 * max(1.0, float(np.abs(ref).max())), 1e-4)
+
+
+@pytest.mark.parametrize("name,train", [("enc_eval_64", False), ("enc_eval_96x80", False), ("enc_train_64", True)])
+def test_encoder_golden(name, train):
+    from oracle import filler
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules import FeatureExtractor
+    g = gold(name)
+    oenc = filler.fill_module(O.FeatureExtractor(mk_args()), seed=33)
+    enc = FeatureExtractor(mk_args()).cuda()
+    enc.load_state_dict(oenc.state_dict())
+    enc.train(train)
+    x = filler.tensor(33, name + ".x", tuple(int(v) for v in g["shape"])).cuda()
+    with torch.no_grad():
+        fs = enc(x)
+    for i, f in enumerate(fs):
+        assert_close("%s.skip%d" % (name, 5 - i), f, g["skip%d" % (5 - i)], 1e-4, 1e-4)
+    if train:
+        sd = enc.state_dict()
+        for k in g.files:
+            if k.startswith("sd."):
+                assert_close(name + "." + k, sd[k[3:]], g[k], 1e-5, 1e-4)
+
+
+def test_encoder_backward_vs_oracle():
+    """train-mode encoder fwd + bwd on (2,3,64,64) against the oracle's autograd."""
+    from oracle import filler
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules import FeatureExtractor
+    oenc = filler.fill_module(O.FeatureExtractor(mk_args()), seed=33).train()
+    enc = FeatureExtractor(mk_args()).cuda()
+    enc.load_state_dict(oenc.state_dict())
+    enc.train()
+    x = filler.tensor(33, "encbwd.x", (2, 3, 64, 64))
+    fs_o = oenc(x)
+    fs = enc(x.cuda())
+    lo, lg = 0.0, 0.0
+    for i, (a, b) in enumerate(zip(fs_o, fs)):
+        gy = filler.tensor(33, "encbwd.g%d" % i, a.shape)
+        lo = lo + (a * gy).sum()
+        lg = lg + (b * gy.cuda()).sum()
+        assert_close("skip%d" % (5 - i), b, a, 1e-4, 1e-4)
+    lo.backward()
+    lg.backward()
+    po, pg = dict(oenc.named_parameters()), dict(enc.named_parameters())
+    worst = 0.0
+    for k in po:
+        if k.startswith("base.fc"):
+            assert pg[k].grad is None
+            continue
+        ref = po[k].grad
+        scale = max(1.0, float(ref.abs().max()))
+        assert_close("grad." + k, pg[k].grad, ref, 1e-3 * scale, 1e-3)
+        worst = max(worst, float((pg[k].grad.cpu() - ref).abs().max()) / scale)
+    print("encoder backward worst scaled err %.3e" % worst)
+
+
+def test_e2e_256_north_star():
+    """BASELINE north star: per-timestep mask logits / class probs / stop logits within 1e-4 of the reference
+    CPU path on identical inputs (256x256, B=2, T=10, ResNet-101, hidden 128)."""
+    from oracle import filler
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.test import test as hip_test
+    g = gold("e2e_256")
+    a = mk_args(maxseqlen=int(g["T"]))
+    oenc = filler.fill_module(O.FeatureExtractor(a), seed=44)
+    odec = filler.fill_module(O.RSIS(a), seed=45)
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    enc.load_state_dict(oenc.state_dict())
+    dec.load_state_dict(odec.state_dict())
+    x = filler.tensor(44, "e2e_256.x", tuple(int(v) for v in g["shape"])).cuda()
+    sub = int(g["sub"])
+    masks, classes, stops = hip_test(a, enc, dec, x)
+    logits, _, stop_logits = hip_test(a, enc, dec, x, return_logits=True)
+    assert_close("e2e.mask_logits", logits[:, :, ::sub, ::sub], g["mask_logits_sub"], 1e-4)
+    assert_close("e2e.mask_probs", masks[:, :, ::sub, ::sub], g["mask_probs_sub"], 1e-4)
+    assert_close("e2e.classes", classes, g["classes"], 1e-4)
+    assert_close("e2e.stops", stops, g["stops"], 1e-4)
+    assert_close("e2e.stop_logits", stop_logits, g["stop_logits"], 1e-4)
+    _loaded_native()
+
+
+def test_e2e_odd_size():
+    from oracle import filler
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.test import test as hip_test
+    g = gold("e2e_200x264")
+    a = mk_args(maxseqlen=int(g["T"]))
+    oenc = filler.fill_module(O.FeatureExtractor(a), seed=44)
+    odec = filler.fill_module(O.RSIS(a), seed=45)
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    enc.load_state_dict(oenc.state_dict())
+    dec.load_state_dict(odec.state_dict())
+    x = filler.tensor(44, "e2e_200x264.x", tuple(int(v) for v in g["shape"])).cuda()
+    masks, classes, stops = hip_test(a, enc, dec, x)
+    sub = int(g["sub"])
+    assert_close("odd.mask_probs", masks[:, :, ::sub, ::sub], g["mask_probs_sub"], 1e-4)
+    assert_close("odd.classes", classes, g["classes"], 1e-4)
+    assert_close("odd.stops", stops, g["stops"], 1e-4)

@@ -1,0 +1,212 @@
+"""GPU parity tests, op level: every C-ABI entry point (through rsis_amd.ops) against the CPU oracle's ops
+(plain torch fp32 on the host) on seeded inputs.  fp32 tolerance: 1e-4 absolute on O(1) values unless stated."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _rng_t(seed, shape, scale=1.0):
+    return torch.from_numpy(np.random.default_rng(seed).normal(0, scale, shape).astype(np.float32))
+
+
+def _dev(t):
+    return t.cuda().requires_grad_(t.requires_grad) if t is not None else None
+
+
+@pytest.fixture(autouse=True)
+def _reset_tile():
+    from rsis_amd import ops
+    ops.FORCE_TILE[0] = 0
+    yield
+    ops.FORCE_TILE[0] = 0
+
+
+CONV_CASES = [
+    # (B, [Cin segs], H, W, Cout, ks, stride, pad, bias)
+    (2, [8], 9, 11, 16, 3, 1, 1, True),
+    (2, [3], 32, 40, 64, 7, 2, 3, False),       # stem
+    (3, [64], 16, 16, 256, 1, 1, 0, False),     # bottleneck 1x1
+    (2, [64], 17, 15, 64, 3, 2, 1, False),      # strided 3x3 (odd size)
+    (2, [256], 8, 8, 512, 1, 2, 0, False),      # downsample 1x1 s2
+    (2, [16, 16], 12, 20, 32, 3, 1, 1, True),   # concat by pointer
+    (2, [8], 20, 24, 1, 3, 1, 1, True),         # conv_out
+    (1, [130], 7, 7, 129, 3, 1, 1, True),       # ragged channels
+    (2, [2048], 4, 4, 128, 3, 1, 1, True),      # sk5-like deep K
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+def test_conv2d_fwd_bwd(case, tile):
+    from rsis_amd import ops
+    B, segs, H, W, Cout, ks, stride, pad, has_bias = case
+    ops.FORCE_TILE[0] = tile
+    Ctot = sum(segs)
+    xs = [_rng_t(10 + i, (B, c, H, W)).requires_grad_() for i, c in enumerate(segs)]
+    w = _rng_t(20, (Cout, Ctot, ks, ks), 1.0 / np.sqrt(Ctot * ks * ks)).requires_grad_()
+    b = _rng_t(21, (Cout,)).requires_grad_() if has_bias else None
+    ref = F.conv2d(torch.cat(xs, 1), w, b, stride=stride, padding=pad)
+    gy = _rng_t(22, tuple(ref.shape))
+    ref.backward(gy)
+    xd = [_dev(x.detach().clone().requires_grad_()) for x in xs]
+    wd = _dev(w.detach().clone().requires_grad_())
+    bd = _dev(b.detach().clone().requires_grad_()) if has_bias else None
+    pack = ops.PackedConv(ks, segs)
+    out = ops.conv2d(xd, wd, bd, stride, pad, pack)
+    out.backward(gy.cuda())
+    torch.cuda.synchronize()
+    tol = 2e-5 * np.sqrt(Ctot * ks * ks) + 1e-5
+    assert_close("fwd", out, ref, tol, 1e-5)
+    for i, x in enumerate(xs):
+        assert_close("dx%d" % i, xd[i].grad, x.grad, 2e-5 * np.sqrt(Cout * ks * ks) + 1e-5, 1e-5)
+    assert_close("dW", wd.grad, w.grad, 1e-4 * max(1.0, float(w.grad.abs().max())), 1e-5)
+    if has_bias:
+        assert_close("db", bd.grad, b.grad, 1e-4 * max(1.0, float(b.grad.abs().max())), 1e-5)
+
+
+LSTM_CASES = [
+    # (B, [x segs], hid, H, W)
+    (2, [8], 4, 5, 7),
+    (2, [16, 16], 8, 16, 16),       # L4-like
+    (3, [24], 16, 9, 12),
+    (2, [64, 64], 32, 8, 8),        # L2-like
+    (1, [128], 128, 4, 4),          # L0-like
+    (2, [6, 5], 3, 6, 5),           # ragged
+]
+
+
+@pytest.mark.parametrize("case", LSTM_CASES)
+@pytest.mark.parametrize("tile", [0, 1, 3, 4, 5])
+def test_convlstm_fwd_bwd(case, tile):
+    from oracle import rsis_oracle as O
+    from rsis_amd import ops
+    from rsis_amd.modules.clstm import ConvLSTMCell
+    from helpers import mk_args
+    B, segs, hid, H, W = case
+    ops.FORCE_TILE[0] = tile
+    Cin = sum(segs)
+    ocell = O.ConvLSTMCell(mk_args(), Cin, hid, 3, 1)
+    with torch.no_grad():
+        ocell.Gates.weight.copy_(_rng_t(1, tuple(ocell.Gates.weight.shape), 2.0 / np.sqrt(9 * (Cin + hid))))
+        ocell.Gates.bias.copy_(_rng_t(2, (4 * hid,), 0.2))
+    cell = ConvLSTMCell(mk_args(), Cin, hid, 3, 1).cuda()
+    cell.load_state_dict(ocell.state_dict())
+    x0 = [_rng_t(30 + i, (B, c, H, W)).requires_grad_() for i, c in enumerate(segs)]
+    x1 = [_rng_t(40 + i, (B, c, H, W)).requires_grad_() for i, c in enumerate(segs)]
+    gh, gc = _rng_t(50, (B, hid, H, W)), _rng_t(51, (B, hid, H, W))
+    h0, c0 = ocell(torch.cat(x0, 1), None)
+    h1, c1 = ocell(torch.cat(x1, 1), (h0, c0))
+    ((h1 * gh).sum() + (c1 * gc).sum() + (h0 * gc).sum()).backward()
+    x0d = [_dev(t.detach().clone().requires_grad_()) for t in x0]
+    x1d = [_dev(t.detach().clone().requires_grad_()) for t in x1]
+    h0d, c0d = cell.forward_multi(x0d, None)
+    h1d, c1d = cell.forward_multi(x1d, (h0d, c0d))
+    ((h1d * gh.cuda()).sum() + (c1d * gc.cuda()).sum() + (h0d * gc.cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    for n, a, b in (("h0", h0d, h0), ("c0", c0d, c0), ("h1", h1d, h1), ("c1", c1d, c1)):
+        assert_close(n, a, b, 2e-5, 1e-5)
+    for i in range(len(segs)):
+        assert_close("dx0_%d" % i, x0d[i].grad, x0[i].grad, 5e-5, 1e-4)
+        assert_close("dx1_%d" % i, x1d[i].grad, x1[i].grad, 5e-5, 1e-4)
+    gw = ocell.Gates.weight.grad
+    assert_close("dW", cell.Gates.weight.grad, gw, 1e-4 * max(1.0, float(gw.abs().max())), 1e-4)
+    gb = ocell.Gates.bias.grad
+    assert_close("db", cell.Gates.bias.grad, gb, 1e-4 * max(1.0, float(gb.abs().max())), 1e-4)
+
+
+@pytest.mark.parametrize("shape,size", [((2, 3, 4, 5), (7, 9)), ((2, 8, 8, 8), (16, 16)), ((1, 2, 13, 25), (25, 50)),
+                                        ((2, 1, 5, 7), (5, 7)), ((2, 4, 1, 1), (3, 3)), ((2, 1, 64, 64), (100, 132))])
+def test_upsample(shape, size):
+    from rsis_amd import ops
+    x = _rng_t(3, shape).requires_grad_()
+    ref = F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+    gy = _rng_t(4, tuple(ref.shape))
+    ref.backward(gy)
+    xd = _dev(x.detach().clone().requires_grad_())
+    y = ops.upsample_bilinear_ac(xd, size)
+    y.backward(gy.cuda())
+    assert_close("fwd", y, ref, 1e-5)
+    assert_close("bwd", xd.grad, x.grad, 2e-5, 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 9), (3, 8, 16, 16), (1, 3, 1, 1), (2, 2, 40, 33)])
+def test_global_maxpool(shape):
+    from rsis_amd import ops
+    x = _rng_t(5, shape).requires_grad_()
+    ref = F.max_pool2d(x, kernel_size=shape[2:])
+    gy = _rng_t(6, tuple(ref.shape))
+    ref.backward(gy)
+    xd = _dev(x.detach().clone().requires_grad_())
+    y = ops.global_maxpool(xd)
+    y.backward(gy.cuda())
+    assert_close("fwd", y, ref, 0)
+    assert_close("bwd", xd.grad, x.grad, 0)
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 8, 8), (3, 5, 9, 11), (1, 2, 16, 6), (2, 3, 7, 7)])
+def test_maxpool3x3s2(shape):
+    from rsis_amd import ops
+    x = _rng_t(7, shape).requires_grad_()
+    ref = F.max_pool2d(x, 3, 2, 1)
+    gy = _rng_t(8, tuple(ref.shape))
+    ref.backward(gy)
+    xd = _dev(x.detach().clone().requires_grad_())
+    y = ops.maxpool3x3s2(xd)
+    y.backward(gy.cuda())
+    assert_close("fwd", y, ref, 0)
+    assert_close("bwd", xd.grad, x.grad, 1e-6)
+
+
+@pytest.mark.parametrize("shape", [(4, 6, 5, 7), (2, 64, 16, 16), (3, 3, 33, 17), (8, 130, 4, 4)])
+@pytest.mark.parametrize("train,relu,res", [(True, False, False), (True, True, False), (True, True, True), (True, False, True),
+                                            (False, True, True), (False, False, False)])
+def test_batchnorm(shape, train, relu, res):
+    from rsis_amd import ops
+    B, C, H, W = shape
+    x = (_rng_t(9, shape, 2.0) + 0.5).requires_grad_()
+    r = _rng_t(10, shape).requires_grad_() if res else None
+    gamma = (_rng_t(11, (C,), 0.3) + 1.0).requires_grad_()
+    beta = _rng_t(12, (C,), 0.3).requires_grad_()
+    rm, rv = _rng_t(13, (C,), 0.1), _rng_t(14, (C,), 0.1).abs() + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, training=train, momentum=0.1, eps=1e-5)
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    gy = _rng_t(15, shape)
+    ref.backward(gy)
+    xd = _dev(x.detach().clone().requires_grad_())
+    rd = _dev(r.detach().clone().requires_grad_()) if res else None
+    gd, bd = _dev(gamma.detach().clone().requires_grad_()), _dev(beta.detach().clone().requires_grad_())
+    rmd, rvd = rm.cuda(), rv.cuda()
+    y = ops.batchnorm(xd, gd, bd, rmd, rvd, train, relu=relu, res=rd)
+    y.backward(gy.cuda())
+    assert_close("fwd", y, ref, 2e-5, 1e-5)
+    assert_close("running_mean", rmd, rm_ref, 1e-6, 1e-5)
+    assert_close("running_var", rvd, rv_ref, 1e-6, 1e-5)
+    assert_close("dx", xd.grad, x.grad, 5e-5, 1e-4)
+    assert_close("dgamma", gd.grad, gamma.grad, 1e-4, 1e-4)
+    assert_close("dbeta", bd.grad, beta.grad, 1e-4, 1e-4)
+    if res:
+        assert_close("dres", rd.grad, r.grad, 1e-6)
+
+
+def test_adam_matches_torch():
+    from rsis_amd import ops
+    n = 10007
+    p = _rng_t(16, (n,))
+    ref_p = p.clone().requires_grad_()
+    opt = torch.optim.Adam([ref_p], lr=1e-3, weight_decay=1e-6)
+    pd, m, v = p.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        g = _rng_t(17 + step, (n,))
+        ref_p.grad = g.clone()
+        opt.step()
+        ops.adam_step_flat(pd, g.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-6, step)
+    assert_close("adam", pd, ref_p, 1e-6, 1e-5)

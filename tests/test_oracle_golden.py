@@ -1,0 +1,120 @@
+"""CPU tests: the oracle (oracle/rsis_oracle.py) reproduces every committed golden vector, i.e. the outputs of the
+UNMODIFIED reference modules captured by oracle/make_golden.py in the build container."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import filler
+from oracle import rsis_oracle as O
+from helpers import assert_close, gold, mk_args
+
+
+@pytest.mark.parametrize("name", ["cell_small", "cell_l4like", "cell_wide"])
+def test_cell_matches_reference(name):
+    g = gold(name)
+    B, Cin, hid, H, W = [int(v) for v in g["shape"]]
+    cell = filler.fill_module(O.ConvLSTMCell(mk_args(), Cin, hid, 3, 1), seed=11)
+    x0 = filler.tensor(11, name + ".x0", (B, Cin, H, W)).requires_grad_()
+    x1 = filler.tensor(11, name + ".x1", (B, Cin, H, W)).requires_grad_()
+    gh = filler.tensor(11, name + ".gh", (B, hid, H, W))
+    gc = filler.tensor(11, name + ".gc", (B, hid, H, W))
+    h0, c0 = cell(x0, None)
+    h1, c1 = cell(x1, (h0, c0))
+    ((h1 * gh).sum() + (c1 * gc).sum()).backward()
+    got = dict(h0=h0, c0=c0, h1=h1, c1=c1, dx0=x0.grad, dx1=x1.grad, dW=cell.Gates.weight.grad, db=cell.Gates.bias.grad)
+    for k, v in got.items():
+        assert_close(name + "." + k, v, g[k], 2e-5, 1e-5)
+
+
+@pytest.mark.parametrize("name", ["dec_pow2", "dec_odd"])
+def test_decoder_matches_reference(name):
+    g = gold(name)
+    hs, B, T = int(g["hidden_size"]), int(g["B"]), int(g["T"])
+    sizes = [tuple(int(v) for v in s) for s in g["sizes"]]
+    dec = filler.fill_module(O.RSIS(mk_args(hidden_size=hs)), seed=22)
+    chans = [hs, hs, hs // 2, hs // 4, hs // 8]
+    feats = [filler.tensor(22, "%s.f%d" % (name, i), (B, chans[i]) + sizes[i]) for i in range(5)]
+    hidden = None
+    with torch.no_grad():
+        for t in range(T):
+            m, c, s, hidden = dec(feats, hidden)
+            assert_close("%s.mask%d" % (name, t), m, g["mask%d" % t], 1e-5)
+            assert_close("%s.class%d" % (name, t), c, g["class%d" % t], 1e-6)
+            assert_close("%s.stop%d" % (name, t), s, g["stop%d" % t], 1e-5)
+    for i, (h, c) in enumerate(hidden):
+        assert_close("%s.h%d" % (name, i), h, g["h%d" % i], 1e-5)
+        assert_close("%s.c%d" % (name, i), c, g["c%d" % i], 1e-5)
+
+
+@pytest.mark.parametrize("name,train", [("enc_eval_64", False), ("enc_train_64", True)])
+def test_encoder_matches_reference(name, train):
+    g = gold(name)
+    enc = filler.fill_module(O.FeatureExtractor(mk_args()), seed=33)
+    enc.train(train)
+    x = filler.tensor(33, name + ".x", tuple(int(v) for v in g["shape"]))
+    with torch.no_grad():
+        fs = enc(x)
+    for i, f in enumerate(fs):
+        assert_close("%s.skip%d" % (name, 5 - i), f, g["skip%d" % (5 - i)], 5e-5, 1e-5)
+    if train:
+        sd = enc.state_dict()
+        for k in g.files:
+            if k.startswith("sd."):
+                assert_close(name + "." + k, sd[k[3:]], g[k], 1e-5, 1e-5)
+
+
+def test_losses_match_reference():
+    g = gold("losses")
+    B, G, T, N, C = 3, 20, 10, 96, 21
+    P = filler.tensor(55, "f5.P", (B * G, N), 2.0)
+    Y = (filler.tensor(55, "f5.Y", (B * G, N)) > 0.3).float()
+    probs = torch.softmax(filler.tensor(55, "f5.logits", (B * T, C)), 1)
+    tgt = torch.from_numpy(np.random.default_rng(55).integers(0, C, (B * T, 1)))
+    stop_logit = filler.tensor(55, "f5.stop", (B, T), 3.0)
+    stop_tgt = (filler.tensor(55, "f5.stopt", (B, T)) > 0).float()
+    sw = (filler.tensor(55, "f5.sw", (B * T, 1)) > -0.5).float()
+    assert_close("softIoU", O.softIoU(Y, P), g["softIoU"], 1e-6)
+    assert_close("MaskedNLL", O.MaskedNLL(tgt, probs), g["MaskedNLL"], 1e-6)
+    assert_close("BCE_bw05", O.StableBalancedMaskedBCE(stop_tgt, stop_logit, 0.5), g["BCE_bw05"], 1e-6)
+    assert_close("BCE_auto", O.StableBalancedMaskedBCE(stop_tgt, stop_logit), g["BCE_auto"], 1e-6)
+    assert_close("softIoULoss", O.softIoULoss(Y[:B * T], P[:B * T], sw), g["softIoULoss"], 1e-6)
+    assert_close("MaskedNLLLoss", O.MaskedNLLLoss(tgt, probs, sw), g["MaskedNLLLoss"], 1e-6)
+    assert_close("MaskedBCELoss", O.MaskedBCELoss(stop_tgt, stop_logit, sw, 0.5), g["MaskedBCELoss"], 1e-6)
+    scores = torch.from_numpy(np.random.default_rng(56).uniform(0, 1, (B, G, T))).float()
+    ym = (filler.tensor(56, "f5.ym", (B, G, N)) > 0).float()
+    yc = torch.from_numpy(np.random.default_rng(57).integers(0, C, (B, G)))
+    pm = filler.tensor(56, "f5.pm", (B, T, N))
+    pc = filler.tensor(56, "f5.pc", (B, T, C))
+    o_m, o_c, o_p = O.match([ym, pm], [yc, pc], scores)
+    assert (o_p == g["match_perm"]).all() and (o_c == g["match_class"]).all()
+    assert np.allclose(o_m.sum(-1), g["match_mask_sum"])
+
+
+def test_runiter_matches_reference():
+    g = gold("runiter_64")
+    B, H, W, T = 2, 64, 64, 3
+    a = mk_args(maxseqlen=T)
+    enc = filler.fill_module(O.FeatureExtractor(a), seed=66)
+    dec = filler.fill_module(O.RSIS(a), seed=67)
+    x = filler.tensor(66, "runiter_64.x", (B, 3, H, W))
+    y_mask, y_class, sw_mask, sw_class = filler.synthetic_targets(66, B, H, W, gt_maxseqlen=20, n_inst=5)
+    r = O.run_iter_forward(a, enc, dec, x, y_mask, y_class, sw_mask, sw_class, mode="train")
+    r["loss"].backward()
+    for k in ("loss", "loss_mask_iou", "loss_stop", "loss_class", "scores", "out_classes", "out_stops"):
+        assert_close("runiter." + k, r[k], g[k], 2e-5, 1e-5)
+    assert (r["y_class_perm"].numpy() == g["y_class_perm"]).all()
+    assert_close("gnorm sk5", dict(enc.named_parameters())["sk5.weight"].grad.norm(), g["gnorm.enc.sk5.weight"], 0, 1e-3)
+
+
+def test_e2e_256_matches_reference():
+    """The north-star fixture itself: oracle.test() at 256x256, B=2, T=10, hidden 128."""
+    g = gold("e2e_256")
+    a = mk_args(maxseqlen=int(g["T"]))
+    enc = filler.fill_module(O.FeatureExtractor(a), seed=44).eval()
+    dec = filler.fill_module(O.RSIS(a), seed=45).eval()
+    x = filler.tensor(44, "e2e_256.x", tuple(int(v) for v in g["shape"]))
+    sub = int(g["sub"])
+    logits, classes, stops = O.test(a, enc, dec, x, return_logits=True)
+    assert_close("e2e.mask_logits", logits[:, :, ::sub, ::sub], g["mask_logits_sub"], 2e-5)
+    assert_close("e2e.classes", classes, g["classes"], 1e-6)
+    assert_close("e2e.stop_logits", stops, g["stop_logits"], 1e-5)
