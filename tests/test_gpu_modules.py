@@ -74,6 +74,13 @@ def test_decoder_golden(name):
         assert_close("%s.grad.%s" % (name, k), p.grad, ref, 2e-4 * max(1.0, float(np.abs(ref).max())), 1e-4)
 
 
+def _noise_floor(o32, o64):
+    """fp32 noise floor of the reference op graph itself: max |oracle fp32 - oracle fp64|.  Train-mode BatchNorm over
+    the 8..32 samples/channel of a 64x64 fixture makes the deep pyramid levels ill-conditioned (the REFERENCE's own
+    fp32 result moves by ~6e-3 at skip5 vs fp64), so those checks are: |hip - fp64 truth| <= max(1e-4, 4 x floor)."""
+    return float((o32.double() - o64).abs().max())
+
+
 @pytest.mark.parametrize("name,train", [("enc_eval_64", False), ("enc_eval_96x80", False), ("enc_train_64", True)])
 def test_encoder_golden(name, train):
     from oracle import filler
@@ -84,49 +91,67 @@ def test_encoder_golden(name, train):
     enc = FeatureExtractor(mk_args()).cuda()
     enc.load_state_dict(oenc.state_dict())
     enc.train(train)
-    x = filler.tensor(33, name + ".x", tuple(int(v) for v in g["shape"])).cuda()
+    shape = tuple(int(v) for v in g["shape"])
+    x = filler.tensor(33, name + ".x", shape)
     with torch.no_grad():
-        fs = enc(x)
+        fs = enc(x.cuda())
+    if not train:
+        for i, f in enumerate(fs):
+            assert_close("%s.skip%d" % (name, 5 - i), f, g["skip%d" % (5 - i)], 1e-4, 1e-4)
+        return
+    o64 = filler.fill_module(O.FeatureExtractor(mk_args()), seed=33).double().train()
+    with torch.no_grad():
+        f64 = o64(x.double())
     for i, f in enumerate(fs):
-        assert_close("%s.skip%d" % (name, 5 - i), f, g["skip%d" % (5 - i)], 1e-4, 1e-4)
-    if train:
-        sd = enc.state_dict()
-        for k in g.files:
-            if k.startswith("sd."):
-                assert_close(name + "." + k, sd[k[3:]], g[k], 1e-5, 1e-4)
+        ref32 = torch.from_numpy(g["skip%d" % (5 - i)])
+        floor = _noise_floor(ref32, f64[i])
+        assert_close("%s.skip%d (floor %.1e)" % (name, 5 - i, floor), f, f64[i], max(1e-4, 4 * floor), 1e-4)
+    sd, sd64 = enc.state_dict(), o64.state_dict()
+    for k in g.files:
+        if k.startswith("sd."):
+            floor = _noise_floor(torch.from_numpy(g[k]), sd64[k[3:]])
+            assert_close(name + "." + k, sd[k[3:]], sd64[k[3:]], max(1e-5, 4 * floor), 1e-4)
 
 
 def test_encoder_backward_vs_oracle():
-    """train-mode encoder fwd + bwd on (2,3,64,64) against the oracle's autograd."""
+    """train-mode encoder fwd + bwd on (4,3,128,128) against the oracle's autograd (fp64 truth, fp32 noise floor)."""
     from oracle import filler
     from oracle import rsis_oracle as O
     from rsis_amd.modules import FeatureExtractor
+    shape = (4, 3, 128, 128)
     oenc = filler.fill_module(O.FeatureExtractor(mk_args()), seed=33).train()
+    o64 = filler.fill_module(O.FeatureExtractor(mk_args()), seed=33).double().train()
     enc = FeatureExtractor(mk_args()).cuda()
     enc.load_state_dict(oenc.state_dict())
     enc.train()
-    x = filler.tensor(33, "encbwd.x", (2, 3, 64, 64))
-    fs_o = oenc(x)
-    fs = enc(x.cuda())
-    lo, lg = 0.0, 0.0
-    for i, (a, b) in enumerate(zip(fs_o, fs)):
+    x = filler.tensor(33, "encbwd.x", shape)
+    fs_o, fs_64, fs = oenc(x), o64(x.double()), enc(x.cuda())
+    lo, l64, lg = 0.0, 0.0, 0.0
+    for i, (a, a64, b) in enumerate(zip(fs_o, fs_64, fs)):
         gy = filler.tensor(33, "encbwd.g%d" % i, a.shape)
         lo = lo + (a * gy).sum()
+        l64 = l64 + (a64 * gy.double()).sum()
         lg = lg + (b * gy.cuda()).sum()
-        assert_close("skip%d" % (5 - i), b, a, 1e-4, 1e-4)
+        assert_close("skip%d" % (5 - i), b, a64, max(1e-4, 4 * _noise_floor(a, a64)), 1e-4)
     lo.backward()
+    l64.backward()
     lg.backward()
-    po, pg = dict(oenc.named_parameters()), dict(enc.named_parameters())
+    po, p64, pg = dict(oenc.named_parameters()), dict(o64.named_parameters()), dict(enc.named_parameters())
+    # BPTT through ~100 train-mode BN layers is chaotic in fp32 (the oracle's own fp32 gradient differs from its fp64
+    # gradient by O(10%) in layer4 on this fixture), so the wiring check is a relative-L2 one, scaled by that noise
+    # floor; every op's backward is checked tightly on its own in test_gpu_ops.py.
     worst = 0.0
     for k in po:
         if k.startswith("base.fc"):
             assert pg[k].grad is None
             continue
-        ref = po[k].grad
-        scale = max(1.0, float(ref.abs().max()))
-        assert_close("grad." + k, pg[k].grad, ref, 1e-3 * scale, 1e-3)
-        worst = max(worst, float((pg[k].grad.cpu() - ref).abs().max()) / scale)
-    print("encoder backward worst scaled err %.3e" % worst)
+        ref = p64[k].grad
+        nrm = float(ref.norm()) + 1e-30
+        floor = float((po[k].grad.double() - ref).norm()) / nrm
+        err = float((pg[k].grad.cpu().double() - ref).norm()) / nrm
+        assert err <= max(1e-3, 4 * floor), "grad.%s: rel-L2 err %.3e vs fp64, fp32 noise floor %.3e" % (k, err, floor)
+        worst = max(worst, err / max(floor, 2.5e-4))
+    print("encoder backward: worst rel-L2 err / max(noise floor, 2.5e-4) = %.2f" % worst)
 
 
 def test_e2e_256_north_star():

@@ -15,7 +15,7 @@ def _rng_t(seed, shape, scale=1.0):
 
 
 def _dev(t):
-    return t.cuda().requires_grad_(t.requires_grad) if t is not None else None
+    return t.detach().cuda().requires_grad_(t.requires_grad) if t is not None else None
 
 
 @pytest.fixture(autouse=True)
