@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py -- training images/sec of the RSIS hot path on MI355X (BASELINE.json metric).
+
+One "step" = one full training iteration of the encoder -> T=10-step ConvLSTM decoder path on one resident synthetic
+batch (B=32 per GPU, 256x256x3, fp32, ResNet-101, hidden 128): encoder fwd, 10 decoder steps, score matrix + Hungarian
+matching, the three losses, backward (BPTT + encoder), gradient all-reduce (N>1), two Adam steps.  Nothing is skipped.
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  "roofline":     ConvLSTM gate kernel (rsis_convlstm_fwd, the 5 pyramid scales of one timestep, B=32):
+                  achieved = algorithmic FLOPs (2*M*K*N with the reference's full K) / HIP-event
+                  time of the launches, against the 157.3 TFLOP/s exact-f32 MFMA peak;
+  "cpu_baseline": the CPU oracle (port of the reference op graph, oracle/rsis_oracle.py) timed on this box's host cores
+                  on a bounded sample of the same workload (rank 0, N=1 only).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# ConvLSTM gate GEMMs at config 2: (x segments, hid, H=W)
+GATE_LAYERS = [([128], 128, 8), ([128, 128], 64, 16), ([64, 64], 32, 32), ([32, 32], 16, 64), ([16, 16], 8, 128)]
+
+
+def bench_args(batch, imsize, T):
+    from rsis_amd.args import get_parser
+    a = get_parser().parse_args([])
+    a.batch_size, a.imsize, a.maxseqlen, a.gt_maxseqlen, a.num_classes = batch, imsize, T, 20, 21
+    a.use_class_loss = a.use_stop_loss = a.update_encoder = True
+    a.synthetic = True
+    return a
+
+
+def gate_kernel_roofline(B, iters, imsize):
+    """Time the fused ConvLSTM gate kernel (with recurrent state = the reference's full K) for the 5 scales with HIP
+    events on the launch stream."""
+    from rsis_amd import ops
+    from rsis_amd._lib import check, int_array, lib, ptr, ptr_array, stream
+    L = lib()
+    scale = imsize // 256 if imsize % 256 == 0 else 1
+    total_flops, total_ms, per_layer = 0.0, 0.0, []
+    for segs, hid, hw in GATE_LAYERS:
+        H = W = hw * imsize // 256
+        cin = sum(segs) + hid
+        w = torch.randn(4 * hid, cin, 3, 3, device="cuda") * (1.0 / (3.0 * cin ** 0.5))
+        bias = torch.randn(4 * hid, device="cuda") * 0.1
+        pack = ops.PackedConv(3, segs + [hid], lstm_hid=hid)
+        wp = pack.fwd(w, bias)
+        srcs = [torch.randn(B, c, H, W, device="cuda") for c in segs] + [torch.tanh(torch.randn(B, hid, H, W, device="cuda"))]
+        c_prev = torch.randn(B, hid, H, W, device="cuda")
+        h, c = torch.empty_like(c_prev), torch.empty_like(c_prev)
+        act = torch.empty(B, 4 * hid, H, W, device="cuda")
+        pa, ia = ptr_array(srcs), int_array(segs + [hid])
+
+        def launch():
+            check(L.rsis_convlstm_fwd(pa, ia, len(srcs), B, H, W, ptr(wp), ptr(pack.bias_p), None, ptr(c_prev), ptr(h), ptr(c),
+                                      ptr(act), hid, 3, 1, 0, stream()), "rsis_convlstm_fwd")
+        for _ in range(3):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        flops = 2.0 * (B * H * W) * (cin * 9) * (4 * hid)
+        per_layer.append({"HxW": "%dx%d" % (H, W), "gemm_MKN": [B * H * W, cin * 9, 4 * hid], "ms": round(ms, 4),
+                          "tflops": round(flops / ms / 1e9, 2)})
+        total_flops += flops
+        total_ms += ms
+    achieved = total_flops / total_ms / 1e9
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel<EPI_LSTM> (rsis_convlstm_fwd), 5 scales of one decoder timestep",
+            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": None, "algorithmic_gflop_per_timestep": round(total_flops / 1e9, 3), "ms_per_timestep": round(total_ms, 4),
+            "per_scale": per_layer}
+
+
+def cpu_baseline(imsize, T, budget_s=25.0):
+    """The oracle's restated train step (oracle.run_iter_forward + backward) on the host cores, bounded sample."""
+    from oracle import rsis_oracle as O
+    from rsis_amd.synthetic import synthetic_batch
+    cores = min(os.cpu_count() or 1, 32)     # a 256-core host oversubscribes a B=2 step; 32 threads are what is timed
+    torch.set_num_threads(cores)
+    B = 2
+    a = bench_args(B, imsize, T)
+    a.use_gpu = False
+    torch.manual_seed(0)
+    enc, dec = O.FeatureExtractor(a), O.RSIS(a)
+    x, y_mask, y_class, sw_mask, sw_class = synthetic_batch(123, B, imsize, imsize, 20, 12, 21, device="cpu")
+
+    def step():
+        enc.zero_grad()
+        dec.zero_grad()
+        r = O.run_iter_forward(a, enc, dec, x, y_mask, y_class, sw_mask, sw_class, mode="train")
+        r["loss"].backward()
+    t0 = time.time()
+    step()                       # warm-up
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while n < 1 or (time.time() - t0 + warm) < budget_s and n < 8:
+        step()
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "oracle train step (fwd+match+losses+bwd, no optimizer), B=%d, %dx%d, T=%d, fp32, %d timed steps after 1 warm-up"
+                      % (B, imsize, imsize, T, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--imsize", type=int, default=256)
+    ap.add_argument("--T", type=int, default=10)
+    ap.add_argument("--kernel-iters", type=int, default=20)
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    o = ap.parse_args()
+    if o.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(o.imsize, o.T)))
+        return
+
+    from rsis_amd.train import build_optimizers, init_distributed, runIter
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.optim import BucketedAllReduce
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+
+    rank, local_rank, world = init_distributed()
+    assert world == o.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % o.gpus
+    assert torch.cuda.is_available(), "bench.py needs the GPU (there is no CPU path)"
+    a = bench_args(o.batch, o.imsize, o.T)
+    torch.manual_seed(a.seed)
+    encoder, decoder = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    if world > 1:
+        for p in list(encoder.parameters()) + list(decoder.parameters()) + list(encoder.buffers()):
+            dist.broadcast(p.data, 0)
+    enc_opt, dec_opt = build_optimizers(a, encoder, decoder)
+    reducer = BucketedAllReduce([dec_opt.group, enc_opt.group]) if world > 1 else None
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
+    batch = synthetic_batch(a.seed + 1000 * rank, o.batch, o.imsize, o.imsize, a.gt_maxseqlen, 12, a.num_classes, "cuda")
+
+    def step():
+        return runIter(a, encoder, decoder, *batch, crits, [enc_opt, dec_opt], mode="train", reducer=reducer, sync_losses=False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def note(msg):
+        if rank == 0:
+            print("[bench] %s" % msg, file=sys.stderr, flush=True)
+
+    tw = time.time()
+    for i in range(o.warmup):
+        losses = step()[0]
+        if i == 0:
+            torch.cuda.synchronize()
+            note("first step %.2f s" % (time.time() - tw))
+    fence()
+    note("warmup done %.2f s" % (time.time() - tw))
+    t0 = time.time()
+    for _ in range(o.steps):
+        losses = step()[0]
+    fence()
+    dt = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss_val = float(losses[0])
+    assert loss_val == loss_val, "loss is NaN"
+
+    roof = cpu = None
+    if rank == 0:
+        note("timed region %.3f s for %d steps" % (dt, o.steps))
+        if not o.skip_roofline:
+            roof = gate_kernel_roofline(o.batch, o.kernel_iters, o.imsize)
+            note("gate kernel roofline: %s TFLOP/s" % roof["achieved"])
+        if world == 1 and not o.skip_cpu:
+            # own process + hard timeout: the CPU leg can never stall the GPU bench
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--imsize", str(o.imsize),
+                                    "--T", str(o.T)], capture_output=True, text=True, timeout=240)
+                cpu = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as ex:  # noqa: BLE001
+                cpu = {"value": None, "unit": "images/s", "cores": None, "kind": "port", "sample": "failed: %r" % (ex,)}
+            note("cpu baseline: %s" % (cpu,))
+        value = world * o.batch * o.steps / dt
+        out = {"metric": "training images/sec at %dx%d, T=%d, batch=%d per GPU" % (o.imsize, o.imsize, o.T, o.batch),
+               "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": o.steps, "warmup": o.warmup,
+               "ms_per_step": round(1000.0 * dt / o.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "configs[1]: synthetic %dx%dx3, T=%d, batch=%d/GPU, ResNet-101 encoder + 5-scale ConvLSTM "
+                                      "decoder, fp32, fwd+match+3 losses+bwd+Adam (update_encoder on)" % (o.imsize, o.imsize, o.T, o.batch),
+                          "global_batch": world * o.batch, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5)},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

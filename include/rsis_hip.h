@@ -11,8 +11,8 @@
  *     (a hipStream_t passed as void*; NULL = the default stream);
  *   - return value: 0 = OK, nonzero = error code (rsis_error_string); nothing throws across the ABI;
  *   - thread-safe / re-entrant per stream.
- *   - "packed" weights are a private MFMA-friendly copy ([K][Cout_pad], K = (segment, ci, r, s) with each
- *     channel-concat segment padded to a multiple of 16 rows; ConvLSTM rows gate-interleaved 4*j+gate);
+ *   - "packed" weights are a private MFMA-friendly copy ([K_pad][Cout_pad], K = (ci, r, s) zero-padded to a
+ *     multiple of 32 rows, Cout to a multiple of 128 columns; ConvLSTM rows gate-interleaved 4*j+gate);
  *     they are rebuilt from the reference-layout weight ([Cout][Cin][k][k], gate order i,f,o,g) and never
  *     serialised.
  */

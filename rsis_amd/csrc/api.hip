@@ -5,7 +5,7 @@
 // launchers implemented in the other translation units
 int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_tile, hipStream_t st);
 int rsis_launch_conv_wgrad(WgradArgs& a, int ks, hipStream_t st);
-int rsis_l_pack_fwd(const float*, float*, int, int, int, int, const int*, int, int, int, hipStream_t);
+int rsis_l_pack_fwd(const float*, float*, int, int, int, int, int, int, hipStream_t);
 int rsis_l_pack_dgrad(const float*, float*, int, int, int, int, int, int, int, int, hipStream_t);
 int rsis_l_lstm_bwd(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
                     hipStream_t);
@@ -22,7 +22,7 @@ int rsis_l_maxpool_bwd(const float*, const unsigned char*, float*, long, int, in
 int rsis_l_channel_sum(const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_adam(float*, const float*, float*, float*, long, float, float, float, float, float, int, float, hipStream_t);
 
-static inline int ktiles_of(int C, int ks) { return (C * ks * ks + RSIS_BK - 1) / RSIS_BK; }
+static inline int krows_of(int C, int ks) { return rsis_roundup(C * ks * ks, RSIS_KPAD); }
 static inline int log2i(int s) { int l = 0; while ((1 << l) < s) ++l; return l; }
 
 extern "C" {
@@ -41,23 +41,23 @@ const char* rsis_error_string(int code) {
 
 long rsis_conv_packed_floats_fwd(int Cout, int ks, int nseg, const int* Cseg) {
   if (nseg < 1 || nseg > RSIS_MAX_SRC || !Cseg) return -1;
-  long kt = 0;
-  for (int s = 0; s < nseg; ++s) kt += ktiles_of(Cseg[s], ks);
-  return kt * RSIS_BK * (long)rsis_roundup(Cout, RSIS_LDW_ALIGN);
+  int c = 0;
+  for (int s = 0; s < nseg; ++s) c += Cseg[s];
+  return (long)krows_of(c, ks) * (long)rsis_roundup(Cout, RSIS_LDW_ALIGN);
 }
 
 long rsis_conv_packed_floats_dgrad(int Cout, int ks, int c_count) {
-  return (long)ktiles_of(Cout, ks) * RSIS_BK * (long)rsis_roundup(c_count, RSIS_LDW_ALIGN);
+  return (long)krows_of(Cout, ks) * (long)rsis_roundup(c_count, RSIS_LDW_ALIGN);
 }
 
 int rsis_conv_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int nseg, const int* Cseg, int lstm_hid,
                        void* stream) {
   if (!W || !Wp || nseg < 1 || nseg > RSIS_MAX_SRC) return RSIS_ERR_ARG;
-  int csum = 0, kt = 0;
-  for (int s = 0; s < nseg; ++s) { csum += Cseg[s]; kt += ktiles_of(Cseg[s], ks); }
+  int csum = 0;
+  for (int s = 0; s < nseg; ++s) csum += Cseg[s];
   if (csum != Ctot) return RSIS_ERR_ARG;
   if (lstm_hid > 0 && Cout != 4 * lstm_hid) return RSIS_ERR_ARG;
-  return rsis_l_pack_fwd(W, Wp, Cout, Ctot, ks, nseg, Cseg, rsis_roundup(Cout, RSIS_LDW_ALIGN), kt * RSIS_BK, lstm_hid,
+  return rsis_l_pack_fwd(W, Wp, Cout, Ctot, ks, rsis_roundup(Cout, RSIS_LDW_ALIGN), krows_of(Ctot, ks), lstm_hid,
                          (hipStream_t)stream);
 }
 
@@ -66,16 +66,17 @@ int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, 
   if (!W || !Wd || c_lo < 0 || c_hi > Ctot || c_lo >= c_hi) return RSIS_ERR_ARG;
   if (lstm_hid > 0 && Cout != 4 * lstm_hid) return RSIS_ERR_ARG;
   return rsis_l_pack_dgrad(W, Wd, Cout, Ctot, ks, c_lo, c_hi, rsis_roundup(c_hi - c_lo, RSIS_LDW_ALIGN),
-                           ktiles_of(Cout, ks) * RSIS_BK, lstm_hid, (hipStream_t)stream);
+                           krows_of(Cout, ks), lstm_hid, (hipStream_t)stream);
 }
 
 static int fill_sources(ConvArgs& a, const float* const* src, const int* Csrc, int nsrc, int ks) {
   if (nsrc < 1 || nsrc > RSIS_MAX_SRC || !src || !Csrc) return RSIS_ERR_ARG;
   a.nsrc = nsrc;
-  for (int s = 0; s < RSIS_MAX_SRC; ++s) { a.src[s] = nullptr; a.C[s] = 0; a.ktiles[s] = 0; }
+  a.K = 0;
+  for (int s = 0; s < RSIS_MAX_SRC; ++s) { a.src[s] = src[0]; a.C[s] = 0; }
   for (int s = 0; s < nsrc; ++s) {
     if (!src[s] || Csrc[s] < 1) return RSIS_ERR_ARG;
-    a.src[s] = src[s]; a.C[s] = Csrc[s]; a.ktiles[s] = ktiles_of(Csrc[s], ks);
+    a.src[s] = src[s]; a.C[s] = Csrc[s]; a.K += Csrc[s] * ks * ks;
   }
   return RSIS_OK;
 }

@@ -8,7 +8,7 @@
 #define RSIS_ERR_LAUNCH 2
 #define RSIS_ERR_UNSUPPORTED 3
 
-#define RSIS_BK 16          // K-tile depth of the implicit-GEMM kernels (fwd / dgrad)
+#define RSIS_KPAD 32        // packed-weight K axis is zero-padded to a multiple of this (BK of every kernel divides it)
 #define RSIS_LDW_ALIGN 128  // packed-weight row stride is a multiple of this many floats
 #define RSIS_MAX_SRC 3      // channel-concatenated sources / split destinations per conv
 
@@ -30,12 +30,12 @@ __device__ __forceinline__ float rsis_sigmoid(float x) { return 1.0f / (1.0f + e
 struct ConvArgs {
   const float* src[RSIS_MAX_SRC];  // gathered tensors, each [B][C[s]][H][W]
   int C[RSIS_MAX_SRC];
-  int ktiles[RSIS_MAX_SRC];        // K-tiles per source segment (= ceil(C*ks*ks / BK))
   int nsrc;
+  int K;                           // sum(C[0..nsrc-1]) * ks * ks  (rows of the packed weights actually walked)
   int B, H, W;                     // gathered-tensor geometry
   int Ho, Wo;                      // output geometry
   int stride, pad, sshift;         // sshift = log2(stride) (dgrad mode)
-  const float* wp;                 // packed weights [sum(ktiles)*BK][ldw]
+  const float* wp;                 // packed weights [roundup(Ktot, RSIS_KPAD)][ldw]
   int ldw;
   int Cout;                        // real number of output rows
   const float* bias;               // [Cout] (packed row order) or null

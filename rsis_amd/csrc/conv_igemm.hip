@@ -5,21 +5,19 @@
 //   * skip convs, conv_out, ResNet-101 trunk convs                     (src/modules/model.py:43-47,109; vision.py:12-19) -> EPI_PLAIN
 //   * the data-gradient of all of them (DGRAD gather mode)
 //
-// GEMM view:  D[co][px] = sum_k Wp[k][co] * Xcol[k][px]
+// GEMM view:  D[co][px] = sum_k Wp[k][co] * Xcol[k][px],  k = (ci over the channel concat, r, s)
 //   MFMA "A" operand = packed weights (rows = output channels), "B" operand = gathered pixels, so that the
 //   accumulator tile is [co][px] with px = lane&31: stores are coalesced along W in NCHW, and (with
 //   gate-interleaved weight rows 4*j+gate) one lane holds i,f,o,g of the same hidden channel/pixel in
 //   acc[4*r4 .. 4*r4+3], so the whole LSTM cell update happens in registers.
-//   Channel concat (torch.cat at clstm.py:43 / model.py:153) is "by pointer": up to 3 source tensors, each owning
-//   a BK-aligned segment of the packed K axis.
+//   Channel concat (torch.cat at clstm.py:43 / model.py:153) is "by pointer": up to 3 source tensors; the source of a
+//   K row is picked with scalar compares on the (wave-uniform) row index.
 //   LDS tiles are k-major ([BK][BM] / [BK][BN]) so every ds_read_b32 of an MFMA operand is conflict-free.
 #include "common.h"
 
-#define BK RSIS_BK
-
 enum { EPI_PLAIN = 0, EPI_LSTM = 1 };
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool DGRAD, int EPI>
+template <int BM, int BN, int BK, int WGM, int WGN, int KS, bool DGRAD, int EPI>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int KK = KS * KS;
@@ -29,6 +27,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int A_LOADS = (A_F4 + 255) / 256;
   static_assert(WGM * WGN == 4, "4 waves per block");
   static_assert(BN == 64 || BN == 128 || BN == 256, "BN");
+  static_assert(RSIS_KPAD % BK == 0, "BK must divide the packed K padding");
 
   __shared__ __attribute__((aligned(16))) float lds[2 * BK * (BM + BN)];
   float* As0 = lds;                 // [2][BK][BM]
@@ -62,6 +61,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   if (!DGRAD) { hi0 = pho * p.stride - p.pad; wi0 = pwo * p.stride - p.pad; }
   else        { hi0 = pho + p.pad;            wi0 = pwo + p.pad; }
   const int smask = (1 << p.sshift) - 1;
+  // channel bounds of the concat segments (scalar)
+  const int cb1 = p.C[0], cb2 = p.C[0] + p.C[1], cb3 = cb2 + p.C[2];
+  const int pbHW = pb * HW;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -74,23 +76,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   float rb[B_LOADS];
   f32x4 ra[A_LOADS];
 
-  int ntiles = 0;
-  for (int s = 0; s < p.nsrc; ++s) ntiles += p.ktiles[s];
+  const int ntiles = (p.K + BK - 1) / BK;
 
-  int seg = 0, lt = 0;  // scalar K-tile cursor: source segment / tile within the segment
-
-  auto load_tile = [&](int gt) {
-    const float* __restrict__ src = p.src[seg];
-    const int Cs = p.C[seg];
-    const int k0 = lt * BK + krow0;
-    const int bbase = pb * Cs * HW;
+  auto load_tile = [&](int t) {
+    const int k0 = t * BK + krow0;
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
       const int kl = k0 + i * B_ROWS;  // wave-uniform
-      const int ci = kl / KK;
-      const int rs = kl - ci * KK;
+      const int cg = kl / KK;           // channel index in the concat
+      const int rs = kl - cg * KK;
       const int r = rs / KS, s = rs - r * KS;
-      bool ok = pxv && (ci < Cs);
+      // source segment of this K row (scalar selects)
+      const float* __restrict__ src = p.src[0];
+      int Cs = p.C[0], ci = cg;
+      if (cg >= cb1) { src = p.src[1]; Cs = p.C[1]; ci = cg - cb1; }
+      if (cg >= cb2) { src = p.src[2]; Cs = p.C[2]; ci = cg - cb2; }
+      bool ok = pxv && (cg < cb3);
       int ih, iw;
       if (!DGRAD) {
         ih = hi0 + r; iw = wi0 + s;
@@ -101,10 +102,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         ih = th >> p.sshift; iw = tw >> p.sshift;
         ok = ok && (ih < p.H) && (iw < p.W);
       }
-      const int off = bbase + ci * HW + ih * p.W + iw;
+      const int off = pbHW * Cs + ci * HW + ih * p.W + iw;
       rb[i] = ok ? src[off] : 0.f;
     }
-    const float* __restrict__ wrow = p.wp + (size_t)gt * BK * p.ldw + co_t * BM;
+    const float* __restrict__ wrow = p.wp + (size_t)t * BK * p.ldw + co_t * BM;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       const int idx = tid + i * 256;
@@ -113,8 +114,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         ra[i] = *reinterpret_cast<const f32x4*>(wrow + (size_t)row * p.ldw + c4 * 4);
       }
     }
-    // advance the cursor
-    if (++lt == p.ktiles[seg]) { lt = 0; ++seg; }
   };
 
   auto store_tile = [&](int buf) {
@@ -224,35 +223,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 // ------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int KS, bool DGRAD, int EPI>
+template <int BM, int BN, int BK, int WGM, int WGN, int KS, bool DGRAD, int EPI>
 static int launch_cfg(ConvArgs& a, hipStream_t st) {
   const long Npx = (long)a.B * a.Ho * a.Wo;
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
   a.n_px_tiles = rsis_cdiv(Npx, BN);
   const int grid = a.n_co_tiles * 8 * rsis_cdiv(a.n_px_tiles, 8);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, KS, DGRAD, EPI>), dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, KS, DGRAD, EPI>), dim3(grid), dim3(256), 0, st, a);
   return rsis_check_launch();
 }
 
-// Tile selection: the widest co tile the layer fills, then the px tile that still gives >= ~1 block per CU.
+// tile codes: 1 = 32x256, 2 = 32x128, 3 = 64x128, 4 = 128x128, 5 = 64x64, 6 = 128x64 (co x px); +10 selects BK=32
 template <int KS, bool DGRAD, int EPI>
 static int launch_ks(ConvArgs& a, hipStream_t st, int force_tile) {
   const long Npx = (long)a.B * a.Ho * a.Wo;
   int tile = force_tile;
   if (tile <= 0) {
-    if (a.Cout <= 32) tile = (Npx >= 256L * 256) ? 1 : 2;                 // 32x256 / 32x128
-    else if (a.Cout <= 64) tile = 3;                                      // 64x128
+    if (a.Cout <= 32) tile = (Npx >= 256L * 256) ? 1 : 2;
+    else if (a.Cout <= 64) tile = 3;
     else {
       const long b128 = (long)rsis_cdiv(a.Cout, 128) * rsis_cdiv(Npx, 128);
-      tile = (b128 >= 200) ? 4 : 5;                                       // 128x128 / 64x64
+      tile = (b128 >= 200) ? 4 : ((b128 >= 100) ? 6 : 5);
     }
+    tile += 10;   // BK = 32 by default
   }
   switch (tile) {
-    case 1: return launch_cfg<32, 256, 1, 4, KS, DGRAD, EPI>(a, st);
-    case 2: return launch_cfg<32, 128, 1, 4, KS, DGRAD, EPI>(a, st);
-    case 3: return launch_cfg<64, 128, 2, 2, KS, DGRAD, EPI>(a, st);
-    case 4: return launch_cfg<128, 128, 2, 2, KS, DGRAD, EPI>(a, st);
-    case 5: return launch_cfg<64, 64, 2, 2, KS, DGRAD, EPI>(a, st);
+    case 1: return launch_cfg<32, 256, 16, 1, 4, KS, DGRAD, EPI>(a, st);
+    case 2: return launch_cfg<32, 128, 16, 1, 4, KS, DGRAD, EPI>(a, st);
+    case 3: return launch_cfg<64, 128, 16, 2, 2, KS, DGRAD, EPI>(a, st);
+    case 4: return launch_cfg<128, 128, 16, 2, 2, KS, DGRAD, EPI>(a, st);
+    case 5: return launch_cfg<64, 64, 16, 2, 2, KS, DGRAD, EPI>(a, st);
+    case 6: return launch_cfg<128, 64, 16, 2, 2, KS, DGRAD, EPI>(a, st);
+    case 11: return launch_cfg<32, 256, 32, 1, 4, KS, DGRAD, EPI>(a, st);
+    case 12: return launch_cfg<32, 128, 32, 1, 4, KS, DGRAD, EPI>(a, st);
+    case 13: return launch_cfg<64, 128, 32, 2, 2, KS, DGRAD, EPI>(a, st);
+    case 14: return launch_cfg<128, 128, 32, 2, 2, KS, DGRAD, EPI>(a, st);
+    case 15: return launch_cfg<64, 64, 32, 2, 2, KS, DGRAD, EPI>(a, st);
+    case 16: return launch_cfg<128, 64, 32, 2, 2, KS, DGRAD, EPI>(a, st);
     default: return RSIS_ERR_ARG;
   }
 }

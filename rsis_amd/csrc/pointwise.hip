@@ -7,31 +7,18 @@
 // ------------------------------------------------------------------------------------------------
 // weight repacking (private layouts; never serialised)
 // ------------------------------------------------------------------------------------------------
-// FWD:   Wp[kbase_s + ci_l*KK + rs][co_p] = W[ref(co_p)][c0_s + ci_l][rs]     (zero in K / Cout padding)
-// DGRAD: Wd[co_p*KK + rs][ci - c_lo]      = W[ref(co_p)][ci][rs]
+// FWD:   Wp[ci*KK + rs][co_p]     = W[ref(co_p)][ci][rs]      (zero in the K / Cout padding)
+// DGRAD: Wd[co_p*KK + rs][ci-c_lo] = W[ref(co_p)][ci][rs]
 // ref(co_p) = (co_p&3)*hid + (co_p>>2) for gate-interleaved ConvLSTM rows, identity otherwise.
-__global__ void pack_fwd_kernel(const float* __restrict__ W, float* __restrict__ Wp, int Cout, int Ctot, int KK,
-                                int nseg, int c0, int c1, int c2, int ldw, int krows, int hid) {
+__global__ void pack_fwd_kernel(const float* __restrict__ W, float* __restrict__ Wp, int Cout, int Ctot, int KK, int ldw,
+                                int krows, int hid) {
   const long total = (long)krows * ldw;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int k = (int)(e / ldw), cop = (int)(e - (long)k * ldw);
     float v = 0.f;
-    if (cop < Cout) {
-      const int Cs[3] = {c0, c1, c2};
-      int kb = 0, cb = 0;
-      for (int s = 0; s < nseg; ++s) {
-        const int kt = ((Cs[s] * KK + RSIS_BK - 1) / RSIS_BK) * RSIS_BK;
-        if (k < kb + kt) {
-          const int kl = k - kb;
-          if (kl < Cs[s] * KK) {
-            const int ci = kl / KK, rs = kl - ci * KK;
-            const int co = hid > 0 ? (cop & 3) * hid + (cop >> 2) : cop;
-            v = W[((long)co * Ctot + cb + ci) * KK + rs];
-          }
-          break;
-        }
-        kb += kt; cb += Cs[s];
-      }
+    if (cop < Cout && k < Ctot * KK) {
+      const int co = hid > 0 ? (cop & 3) * hid + (cop >> 2) : cop;
+      v = W[(long)co * Ctot * KK + k];
     }
     Wp[e] = v;
   }
@@ -110,23 +97,35 @@ __global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
-// dx must be zero-filled by the caller (the C entry point does it)
+// backward as a GATHER (no atomics, deterministic): dx[hi][wi] = sum over the few output pixels whose 2x2 stencil touches
+// (hi, wi).  Membership is decided by re-evaluating ac_coord for every candidate, so it is bit-consistent with the forward.
 __global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Hi, int Wi, int Ho, int Wo,
                                     float sh, float sw, long total) {
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int wo = (int)(e % Wo);
-    const long t = e / Wo;
-    const int ho = (int)(t % Ho);
-    const long bc = t / Ho;
-    int h0, h1, w0, w1; float lh, lw;
-    ac_coord(ho, sh, Hi, h0, h1, lh);
-    ac_coord(wo, sw, Wi, w0, w1, lw);
-    const float g = dy[e];
-    float* xb = dx + bc * Hi * Wi;
-    atomicAdd(xb + h0 * Wi + w0, (1.f - lh) * (1.f - lw) * g);
-    atomicAdd(xb + h0 * Wi + w1, (1.f - lh) * lw * g);
-    atomicAdd(xb + h1 * Wi + w0, lh * (1.f - lw) * g);
-    atomicAdd(xb + h1 * Wi + w1, lh * lw * g);
+    const int wi = (int)(e % Wi);
+    const long t = e / Wi;
+    const int hi = (int)(t % Hi);
+    const long bc = t / Hi;
+    int ho_lo = 0, ho_hi = Ho - 1, wo_lo = 0, wo_hi = Wo - 1;
+    if (sh > 0.f) { ho_lo = max(0, (int)floorf((hi - 1) / sh) - 1); ho_hi = min(Ho - 1, (int)ceilf((hi + 1) / sh) + 1); }
+    if (sw > 0.f) { wo_lo = max(0, (int)floorf((wi - 1) / sw) - 1); wo_hi = min(Wo - 1, (int)ceilf((wi + 1) / sw) + 1); }
+    const float* yb = dy + bc * Ho * Wo;
+    float acc = 0.f;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      int h0, h1; float lh;
+      ac_coord(ho, sh, Hi, h0, h1, lh);
+      const float wh = (h0 == hi ? 1.f - lh : 0.f) + (h1 == hi ? lh : 0.f);
+      if (wh == 0.f) continue;
+      float row = 0.f;
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        int w0, w1; float lw;
+        ac_coord(wo, sw, Wi, w0, w1, lw);
+        const float ww = (w0 == wi ? 1.f - lw : 0.f) + (w1 == wi ? lw : 0.f);
+        if (ww != 0.f) row += ww * yb[ho * Wo + wo];
+      }
+      acc += wh * row;
+    }
+    dx[e] = acc;
   }
 }
 
@@ -377,11 +376,9 @@ static inline int chan_splits(int C, long N) {
   return (int)s;
 }
 
-int rsis_l_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int nseg, const int* Cseg, int ldw, int krows,
-                    int hid, hipStream_t st) {
+int rsis_l_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int ldw, int krows, int hid, hipStream_t st) {
   const long total = (long)krows * ldw;
-  hipLaunchKernelGGL(pack_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, W, Wp, Cout, Ctot, ks * ks, nseg, Cseg[0],
-                     nseg > 1 ? Cseg[1] : 0, nseg > 2 ? Cseg[2] : 0, ldw, krows, hid);
+  hipLaunchKernelGGL(pack_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, W, Wp, Cout, Ctot, ks * ks, ldw, krows, hid);
   return rsis_check_launch();
 }
 int rsis_l_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int c_lo, int c_hi, int ldw, int krows, int hid,
@@ -406,8 +403,7 @@ int rsis_l_upsample_fwd(const float* x, float* y, long BC, int Hi, int Wi, int H
   return rsis_check_launch();
 }
 int rsis_l_upsample_bwd(const float* dy, float* dx, long BC, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
-  if (hipMemsetAsync(dx, 0, sizeof(float) * BC * Hi * Wi, st) != hipSuccess) return RSIS_ERR_LAUNCH;
-  const long total = BC * Ho * Wo;
+  const long total = BC * Hi * Wi;
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, ac_scale(Hi, Ho),
                      ac_scale(Wi, Wo), total);
   return rsis_check_launch();

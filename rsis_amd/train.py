@@ -1,0 +1,325 @@
+"""Training driver -- python-3 / MI355X counterpart of reference src/train.py (which is Python-2 only).
+
+`runIter` keeps the reference's signature and return value (train.py:54-197) and reproduces its arithmetic
+(SURVEY.md section 8(a) row R9 / Appendix E), restructured for one-process-per-GPU execution:
+  * ONE host sync up front for the early-stop rule instead of one per timestep (train.py:91),
+  * the all-pairs soft-IoU score matrix is one batched contraction after the T decoder steps instead of a
+    gt_T-fold `repeat` per step + a D2H copy per step (train.py:102-110),
+  * the Hungarian assignment runs on ONE D2H copy of the (B, gt_T, T) scores; GT masks are permuted on the device
+    (the reference moves every GT mask to the host and back: hungarian.py:110-111, train.py:140-145),
+  * masked means are computed as sum(c*sw)/sum(sw) (no data-dependent-size masked_select => no sync),
+  * gradients are all-reduced by bucketed RCCL collectives overlapped with the encoder backward (rsis_amd/optim.py)
+    instead of nn.DataParallel replication (train.py:269-274).
+Launch: `python -m rsis_amd.train --synthetic ...` or `torchrun --nproc_per_node=8 -m rsis_amd.train ...`.
+"""
+import os
+import pickle
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .args import get_parser
+from .modules.model import RSIS, FeatureExtractor
+from .optim import BucketedAllReduce, FlatAdam
+from .synthetic import SyntheticLoader
+from .utils.hungarian import match_indices, softIoU_matrix
+from .utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+from .utils.utils import (check_parallel, get_base_params, get_skip_params, load_checkpoint, make_dir, save_checkpoint)
+
+
+def _masked_mean(costs, sw):
+    """mean(masked_select(costs, sw)) for sw in {0,1} without a data-dependent shape (objectives.py:13,23,32)."""
+    sw = sw.reshape(costs.shape).to(costs.dtype)
+    return torch.where(sw > 0, costs, torch.zeros_like(costs)).sum() / sw.sum()
+
+
+def steps_to_run(args, sw_mask):
+    """train.py:80-92: T (curriculum-capped); step t still runs when sw_mask[:, t] is all zero, the next does not."""
+    T = args.maxseqlen
+    if getattr(args, "curriculum_learning", False):
+        T = min(args.maxseqlen, args.limit_seqlen_to)
+    empty = (sw_mask[:, :T].sum(0) == 0).cpu().numpy()      # the ONE early-stop sync of the iteration
+    idx = np.nonzero(empty)[0]
+    return T if len(idx) == 0 else int(idx[0]) + 1
+
+
+def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits, optims, mode="train", reducer=None,
+            sync_losses=True):
+    """Runs forward, computes loss and (if train mode) updates parameters for the provided batch (train.py:54-197).
+    Returns (losses [total, iou, stop, class], outs [sigmoid(masks), class probs], perms [y_mask_perm, y_class_perm])."""
+    from .utils.hungarian import MaskedNLL, StableBalancedMaskedBCE, softIoU
+    mask_siou, class_crit, stop_xentropy = crits
+    enc_opt, dec_opt = optims
+    train = mode == "train"
+    encoder.train(train)                                             # train.py:71-76
+    decoder.train(train)
+    y_mask = y_mask.float()
+    sw_mask = sw_mask.float()
+    sw_class = sw_class.float()
+    t_run = steps_to_run(args, sw_mask)
+
+    hidden = None
+    out_masks, out_classes, out_stops = [], [], []
+    with torch.set_grad_enabled(train):
+        feats = encoder(x)                                           # train.py:77 (once per iteration)
+        for _t in range(t_run):                                      # train.py:85
+            out_mask, out_class, out_stop, hidden = decoder(feats, hidden)                  # :94
+            out_mask = ops.upsample_bilinear_ac(out_mask, (x.size(-2), x.size(-1)))         # :96-97
+            out_masks.append(out_mask.reshape(out_mask.size(0), -1))                        # :98
+            out_classes.append(out_class)
+            out_stops.append(out_stop)
+        t = len(out_masks)                                           # :117
+        out_masks = torch.stack(out_masks, 1)                        # (B, t, N)   :118
+        out_classes = torch.stack(out_classes, 1)                    # (B, t, C)   :119
+        out_stops = torch.stack(out_stops, 1)                        # (B, t, 1)   :120
+
+    # ---- scores + matching (no grad) : train.py:78,102-110,127-137 ----
+    with torch.no_grad():
+        scores = torch.ones(y_mask.size(0), args.gt_maxseqlen, args.maxseqlen, device=x.device)
+        scores[:, :, :t] = args.iou_weight * softIoU_matrix(y_mask, out_masks)
+        valid = (sw_mask.unsqueeze(-1) * sw_mask[:, 0:args.maxseqlen].unsqueeze(1) > 0).float()   # :127-130
+        scores = scores * valid + (1 - valid) * 10                                                 # :131
+        perm = torch.from_numpy(match_indices(scores)).to(x.device)                               # :137 (ONE D2H)
+        idx = perm[:, 0:t]
+        y_mask_perm = torch.gather(y_mask, 1, idx.unsqueeze(-1).expand(-1, -1, y_mask.size(2)))   # :140
+        y_class_perm = torch.gather(y_class, 1, idx)                                               # :141
+    sw_mask_t = sw_mask[:, 0:t].contiguous()                         # :147
+    sw_class_t = sw_class[:, 0:t].contiguous()                       # :148
+
+    # ---- losses : train.py:159-176 (masked means) ----
+    with torch.set_grad_enabled(train):
+        N, C = out_masks.size(-1), out_classes.size(-1)
+        nll = MaskedNLL(y_class_perm.reshape(-1, 1), out_classes.reshape(-1, C), getattr(class_crit, "balance_weight", None))
+        loss_class = _masked_mean(nll.reshape(-1, 1), sw_mask_t.reshape(-1, 1))                   # :159-161
+        siou = softIoU(y_mask_perm.reshape(-1, N), out_masks.reshape(-1, N))
+        loss_mask_iou = _masked_mean(siou.reshape(-1, 1), sw_mask_t.reshape(-1, 1))               # :162-163
+        bce = StableBalancedMaskedBCE(sw_mask_t, out_stops.squeeze(-1), getattr(stop_xentropy, "balance_weight", None))
+        loss_stop = _masked_mean(bce.reshape(-1, 1), sw_class_t.reshape(-1, 1))                   # :167-168
+        loss = args.iou_weight * loss_mask_iou                                                      # :171
+        if args.use_class_loss:
+            loss = loss + args.class_weight * loss_class                                            # :173-174
+        if args.use_stop_loss:
+            loss = loss + args.stop_weight * loss_stop                                              # :175-176
+
+    enc_opt.zero_grad()                                               # :178-181
+    dec_opt.zero_grad()
+    if train:
+        if reducer is not None:
+            reducer.reset()
+        loss.backward()                                               # :184
+        gscale = reducer.finish() if reducer is not None else 1.0
+        dec_opt.gscale = gscale
+        enc_opt.gscale = gscale
+        dec_opt.step()                                                # :185
+        if args.update_encoder:
+            enc_opt.step()                                            # :186-187
+
+    losses = [loss.detach(), loss_mask_iou.detach(), loss_stop.detach(), loss_class.detach()]
+    if sync_losses:
+        losses = [float(v) for v in torch.stack(losses).cpu()]        # :189 (one D2H for all four)
+    outs = [torch.sigmoid(out_masks.detach()), out_classes.detach()]  # :191-192
+    perms = [y_mask_perm, y_class_perm]
+    return losses, outs, perms
+
+
+# --------------------------------------------------------------------------------------------------
+def init_distributed():
+    """one process per GPU; torchrun provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def build_optimizers(args, encoder, decoder):
+    """train.py:236-240: dec_opt = decoder + skip convs/BNs (lr), enc_opt = trunk (lr_cnn).  Fused flat Adam.
+    The reference's get_base_params yields trunk tensors 1-4 times, i.e. an effective 1x/3x/4x
+    lr_cnn; that quirk is NOT reproduced here (each tensor is stepped once)."""
+    if args.optim != "adam" or args.optim_cnn != "adam":
+        raise Exception("only -optim adam / -optim_cnn adam run on the fused HIP optimizer")
+    decoder_params = list(decoder.parameters()) + list(get_skip_params(encoder))
+    dec_opt = FlatAdam(decoder_params, lr=args.lr, weight_decay=args.weight_decay, name="dec")
+    enc_opt = FlatAdam(list(get_base_params(args, encoder)), lr=args.lr_cnn, weight_decay=args.weight_decay_cnn, name="enc")
+    return enc_opt, dec_opt
+
+
+def init_dataloaders(args, rank=0):
+    if not getattr(args, "synthetic", False):
+        raise Exception("only --synthetic data is wired in this build (the dataset readers of the reference's "
+                        "src/dataloader are host-side I/O outside the hot path: SURVEY.md section 8(f) row N3)")
+    loaders = {"train": SyntheticLoader(args, args.synthetic_batches, args.seed, rank=rank),
+               "val": SyntheticLoader(args, max(1, args.synthetic_batches // 4), args.seed + 7, rank=rank)}
+    return loaders, ["<eos>"] + ["class%d" % i for i in range(1, args.num_classes)]
+
+
+def trainIters(args):
+    rank, _local_rank, world = init_distributed()
+    epoch_resume = 0
+    model_dir = os.path.join(args.models_root, args.model_name)
+    enc_opt_dict = dec_opt_dict = None
+    if args.resume:                                                       # train.py:204-215
+        encoder_dict, decoder_dict, enc_opt_dict, dec_opt_dict, load_args = load_checkpoint(args.model_name, args.use_gpu,
+                                                                                            root=args.models_root)
+        epoch_resume = load_args.epoch_resume
+        encoder, decoder = FeatureExtractor(load_args), RSIS(load_args)
+        encoder_dict, decoder_dict = check_parallel(encoder_dict, decoder_dict)
+        encoder.load_state_dict(encoder_dict)
+        decoder.load_state_dict(decoder_dict)
+        for k in ("synthetic", "synthetic_batches", "synthetic_instances", "models_root", "max_epoch", "log_term"):
+            setattr(load_args, k, getattr(args, k))
+        args = load_args
+    elif args.transfer:                                                   # train.py:217-224
+        encoder_dict, decoder_dict, enc_opt_dict, dec_opt_dict, load_args = load_checkpoint(args.transfer_from, args.use_gpu,
+                                                                                            root=args.models_root)
+        encoder, decoder = FeatureExtractor(load_args), RSIS(load_args)
+        encoder_dict, decoder_dict = check_parallel(encoder_dict, decoder_dict)
+        encoder.load_state_dict(encoder_dict)
+        decoder.load_state_dict(decoder_dict)
+        if load_args.num_classes != args.num_classes:                     # train.py:249-251: new classification head
+            decoder.fc_class = torch.nn.Linear(decoder.fc_class.weight.size(1), args.num_classes)
+            decoder.num_classes = args.num_classes
+    else:
+        encoder, decoder = FeatureExtractor(args), RSIS(args)             # train.py:227-228
+    if not args.use_gpu:
+        raise Exception("--cpu: this build has no CPU path (the HIP library is the product)")
+    encoder.cuda()
+    decoder.cuda()
+    if world > 1:                                                         # identical replicas
+        for p in list(encoder.parameters()) + list(decoder.parameters()) + list(encoder.buffers()):
+            dist.broadcast(p.data, 0)
+    if rank == 0:
+        make_dir(args.models_root)
+        make_dir(model_dir)
+        pickle.dump(args, open(os.path.join(model_dir, "args.pkl"), "wb"))   # train.py:234
+    enc_opt, dec_opt = build_optimizers(args, encoder, decoder)
+    if (args.resume or args.transfer) and enc_opt_dict is not None and "exp_avg" in enc_opt_dict:
+        enc_opt.load_state_dict(enc_opt_dict)
+        if not (args.transfer and dec_opt_dict["exp_avg"].numel() != dec_opt.group.exp_avg.numel()):
+            dec_opt.load_state_dict(dec_opt_dict)
+    reducer = BucketedAllReduce([dec_opt.group, enc_opt.group]) if world > 1 else None
+    if not args.log_term and rank == 0:                                   # train.py:253-256
+        print("Training logs will be saved to:", os.path.join(model_dir, "train.log"))
+        sys.stdout = open(os.path.join(model_dir, "train.log"), "w")
+        sys.stderr = open(os.path.join(model_dir, "train.err"), "w")
+    if rank == 0:
+        print(args)
+    crits = [softIoULoss(), MaskedNLLLoss(balance_weight=None), MaskedBCELoss(balance_weight=args.stop_balance_weight)]
+    optims = [enc_opt, dec_opt]
+    torch.cuda.synchronize()
+    start = time.time()
+    best_val_loss = args.best_val_loss
+    acc_patience = 0
+    mt_val = -1
+    if args.curriculum_learning and epoch_resume == 0:
+        args.limit_seqlen_to = 2                                          # train.py:299-300
+    loaders, _class_names = init_dataloaders(args, rank)
+
+    def reload_best():                                                    # train.py:456-460 etc.
+        e_d, d_d, eo, do, _ = load_checkpoint(args.model_name, args.use_gpu, root=args.models_root)
+        encoder.load_state_dict(e_d)
+        decoder.load_state_dict(d_d)
+        enc_opt.load_state_dict(eo)
+        dec_opt.load_state_dict(do)
+        ops.bump_weight_epoch()
+
+    for e in range(args.max_epoch):
+        if rank == 0:
+            print("Epoch", e + epoch_resume)
+        epoch_losses = {s: {"total": [], "iou": [], "stop": [], "class": []} for s in ("train", "val")}
+        ep = e + epoch_resume
+        if ep >= args.finetune_after and not args.update_encoder and not args.finetune_after == -1:     # :313-318
+            print("Starting to update encoder")
+            args.update_encoder = True
+            acc_patience, mt_val = 0, -1
+        if ep >= args.class_loss_after and not args.use_class_loss and not args.class_loss_after == -1:  # :319-324
+            print("Starting to learn class loss")
+            args.use_class_loss = True
+            best_val_loss, acc_patience, mt_val = 1000, 0, -1
+        if ep >= args.stop_loss_after and not args.use_stop_loss and not args.stop_loss_after == -1:     # :325-339
+            if (not args.curriculum_learning) or args.limit_seqlen_to > args.min_steps:
+                print("Starting to learn stop loss")
+                args.use_stop_loss = True
+                best_val_loss, acc_patience, mt_val = 1000, 0, -1
+        for split in ("train", "val"):                                    # :341
+            n_img, t_split = 0, time.time()
+            for batch_idx, (x, y_mask, y_class, sw_mask, sw_class) in enumerate(loaders[split]):
+                losses, _outs, _perm = runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits, optims,
+                                               mode=split, reducer=reducer, sync_losses=False)
+                for k, v in zip(("total", "iou", "stop", "class"), losses):
+                    epoch_losses[split][k].append(v)
+                n_img += x.size(0) * world
+                if (batch_idx + 1) % args.print_every == 0:               # :360-401
+                    m = {k: float(torch.stack(v).mean()) for k, v in epoch_losses[split].items()}
+                    torch.cuda.synchronize()
+                    te = time.time() - start
+                    if rank == 0:
+                        print("iter %d:\ttotal:%.4f\tclass:%.4f\tiou:%.4f\tstop:%.4f\ttime:%.4f\timg/s:%.1f"
+                              % (batch_idx, m["total"], m["class"], m["iou"], m["stop"], te,
+                                 args.print_every * x.size(0) * world / max(te, 1e-9)))
+                    start = time.time()
+            m = {k: float(torch.stack(v).mean()) for k, v in epoch_losses[split].items()}
+            if world > 1:                                                 # epoch means over all ranks
+                tv = torch.tensor([m["total"], m["iou"], m["stop"], m["class"]], device="cuda")
+                dist.all_reduce(tv)
+                m = dict(zip(("total", "iou", "stop", "class"), (tv / world).tolist()))
+            mt = m["total"]
+            if split == "val" and args.smooth_curves:                     # :406-411
+                mt = mt if mt_val == -1 else 0.9 * mt_val + 0.1 * mt
+                mt_val = mt
+            args.epoch_resume = ep
+            if rank == 0:
+                print("Epoch %d:\ttotal:%.4f\tclass:%.4f\tiou:%.4f\tstop:%.4f\t(%s)" % (e, mt, m["class"], m["iou"], m["stop"], split))
+        if mt < (best_val_loss - args.min_delta):                         # :440-446
+            best_val_loss = mt
+            args.best_val_loss = best_val_loss
+            if rank == 0:
+                print("Saving checkpoint.")
+                save_checkpoint(args, encoder, decoder, enc_opt, dec_opt, root=args.models_root)
+            if world > 1:
+                dist.barrier()
+            acc_patience = 0
+        else:
+            acc_patience += 1
+        if acc_patience > args.patience and not args.use_class_loss and not args.class_loss_after == -1:   # :450-460
+            print("Starting to learn class loss")
+            acc_patience, args.use_class_loss, best_val_loss, mt_val = 0, True, 1000, -1
+            reload_best()
+        if acc_patience > args.patience and args.curriculum_learning and args.limit_seqlen_to < args.maxseqlen:  # :461-467
+            acc_patience = 0
+            args.limit_seqlen_to += args.steps_cl
+            print("Adding one step more:", args.limit_seqlen_to)
+            best_val_loss, mt_val = 1000, -1
+        if acc_patience > args.patience and not args.update_encoder and not args.finetune_after == -1:     # :469-479
+            print("Starting to update encoder")
+            acc_patience, args.update_encoder, best_val_loss, mt_val = 0, True, 1000, -1
+            reload_best()
+        if acc_patience > args.patience and not args.use_stop_loss and not args.stop_loss_after == -1:     # :480-499
+            if (not args.curriculum_learning) or args.limit_seqlen_to > args.min_steps:
+                print("Starting to learn stop loss")
+                acc_patience, args.use_stop_loss, best_val_loss, mt_val = 0, True, 1000, -1
+            reload_best()
+        if acc_patience > args.patience_stop:                             # :501-502
+            break
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    parser = get_parser()
+    args = parser.parse_args()
+    torch.manual_seed(args.seed)                                          # train.py:509-513
+    random.seed(args.seed)
+    if args.use_gpu and torch.cuda.is_available():
+        torch.cuda.manual_seed(args.seed)
+    trainIters(args)

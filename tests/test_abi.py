@@ -41,9 +41,9 @@ def test_version_and_error_strings():
 def test_packed_size_queries():
     L = _lib.lib()
     segs = _lib.int_array([16, 16, 8])
-    # K segments 144,144,72 -> 9+9+5 tiles of 16 rows; Cout 32 -> row stride 128
-    assert L.rsis_conv_packed_floats_fwd(32, 3, 3, segs) == (9 + 9 + 5) * 16 * 128
-    assert L.rsis_conv_packed_floats_dgrad(32, 3, 40) == 18 * 16 * 128
+    # K = 40*9 = 360 -> 384 rows (multiple of 32); Cout 32 -> row stride 128
+    assert L.rsis_conv_packed_floats_fwd(32, 3, 3, segs) == 384 * 128
+    assert L.rsis_conv_packed_floats_dgrad(32, 3, 40) == 288 * 128
 
 
 def test_product_has_no_cpu_path():

@@ -1,0 +1,133 @@
+"""CPU tests of the multi-GPU path (one process per GPU, gradient all-reduce in buckets): world_size 2 over gloo.
+The data path shards the batch with no collective; the only exchange is the bucketed SUM all-reduce of the flat
+gradient buffers (rsis_amd/optim.py), whose 1/world scaling is folded into the Adam kernel."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rsis_amd.optim import BucketedAllReduce, FlatGroup
+    torch.manual_seed(0)                       # identical replicas
+    dec = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    enc = torch.nn.Sequential(torch.nn.Linear(4, 7), torch.nn.Linear(7, 7), torch.nn.Linear(7, 7))
+    unused = torch.nn.Linear(3, 3)             # e.g. fc_class while its loss is off: never receives a gradient
+    g_dec = FlatGroup(list(dec.parameters()) + list(unused.parameters()), lr=1e-3, name="dec")
+    g_enc = FlatGroup(list(enc.parameters()), lr=1e-6, name="enc")
+    red = BucketedAllReduce([g_dec, g_enc], bucket_bytes=200)     # tiny buckets -> several per group
+    assert len(red.buckets) >= 4
+    # per-rank shard of a global batch of 6 samples
+    torch.manual_seed(123)
+    X = torch.randn(6, 4)
+    shard = X[rank * 3:(rank + 1) * 3]
+    for it in range(2):
+        g_dec.zero_grad()
+        g_enc.zero_grad()
+        red.reset()
+        loss = dec(enc(shard)).square().mean()
+        loss.backward()
+        gscale = red.finish()
+        assert gscale == 1.0 / world
+    flat = torch.cat([g_dec.flat_g, g_enc.flat_g]) * gscale
+    # reference: single process, mean of the per-rank means == full-batch mean here (equal shard sizes)
+    torch.manual_seed(0)
+    dec2 = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    enc2 = torch.nn.Sequential(torch.nn.Linear(4, 7), torch.nn.Linear(7, 7), torch.nn.Linear(7, 7))
+    dec2(enc2(X)).square().mean().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in dec2.parameters()] + [torch.zeros(12)] +
+                    [p.grad.reshape(-1) for p in enc2.parameters()])
+    q.put((rank, float((flat - ref).abs().max()), flat.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] < 1e-6 and res[1][1] < 1e-6, res          # averaged grads == single-process full-batch grads
+    assert torch.equal(res[0][2], res[1][2])                     # and identical on both ranks
+
+
+def test_flatgroup_views_and_zero_grad():
+    from rsis_amd.optim import FlatGroup
+    lin = torch.nn.Linear(3, 2)
+    w0 = lin.weight.detach().clone()
+    g = FlatGroup(list(lin.parameters()), lr=1e-3)
+    assert torch.equal(lin.weight.detach(), w0)                  # values preserved, now views of one flat buffer
+    assert lin.weight.data_ptr() == g.flat_p.data_ptr()
+    lin(torch.ones(1, 3)).sum().backward()
+    assert float(g.flat_g.abs().sum()) > 0                       # autograd accumulated INTO the flat buffer
+    g.zero_grad()
+    assert float(g.flat_g.abs().sum()) == 0
+    with pytest.raises(RuntimeError):
+        g.step()                                                  # the fused Adam step is GPU-only: no CPU path
+
+
+def test_steps_to_run_early_stop_rule():
+    import argparse
+    from rsis_amd.train import steps_to_run
+    a = argparse.Namespace(maxseqlen=10, curriculum_learning=False)
+    sw = torch.zeros(2, 20)
+    sw[:, :4] = 1
+    assert steps_to_run(a, sw) == 5       # train.py:87-92: the first all-zero step still runs, the next does not
+    sw[:, :] = 1
+    assert steps_to_run(a, sw) == 10
+    a.curriculum_learning, a.limit_seqlen_to = True, 3
+    assert steps_to_run(a, sw) == 3       # train.py:80-81
+
+
+def test_host_loss_math_matches_golden():
+    """rsis_amd.utils.hungarian / objectives (the product's host-side mirrors) against the reference golden values."""
+    import numpy as np
+    from oracle import filler
+    from helpers import assert_close, gold
+    from rsis_amd.utils import hungarian as Hn
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    g = gold("losses")
+    B, G, T, N, C = 3, 20, 10, 96, 21
+    P = filler.tensor(55, "f5.P", (B * G, N), 2.0)
+    Y = (filler.tensor(55, "f5.Y", (B * G, N)) > 0.3).float()
+    probs = torch.softmax(filler.tensor(55, "f5.logits", (B * T, C)), 1)
+    tgt = torch.from_numpy(np.random.default_rng(55).integers(0, C, (B * T, 1)))
+    stop_logit = filler.tensor(55, "f5.stop", (B, T), 3.0)
+    stop_tgt = (filler.tensor(55, "f5.stopt", (B, T)) > 0).float()
+    sw = (filler.tensor(55, "f5.sw", (B * T, 1)) > -0.5).float()
+    assert_close("softIoU", Hn.softIoU(Y, P), g["softIoU"], 1e-6)
+    assert_close("MaskedNLL", Hn.MaskedNLL(tgt, probs), g["MaskedNLL"], 1e-6)
+    assert_close("BCE", Hn.StableBalancedMaskedBCE(stop_tgt, stop_logit, 0.5), g["BCE_bw05"], 1e-6)
+    assert_close("softIoULoss", softIoULoss()(Y[:B * T], P[:B * T], sw), g["softIoULoss"], 1e-6)
+    assert_close("MaskedNLLLoss", MaskedNLLLoss()(tgt, probs, sw), g["MaskedNLLLoss"], 1e-6)
+    assert_close("MaskedBCELoss", MaskedBCELoss(0.5)(stop_tgt, stop_logit, sw), g["MaskedBCELoss"], 1e-6)
+    # all-pairs score matrix == the reference's repeat + softIoU
+    Yb, Pb = Y.view(B, G, N), P.view(B, G, N)[:, :T]
+    M = Hn.softIoU_matrix(Yb, Pb)
+    ref = torch.stack([Hn.softIoU(Yb[b].repeat_interleave(T, 0), Pb[b].repeat(G, 1)).view(G, T) for b in range(B)])
+    assert_close("softIoU_matrix", M, ref, 1e-6)
+    scores = torch.from_numpy(np.random.default_rng(56).uniform(0, 1, (B, G, T))).float()
+    ym = (filler.tensor(56, "f5.ym", (B, G, N)) > 0).float()
+    yc = torch.from_numpy(np.random.default_rng(57).integers(0, C, (B, G)))
+    m, c, perm = Hn.match([ym, None], [yc, None], scores)
+    assert (perm == g["match_perm"]).all() and (c.numpy() == g["match_class"]).all()
+    assert np.allclose(m.sum(-1).numpy(), g["match_mask_sum"])
