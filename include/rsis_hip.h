@@ -11,8 +11,9 @@
  *     (a hipStream_t passed as void*; NULL = the default stream);
  *   - return value: 0 = OK, nonzero = error code (rsis_error_string); nothing throws across the ABI;
  *   - thread-safe / re-entrant per stream.
- *   - "packed" weights are a private MFMA-friendly copy ([K_pad][Cout_pad], K = (ci, r, s) zero-padded to a
- *     multiple of 32 rows, Cout to a multiple of 128 columns; ConvLSTM rows gate-interleaved 4*j+gate);
+ *   - "packed" weights are a private MFMA-friendly copy ([K rows][Cout padded to 128 columns]; K order and padding
+ *     depend on the kernel that consumes them: implicit-GEMM (k = ci,r,s padded to 32 rows) or direct 3x3 (8-channel
+ *     chunks per concat source, channel pairs interleaved per tap); ConvLSTM rows gate-interleaved 4*j+gate);
  *     they are rebuilt from the reference-layout weight ([Cout][Cin][k][k], gate order i,f,o,g) and never
  *     serialised.
  */
@@ -29,15 +30,16 @@ int rsis_version(void);
 const char* rsis_error_string(int code);
 
 /* ---- weight repacking (private cache of nn.Conv2d.weight; clstm.py:17, model.py:43-47,109, torchvision trunk) ---- */
-/* number of floats of the packed forward copy for a conv whose input is the channel concat of nseg tensors */
-long rsis_conv_packed_floats_fwd(int Cout, int ks, int nseg, const int* Cseg);
-/* number of floats of the packed dgrad copy producing input channels [c_lo, c_hi) */
-long rsis_conv_packed_floats_dgrad(int Cout, int ks, int c_count);
+/* number of floats of the packed forward copy for a conv whose input is the channel concat of nseg tensors.
+ * (ks, stride, pad) select the layout: 3x3/s1/p1 convs use the direct-kernel layout, everything else the implicit-GEMM one */
+long rsis_conv_packed_floats_fwd(int Cout, int ks, int stride, int pad, int nseg, const int* Cseg);
+/* number of floats of the packed dgrad copy producing c_count input channels */
+long rsis_conv_packed_floats_dgrad(int Cout, int ks, int stride, int pad, int c_count);
 /* lstm_hid > 0: rows of W are [i|f|o|g] x hid (clstm.py:47) and are interleaved to 4*j+gate */
-int rsis_conv_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int nseg, const int* Cseg, int lstm_hid,
-                       void* stream);
-int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int c_lo, int c_hi, int lstm_hid,
-                         void* stream);
+int rsis_conv_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
+                       int lstm_hid, void* stream);
+int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int stride, int pad, int c_lo, int c_hi,
+                         int lstm_hid, void* stream);
 
 /* ---- nn.Conv2d forward (model.py:59-63 skip convs, :167 conv_out, vision.py:12-19 trunk convs) ----
  * out[B][Cout][Ho][Wo] = conv(cat(src[0..nsrc-1], dim=1), W, stride, pad) + bias (+ addend, same shape as out).

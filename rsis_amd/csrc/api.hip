@@ -5,6 +5,9 @@
 // launchers implemented in the other translation units
 int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_tile, hipStream_t st);
 int rsis_launch_conv_wgrad(WgradArgs& a, int ks, hipStream_t st);
+int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st);
+int rsis_l_pack_direct_fwd(const float*, float*, int, int, int, const int*, int, int, int, hipStream_t);
+int rsis_l_pack_direct_dgrad(const float*, float*, int, int, int, int, int, int, int, hipStream_t);
 int rsis_l_pack_fwd(const float*, float*, int, int, int, int, int, int, hipStream_t);
 int rsis_l_pack_dgrad(const float*, float*, int, int, int, int, int, int, int, int, hipStream_t);
 int rsis_l_lstm_bwd(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
@@ -24,6 +27,14 @@ int rsis_l_adam(float*, const float*, float*, float*, long, float, float, float,
 
 static inline int krows_of(int C, int ks) { return rsis_roundup(C * ks * ks, RSIS_KPAD); }
 static inline int log2i(int s) { int l = 0; while ((1 << l) < s) ++l; return l; }
+// 3x3 / stride 1 / pad 1 convs (and their data gradients) run on the direct LDS-patch kernel with its own packed layout
+static inline bool use_direct(int ks, int stride, int pad) { return ks == 3 && stride == 1 && pad == 1; }
+static inline int direct_rows(int nseg, const int* Cseg) {
+  int q = 0;
+  for (int s = 0; s < nseg; ++s) q += (Cseg[s] + RSIS_CK - 1) / RSIS_CK;
+  return q * RSIS_CK * 9;
+}
+static inline int direct_variant(int tile) { const int v = tile % 10; return (tile > 0 && v >= 1 && v <= 5) ? v : 0; }
 
 extern "C" {
 
@@ -39,34 +50,42 @@ const char* rsis_error_string(int code) {
   }
 }
 
-long rsis_conv_packed_floats_fwd(int Cout, int ks, int nseg, const int* Cseg) {
+long rsis_conv_packed_floats_fwd(int Cout, int ks, int stride, int pad, int nseg, const int* Cseg) {
   if (nseg < 1 || nseg > RSIS_MAX_SRC || !Cseg) return -1;
+  const long ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN);
+  if (use_direct(ks, stride, pad)) return (long)direct_rows(nseg, Cseg) * ldw;
   int c = 0;
   for (int s = 0; s < nseg; ++s) c += Cseg[s];
-  return (long)krows_of(c, ks) * (long)rsis_roundup(Cout, RSIS_LDW_ALIGN);
+  return (long)krows_of(c, ks) * ldw;
 }
 
-long rsis_conv_packed_floats_dgrad(int Cout, int ks, int c_count) {
-  return (long)krows_of(Cout, ks) * (long)rsis_roundup(c_count, RSIS_LDW_ALIGN);
+long rsis_conv_packed_floats_dgrad(int Cout, int ks, int stride, int pad, int c_count) {
+  const long ldw = rsis_roundup(c_count, RSIS_LDW_ALIGN);
+  if (use_direct(ks, stride, pad)) return (long)direct_rows(1, &Cout) * ldw;
+  return (long)krows_of(Cout, ks) * ldw;
 }
 
-int rsis_conv_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int nseg, const int* Cseg, int lstm_hid,
-                       void* stream) {
+int rsis_conv_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
+                       int lstm_hid, void* stream) {
   if (!W || !Wp || nseg < 1 || nseg > RSIS_MAX_SRC) return RSIS_ERR_ARG;
   int csum = 0;
   for (int s = 0; s < nseg; ++s) csum += Cseg[s];
   if (csum != Ctot) return RSIS_ERR_ARG;
   if (lstm_hid > 0 && Cout != 4 * lstm_hid) return RSIS_ERR_ARG;
-  return rsis_l_pack_fwd(W, Wp, Cout, Ctot, ks, rsis_roundup(Cout, RSIS_LDW_ALIGN), krows_of(Ctot, ks), lstm_hid,
-                         (hipStream_t)stream);
+  const int ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN);
+  if (use_direct(ks, stride, pad))
+    return rsis_l_pack_direct_fwd(W, Wp, Cout, Ctot, nseg, Cseg, ldw, direct_rows(nseg, Cseg), lstm_hid, (hipStream_t)stream);
+  return rsis_l_pack_fwd(W, Wp, Cout, Ctot, ks, ldw, krows_of(Ctot, ks), lstm_hid, (hipStream_t)stream);
 }
 
-int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int c_lo, int c_hi, int lstm_hid,
-                         void* stream) {
+int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int stride, int pad, int c_lo, int c_hi,
+                         int lstm_hid, void* stream) {
   if (!W || !Wd || c_lo < 0 || c_hi > Ctot || c_lo >= c_hi) return RSIS_ERR_ARG;
   if (lstm_hid > 0 && Cout != 4 * lstm_hid) return RSIS_ERR_ARG;
-  return rsis_l_pack_dgrad(W, Wd, Cout, Ctot, ks, c_lo, c_hi, rsis_roundup(c_hi - c_lo, RSIS_LDW_ALIGN),
-                           krows_of(Cout, ks), lstm_hid, (hipStream_t)stream);
+  const int ldw = rsis_roundup(c_hi - c_lo, RSIS_LDW_ALIGN);
+  if (use_direct(ks, stride, pad))
+    return rsis_l_pack_direct_dgrad(W, Wd, Cout, Ctot, c_lo, c_hi, ldw, direct_rows(1, &Cout), lstm_hid, (hipStream_t)stream);
+  return rsis_l_pack_dgrad(W, Wd, Cout, Ctot, ks, c_lo, c_hi, ldw, krows_of(Cout, ks), lstm_hid, (hipStream_t)stream);
 }
 
 static int fill_sources(ConvArgs& a, const float* const* src, const int* Csrc, int nsrc, int ks) {
@@ -92,6 +111,7 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
   a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = pad; a.sshift = 0;
   a.wp = Wp; a.ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN); a.Cout = Cout; a.bias = bias; a.addend = addend;
   a.dst[0] = out; a.Cd[0] = Cout; a.ndst = 1;
+  if (use_direct(ks, stride, pad)) return rsis_launch_conv3x3_direct(a, 0, direct_variant(tile), (hipStream_t)stream);
   return rsis_launch_conv_igemm(a, ks, false, 0, tile, (hipStream_t)stream);
 }
 
@@ -110,6 +130,10 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const fl
   a.B = B; a.H = Hy; a.W = Wy; a.Ho = Hx; a.Wo = Wx; a.stride = stride; a.pad = pad; a.sshift = log2i(stride);
   if (ctot > Cin_packed) return RSIS_ERR_ARG;
   a.wp = Wd; a.ldw = rsis_roundup(Cin_packed, RSIS_LDW_ALIGN); a.Cout = ctot; a.bias = nullptr; a.addend = nullptr;
+  if (use_direct(ks, stride, pad)) {
+    if (Hx != Hy || Wx != Wy) return RSIS_ERR_ARG;
+    return rsis_launch_conv3x3_direct(a, 0, direct_variant(tile), (hipStream_t)stream);
+  }
   return rsis_launch_conv_igemm(a, ks, true, 0, tile, (hipStream_t)stream);
 }
 
@@ -139,6 +163,7 @@ int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B,
   a.wp = Wp; a.ldw = rsis_roundup(4 * hid, RSIS_LDW_ALIGN); a.Cout = 4 * hid; a.bias = bias_packed; a.addend = addend;
   a.ndst = 1; a.dst[0] = nullptr; a.Cd[0] = 4 * hid;
   a.hid = hid; a.c_prev = c_prev; a.h_out = h_out; a.c_out = c_out; a.act_out = act_out;
+  if (use_direct(ks, 1, pad)) return rsis_launch_conv3x3_direct(a, 1, direct_variant(tile), (hipStream_t)stream);
   return rsis_launch_conv_igemm(a, ks, false, 1, tile, (hipStream_t)stream);
 }
 

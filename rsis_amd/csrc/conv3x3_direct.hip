@@ -1,0 +1,277 @@
+// Direct 3x3 / stride 1 / pad 1 convolution for gfx950 on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32), NCHW fp32.
+//
+// This is the kernel behind the ConvLSTM gates (reference src/modules/clstm.py:43-58, fused EPI_LSTM epilogue), the skip
+// convs and conv_out (model.py:43-47,109), the 3x3 convs of the ResNet-101 bottlenecks, and the data-gradient of all of
+// them (a 3x3/s1/p1 dgrad is the same conv with flipped taps and swapped channel roles: only the weight packing differs).
+//
+// Structure (why it exists next to the generic implicit-GEMM kernel): a block owns a TWxTHxNI spatial patch of the
+// output and a BM-wide slice of the output channels.  For each chunk of CK=8 input channels it stages
+//   * the input patch WITH its 1-pixel halo, zero-filled outside the image:  Xs[CK][NI][TH+2][TW+2]   (row-coalesced
+//     global loads, each input element is fetched once per block instead of 9 times), and
+//   * the chunk's weights Ws[CK*9][BM]
+// in LDS, and the MFMA loop then needs NO address arithmetic and NO masks at all: with the K order (channel pair, tap)
+// the B-operand of lane l is Xs[lane_base + compile-time offset] (lanes 0-31 take the even channel of the pair, lanes
+// 32-63 the odd one), i.e. a bare `ds_read_b32 v, v_base offset:imm`; the A-operand likewise.  Per MFMA (64 cycles) the
+// wave issues 1.25-2 LDS reads and nothing else, which is what makes the exact-f32 MFMA the bound.
+// Channel concat (torch.cat at clstm.py:43 / model.py:153) is by pointer: chunks never straddle a source.
+#include "common.h"
+
+enum { EPI_PLAIN = 0, EPI_LSTM = 1 };
+#define CK RSIS_CK
+
+typedef const float __attribute__((address_space(1)))* gcf_t;
+typedef float __attribute__((address_space(1)))* gf_t;
+typedef const f32x4 __attribute__((address_space(1)))* gcf4_t;
+
+template <int BM, int TW, int TH, int NI, int EPI>
+__global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
+  constexpr int BN = TW * TH * NI;
+  constexpr int WGM = BM / 32, WGN = 4 / WGM;      // BM=64: 2x2 waves, BM=32: 1x4
+  constexpr int TN = BN / WGN / 32;                 // 32-pixel MFMA column tiles per wave (TM == 1)
+  constexpr int PW = TW + 2, PH = TH + 2;
+  constexpr int IMS = PH * PW;                      // one image of the patch
+  constexpr int CHS = NI * IMS;                     // channel stride of the patch
+  constexpr int XS = CK * CHS, WS = CK * 9 * BM;    // floats per LDS stage
+  constexpr int NX = (XS + 255) / 256;              // patch loads per thread per chunk
+  constexpr int W_F4 = WS / 4;
+  constexpr int NW = (W_F4 + 255) / 256;            // weight float4 loads per thread per chunk
+  static_assert(TN >= 1 && BN % (WGN * 32) == 0, "tile");
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * (XS + WS)];
+  float* const Xs0 = lds;
+  float* const Ws0 = lds + 2 * XS;
+
+  const gcf_t src0 = (gcf_t)p.src[0], src1 = (gcf_t)p.src[1], src2 = (gcf_t)p.src[2];
+  const int C0 = p.C[0], C1 = p.C[1], C2 = p.C[2];
+  const int q0 = (C0 + CK - 1) / CK, q1 = (C1 + CK - 1) / CK, q2 = (C2 + CK - 1) / CK;   // chunks per source
+  const int nq = q0 + q1 + q2;
+  const int H = p.H, W = p.W, HW = H * W, B = p.B;
+  const int ldw = p.ldw;
+
+  // ---- block -> (co tile, spatial tile); blocks b, b+8, ... share an XCD: a tile's co tiles stay on one L2 ----
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = bid >> 3;
+  const int co_t = q % p.n_co_tiles;
+  const int sp_t = (q / p.n_co_tiles) * 8 + xcd;
+  if (sp_t >= p.n_px_tiles) return;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int tx = sp_t % tiles_x;
+  const int ty = (sp_t / tiles_x) % tiles_y;
+  const int b0 = (sp_t / (tiles_x * tiles_y)) * NI;
+  const int x0 = tx * TW, y0 = ty * TH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // ---- loop-invariant decode of this thread's patch elements: element e -> (channel-in-chunk, image, row, col) ----
+  int goff[NX];      // offset inside one channel plane set: img*Cs*HW is added per source (NI > 1 only)
+  int gimg[NX];
+  int gcl[NX];
+  bool gok[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int e = tid + i * 256;
+    const int cl = e / CHS, rem = e - cl * CHS;
+    const int img = rem / IMS, rem2 = rem - img * IMS;
+    const int py = rem2 / PW, pxx = rem2 - py * PW;
+    const int gy = y0 + py - 1, gx = x0 + pxx - 1;
+    gok[i] = (e < XS) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W) && (b0 + img < B);
+    goff[i] = cl * HW + gy * W + gx;
+    gimg[i] = b0 + img;
+    gcl[i] = cl;
+  }
+
+  // ---- per-lane LDS read bases (bytes are immediates in the unrolled loop) ----
+  int xoff[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int pp = (wn * TN + j) * 32 + l31;
+    const int x = pp % TW, y = (pp / TW) % TH, img = pp / (TW * TH);
+    xoff[j] = hi * CHS + img * IMS + y * PW + x;
+  }
+  const int woff = hi * BM + wm * 32 + l31;
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  float rx[NX];
+  f32x4 rw[NW];
+  const gcf_t wbase = (gcf_t)p.wp + co_t * BM;
+
+  // scalar chunk cursor
+  int cs = 0, cq = 0;   // source index, chunk index inside the source
+
+#define DIRECT_LOAD(QG)                                                                                   \
+  {                                                                                                       \
+    gcf_t src = src0; int Cs = C0;                                                                        \
+    if (cs == 1) { src = src1; Cs = C1; }                                                                 \
+    if (cs == 2) { src = src2; Cs = C2; }                                                                 \
+    const int c0 = cq * CK;                                                                               \
+    const gcf_t sb = src + (size_t)c0 * HW;                                                               \
+    const int crem = Cs - c0;                                                                             \
+    const int CsHW = Cs * HW;                                                                             \
+    _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                      \
+      float v = 0.f;                                                                                      \
+      if (gok[i] && gcl[i] < crem) v = sb[(size_t)gimg[i] * CsHW + goff[i]];                              \
+      rx[i] = v;                                                                                          \
+    }                                                                                                     \
+    const gcf_t wrow = wbase + (size_t)(QG) * (CK * 9) * ldw;                                             \
+    _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                      \
+      const int idx = tid + i * 256;                                                                      \
+      if (W_F4 % 256 == 0 || idx < W_F4) {                                                                \
+        const int row = idx / (BM / 4), c4 = idx % (BM / 4);                                              \
+        rw[i] = *(gcf4_t)(wrow + (size_t)row * ldw + c4 * 4);                                             \
+      }                                                                                                   \
+    }                                                                                                     \
+    if (++cq == (cs == 0 ? q0 : (cs == 1 ? q1 : q2))) { cq = 0; ++cs; if (cs == 1 && q1 == 0) ++cs; }     \
+  }
+
+#define DIRECT_STORE(BUF)                                                                                 \
+  {                                                                                                       \
+    float* Xs = Xs0 + (BUF) * XS;                                                                         \
+    float* Ws = Ws0 + (BUF) * WS;                                                                         \
+    _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                      \
+      const int e = tid + i * 256;                                                                        \
+      if (XS % 256 == 0 || e < XS) Xs[e] = rx[i];                                                         \
+    }                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                      \
+      const int idx = tid + i * 256;                                                                      \
+      if (W_F4 % 256 == 0 || idx < W_F4) *reinterpret_cast<f32x4*>(Ws + idx * 4) = rw[i];                 \
+    }                                                                                                     \
+  }
+
+  DIRECT_LOAD(0)
+  DIRECT_STORE(0)
+  __syncthreads();
+  for (int t = 0; t < nq; ++t) {
+    const int cur = t & 1;
+    const bool more = t + 1 < nq;
+    if (more) DIRECT_LOAD(t + 1)
+    {
+      const float* Xs = Xs0 + cur * XS;
+      const float* Ws = Ws0 + cur * WS + woff;
+#pragma unroll
+      for (int c2 = 0; c2 < CK / 2; ++c2)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int s = 0; s < 3; ++s) {
+            const float a = Ws[((c2 * 9 + r * 3 + s) * 2) * BM];
+            float b[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Xs[xoff[j] + (2 * c2) * CHS + r * PW + s];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
+          }
+    }
+    if (more) DIRECT_STORE(cur ^ 1)
+    __syncthreads();
+  }
+#undef DIRECT_LOAD
+#undef DIRECT_STORE
+
+  // ---- epilogue ----
+  const int co_base = co_t * BM + wm * 32;
+  const gcf_t bias = (gcf_t)p.bias, addend = (gcf_t)p.addend;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int pp = (wn * TN + j) * 32 + l31;
+    const int x = pp % TW, y = (pp / TW) % TH, img = pp / (TW * TH);
+    const int ob = b0 + img, oy = y0 + y, ox = x0 + x;
+    if (ob >= B || oy >= H || ox >= W) continue;
+    const int osp = oy * W + ox;
+    if (EPI == EPI_PLAIN) {
+      const gf_t d0 = (gf_t)p.dst[0], d1 = (gf_t)p.dst[1], d2 = (gf_t)p.dst[2];
+      const int Cd0 = p.Cd[0], Cd1 = p.Cd[1], Cd2 = p.Cd[2], Cout = p.Cout;
+      const int e1 = Cd0, e2 = Cd0 + Cd1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (co >= Cout) continue;
+        float v = acc[j][r];
+        if (bias) v += bias[co];
+        gf_t d = d0;
+        int cl = co, Cd = Cd0;
+        if (co >= e1) { d = d1; cl = co - e1; Cd = Cd1; }
+        if (co >= e2) { d = d2; cl = co - e2; Cd = Cd2; }
+        const size_t idx = ((size_t)ob * Cd + cl) * HW + osp;
+        if (addend) v += addend[idx];
+        d[idx] = v;
+      }
+    } else {
+      const int hid = p.hid;
+      const gcf_t c_prev = (gcf_t)p.c_prev;
+      const gf_t c_out = (gf_t)p.c_out, h_out = (gf_t)p.h_out, act_out = (gf_t)p.act_out;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int jh = (co_base >> 2) + 2 * r4 + hi;   // hidden channel
+        if (jh >= hid) continue;
+        const int cop = jh * 4;
+        float ai = acc[j][4 * r4 + 0], af = acc[j][4 * r4 + 1], ao = acc[j][4 * r4 + 2], ag = acc[j][4 * r4 + 3];
+        if (bias) { ai += bias[cop]; af += bias[cop + 1]; ao += bias[cop + 2]; ag += bias[cop + 3]; }
+        const size_t gidx = ((size_t)ob * 4 * hid + cop) * HW + osp;
+        if (addend) {
+          ai += addend[gidx]; af += addend[gidx + HW];
+          ao += addend[gidx + 2 * (size_t)HW]; ag += addend[gidx + 3 * (size_t)HW];
+        }
+        const float gi = rsis_sigmoid(ai), gf = rsis_sigmoid(af), go = rsis_sigmoid(ao), gg = tanhf(ag);
+        const size_t sidx = ((size_t)ob * hid + jh) * HW + osp;
+        const float cp = c_prev ? c_prev[sidx] : 0.f;
+        const float c = gf * cp + gi * gg;       // clstm.py:57
+        const float h = go * tanhf(c);           // clstm.py:58
+        c_out[sidx] = c;
+        h_out[sidx] = h;
+        if (act_out) {
+          act_out[gidx] = gi; act_out[gidx + HW] = gf;
+          act_out[gidx + 2 * (size_t)HW] = go; act_out[gidx + 3 * (size_t)HW] = gg;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int BM, int TW, int TH, int NI, int EPI>
+static int launch_direct_cfg(ConvArgs& a, hipStream_t st) {
+  a.n_co_tiles = rsis_cdiv(a.Cout, BM);
+  a.n_px_tiles = rsis_cdiv(a.W, TW) * rsis_cdiv(a.H, TH) * rsis_cdiv(a.B, NI);
+  const int grid = a.n_co_tiles * 8 * rsis_cdiv(a.n_px_tiles, 8);
+  hipLaunchKernelGGL((conv3x3_direct_kernel<BM, TW, TH, NI, EPI>), dim3(grid), dim3(256), 0, st, a);
+  return rsis_check_launch();
+}
+
+// variant codes: 1 = BM64 8x8x1 (64 px), 2 = BM64 16x8 (128 px), 3 = BM64 32x8 (256 px), 4 = BM32 16x8, 5 = BM32 32x8
+template <int EPI>
+static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
+  int v = force;
+  if (v <= 0) {
+    const bool small_co = a.Cout <= 32;
+    if (a.W <= 8 && a.H <= 8) v = 1;
+    else if (a.W <= 16) v = small_co ? 4 : 2;
+    else v = small_co ? 5 : 3;
+    // keep >= ~1 block per CU: fall back to the smaller pixel tile when the big one leaves CUs idle
+    if (v == 3) {
+      const long blocks = (long)rsis_cdiv(a.Cout, 64) * rsis_cdiv(a.W, 32) * rsis_cdiv(a.H, 8) * a.B;
+      if (blocks < 200) v = 2;
+    }
+  }
+  switch (v) {
+    case 1: return launch_direct_cfg<64, 8, 8, 1, EPI>(a, st);
+    case 2: return launch_direct_cfg<64, 16, 8, 1, EPI>(a, st);
+    case 3: return launch_direct_cfg<64, 32, 8, 1, EPI>(a, st);
+    case 4: return launch_direct_cfg<32, 16, 8, 1, EPI>(a, st);
+    case 5: return launch_direct_cfg<32, 32, 8, 1, EPI>(a, st);
+    default: return RSIS_ERR_ARG;
+  }
+}
+
+int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st) {
+  if (a.nsrc < 1 || a.nsrc > RSIS_MAX_SRC) return RSIS_ERR_ARG;
+  if (epi == EPI_LSTM) return launch_direct_epi<EPI_LSTM>(a, st, force_variant);
+  return launch_direct_epi<EPI_PLAIN>(a, st, force_variant);
+}

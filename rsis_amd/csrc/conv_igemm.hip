@@ -12,10 +12,18 @@
 //   acc[4*r4 .. 4*r4+3], so the whole LSTM cell update happens in registers.
 //   Channel concat (torch.cat at clstm.py:43 / model.py:153) is "by pointer": up to 3 source tensors; the source of a
 //   K row is picked with scalar compares on the (wave-uniform) row index.
+//   Gather cost: all per-pixel work (validity bit per filter tap, centre address) is hoisted out of the K loop; per K
+//   row only SCALAR work remains, so a gathered element costs ~6 VALU + 1 global_load.
 //   LDS tiles are k-major ([BK][BM] / [BK][BN]) so every ds_read_b32 of an MFMA operand is conflict-free.
 #include "common.h"
+#include <type_traits>
 
 enum { EPI_PLAIN = 0, EPI_LSTM = 1 };
+
+typedef const float __attribute__((address_space(1)))* gcf_t;   // explicit global pointers: global_load, never flat_load
+typedef const char __attribute__((address_space(1)))* gcc_t;
+typedef float __attribute__((address_space(1)))* gf_t;
+typedef const f32x4 __attribute__((address_space(1)))* gcf4_t;
 
 template <int BM, int BN, int BK, int WGM, int WGN, int KS, bool DGRAD, int EPI>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
@@ -28,10 +36,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   static_assert(WGM * WGN == 4, "4 waves per block");
   static_assert(BN == 64 || BN == 128 || BN == 256, "BN");
   static_assert(RSIS_KPAD % BK == 0, "BK must divide the packed K padding");
+  typedef typename std::conditional<(KK > 32), unsigned long long, unsigned>::type mask_t;
 
   __shared__ __attribute__((aligned(16))) float lds[2 * BK * (BM + BN)];
-  float* As0 = lds;                 // [2][BK][BM]
-  float* Bs0 = lds + 2 * BK * BM;   // [2][BK][BN]
+  float* const As0 = lds;                 // [2][BK][BM]
+  float* const Bs0 = lds + 2 * BK * BM;   // [2][BK][BN]
+
+  // ---- scalar copies of the arguments (no dynamic indexing of the by-value struct: that would spill it to scratch) ----
+  const gcc_t src0 = (gcc_t)p.src[0], src1 = (gcc_t)p.src[1], src2 = (gcc_t)p.src[2];
+  const int C0 = p.C[0], C1 = p.C[1], C2 = p.C[2];
+  const int cb1 = C0, cb2 = C0 + C1, cb3 = C0 + C1 + C2;
+  const int H = p.H, W = p.W, Ho = p.Ho, Wo = p.Wo, pad = p.pad, stride = p.stride, sshift = p.sshift;
+  const int HoWo = Ho * Wo, HW = H * W;
+  const int Npx = p.B * HoWo;
+  const int ldw = p.ldw;
 
   // ---- block -> (co tile, px tile); blocks b, b+8, ... share an XCD (L2): keep a pixel tile's co tiles there ----
   const int bid = blockIdx.x;
@@ -45,9 +63,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
 
-  const int HoWo = p.Ho * p.Wo, HW = p.H * p.W;
-  const int Npx = p.B * HoWo;
-
   // ---- per-thread pixel of the gathered operand (fixed for the whole K loop) ----
   const int px_local = tid % BN;
   const int krow0 = __builtin_amdgcn_readfirstlane(tid / BN);
@@ -56,14 +71,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   if (!pxv) px = 0;
   const int pb = px / HoWo;
   const int psp = px - pb * HoWo;
-  const int pho = psp / p.Wo, pwo = psp - pho * p.Wo;
-  int hi0, wi0;
-  if (!DGRAD) { hi0 = pho * p.stride - p.pad; wi0 = pwo * p.stride - p.pad; }
-  else        { hi0 = pho + p.pad;            wi0 = pwo + p.pad; }
-  const int smask = (1 << p.sshift) - 1;
-  // channel bounds of the concat segments (scalar)
-  const int cb1 = p.C[0], cb2 = p.C[0] + p.C[1], cb3 = cb2 + p.C[2];
-  const int pbHW = pb * HW;
+  const int pho = psp / Wo, pwo = psp - pho * Wo;
+  // loop-invariant part of the gather: a validity bit per filter tap (zero padding / stride parity / image border) and the
+  // byte offset of the tap-independent "centre" address inside each concat source
+  mask_t vmask = 0;
+  int center;
+  {
+    const int hi0 = DGRAD ? pho + pad : pho * stride - pad;
+    const int wi0 = DGRAD ? pwo + pad : pwo * stride - pad;
+    const int smask = (1 << sshift) - 1;
+#pragma unroll
+    for (int r = 0; r < KS; ++r)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        bool ok;
+        if (!DGRAD) {
+          ok = ((unsigned)(hi0 + r) < (unsigned)H) && ((unsigned)(wi0 + s) < (unsigned)W);
+        } else {
+          const int th = hi0 - r, tw = wi0 - s;
+          ok = (th >= 0) && (tw >= 0) && (((th | tw) & smask) == 0) && ((th >> sshift) < H) && ((tw >> sshift) < W);
+        }
+        if (ok && pxv) vmask |= (mask_t)1 << (r * KS + s);
+      }
+    center = DGRAD ? (hi0 >> sshift) * W + (wi0 >> sshift) : (pho * stride) * W + pwo * stride;
+  }
+  const unsigned voff0 = (unsigned)(pb * C0 * HW + center) * 4u;
+  const unsigned voff1 = (unsigned)(pb * C1 * HW + center) * 4u;
+  const unsigned voff2 = (unsigned)(pb * C2 * HW + center) * 4u;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -75,119 +109,125 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 
   float rb[B_LOADS];
   f32x4 ra[A_LOADS];
-
   const int ntiles = (p.K + BK - 1) / BK;
+  const gcf_t wbase = (gcf_t)p.wp + co_t * BM;
 
-  auto load_tile = [&](int t) {
-    const int k0 = t * BK + krow0;
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      const int kl = k0 + i * B_ROWS;  // wave-uniform
-      const int cg = kl / KK;           // channel index in the concat
-      const int rs = kl - cg * KK;
-      const int r = rs / KS, s = rs - r * KS;
-      // source segment of this K row (scalar selects)
-      const float* __restrict__ src = p.src[0];
-      int Cs = p.C[0], ci = cg;
-      if (cg >= cb1) { src = p.src[1]; Cs = p.C[1]; ci = cg - cb1; }
-      if (cg >= cb2) { src = p.src[2]; Cs = p.C[2]; ci = cg - cb2; }
-      bool ok = pxv && (cg < cb3);
-      int ih, iw;
-      if (!DGRAD) {
-        ih = hi0 + r; iw = wi0 + s;
-        ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-      } else {
-        const int th = hi0 - r, tw = wi0 - s;
-        ok = ok && (th >= 0) && (tw >= 0) && (((th | tw) & smask) == 0);
-        ih = th >> p.sshift; iw = tw >> p.sshift;
-        ok = ok && (ih < p.H) && (iw < p.W);
-      }
-      const int off = pbHW * Cs + ci * HW + ih * p.W + iw;
-      rb[i] = ok ? src[off] : 0.f;
-    }
-    const float* __restrict__ wrow = p.wp + (size_t)t * BK * p.ldw + co_t * BM;
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      const int idx = tid + i * 256;
-      if (A_F4 % 256 == 0 || idx < A_F4) {
-        const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-        ra[i] = *reinterpret_cast<const f32x4*>(wrow + (size_t)row * p.ldw + c4 * 4);
-      }
-    }
-  };
+#define RSIS_LOAD_TILE(T)                                                                                          \
+  {                                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) {                                                          \
+      const int kl = __builtin_amdgcn_readfirstlane((T) * BK + krow0 + i * B_ROWS); /* scalar from here on */      \
+      const int cg = kl / KK;                                                                                      \
+      const int rs = kl - cg * KK;                                                                                 \
+      const int r = rs / KS, s = rs - r * KS;                                                                      \
+      gcc_t src = src0;                                                                                            \
+      int ci = cg;                                                                                                 \
+      unsigned voff = voff0;                                                                                       \
+      if (cg >= cb1) { src = src1; ci = cg - cb1; voff = voff1; }                                                  \
+      if (cg >= cb2) { src = src2; ci = cg - cb2; voff = voff2; }                                                  \
+      const int soff = DGRAD ? -((r >> sshift) * W + (s >> sshift)) : (r - pad) * W + (s - pad);                   \
+      const gcc_t sbase = src + ((long)ci * HW + soff) * 4;                                                        \
+      const bool ok = (cg < cb3) && ((vmask >> rs) & 1);                                                           \
+      float v = 0.f;                                                                                               \
+      if (ok) v = *(gcf_t)(sbase + voff);                                                                          \
+      rb[i] = v;                                                                                                   \
+    }                                                                                                              \
+    const gcf_t wrow = wbase + (size_t)(T) * BK * ldw;                                                             \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                                          \
+      const int idx = tid + i * 256;                                                                               \
+      if (A_F4 % 256 == 0 || idx < A_F4) {                                                                         \
+        const int row = idx / (BM / 4), c4 = idx % (BM / 4);                                                       \
+        ra[i] = *(gcf4_t)(wrow + (size_t)row * ldw + c4 * 4);                                                      \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
 
-  auto store_tile = [&](int buf) {
-    float* As = As0 + buf * BK * BM;
-    float* Bs = Bs0 + buf * BK * BN;
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) Bs[(krow0 + i * B_ROWS) * BN + px_local] = rb[i];
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      const int idx = tid + i * 256;
-      if (A_F4 % 256 == 0 || idx < A_F4) {
-        const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-        *reinterpret_cast<f32x4*>(As + row * BM + c4 * 4) = ra[i];
-      }
-    }
-  };
-
-  auto compute = [&](int buf) {
-    const float* As = As0 + buf * BK * BM + wm * TM * 32 + l31;
-    const float* Bs = Bs0 + buf * BK * BN + wn * TN * 32 + l31;
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      const int krow = kk * 2 + hi;
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[krow * BM + i * 32];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[krow * BN + j * 32];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  };
+#define RSIS_STORE_TILE(BUF)                                                                                       \
+  {                                                                                                                \
+    float* As = As0 + (BUF) * BK * BM;                                                                             \
+    float* Bs = Bs0 + (BUF) * BK * BN;                                                                             \
+    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) Bs[(krow0 + i * B_ROWS) * BN + px_local] = rb[i];          \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                                          \
+      const int idx = tid + i * 256;                                                                               \
+      if (A_F4 % 256 == 0 || idx < A_F4) {                                                                         \
+        const int row = idx / (BM / 4), c4 = idx % (BM / 4);                                                       \
+        *reinterpret_cast<f32x4*>(As + row * BM + c4 * 4) = ra[i];                                                 \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
 
   // ---- software pipeline: global->regs for tile t+1 overlaps MFMA on tile t; one barrier per tile ----
-  load_tile(0);
-  store_tile(0);
+  RSIS_LOAD_TILE(0)
+  RSIS_STORE_TILE(0)
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntiles) load_tile(t + 1);
-    compute(cur);
-    if (t + 1 < ntiles) store_tile(cur ^ 1);
+    const bool more = t + 1 < ntiles;
+    if (more) RSIS_LOAD_TILE(t + 1)
+    {
+      const float* As = As0 + cur * BK * BM + wm * TM * 32 + l31;
+      const float* Bs = Bs0 + cur * BK * BN + wn * TN * 32 + l31;
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const int krow = kk * 2 + hi;
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = As[krow * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bs[krow * BN + j * 32];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) RSIS_STORE_TILE(cur ^ 1)
     __syncthreads();
   }
+#undef RSIS_LOAD_TILE
+#undef RSIS_STORE_TILE
 
   // ---- epilogue ----
   const int co_base = co_t * BM + wm * TM * 32;
+  const gcf_t bias = (gcf_t)p.bias, addend = (gcf_t)p.addend;
+  if (EPI == EPI_PLAIN) {
+    const gf_t d0 = (gf_t)p.dst[0], d1 = (gf_t)p.dst[1], d2 = (gf_t)p.dst[2];
+    const int Cd0 = p.Cd[0], Cd1 = p.Cd[1], Cd2 = p.Cd[2], Cout = p.Cout;
+    const int e1 = Cd0, e2 = Cd0 + Cd1;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int opx = px_t * BN + wn * TN * 32 + j * 32 + l31;
-    if (opx >= Npx) continue;
-    const int ob = opx / HoWo;
-    const int osp = opx - ob * HoWo;
-    if (EPI == EPI_PLAIN) {
+    for (int j = 0; j < TN; ++j) {
+      const int opx = px_t * BN + wn * TN * 32 + j * 32 + l31;
+      if (opx >= Npx) continue;
+      const int ob = opx / HoWo;
+      const int osp = opx - ob * HoWo;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (co >= p.Cout) continue;
+          if (co >= Cout) continue;
           float v = acc[i][j][r];
-          if (p.bias) v += p.bias[co];
-          int cl = co, d = 0;
-          if (p.ndst > 1 && cl >= p.Cd[0]) { cl -= p.Cd[0]; d = 1; if (p.ndst > 2 && cl >= p.Cd[1]) { cl -= p.Cd[1]; d = 2; } }
-          const size_t idx = ((size_t)ob * p.Cd[d] + cl) * HoWo + osp;
-          if (p.addend) v += p.addend[idx];
-          p.dst[d][idx] = v;
+          if (bias) v += bias[co];
+          gf_t d = d0;
+          int cl = co, Cd = Cd0;
+          if (co >= e1) { d = d1; cl = co - e1; Cd = Cd1; }
+          if (co >= e2) { d = d2; cl = co - e2; Cd = Cd2; }
+          const size_t idx = ((size_t)ob * Cd + cl) * HoWo + osp;
+          if (addend) v += addend[idx];
+          d[idx] = v;
         }
       }
-    } else {
-      const int hid = p.hid;
+    }
+  } else {
+    const int hid = p.hid;
+    const gcf_t c_prev = (gcf_t)p.c_prev;
+    const gf_t c_out = (gf_t)p.c_out, h_out = (gf_t)p.h_out, act_out = (gf_t)p.act_out;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int opx = px_t * BN + wn * TN * 32 + j * 32 + l31;
+      if (opx >= Npx) continue;
+      const int ob = opx / HoWo;
+      const int osp = opx - ob * HoWo;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -197,22 +237,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
           const int cop = jh * 4;                                      // packed gate row of gate i
           float ai = acc[i][j][4 * r4 + 0], af = acc[i][j][4 * r4 + 1];
           float ao = acc[i][j][4 * r4 + 2], ag = acc[i][j][4 * r4 + 3];
-          if (p.bias) { ai += p.bias[cop]; af += p.bias[cop + 1]; ao += p.bias[cop + 2]; ag += p.bias[cop + 3]; }
+          if (bias) { ai += bias[cop]; af += bias[cop + 1]; ao += bias[cop + 2]; ag += bias[cop + 3]; }
           const size_t gidx = ((size_t)ob * 4 * hid + cop) * HoWo + osp;
-          if (p.addend) {
-            ai += p.addend[gidx]; af += p.addend[gidx + HoWo];
-            ao += p.addend[gidx + 2 * (size_t)HoWo]; ag += p.addend[gidx + 3 * (size_t)HoWo];
+          if (addend) {
+            ai += addend[gidx]; af += addend[gidx + HoWo];
+            ao += addend[gidx + 2 * (size_t)HoWo]; ag += addend[gidx + 3 * (size_t)HoWo];
           }
           const float gi = rsis_sigmoid(ai), gf = rsis_sigmoid(af), go = rsis_sigmoid(ao), gg = tanhf(ag);
           const size_t sidx = ((size_t)ob * hid + jh) * HoWo + osp;
-          const float cp = p.c_prev ? p.c_prev[sidx] : 0.f;
+          const float cp = c_prev ? c_prev[sidx] : 0.f;
           const float c = gf * cp + gi * gg;       // clstm.py:57
           const float h = go * tanhf(c);           // clstm.py:58
-          p.c_out[sidx] = c;
-          p.h_out[sidx] = h;
-          if (p.act_out) {
-            p.act_out[gidx] = gi; p.act_out[gidx + HoWo] = gf;
-            p.act_out[gidx + 2 * (size_t)HoWo] = go; p.act_out[gidx + 3 * (size_t)HoWo] = gg;
+          c_out[sidx] = c;
+          h_out[sidx] = h;
+          if (act_out) {
+            act_out[gidx] = gi; act_out[gidx + HoWo] = gf;
+            act_out[gidx + 2 * (size_t)HoWo] = go; act_out[gidx + 3 * (size_t)HoWo] = gg;
           }
         }
       }

@@ -43,7 +43,8 @@ class ConvLSTMCell(nn.Module):
         if key not in self._packs:
             if sum(key) != self.input_size:
                 raise Exception("ConvLSTMCell: input has %d channels, expected %d" % (sum(key), self.input_size))
-            self._packs[key] = ops.PackedConv(self.kernel_size, list(key) + [self.hidden_size], lstm_hid=self.hidden_size)
+            self._packs[key] = ops.PackedConv(self.kernel_size, list(key) + [self.hidden_size], lstm_hid=self.hidden_size, stride=1,
+                                              pad=self.padding)
         return self._packs[key]
 
     def forward_multi(self, inputs, prev_state):

@@ -29,7 +29,7 @@ class HipConv2d(nn.Module):
             nn.init.uniform_(self.bias, -bound, bound)
         else:
             self.register_parameter("bias", None)
-        self._pack = ops.PackedConv(self.kernel_size, [self.in_channels])
+        self._pack = ops.PackedConv(self.kernel_size, [self.in_channels], stride=self.stride, pad=self.padding)
 
     def forward(self, x):
         return ops.conv2d([x], self.weight, self.bias, self.stride, self.padding, self._pack)

@@ -29,8 +29,10 @@ class PackedConv(object):
     lstm_hid > 0: ConvLSTM `Gates` conv -- rows [i|f|o|g] are interleaved to 4*j+gate (clstm.py:47).
     """
 
-    def __init__(self, ks, segs, lstm_hid=0):
+    def __init__(self, ks, segs, lstm_hid=0, stride=1, pad=None):
         self.ks = int(ks)
+        self.stride = int(stride)
+        self.pad = int(ks // 2 if pad is None else pad)
         self.segs = [int(s) for s in segs]
         self.lstm_hid = int(lstm_hid)
         self._key_f = None
@@ -48,12 +50,12 @@ class PackedConv(object):
             L = lib()
             Cout, Ctot = w.shape[0], w.shape[1]
             segs = int_array(self.segs)
-            n = L.rsis_conv_packed_floats_fwd(Cout, self.ks, len(self.segs), segs)
+            n = L.rsis_conv_packed_floats_fwd(Cout, self.ks, self.stride, self.pad, len(self.segs), segs)
             if self.wp is None or self.wp.numel() != n:
                 self.wp = torch.empty(n, dtype=torch.float32, device=w.device)
             wd = w.detach()
-            check(L.rsis_conv_pack_fwd(ptr(wd), ptr(self.wp), Cout, Ctot, self.ks, len(self.segs), segs, self.lstm_hid,
-                                       stream()), "rsis_conv_pack_fwd")
+            check(L.rsis_conv_pack_fwd(ptr(wd), ptr(self.wp), Cout, Ctot, self.ks, self.stride, self.pad, len(self.segs), segs,
+                                       self.lstm_hid, stream()), "rsis_conv_pack_fwd")
             if bias is not None and self.lstm_hid > 0:
                 self.bias_p = bias.detach().view(4, self.lstm_hid).t().contiguous().view(-1)
             self._key_f = key
@@ -64,11 +66,11 @@ class PackedConv(object):
         if self._key_d != key:
             L = lib()
             Cout, Ctot = w.shape[0], w.shape[1]
-            n = L.rsis_conv_packed_floats_dgrad(Cout, self.ks, Ctot)
+            n = L.rsis_conv_packed_floats_dgrad(Cout, self.ks, self.stride, self.pad, Ctot)
             if self.wd is None or self.wd.numel() != n:
                 self.wd = torch.empty(n, dtype=torch.float32, device=w.device)
-            check(L.rsis_conv_pack_dgrad(ptr(w.detach()), ptr(self.wd), Cout, Ctot, self.ks, 0, Ctot, self.lstm_hid, stream()),
-                  "rsis_conv_pack_dgrad")
+            check(L.rsis_conv_pack_dgrad(ptr(w.detach()), ptr(self.wd), Cout, Ctot, self.ks, self.stride, self.pad, 0, Ctot,
+                                         self.lstm_hid, stream()), "rsis_conv_pack_dgrad")
             self._key_d = key
         return self.wd
 
@@ -113,6 +115,8 @@ class _Conv2dFn(torch.autograd.Function):
         B, _, H, W = srcs[0].shape
         Cout, ks = weight.shape[0], weight.shape[2]
         Ho, Wo = _conv_out_size(H, ks, stride, pad), _conv_out_size(W, ks, stride, pad)
+        if pack.stride != stride or pack.pad != pad:
+            raise _lib.RsisHipError("PackedConv was built for stride %d pad %d, used with %d/%d" % (pack.stride, pack.pad, stride, pad))
         wp = pack.fwd(weight)
         out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=weight.device)
         check(L.rsis_conv2d_fwd(ptr_array(srcs), int_array([s.shape[1] for s in srcs]), nsrc, B, H, W, ptr(wp), Cout, ks, stride,

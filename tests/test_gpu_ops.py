@@ -41,7 +41,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 13, 14])
 def test_conv2d_fwd_bwd(case, tile):
     from rsis_amd import ops
     B, segs, H, W, Cout, ks, stride, pad, has_bias = case
@@ -56,7 +56,7 @@ def test_conv2d_fwd_bwd(case, tile):
     xd = [_dev(x.detach().clone().requires_grad_()) for x in xs]
     wd = _dev(w.detach().clone().requires_grad_())
     bd = _dev(b.detach().clone().requires_grad_()) if has_bias else None
-    pack = ops.PackedConv(ks, segs)
+    pack = ops.PackedConv(ks, segs, stride=stride, pad=pad)
     out = ops.conv2d(xd, wd, bd, stride, pad, pack)
     out.backward(gy.cuda())
     torch.cuda.synchronize()
@@ -81,7 +81,7 @@ LSTM_CASES = [
 
 
 @pytest.mark.parametrize("case", LSTM_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 def test_convlstm_fwd_bwd(case, tile):
     from oracle import rsis_oracle as O
     from rsis_amd import ops

@@ -89,7 +89,7 @@ def main():
             Hi = hw * stride
             x = torch.randn(B, cin, Hi, Hi, device="cuda")
             w = torch.randn(cout, cin, ks, ks, device="cuda") / (ks * cin ** 0.5)
-            pack = ops.PackedConv(ks, [cin])
+            pack = ops.PackedConv(ks, [cin], stride=stride, pad=pad)
             wp, wd = pack.fwd(w), pack.dgrad(w)
             y = torch.empty(B, cout, hw, hw, device="cuda")
             pa, ia = ptr_array([x]), int_array([cin])
