@@ -146,11 +146,12 @@ def main():
     a = bench_args(o.batch, o.imsize, o.T)
     torch.manual_seed(a.seed)
     encoder, decoder = FeatureExtractor(a).cuda(), RSIS(a).cuda()
-    if world > 1:
+    if world > 1 or os.environ.get("RSIS_FORCE_DIST", "") == "1":
         for p in list(encoder.parameters()) + list(decoder.parameters()) + list(encoder.buffers()):
             dist.broadcast(p.data, 0)
     enc_opt, dec_opt = build_optimizers(a, encoder, decoder)
-    reducer = BucketedAllReduce([dec_opt.group, enc_opt.group]) if world > 1 else None
+    force = os.environ.get("RSIS_FORCE_DIST", "") == "1"
+    reducer = BucketedAllReduce([dec_opt.group, enc_opt.group], force=force) if (world > 1 or force) else None
     crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
     batch = synthetic_batch(a.seed + 1000 * rank, o.batch, o.imsize, o.imsize, a.gt_maxseqlen, 12, a.num_classes, "cuda")
 
@@ -213,7 +214,7 @@ def main():
                           "global_batch": world * o.batch, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5)},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -90,9 +90,10 @@ class BucketedAllReduce(object):
     Works with any torch.distributed backend (`nccl` = RCCL over xGMI on the GPU box, `gloo` in the CPU tests).
     """
 
-    def __init__(self, groups, bucket_bytes=64 << 20, process_group=None):
+    def __init__(self, groups, bucket_bytes=64 << 20, process_group=None, force=False):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized() and (self.world > 1 or force)   # force: exercise the collective path at world 1
         self.buckets = []      # (flat_g view, n_params)
         self._pending = []
         self._handles = []
@@ -111,7 +112,7 @@ class BucketedAllReduce(object):
                     for q in g.params[first:i + 1]:
                         self._param_bucket[q] = bi
                     start, count = None, 0
-        if self.world > 1:
+        if self.active:
             for p, bi in self._param_bucket.items():
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
         self.reset()
@@ -131,7 +132,7 @@ class BucketedAllReduce(object):
     def finish(self):
         """call after backward: launches the buckets whose hooks did not all fire (params without grad this step,
         e.g. fc_class / fc_stop while their losses are off) and waits for everything."""
-        if self.world > 1:
+        if self.active:
             for bi, left in enumerate(self._pending):
                 if left > 0:
                     self._handles.append(dist.all_reduce(self.buckets[bi][0], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
