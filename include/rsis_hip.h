@@ -35,11 +35,14 @@ const char* rsis_error_string(int code);
 long rsis_conv_packed_floats_fwd(int Cout, int ks, int stride, int pad, int nseg, const int* Cseg);
 /* number of floats of the packed dgrad copy producing c_count input channels */
 long rsis_conv_packed_floats_dgrad(int Cout, int ks, int stride, int pad, int c_count);
-/* lstm_hid > 0: rows of W are [i|f|o|g] x hid (clstm.py:47) and are interleaved to 4*j+gate */
+/* The packed copy covers nseg (<= 3) input-channel segments of W: Cseg[s] channels starting at Coff[s] (Coff == NULL:
+ * consecutive from 0) -- the channel concat the conv will gather from, or any subset of the input channels.
+ * lstm_hid > 0: rows of W are [i|f|o|g] x hid (clstm.py:47) and are interleaved to 4*j+gate */
 int rsis_conv_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
-                       int lstm_hid, void* stream);
-int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int stride, int pad, int c_lo, int c_hi,
-                         int lstm_hid, void* stream);
+                       const int* Coff, int lstm_hid, void* stream);
+/* dgrad copy: produces the gradient of the sum(Cseg) input channels of the segments (in segment order) */
+int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
+                         const int* Coff, int lstm_hid, void* stream);
 
 /* ---- nn.Conv2d forward (model.py:59-63 skip convs, :167 conv_out, vision.py:12-19 trunk convs) ----
  * out[B][Cout][Ho][Wo] = conv(cat(src[0..nsrc-1], dim=1), W, stride, pad) + bias (+ addend, same shape as out).
@@ -50,7 +53,7 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
 
 /* ---- nn.Conv2d backward-data (autograd of the above): dx for input channels [c_lo,c_hi) of the conv input, written
  * to ndst tensors dx[i] = [B][Cdx[i]][Hx][Wx] (the inverse of the channel concat). dy = [B][Cout][Hy][Wy].
- * Cin_packed = c_hi - c_lo given to rsis_conv_pack_dgrad; sum(Cdx) <= Cin_packed (leading channels are produced). ---- */
+ * Cin_packed = sum(Cseg) given to rsis_conv_pack_dgrad; sum(Cdx) <= Cin_packed (leading channels are produced). ---- */
 int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const float* Wd, int Cin_packed, int ks, int stride,
                       int pad, float* const* dx, const int* Cdx, int ndst, int Hx, int Wx, int tile, void* stream);
 
@@ -66,7 +69,9 @@ int rsis_bias_grad(const float* dy, float* db, int B, int C, int HW, int lstm_hi
 /* ---- ConvLSTMCell.forward (clstm.py:19-62): cat(x.., h_prev) -> Gates conv -> chunk -> sigmoid/tanh -> c,h in ONE
  * kernel.  src = the x tensor(s) followed by h_prev (omit h_prev and pass c_prev = NULL for the zero state of
  * clstm.py:26-37).  bias_packed / act_out / addend use interleaved rows.  act_out (post-nonlinearity i,f,o,g, needed
- * by the backward) may be NULL for inference. addend: optional precomputed time-invariant gate contribution. ---- */
+ * by the backward) may be NULL for inference. addend: optional precomputed time-invariant gate contribution (the
+ * skip-feature part of the gate conv + bias, computed once per iteration by rsis_conv2d_fwd on interleaved rows); with an
+ * addend nsrc may be 0 (level 0 at t = 0). ---- */
 int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const float* Wp,
                       const float* bias_packed, const float* addend, const float* c_prev, float* h_out, float* c_out,
                       float* act_out, int hid, int ks, int pad, int tile, void* stream);

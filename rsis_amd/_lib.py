@@ -21,8 +21,8 @@ SIGNATURES = {
     "rsis_error_string": (ctypes.c_char_p, [_i]),
     "rsis_conv_packed_floats_fwd": (_l, [_i, _i, _i, _i, _i, _ip]),
     "rsis_conv_packed_floats_dgrad": (_l, [_i, _i, _i, _i, _i]),
-    "rsis_conv_pack_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ip, _i, _vp]),
-    "rsis_conv_pack_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsis_conv_pack_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ip, _ip, _i, _vp]),
+    "rsis_conv_pack_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ip, _ip, _i, _vp]),
     "rsis_conv2d_fwd": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "rsis_conv2d_dgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vpp, _ip, _i, _i, _i, _i, _vp]),
     "rsis_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

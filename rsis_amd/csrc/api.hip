@@ -6,10 +6,8 @@
 int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_tile, hipStream_t st);
 int rsis_launch_conv_wgrad(WgradArgs& a, int ks, hipStream_t st);
 int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st);
-int rsis_l_pack_direct_fwd(const float*, float*, int, int, int, const int*, int, int, int, hipStream_t);
-int rsis_l_pack_direct_dgrad(const float*, float*, int, int, int, int, int, int, int, hipStream_t);
-int rsis_l_pack_fwd(const float*, float*, int, int, int, int, int, int, hipStream_t);
-int rsis_l_pack_dgrad(const float*, float*, int, int, int, int, int, int, int, int, hipStream_t);
+int rsis_l_pack(int, const float*, float*, int, int, int, int, const int*, const int*, int, int, int, hipStream_t);
+
 int rsis_l_lstm_bwd(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
                     hipStream_t);
 int rsis_l_upsample_fwd(const float*, float*, long, int, int, int, int, hipStream_t);
@@ -65,34 +63,46 @@ long rsis_conv_packed_floats_dgrad(int Cout, int ks, int stride, int pad, int c_
   return (long)krows_of(Cout, ks) * ldw;
 }
 
+static int check_segments(int Ctot, int nseg, const int* Cseg, const int* Coff) {
+  if (nseg < 1 || nseg > RSIS_MAX_SRC || !Cseg) return RSIS_ERR_ARG;
+  int base = 0;
+  for (int s = 0; s < nseg; ++s) {
+    const int off = Coff ? Coff[s] : base;
+    if (Cseg[s] < 1 || off < 0 || off + Cseg[s] > Ctot) return RSIS_ERR_ARG;
+    base += Cseg[s];
+  }
+  return RSIS_OK;
+}
+
 int rsis_conv_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
-                       int lstm_hid, void* stream) {
-  if (!W || !Wp || nseg < 1 || nseg > RSIS_MAX_SRC) return RSIS_ERR_ARG;
-  int csum = 0;
-  for (int s = 0; s < nseg; ++s) csum += Cseg[s];
-  if (csum != Ctot) return RSIS_ERR_ARG;
+                       const int* Coff, int lstm_hid, void* stream) {
+  if (!W || !Wp || check_segments(Ctot, nseg, Cseg, Coff)) return RSIS_ERR_ARG;
   if (lstm_hid > 0 && Cout != 4 * lstm_hid) return RSIS_ERR_ARG;
   const int ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN);
+  int csum = 0;
+  for (int s = 0; s < nseg; ++s) csum += Cseg[s];
   if (use_direct(ks, stride, pad))
-    return rsis_l_pack_direct_fwd(W, Wp, Cout, Ctot, nseg, Cseg, ldw, direct_rows(nseg, Cseg), lstm_hid, (hipStream_t)stream);
-  return rsis_l_pack_fwd(W, Wp, Cout, Ctot, ks, ldw, krows_of(Ctot, ks), lstm_hid, (hipStream_t)stream);
+    return rsis_l_pack(2, W, Wp, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, direct_rows(nseg, Cseg), lstm_hid, (hipStream_t)stream);
+  return rsis_l_pack(0, W, Wp, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, krows_of(csum, ks), lstm_hid, (hipStream_t)stream);
 }
 
-int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int stride, int pad, int c_lo, int c_hi,
-                         int lstm_hid, void* stream) {
-  if (!W || !Wd || c_lo < 0 || c_hi > Ctot || c_lo >= c_hi) return RSIS_ERR_ARG;
+int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
+                         const int* Coff, int lstm_hid, void* stream) {
+  if (!W || !Wd || check_segments(Ctot, nseg, Cseg, Coff)) return RSIS_ERR_ARG;
   if (lstm_hid > 0 && Cout != 4 * lstm_hid) return RSIS_ERR_ARG;
-  const int ldw = rsis_roundup(c_hi - c_lo, RSIS_LDW_ALIGN);
+  int csum = 0;
+  for (int s = 0; s < nseg; ++s) csum += Cseg[s];
+  const int ldw = rsis_roundup(csum, RSIS_LDW_ALIGN);
   if (use_direct(ks, stride, pad))
-    return rsis_l_pack_direct_dgrad(W, Wd, Cout, Ctot, c_lo, c_hi, ldw, direct_rows(1, &Cout), lstm_hid, (hipStream_t)stream);
-  return rsis_l_pack_dgrad(W, Wd, Cout, Ctot, ks, c_lo, c_hi, ldw, krows_of(Cout, ks), lstm_hid, (hipStream_t)stream);
+    return rsis_l_pack(3, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, direct_rows(1, &Cout), lstm_hid, (hipStream_t)stream);
+  return rsis_l_pack(1, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, krows_of(Cout, ks), lstm_hid, (hipStream_t)stream);
 }
 
-static int fill_sources(ConvArgs& a, const float* const* src, const int* Csrc, int nsrc, int ks) {
-  if (nsrc < 1 || nsrc > RSIS_MAX_SRC || !src || !Csrc) return RSIS_ERR_ARG;
+static int fill_sources(ConvArgs& a, const float* const* src, const int* Csrc, int nsrc, int ks, bool allow_empty = false) {
+  if (nsrc < (allow_empty ? 0 : 1) || nsrc > RSIS_MAX_SRC || (nsrc > 0 && (!src || !Csrc))) return RSIS_ERR_ARG;
   a.nsrc = nsrc;
   a.K = 0;
-  for (int s = 0; s < RSIS_MAX_SRC; ++s) { a.src[s] = src[0]; a.C[s] = 0; }
+  for (int s = 0; s < RSIS_MAX_SRC; ++s) { a.src[s] = nsrc > 0 ? src[0] : nullptr; a.C[s] = 0; }
   for (int s = 0; s < nsrc; ++s) {
     if (!src[s] || Csrc[s] < 1) return RSIS_ERR_ARG;
     a.src[s] = src[s]; a.C[s] = Csrc[s]; a.K += Csrc[s] * ks * ks;
@@ -155,7 +165,7 @@ int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B,
                       const float* bias_packed, const float* addend, const float* c_prev, float* h_out, float* c_out,
                       float* act_out, int hid, int ks, int pad, int tile, void* stream) {
   ConvArgs a = {};
-  int rc = fill_sources(a, src, Csrc, nsrc, ks);
+  int rc = fill_sources(a, src, Csrc, nsrc, ks, /*allow_empty=*/addend != nullptr);   // nsrc == 0: gates = addend only
   if (rc) return rc;
   if (!Wp || !h_out || !c_out || hid < 1) return RSIS_ERR_ARG;
   if (2 * pad != ks - 1) return RSIS_ERR_UNSUPPORTED;   // "same" conv only (the state keeps its size)

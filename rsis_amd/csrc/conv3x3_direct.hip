@@ -145,8 +145,10 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
     }                                                                                                     \
   }
 
-  DIRECT_LOAD(0)
-  DIRECT_STORE(0)
+  if (nq > 0) {   // nq == 0: no dynamic source at all (ConvLSTM level 0 at t = 0 with the hoisted skip term): gates = addend
+    DIRECT_LOAD(0)
+    DIRECT_STORE(0)
+  }
   __syncthreads();
   for (int t = 0; t < nq; ++t) {
     const int cur = t & 1;
@@ -271,7 +273,7 @@ static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
 }
 
 int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st) {
-  if (a.nsrc < 1 || a.nsrc > RSIS_MAX_SRC) return RSIS_ERR_ARG;
+  if (a.nsrc < 0 || a.nsrc > RSIS_MAX_SRC) return RSIS_ERR_ARG;
   if (epi == EPI_LSTM) return launch_direct_epi<EPI_LSTM>(a, st, force_variant);
   return launch_direct_epi<EPI_PLAIN>(a, st, force_variant);
 }

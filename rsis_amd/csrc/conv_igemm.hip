@@ -156,8 +156,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   }
 
   // ---- software pipeline: global->regs for tile t+1 overlaps MFMA on tile t; one barrier per tile ----
-  RSIS_LOAD_TILE(0)
-  RSIS_STORE_TILE(0)
+  if (ntiles > 0) {
+    RSIS_LOAD_TILE(0)
+    RSIS_STORE_TILE(0)
+  }
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
@@ -305,7 +307,7 @@ static int launch_ks(ConvArgs& a, hipStream_t st, int force_tile) {
 }
 
 int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_tile, hipStream_t st) {
-  if (a.nsrc < 1 || a.nsrc > RSIS_MAX_SRC) return RSIS_ERR_ARG;
+  if (a.nsrc < 0 || a.nsrc > RSIS_MAX_SRC) return RSIS_ERR_ARG;
   if (epi == EPI_LSTM) {
     if (dgrad) return RSIS_ERR_UNSUPPORTED;
     if (ks == 3) return launch_ks<3, false, EPI_LSTM>(a, st, force_tile);

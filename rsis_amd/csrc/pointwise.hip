@@ -1,92 +1,8 @@
 // Bandwidth-bound kernels of the RSIS hot path for gfx950 (NCHW fp32): ConvLSTM pointwise backward, bilinear
 // align-corners upsample fwd/bwd, global max-pool fwd/bwd, train/eval BatchNorm(+residual)(+ReLU) fwd/bwd,
-// 3x3/2 max-pool fwd/bwd, per-channel bias-grad reduction, weight repacking and the flat fused Adam step.
+// 3x3/2 max-pool fwd/bwd, per-channel bias-grad reduction and the flat fused Adam step (weight repacking: pack.hip).
 // All are HBM-roofline kernels: coalesced along W, grid-stride, float4 where the row length allows it.
 #include "common.h"
-
-// ------------------------------------------------------------------------------------------------
-// weight repacking (private layouts; never serialised)
-// ------------------------------------------------------------------------------------------------
-// FWD:   Wp[ci*KK + rs][co_p]     = W[ref(co_p)][ci][rs]      (zero in the K / Cout padding)
-// DGRAD: Wd[co_p*KK + rs][ci-c_lo] = W[ref(co_p)][ci][rs]
-// ref(co_p) = (co_p&3)*hid + (co_p>>2) for gate-interleaved ConvLSTM rows, identity otherwise.
-__global__ void pack_fwd_kernel(const float* __restrict__ W, float* __restrict__ Wp, int Cout, int Ctot, int KK, int ldw,
-                                int krows, int hid) {
-  const long total = (long)krows * ldw;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(e / ldw), cop = (int)(e - (long)k * ldw);
-    float v = 0.f;
-    if (cop < Cout && k < Ctot * KK) {
-      const int co = hid > 0 ? (cop & 3) * hid + (cop >> 2) : cop;
-      v = W[(long)co * Ctot * KK + k];
-    }
-    Wp[e] = v;
-  }
-}
-
-__global__ void pack_dgrad_kernel(const float* __restrict__ W, float* __restrict__ Wd, int Cout, int Ctot, int KK,
-                                  int c_lo, int c_hi, int ldw, int krows, int hid) {
-  const long total = (long)krows * ldw;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(e / ldw), cl = (int)(e - (long)k * ldw);
-    float v = 0.f;
-    const int cop = k / KK, rs = k - cop * KK;
-    if (cop < Cout && cl < c_hi - c_lo) {
-      const int co = hid > 0 ? (cop & 3) * hid + (cop >> 2) : cop;
-      v = W[((long)co * Ctot + c_lo + cl) * KK + rs];
-    }
-    Wd[e] = v;
-  }
-}
-
-// Direct-3x3 layout (conv3x3_direct.hip): chunks of CK=8 input channels per concat source (zero-padded), inside a chunk
-// row (c2*9 + rs)*2 + h  <->  channel c0 + 2*c2 + h, tap rs.  DGRAD = same conv with flipped taps / swapped channel roles.
-__global__ void pack_direct_fwd_kernel(const float* __restrict__ W, float* __restrict__ Wp, int Cout, int Ctot, int nseg,
-                                       int c0, int c1, int c2n, int ldw, int krows, int hid) {
-  const long total = (long)krows * ldw;
-  const int Cs[3] = {c0, c1, c2n};
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int row = (int)(e / ldw), col = (int)(e - (long)row * ldw);
-    float v = 0.f;
-    if (col < Cout) {
-      const int qg = row / (RSIS_CK * 9), kin = row - qg * (RSIS_CK * 9);
-      const int pair = kin >> 1, h = kin & 1;
-      const int cc = pair / 9, rs = pair - cc * 9;
-      int qs = 0, cb = 0;
-      for (int s = 0; s < nseg; ++s) {
-        const int nq = (Cs[s] + RSIS_CK - 1) / RSIS_CK;
-        if (qg < qs + nq) {
-          const int c = (qg - qs) * RSIS_CK + 2 * cc + h;
-          if (c < Cs[s]) {
-            const int co = hid > 0 ? (col & 3) * hid + (col >> 2) : col;
-            v = W[((long)co * Ctot + cb + c) * 9 + rs];
-          }
-          break;
-        }
-        qs += nq; cb += Cs[s];
-      }
-    }
-    Wp[e] = v;
-  }
-}
-
-__global__ void pack_direct_dgrad_kernel(const float* __restrict__ W, float* __restrict__ Wd, int Cout, int Ctot, int c_lo,
-                                         int c_hi, int ldw, int krows, int hid) {
-  const long total = (long)krows * ldw;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int row = (int)(e / ldw), col = (int)(e - (long)row * ldw);
-    float v = 0.f;
-    const int qg = row / (RSIS_CK * 9), kin = row - qg * (RSIS_CK * 9);
-    const int pair = kin >> 1, h = kin & 1;
-    const int cc = pair / 9, rs = pair - cc * 9;
-    const int c = qg * RSIS_CK + 2 * cc + h;      // channel of dy (packed row order for ConvLSTM)
-    if (c < Cout && col < c_hi - c_lo) {
-      const int co = hid > 0 ? (c & 3) * hid + (c >> 2) : c;
-      v = W[((long)co * Ctot + c_lo + col) * 9 + (8 - rs)];
-    }
-    Wd[e] = v;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // ConvLSTM pointwise backward (derivative of reference clstm.py:47-58; formulas in SURVEY.md 8(a))
@@ -425,32 +341,6 @@ static inline int chan_splits(int C, long N) {
   return (int)s;
 }
 
-int rsis_l_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int ldw, int krows, int hid, hipStream_t st) {
-  const long total = (long)krows * ldw;
-  hipLaunchKernelGGL(pack_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, W, Wp, Cout, Ctot, ks * ks, ldw, krows, hid);
-  return rsis_check_launch();
-}
-int rsis_l_pack_direct_fwd(const float* W, float* Wp, int Cout, int Ctot, int nseg, const int* Cseg, int ldw, int krows, int hid,
-                           hipStream_t st) {
-  const long total = (long)krows * ldw;
-  hipLaunchKernelGGL(pack_direct_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, W, Wp, Cout, Ctot, nseg, Cseg[0],
-                     nseg > 1 ? Cseg[1] : 0, nseg > 2 ? Cseg[2] : 0, ldw, krows, hid);
-  return rsis_check_launch();
-}
-int rsis_l_pack_direct_dgrad(const float* W, float* Wd, int Cout, int Ctot, int c_lo, int c_hi, int ldw, int krows, int hid,
-                             hipStream_t st) {
-  const long total = (long)krows * ldw;
-  hipLaunchKernelGGL(pack_direct_dgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, st, W, Wd, Cout, Ctot, c_lo, c_hi, ldw, krows,
-                     hid);
-  return rsis_check_launch();
-}
-int rsis_l_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int c_lo, int c_hi, int ldw, int krows, int hid,
-                      hipStream_t st) {
-  const long total = (long)krows * ldw;
-  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, st, W, Wd, Cout, Ctot, ks * ks, c_lo, c_hi, ldw,
-                     krows, hid);
-  return rsis_check_launch();
-}
 int rsis_l_lstm_bwd(const float* dh, const float* dc_next, const float* act, const float* c_prev, const float* c, float* da,
                     float* dc_prev, float* da_sum, int B, int hid, int HW, hipStream_t st) {
   const long total = (long)B * hid * HW;

@@ -1,0 +1,295 @@
+"""Time-invariant hoisting + time-batched weight gradients for the RSIS recurrent decoder (skip_mode == 'concat').
+
+The encoder features are identical at every timestep (reference train.py:77,94), so in every `Gates` conv the channels
+fed by the skip features are time-invariant.  Per ConvLSTM level i this module therefore splits the conv of
+clstm.py:43-44   gates = W * [x | h_prev] + b   into
+
+    G_i      = W[:, skip channels] * skip_i + b             -- ONE conv per iteration      (_HoistFn)
+    gates_t  = G_i + W[:, up(h_{i-1,t}) | h_{i,t-1}] * [..] -- per timestep, fused kernel  (_StepFn, G_i is the kernel's addend)
+
+(identical to the reference up to fp32 summation order).  The backward mirrors it:
+  * sum_t d(gates_t) is accumulated in-kernel (rsis_convlstm_bwd_gates da_sum) and the skip-channel data/weight/bias
+    gradients are computed ONCE from that sum (linearity), instead of T times;
+  * h, c, saved gates, up-sampled inputs and d(gates) of all timesteps live in stacked [T][B][C][H][W] buffers written
+    in place by the kernels, so the weight gradient of the recurrent channels is ONE split-K launch over T*B images per
+    source instead of T launches (run by the t = 0 backward, which autograd necessarily executes last).
+Module surface is unchanged: RSIS.forward(skip_feats, prev_hidden_list) is still called once per timestep; the tape is a
+private per-iteration cache on the module, keyed on the identity of the state tensors it handed out.
+"""
+import torch
+
+from . import ops
+from ._lib import check, int_array, lib, ptr, ptr_array, require_cuda_f32, stream
+
+
+class LevelTape(object):
+    """Per-iteration state of one ConvLSTM level."""
+
+    def __init__(self, cell, level, c_up, c_skip, cap):
+        self.cell, self.level, self.c_up, self.c_skip, self.cap = cell, level, c_up, c_skip, cap
+        self.hid = cell.hidden_size
+        self.ks, self.pad = cell.kernel_size, cell.padding
+        self.H = self.C = self.ACT = self.UP = self.DA = self.da_sum = None
+        self.G = None
+        self.n_fwd = 0
+        self.n_bwd = 0
+        self.last_h = self.last_c = None
+        self.need_grad = False
+
+    def alloc_forward(self, B, Hh, Ww, device, need_grad):
+        hid, cap = self.hid, self.cap
+        self.need_grad = need_grad
+        if need_grad:
+            self.H = torch.empty((cap, B, hid, Hh, Ww), dtype=torch.float32, device=device)
+            self.C = torch.empty_like(self.H)
+            self.ACT = torch.empty((cap, B, 4 * hid, Hh, Ww), dtype=torch.float32, device=device)
+            if self.c_up > 0:
+                self.UP = torch.empty((cap, B, self.c_up, Hh, Ww), dtype=torch.float32, device=device)
+
+
+def _packs(cell, c_up, c_skip):
+    """PackedConv triples of one cell: hoisted (skip channels), dynamic (up + h_prev channels)."""
+    key = ("fused", c_up, c_skip)
+    if key not in cell._packs:
+        hid, ks, pad = cell.hidden_size, cell.kernel_size, cell.padding
+        skip_off = c_up
+        h_off = c_up + c_skip
+        hoist = ops.PackedConv(ks, [c_skip], lstm_hid=hid, stride=1, pad=pad, offs=[skip_off])
+        segs, offs = ([c_up], [0]) if c_up > 0 else ([], [])
+        dyn = ops.PackedConv(ks, segs + [hid], lstm_hid=hid, stride=1, pad=pad, offs=offs + [h_off])
+        cell._packs[key] = (hoist, dyn)
+    return cell._packs[key]
+
+
+class _HoistFn(torch.autograd.Function):
+    """G = conv(skip, W[:, skip channels]) + b on gate-interleaved rows (once per iteration)."""
+
+    @staticmethod
+    def forward(ctx, tl, skip, weight, bias):
+        skip = skip if skip.is_contiguous() else skip.contiguous()
+        require_cuda_f32(skip, weight, bias)
+        L = lib()
+        hoist, _dyn = _packs(tl.cell, tl.c_up, tl.c_skip)
+        B, Cs, H, W = skip.shape
+        wp = hoist.fwd(weight, bias)
+        G = torch.empty((B, 4 * tl.hid, H, W), dtype=torch.float32, device=skip.device)
+        check(L.rsis_conv2d_fwd(ptr_array([skip]), int_array([Cs]), 1, B, H, W, ptr(wp), 4 * tl.hid, tl.ks, 1, tl.pad,
+                                ptr(hoist.bias_p), None, ptr(G), H, W, ops.FORCE_TILE[0], stream()), "rsis_conv2d_fwd(hoist)")
+        ctx.tl = tl
+        ctx.save_for_backward(skip, weight)
+        return G
+
+    @staticmethod
+    def backward(ctx, dG):
+        tl = ctx.tl
+        skip, weight = ctx.saved_tensors
+        L = lib()
+        dG = dG if dG.is_contiguous() else dG.contiguous()
+        hoist, _dyn = _packs(tl.cell, tl.c_up, tl.c_skip)
+        B, Cs, H, W = skip.shape
+        dskip = dW = db = None
+        if ctx.needs_input_grad[1]:
+            wd = hoist.dgrad(weight)
+            dskip = torch.empty_like(skip)
+            check(L.rsis_conv2d_dgrad(ptr(dG), B, 4 * tl.hid, H, W, ptr(wd), hoist.cin, tl.ks, 1, tl.pad, ptr_array([dskip]),
+                                      int_array([Cs]), 1, H, W, ops.FORCE_TILE[0], stream()), "rsis_conv2d_dgrad(hoist)")
+        if ctx.needs_input_grad[2]:
+            dW = torch.zeros_like(weight)
+            check(L.rsis_conv2d_wgrad(ptr(dG), ptr(skip), ptr(dW), B, Cs, H, W, 4 * tl.hid, H, W, tl.ks, 1, tl.pad, weight.shape[1],
+                                      tl.c_up, tl.hid, stream()), "rsis_conv2d_wgrad(hoist)")
+        if ctx.needs_input_grad[3]:
+            db = torch.zeros(4 * tl.hid, dtype=torch.float32, device=dG.device)
+            check(L.rsis_bias_grad(ptr(dG), ptr(db), B, 4 * tl.hid, H * W, tl.hid, stream()), "rsis_bias_grad(hoist)")
+        return None, dskip, dW, db
+
+
+class _StepFn(torch.autograd.Function):
+    """One ConvLSTM level at one timestep: gates = G + conv([up | h_prev], W[:, dynamic channels]) -> (h, c)."""
+
+    @staticmethod
+    def forward(ctx, tl, t, up, h_prev, c_prev, G, weight):
+        require_cuda_f32(up, h_prev, c_prev, G, weight)
+        L = lib()
+        _hoist, dyn = _packs(tl.cell, tl.c_up, tl.c_skip)
+        B, _, H, W = G.shape
+        hid = tl.hid
+        need_grad = any(ctx.needs_input_grad)
+        stacked = need_grad and tl.need_grad and t < tl.cap
+        srcs = []
+        if up is not None:
+            srcs.append(up if up.is_contiguous() else up.contiguous())
+        if h_prev is not None:
+            h_prev = h_prev if h_prev.is_contiguous() else h_prev.contiguous()
+            c_prev = c_prev if c_prev.is_contiguous() else c_prev.contiguous()
+            srcs.append(h_prev)
+        if stacked:
+            h, c, act = tl.H[t], tl.C[t], tl.ACT[t]
+        else:
+            h = torch.empty((B, hid, H, W), dtype=torch.float32, device=G.device)
+            c = torch.empty_like(h)
+            act = torch.empty((B, 4 * hid, H, W), dtype=torch.float32, device=G.device) if need_grad else None
+        wp = dyn.fwd(weight)
+        pa = ptr_array(srcs) if srcs else None
+        ia = int_array([s.shape[1] for s in srcs]) if srcs else None
+        check(L.rsis_convlstm_fwd(pa, ia, len(srcs), B, H, W, ptr(wp), None, ptr(G), ptr(c_prev) if h_prev is not None else None,
+                                  ptr(h), ptr(c), ptr(act), hid, tl.ks, tl.pad, ops.FORCE_TILE[0], stream()), "rsis_convlstm_fwd(step)")
+        ctx.tl, ctx.t, ctx.stacked = tl, t, stacked
+        ctx.has_up, ctx.has_state = up is not None, h_prev is not None
+        if need_grad:
+            if stacked:
+                tl.n_fwd = max(tl.n_fwd, t + 1)
+                ctx.save_for_backward(weight)
+            else:   # beyond the tape capacity / no tape: keep what the per-step backward needs
+                ctx.save_for_backward(weight, act, c, c_prev if h_prev is not None else None, *srcs)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        tl, t = ctx.tl, ctx.t
+        L = lib()
+        _hoist, dyn = _packs(tl.cell, tl.c_up, tl.c_skip)
+        hid, ks, pad = tl.hid, tl.ks, tl.pad
+        weight = ctx.saved_tensors[0]
+        dh = (dh if dh.is_contiguous() else dh.contiguous()) if dh is not None else None
+        dc = (dc if dc.is_contiguous() else dc.contiguous()) if dc is not None else None
+        if ctx.stacked:
+            act, c = tl.ACT[t], tl.C[t]
+            c_prev = tl.C[t - 1] if ctx.has_state else None
+            if tl.DA is None:
+                tl.DA = torch.empty_like(tl.ACT)
+            if tl.da_sum is None:
+                tl.da_sum = torch.zeros_like(tl.ACT[0])
+            da = tl.DA[t]
+            srcs = ([tl.UP[t]] if ctx.has_up else []) + ([tl.H[t - 1]] if ctx.has_state else [])
+        else:
+            act, c, c_prev = ctx.saved_tensors[1:4]
+            srcs = list(ctx.saved_tensors[4:])
+            da = torch.empty_like(act)
+            if tl.da_sum is None:
+                tl.da_sum = torch.zeros_like(act)
+        B, _, H, W = c.shape
+        dc_prev = torch.empty_like(c) if ctx.has_state else None
+        check(L.rsis_convlstm_bwd_gates(ptr(dh), ptr(dc), ptr(act), ptr(c_prev), ptr(c), ptr(da), ptr(dc_prev), ptr(tl.da_sum), B, hid,
+                                        H * W, stream()), "rsis_convlstm_bwd_gates(step)")
+        tl.n_bwd += 1
+        d_up = dh_prev = None
+        if srcs:
+            wd = dyn.dgrad(weight)
+            dxs = [torch.empty_like(s) for s in srcs]
+            check(L.rsis_conv2d_dgrad(ptr(da), B, 4 * hid, H, W, ptr(wd), dyn.cin, ks, 1, pad, ptr_array(dxs),
+                                      int_array([s.shape[1] for s in srcs]), len(srcs), H, W, ops.FORCE_TILE[0], stream()),
+                  "rsis_conv2d_dgrad(step)")
+            k = 0
+            if ctx.has_up:
+                d_up = dxs[k]
+                k += 1
+            if ctx.has_state:
+                dh_prev = dxs[k]
+        dW = dG = None
+        Ctot = weight.shape[1]
+        h_off = tl.c_up + tl.c_skip
+        if not ctx.stacked:
+            # un-batched fallback: this step's own weight gradient
+            dW = torch.zeros_like(weight)
+            off = [0] if ctx.has_up else []
+            off += [h_off] if ctx.has_state else []
+            for s, o in zip(srcs, off):
+                check(L.rsis_conv2d_wgrad(ptr(da), ptr(s), ptr(dW), B, s.shape[1], H, W, 4 * hid, H, W, ks, 1, pad, Ctot, o, hid,
+                                          stream()), "rsis_conv2d_wgrad(step)")
+        if t == 0:
+            # autograd runs the t = 0 backward last (every later step depends on it): flush the time-batched work
+            dG = tl.da_sum
+            if ctx.stacked and ctx.needs_input_grad[6]:
+                n = tl.n_fwd
+                if tl.n_bwd < n:   # steps that never received a gradient contribute zero
+                    raise RuntimeError("fused RSIS decoder: %d of %d timesteps were back-propagated" % (tl.n_bwd, n))
+                dW = torch.zeros_like(weight) if dW is None else dW
+                if tl.c_up > 0:
+                    check(L.rsis_conv2d_wgrad(ptr(tl.DA), ptr(tl.UP), ptr(dW), n * B, tl.c_up, H, W, 4 * hid, H, W, ks, 1, pad, Ctot, 0,
+                                              hid, stream()), "rsis_conv2d_wgrad(batched up)")
+                if n > 1:
+                    check(L.rsis_conv2d_wgrad(ptr(tl.DA[1]), ptr(tl.H), ptr(dW), (n - 1) * B, hid, H, W, 4 * hid, H, W, ks, 1, pad, Ctot,
+                                              h_off, hid, stream()), "rsis_conv2d_wgrad(batched h)")
+        return None, None, d_up, dh_prev, dc_prev, dG, dW
+
+
+class DecoderTape(object):
+    """Per-iteration cache of the fused decoder: the hoisted gate terms and the stacked per-level buffers."""
+
+    def __init__(self, decoder, skip_feats, need_grad):
+        self.skip_ids = tuple(f.data_ptr() for f in skip_feats)
+        self.t = 0
+        self.levels = []
+        hs = [cell.hidden_size for cell in decoder.clstm_list]
+        for i, cell in enumerate(decoder.clstm_list):
+            c_up = 0 if i == 0 else hs[i - 1]
+            c_skip = skip_feats[i].shape[1]
+            tl = LevelTape(cell, i, c_up, c_skip, decoder._tcap)
+            B, _, H, W = skip_feats[i].shape
+            tl.alloc_forward(B, H, W, skip_feats[i].device, need_grad)
+            tl.G = _HoistFn.apply(tl, skip_feats[i], cell.Gates.weight, cell.Gates.bias)
+            self.levels.append(tl)
+
+    def matches(self, skip_feats, prev_hidden_list):
+        """the caller is continuing the sequence this tape belongs to"""
+        if tuple(f.data_ptr() for f in skip_feats) != self.skip_ids or self.t == 0:
+            return False
+        for tl, st in zip(self.levels, prev_hidden_list):
+            if tl.last_h is None or st[0].data_ptr() != tl.last_h.data_ptr() or st[1].data_ptr() != tl.last_c.data_ptr():
+                return False
+        return True
+
+
+class _UpsampleIntoFn(torch.autograd.Function):
+    """align-corners bilinear upsample written straight into the level's stacked UP[t] buffer."""
+
+    @staticmethod
+    def forward(ctx, tl, t, x):
+        x = x if x.is_contiguous() else x.contiguous()
+        B, C, Hi, Wi = x.shape
+        y = tl.UP[t]
+        Ho, Wo = y.shape[-2], y.shape[-1]
+        check(lib().rsis_upsample_bilinear_ac_fwd(ptr(x), ptr(y), B * C, Hi, Wi, Ho, Wo, stream()), "rsis_upsample_fwd")
+        ctx.dims = (B, C, Hi, Wi, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, Hi, Wi, Ho, Wo = ctx.dims
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty((B, C, Hi, Wi), dtype=torch.float32, device=dy.device)
+        check(lib().rsis_upsample_bilinear_ac_bwd(ptr(dy), ptr(dx), B * C, Hi, Wi, Ho, Wo, stream()), "rsis_upsample_bwd")
+        return None, None, dx
+
+
+def decoder_levels(decoder, skip_feats, prev_hidden_list):
+    """The 5-level ConvLSTM pyramid of RSIS.forward (model.py:129-165) with hoisting; returns (hidden_list, side_feats,
+    last up-sampled hidden) or None when the fused path does not apply to this call."""
+    need_grad = torch.is_grad_enabled() and (any(f.requires_grad for f in skip_feats) or
+                                            any(p.requires_grad for p in decoder.clstm_list.parameters()))
+    tape = decoder._tape
+    if prev_hidden_list is None:
+        tape = decoder._tape = DecoderTape(decoder, skip_feats, need_grad)
+    elif tape is None or not tape.matches(skip_feats, prev_hidden_list):
+        return None
+    t = tape.t
+    hidden_list, side_feats = [], []
+    up = None
+    n_levels = len(tape.levels)
+    for i, tl in enumerate(tape.levels):
+        cell = tl.cell
+        h_prev, c_prev = (None, None) if prev_hidden_list is None else (prev_hidden_list[i][0], prev_hidden_list[i][1])
+        h, c = _StepFn.apply(tl, t, up, h_prev, c_prev, tl.G, cell.Gates.weight)
+        tl.last_h, tl.last_c = h, c
+        hidden_list.append([h, c])                                       # model.py:137
+        side_feats.append(ops.global_maxpool(h))                         # model.py:143
+        if i + 1 < n_levels:
+            nxt = tape.levels[i + 1]
+            if nxt.UP is not None and t < nxt.cap:
+                up = _UpsampleIntoFn.apply(nxt, t, h)                    # model.py:149-150 (into the stacked buffer)
+            else:
+                up = ops.upsample_bilinear_ac(h, skip_feats[i + 1].shape[-2:])
+        else:
+            up = ops.upsample_bilinear_ac(h, (h.shape[-2] * 2, h.shape[-1] * 2))   # model.py:163-164
+    tape.t += 1
+    return hidden_list, side_feats, up

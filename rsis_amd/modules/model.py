@@ -9,7 +9,9 @@ forward.
 import torch
 from torch import nn
 
-from .. import ops
+import os
+
+from .. import decoder_fused, ops
 from ..utils.utils import get_skip_dims
 from .clstm import ConvLSTMCell
 from .vision import HipBatchNorm2d, HipConv2d, ResNet101
@@ -83,8 +85,34 @@ class RSIS(nn.Module):
         fc_dim = sum(skip_dims_out)                                      # model.py:115-117
         self.fc_class = nn.Linear(fc_dim, self.num_classes)              # model.py:119
         self.fc_stop = nn.Linear(fc_dim, 1)                              # model.py:120
+        # private per-iteration cache of the fused path (time-invariant hoisting + time-batched weight gradients)
+        self._tcap = int(getattr(args, "maxseqlen", 10))
+        self._tape = None
+        self.fused = os.environ.get("RSIS_DECODER_FUSED", "1") != "0"
+
+    def _heads(self, clstm_in, side_feats, hidden_list):
+        out_mask = self.conv_out(clstm_in)                               # model.py:167
+        side_feats = torch.cat(side_feats, 1).squeeze()                  # model.py:169 (drops the batch dim at B == 1)
+        if self.dropout_cls > 0:
+            class_feats = nn.functional.dropout(side_feats, self.dropout_cls, training=True)
+        else:
+            class_feats = side_feats
+        class_feats = self.fc_class(class_feats)                         # model.py:174
+        if self.dropout_stop > 0:
+            stop_feats = nn.functional.dropout(side_feats, self.dropout_stop, training=True)
+        else:
+            stop_feats = side_feats
+        stop_probs = self.fc_stop(stop_feats)                            # model.py:179 (a logit)
+        # model.py:182: implicit-dim nn.Softmax() -> dim 1 for 2-D input (dim 0 for the 1-D B == 1 quirk)
+        class_probs = torch.softmax(class_feats, dim=1 if class_feats.dim() == 2 else 0)
+        return out_mask, class_probs, stop_probs, hidden_list            # model.py:184
 
     def forward(self, skip_feats, prev_hidden_list):
+        if self.fused and self.skip_mode == "concat" and self.dropout == 0 and len(skip_feats) == len(self.clstm_list):
+            res = decoder_fused.decoder_levels(self, skip_feats, prev_hidden_list)
+            if res is not None:
+                hidden_list, side_feats, up = res
+                return self._heads(up, side_feats, hidden_list)
         clstm_in = [skip_feats[0]]                                       # model.py:124
         skip_feats = skip_feats[1:]
         side_feats = []
@@ -112,18 +140,4 @@ class RSIS(nn.Module):
             else:
                 hidden = ops.upsample_bilinear_ac(hidden, (hidden.shape[-2] * 2, hidden.shape[-1] * 2))   # model.py:163-164
                 clstm_in = [hidden]
-        out_mask = self.conv_out(clstm_in[0])                            # model.py:167
-        side_feats = torch.cat(side_feats, 1).squeeze()                  # model.py:169 (drops the batch dim at B == 1)
-        if self.dropout_cls > 0:
-            class_feats = nn.functional.dropout(side_feats, self.dropout_cls, training=True)
-        else:
-            class_feats = side_feats
-        class_feats = self.fc_class(class_feats)                         # model.py:174
-        if self.dropout_stop > 0:
-            stop_feats = nn.functional.dropout(side_feats, self.dropout_stop, training=True)
-        else:
-            stop_feats = side_feats
-        stop_probs = self.fc_stop(stop_feats)                            # model.py:179 (a logit)
-        # model.py:182: implicit-dim nn.Softmax() -> dim 1 for 2-D input (dim 0 for the 1-D B == 1 quirk)
-        class_probs = torch.softmax(class_feats, dim=1 if class_feats.dim() == 2 else 0)
-        return out_mask, class_probs, stop_probs, hidden_list            # model.py:184
+        return self._heads(clstm_in[0], side_feats, hidden_list)

@@ -25,15 +25,18 @@ def bump_weight_epoch():
 class PackedConv(object):
     """Private MFMA-friendly copies of one nn.Conv2d weight (never serialised; rebuilt when the weight changes).
 
-    segs: channel counts of the tensors whose concat forms the conv input (torch.cat folded into the kernel).
+    segs / offs: channel counts (and offsets inside the weight's input channels; default consecutive) of the tensors the
+    conv gathers from -- the channel concat (torch.cat folded into the kernel) or a subset of the input channels.
     lstm_hid > 0: ConvLSTM `Gates` conv -- rows [i|f|o|g] are interleaved to 4*j+gate (clstm.py:47).
     """
 
-    def __init__(self, ks, segs, lstm_hid=0, stride=1, pad=None):
+    def __init__(self, ks, segs, lstm_hid=0, stride=1, pad=None, offs=None):
         self.ks = int(ks)
         self.stride = int(stride)
         self.pad = int(ks // 2 if pad is None else pad)
         self.segs = [int(s) for s in segs]
+        self.offs = [int(o) for o in offs] if offs is not None else None
+        self.cin = sum(self.segs)
         self.lstm_hid = int(lstm_hid)
         self._key_f = None
         self._key_d = None
@@ -44,17 +47,19 @@ class PackedConv(object):
     def _key(self, w):
         return (_WEIGHT_EPOCH[0], w._version, w.data_ptr())
 
+    def _seg_args(self):
+        return len(self.segs), int_array(self.segs), (int_array(self.offs) if self.offs is not None else None)
+
     def fwd(self, w, bias=None):
         key = self._key(w) + ((bias._version, bias.data_ptr()) if bias is not None else ())
         if self._key_f != key:
             L = lib()
             Cout, Ctot = w.shape[0], w.shape[1]
-            segs = int_array(self.segs)
-            n = L.rsis_conv_packed_floats_fwd(Cout, self.ks, self.stride, self.pad, len(self.segs), segs)
+            nseg, segs, offs = self._seg_args()
+            n = L.rsis_conv_packed_floats_fwd(Cout, self.ks, self.stride, self.pad, nseg, segs)
             if self.wp is None or self.wp.numel() != n:
                 self.wp = torch.empty(n, dtype=torch.float32, device=w.device)
-            wd = w.detach()
-            check(L.rsis_conv_pack_fwd(ptr(wd), ptr(self.wp), Cout, Ctot, self.ks, self.stride, self.pad, len(self.segs), segs,
+            check(L.rsis_conv_pack_fwd(ptr(w.detach()), ptr(self.wp), Cout, Ctot, self.ks, self.stride, self.pad, nseg, segs, offs,
                                        self.lstm_hid, stream()), "rsis_conv_pack_fwd")
             if bias is not None and self.lstm_hid > 0:
                 self.bias_p = bias.detach().view(4, self.lstm_hid).t().contiguous().view(-1)
@@ -66,10 +71,11 @@ class PackedConv(object):
         if self._key_d != key:
             L = lib()
             Cout, Ctot = w.shape[0], w.shape[1]
-            n = L.rsis_conv_packed_floats_dgrad(Cout, self.ks, self.stride, self.pad, Ctot)
+            nseg, segs, offs = self._seg_args()
+            n = L.rsis_conv_packed_floats_dgrad(Cout, self.ks, self.stride, self.pad, self.cin)
             if self.wd is None or self.wd.numel() != n:
                 self.wd = torch.empty(n, dtype=torch.float32, device=w.device)
-            check(L.rsis_conv_pack_dgrad(ptr(w.detach()), ptr(self.wd), Cout, Ctot, self.ks, self.stride, self.pad, 0, Ctot,
+            check(L.rsis_conv_pack_dgrad(ptr(w.detach()), ptr(self.wd), Cout, Ctot, self.ks, self.stride, self.pad, nseg, segs, offs,
                                          self.lstm_hid, stream()), "rsis_conv_pack_dgrad")
             self._key_d = key
         return self.wd
@@ -138,7 +144,7 @@ class _Conv2dFn(torch.autograd.Function):
         grads = [None] * (nsrc + 2)
         if any(ctx.needs_input_grad[4:4 + nsrc]):
             wd = ctx.pack.dgrad(weight)
-            dxs = _dgrad_all(L, dy, wd, weight.shape[1], ks, ctx.stride, ctx.pad, srcs, srcs[0].shape[2], srcs[0].shape[3])
+            dxs = _dgrad_all(L, dy, wd, ctx.pack.cin, ks, ctx.stride, ctx.pad, srcs, srcs[0].shape[2], srcs[0].shape[3])
             for i in range(nsrc):
                 if ctx.needs_input_grad[4 + i]:
                     grads[i] = dxs[i]
@@ -206,7 +212,7 @@ class _ConvLSTMFn(torch.autograd.Function):
         need_src = list(ctx.needs_input_grad[4:4 + nx]) + ([ctx.needs_input_grad[4 + nx]] if has_state else [])
         if any(need_src):
             wd = ctx.pack.dgrad(weight)
-            dxs = _dgrad_all(L, da, wd, weight.shape[1], ks, 1, ctx.pad, srcs, H, W)
+            dxs = _dgrad_all(L, da, wd, ctx.pack.cin, ks, 1, ctx.pad, srcs, H, W)
             for i in range(nx):
                 if need_src[i]:
                     grads[i] = dxs[i]

@@ -249,3 +249,39 @@ def test_training_reduces_loss():
     ls = [runIter(a, enc, dec, *batch, crits, opts, mode="train")[0][0] for _ in range(8)]
     assert all(v == v for v in ls), ls
     assert ls[-1] < ls[0], ls
+
+
+@pytest.mark.parametrize("tcap", [10, 2])
+def test_fused_decoder_equals_unfused(tcap):
+    """hoisted + time-batched decoder path == plain per-cell path (same kernels, different schedule), incl. all grads;
+    tcap=2 < T exercises the beyond-capacity fallback steps."""
+    from oracle import filler
+    from rsis_amd.modules import RSIS
+    hs, B, T = 32, 2, 4
+    sizes = [(3, 4), (5, 7), (10, 13), (19, 25), (37, 50)]
+    chans = [hs, hs, hs // 2, hs // 4, hs // 8]
+    a = mk_args(hidden_size=hs, maxseqlen=tcap)
+    torch.manual_seed(1)
+    ref = RSIS(a).cuda()
+    ref.fused = False
+    fus = RSIS(a).cuda()
+    fus.load_state_dict(ref.state_dict())
+    assert fus.fused
+    res = []
+    for dec in (ref, fus):
+        feats = [filler.tensor(7, "fz.f%d" % i, (B, chans[i]) + sizes[i]).cuda().requires_grad_() for i in range(5)]
+        hidden, loss, outs = None, 0.0, []
+        for t in range(T):
+            m, c, s, hidden = dec(feats, hidden)
+            outs += [m, c, s]
+            loss = loss + (m * filler.tensor(7, "fz.gm%d" % t, m.shape).cuda()).sum() + (c * c).sum() + s.sum()
+        loss = loss + sum((h * h).mean() + c.mean() for h, c in hidden)
+        loss.backward()
+        res.append((outs, [f.grad for f in feats], {k: p.grad for k, p in dec.named_parameters()}))
+    for i, (p, q) in enumerate(zip(res[0][0], res[1][0])):
+        assert_close("out%d" % i, q, p, 2e-5, 1e-5)
+    for i, (p, q) in enumerate(zip(res[0][1], res[1][1])):
+        assert_close("dfeat%d" % i, q, p, 1e-4 * max(1.0, float(p.abs().max())), 1e-4)
+    for k in res[0][2]:
+        p, q = res[0][2][k], res[1][2][k]
+        assert_close("grad." + k, q, p, 1e-4 * max(1.0, float(p.abs().max())), 1e-4)
