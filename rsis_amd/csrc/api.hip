@@ -1,11 +1,13 @@
 // extern "C" entry points of librsis_hip.so (declared in include/rsis_hip.h).  Argument validation + dispatch only.
 #include "common.h"
 #include "../../include/rsis_hip.h"
+#include <stdlib.h>
 
 // launchers implemented in the other translation units
 int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_tile, hipStream_t st);
 int rsis_launch_conv_wgrad(WgradArgs& a, int ks, hipStream_t st);
 int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st);
+int rsis_launch_conv3x3_wgrad_direct(const WgradArgs& w, hipStream_t st);
 int rsis_l_pack(int, const float*, float*, int, int, int, int, const int*, const int*, int, int, int, hipStream_t);
 
 int rsis_l_lstm_bwd(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
@@ -153,6 +155,10 @@ int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs,
   WgradArgs a = {};
   a.dy = dy; a.x = x; a.dw = dW; a.B = B; a.Cs = Cs; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.stride = stride; a.pad = pad; a.ldo = Ctot * ks * ks; a.n_off = c_off * ks * ks; a.interleave_hid = lstm_hid;
+  // experimental LDS-patch wgrad (conv3x3_wgrad_direct.hip): measured no faster than the split-K implicit GEMM on this
+  // round's shapes (staging is not overlapped, atomics double), so it is opt-in: RSIS_WGRAD_DIRECT=1
+  static const bool direct_ok = getenv("RSIS_WGRAD_DIRECT") && getenv("RSIS_WGRAD_DIRECT")[0] == '1';
+  if (direct_ok && use_direct(ks, stride, pad) && H == Ho && W == Wo) return rsis_launch_conv3x3_wgrad_direct(a, (hipStream_t)stream);
   return rsis_launch_conv_wgrad(a, ks, (hipStream_t)stream);
 }
 

@@ -25,7 +25,9 @@ typedef const char __attribute__((address_space(1)))* gcc_t;
 typedef float __attribute__((address_space(1)))* gf_t;
 typedef const f32x4 __attribute__((address_space(1)))* gcf4_t;
 
-template <int BM, int BN, int BK, int WGM, int WGN, int KS, bool DGRAD, int EPI>
+// V4: 1x1 / stride 1 / single source with H*W % 4 == 0 (the bottleneck 1x1 convs and their data gradients): the pixel
+// operand is loaded as float4 runs along W (a plain GEMM B-tile), 4x fewer load instructions and no per-tap masks.
+template <int BM, int BN, int BK, int WGM, int WGN, int KS, bool DGRAD, int EPI, bool V4>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int KK = KS * KS;
@@ -36,6 +38,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   static_assert(WGM * WGN == 4, "4 waves per block");
   static_assert(BN == 64 || BN == 128 || BN == 256, "BN");
   static_assert(RSIS_KPAD % BK == 0, "BK must divide the packed K padding");
+  static_assert(!V4 || (KS == 1 && !DGRAD), "V4 is the 1x1 GEMM path");
+  constexpr int BV_COLS = BN / 4;            // float4 columns of the pixel tile
+  constexpr int BV_ROWS = 256 / BV_COLS;     // k rows per load pass
+  constexpr int BV_LOADS = V4 ? BK / BV_ROWS : 1;
   typedef typename std::conditional<(KK > 32), unsigned long long, unsigned>::type mask_t;
 
   __shared__ __attribute__((aligned(16))) float lds[2 * BK * (BM + BN)];
@@ -107,13 +113,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float rb[B_LOADS];
+  float rb[V4 ? 1 : B_LOADS];
+  f32x4 rbv[BV_LOADS];
   f32x4 ra[A_LOADS];
+  // V4 mapping: thread -> (float4 column, first k row); the 4 pixels share an image because H*W % 4 == 0
+  const int v_col = tid % BV_COLS, v_row0 = tid / BV_COLS;
+  int v_px = px_t * BN + v_col * 4;
+  const bool v_ok = v_px < Npx;
+  if (!v_ok) v_px = 0;
+  const int v_b = v_px / HoWo;
+  const int v_base = v_b * C0 * HW + (v_px - v_b * HoWo);   // V4 => H == Ho, W == Wo, one source
   const int ntiles = (p.K + BK - 1) / BK;
   const gcf_t wbase = (gcf_t)p.wp + co_t * BM;
 
 #define RSIS_LOAD_TILE(T)                                                                                          \
   {                                                                                                                \
+    if constexpr (V4) {                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < BV_LOADS; ++i) {                                                       \
+        const int ci = (T) * BK + v_row0 + i * BV_ROWS;                                                            \
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                            \
+        if (v_ok && ci < C0) v = *(gcf4_t)((gcf_t)src0 + (size_t)(v_base + ci * HW));                              \
+        rbv[i] = v;                                                                                                \
+      }                                                                                                            \
+    } else                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) {                                                          \
       const int kl = __builtin_amdgcn_readfirstlane((T) * BK + krow0 + i * B_ROWS); /* scalar from here on */      \
       const int cg = kl / KK;                                                                                      \
@@ -145,6 +167,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   {                                                                                                                \
     float* As = As0 + (BUF) * BK * BM;                                                                             \
     float* Bs = Bs0 + (BUF) * BK * BN;                                                                             \
+    if constexpr (V4) {                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < BV_LOADS; ++i)                                                         \
+        *reinterpret_cast<f32x4*>(Bs + (v_row0 + i * BV_ROWS) * BN + v_col * 4) = rbv[i];                          \
+    } else                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) Bs[(krow0 + i * B_ROWS) * BN + px_local] = rb[i];          \
     _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                                          \
       const int idx = tid + i * 256;                                                                               \
@@ -271,7 +297,13 @@ static int launch_cfg(ConvArgs& a, hipStream_t st) {
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
   a.n_px_tiles = rsis_cdiv(Npx, BN);
   const int grid = a.n_co_tiles * 8 * rsis_cdiv(a.n_px_tiles, 8);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, KS, DGRAD, EPI>), dim3(grid), dim3(256), 0, st, a);
+  if constexpr (KS == 1 && !DGRAD && EPI == EPI_PLAIN) {
+    if (a.stride == 1 && a.pad == 0 && a.nsrc == 1 && (a.H * a.W) % 4 == 0) {
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, KS, DGRAD, EPI, true>), dim3(grid), dim3(256), 0, st, a);
+      return rsis_check_launch();
+    }
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, KS, DGRAD, EPI, false>), dim3(grid), dim3(256), 0, st, a);
   return rsis_check_launch();
 }
 
@@ -282,6 +314,7 @@ static int launch_ks(ConvArgs& a, hipStream_t st, int force_tile) {
   int tile = force_tile;
   if (tile <= 0) {
     if (a.Cout <= 32) tile = (Npx >= 256L * 256) ? 1 : 2;
+    else if (KS == 1) tile = 5;   // 1x1 GEMMs of the trunk (8k..131k px, 64..2048 ch): 64x64 tiles measured best (79-95 TF/s)
     else if (a.Cout <= 64) tile = 3;
     else {
       const long b128 = (long)rsis_cdiv(a.Cout, 128) * rsis_cdiv(Npx, 128);
@@ -319,6 +352,7 @@ int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_t
     if (ks == 3) return launch_ks<3, false, EPI_PLAIN>(a, st, force_tile);
     if (ks == 7) return launch_ks<7, false, EPI_PLAIN>(a, st, force_tile);
   } else {
+    if (ks == 1 && a.stride == 1 && a.pad == 0) return launch_ks<1, false, EPI_PLAIN>(a, st, force_tile);  // 1x1/s1 dgrad == a 1x1 conv
     if (ks == 1) return launch_ks<1, true, EPI_PLAIN>(a, st, force_tile);
     if (ks == 3) return launch_ks<3, true, EPI_PLAIN>(a, st, force_tile);
     if (ks == 7) return launch_ks<7, true, EPI_PLAIN>(a, st, force_tile);
