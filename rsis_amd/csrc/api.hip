@@ -8,6 +8,10 @@ int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_t
 int rsis_launch_conv_wgrad(WgradArgs& a, int ks, hipStream_t st);
 int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st);
 int rsis_launch_conv3x3_wgrad_direct(const WgradArgs& w, hipStream_t st);
+bool rsis_c1_supported(int Cin);
+int rsis_l_c1_fwd(const float*, const float*, int, const float*, float*, int, int, int, int, hipStream_t);
+int rsis_l_c1_dgrad(const float*, const float*, int, float*, int, int, int, int, hipStream_t);
+int rsis_l_c1_wgrad(const float*, const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_pack(int, const float*, float*, int, int, int, int, const int*, const int*, int, int, int, hipStream_t);
 
 int rsis_l_lstm_bwd(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
@@ -123,6 +127,8 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
   a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = pad; a.sshift = 0;
   a.wp = Wp; a.ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN); a.Cout = Cout; a.bias = bias; a.addend = addend;
   a.dst[0] = out; a.Cd[0] = Cout; a.ndst = 1;
+  if (use_direct(ks, stride, pad) && Cout == 1 && nsrc == 1 && !addend && rsis_c1_supported(Csrc[0]))   // conv_out: HBM-bound VALU kernel
+    return rsis_l_c1_fwd(src[0], Wp, a.ldw, bias, out, B, Csrc[0], H, W, (hipStream_t)stream);
   if (use_direct(ks, stride, pad)) return rsis_launch_conv3x3_direct(a, 0, direct_variant(tile), (hipStream_t)stream);
   return rsis_launch_conv_igemm(a, ks, false, 0, tile, (hipStream_t)stream);
 }
@@ -144,6 +150,8 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const fl
   a.wp = Wd; a.ldw = rsis_roundup(Cin_packed, RSIS_LDW_ALIGN); a.Cout = ctot; a.bias = nullptr; a.addend = nullptr;
   if (use_direct(ks, stride, pad)) {
     if (Hx != Hy || Wx != Wy) return RSIS_ERR_ARG;
+    if (Cout == 1 && ndst == 1 && Cin_packed == Cdx[0] && rsis_c1_supported(Cdx[0]))
+      return rsis_l_c1_dgrad(dy, Wd, a.ldw, dx[0], B, Cdx[0], Hx, Wx, (hipStream_t)stream);
     return rsis_launch_conv3x3_direct(a, 0, direct_variant(tile), (hipStream_t)stream);
   }
   return rsis_launch_conv_igemm(a, ks, true, 0, tile, (hipStream_t)stream);
@@ -155,6 +163,8 @@ int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs,
   WgradArgs a = {};
   a.dy = dy; a.x = x; a.dw = dW; a.B = B; a.Cs = Cs; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.stride = stride; a.pad = pad; a.ldo = Ctot * ks * ks; a.n_off = c_off * ks * ks; a.interleave_hid = lstm_hid;
+  if (use_direct(ks, stride, pad) && Cout == 1 && lstm_hid == 0 && rsis_c1_supported(Cs) && H == Ho && W == Wo)
+    return rsis_l_c1_wgrad(dy, x, dW + a.n_off, B, Cs, H, W, (hipStream_t)stream);
   // experimental LDS-patch wgrad (conv3x3_wgrad_direct.hip): measured no faster than the split-K implicit GEMM on this
   // round's shapes (staging is not overlapped, atomics double), so it is opt-in: RSIS_WGRAD_DIRECT=1
   static const bool direct_ok = getenv("RSIS_WGRAD_DIRECT") && getenv("RSIS_WGRAD_DIRECT")[0] == '1';

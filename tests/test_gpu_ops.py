@@ -34,7 +34,9 @@ CONV_CASES = [
     (2, [64], 17, 15, 64, 3, 2, 1, False),      # strided 3x3 (odd size)
     (2, [256], 8, 8, 512, 1, 2, 0, False),      # downsample 1x1 s2
     (2, [16, 16], 12, 20, 32, 3, 1, 1, True),   # concat by pointer
-    (2, [8], 20, 24, 1, 3, 1, 1, True),         # conv_out
+    (2, [8], 20, 24, 1, 3, 1, 1, True),         # conv_out (Cout = 1: bandwidth kernel)
+    (3, [16], 9, 13, 1, 3, 1, 1, True),         # conv_out, 16 channels, odd size
+    (2, [6], 8, 8, 1, 3, 1, 1, False),          # Cout = 1 with an unsupported Cin -> MFMA path
     (1, [130], 7, 7, 129, 3, 1, 1, True),       # ragged channels
     (2, [2048], 4, 4, 128, 3, 1, 1, True),      # sk5-like deep K
 ]
