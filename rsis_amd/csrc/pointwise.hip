@@ -145,15 +145,34 @@ __device__ __forceinline__ void block_reduce2_atomic(double a, double b, double*
   }
 }
 
-// grid (C, S): block (c, s) reduces elements e = s*256+tid, stride S*256, of channel c (e over B*HW)
+// Iteration scheme of the BN kernels: grid (C, S); block (c, s) walks channel c's B*HW elements in float4 groups
+// (H*W % 4 == 0: a group never straddles an image) g = s*256 + tid, stride S*256, or element-wise otherwise.
+// VEC = 4 or 1 elements per step; `body(idx, k)` sees the flat NCHW index of element k of the group.
+#define BN_FOREACH(VEC, ...)                                                                    \
+  {                                                                                             \
+    const long ng = N / (VEC);                                                                  \
+    const int hwg = HW / (VEC);                                                                 \
+    for (long g = blockIdx.y * 256L + threadIdx.x; g < ng; g += gridDim.y * 256L) {            \
+      const long b = g / hwg;                                                                   \
+      const int sp = (int)(g - b * hwg) * (VEC);                                                \
+      const long idx = (b * C + c) * HW + sp;                                                   \
+      __VA_ARGS__                                                                               \
+    }                                                                                           \
+  }
+
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int C, int HW,
                                                        long N) {
   const int c = blockIdx.x;
   double s = 0.0, ss = 0.0;
-  for (long e = blockIdx.y * 256L + threadIdx.x; e < N; e += gridDim.y * 256L) {
-    const long b = e / HW; const int sp = (int)(e - b * HW);
-    const float v = x[(b * C + c) * HW + sp];
-    s += v; ss += (double)v * v;
+  if ((HW & 3) == 0) {
+    BN_FOREACH(4, {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + idx);
+      const float ps = (v[0] + v[1]) + (v[2] + v[3]);
+      const float pq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      s += ps; ss += pq;
+    })
+  } else {
+    BN_FOREACH(1, { const float v = x[idx]; s += v; ss += (double)v * v; })
   }
   block_reduce2_atomic(s, ss, stats + 2 * c);
 }
@@ -184,13 +203,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     rstd = 1.0f / sqrtf(run_var[c] + eps);
   }
   const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
-  for (long e = blockIdx.y * 256L + threadIdx.x; e < N; e += gridDim.y * 256L) {
-    const long b = e / HW; const int sp = (int)(e - b * HW);
-    const long idx = (b * C + c) * HW + sp;
-    float v = x[idx] * sc + sh;
-    if (res) v += res[idx];
-    if (relu) v = fmaxf(v, 0.f);
-    y[idx] = v;
+  if ((HW & 3) == 0) {
+    BN_FOREACH(4, {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + idx);
+      f32x4 r = {0.f, 0.f, 0.f, 0.f};
+      if (res) r = *reinterpret_cast<const f32x4*>(res + idx);
+      for (int k = 0; k < 4; ++k) { float t = v[k] * sc + sh + r[k]; v[k] = relu ? fmaxf(t, 0.f) : t; }
+      *reinterpret_cast<f32x4*>(y + idx) = v;
+    })
+  } else {
+    BN_FOREACH(1, {
+      float v = x[idx] * sc + sh;
+      if (res) v += res[idx];
+      if (relu) v = fmaxf(v, 0.f);
+      y[idx] = v;
+    })
   }
 }
 
@@ -202,12 +229,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   const int c = blockIdx.x;
   const float m = mean[c], r = rstd[c];
   double s1 = 0.0, s2 = 0.0;
-  for (long e = blockIdx.y * 256L + threadIdx.x; e < N; e += gridDim.y * 256L) {
-    const long b = e / HW; const int sp = (int)(e - b * HW);
-    const long idx = (b * C + c) * HW + sp;
-    float g = dy[idx];
-    if (relu && !(y[idx] > 0.f)) g = 0.f;
-    s1 += g; s2 += (double)g * ((x[idx] - m) * r);
+  if ((HW & 3) == 0) {
+    BN_FOREACH(4, {
+      f32x4 g = *reinterpret_cast<const f32x4*>(dy + idx);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + idx);
+      if (relu) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + idx);
+        for (int k = 0; k < 4; ++k) if (!(yv[k] > 0.f)) g[k] = 0.f;
+      }
+      float p1 = 0.f, p2 = 0.f;
+      for (int k = 0; k < 4; ++k) { p1 += g[k]; p2 += g[k] * ((xv[k] - m) * r); }
+      s1 += p1; s2 += p2;
+    })
+  } else {
+    BN_FOREACH(1, {
+      float g = dy[idx];
+      if (relu && !(y[idx] > 0.f)) g = 0.f;
+      s1 += g; s2 += (double)g * ((x[idx] - m) * r);
+    })
   }
   block_reduce2_atomic(s1, s2, stats + 2 * c);
 }
@@ -222,18 +261,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const int c = blockIdx.x;
   const float m = mean[c], r = rstd[c];
   const float mg = (float)(stats[2 * c] / (double)N), mgx = (float)(stats[2 * c + 1] / (double)N);
-  const float k = gamma[c] * r;
+  const float kk = gamma[c] * r;
   if (blockIdx.y == 0 && threadIdx.x == 0) { dgamma[c] = (float)stats[2 * c + 1]; dbeta[c] = (float)stats[2 * c]; }
-  for (long e = blockIdx.y * 256L + threadIdx.x; e < N; e += gridDim.y * 256L) {
-    const long b = e / HW; const int sp = (int)(e - b * HW);
-    const long idx = (b * C + c) * HW + sp;
-    float g = dy[idx];
-    if (relu && !(y[idx] > 0.f)) g = 0.f;
-    const float xh = (x[idx] - m) * r;
-    dx[idx] = k * (g - mg - xh * mgx);
-    if (dres) dres[idx] = g;
+  if ((HW & 3) == 0) {
+    BN_FOREACH(4, {
+      f32x4 g = *reinterpret_cast<const f32x4*>(dy + idx);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + idx);
+      if (relu) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + idx);
+        for (int k = 0; k < 4; ++k) if (!(yv[k] > 0.f)) g[k] = 0.f;
+      }
+      f32x4 o;
+      for (int k = 0; k < 4; ++k) o[k] = kk * (g[k] - mg - ((xv[k] - m) * r) * mgx);
+      *reinterpret_cast<f32x4*>(dx + idx) = o;
+      if (dres) *reinterpret_cast<f32x4*>(dres + idx) = g;
+    })
+  } else {
+    BN_FOREACH(1, {
+      float g = dy[idx];
+      if (relu && !(y[idx] > 0.f)) g = 0.f;
+      const float xh = (x[idx] - m) * r;
+      dx[idx] = kk * (g - mg - xh * mgx);
+      if (dres) dres[idx] = g;
+    })
   }
 }
+#undef BN_FOREACH
 
 // ------------------------------------------------------------------------------------------------
 // MaxPool2d(3, stride 2, pad 1) of the ResNet stem (torchvision; reference vision.py:15)
