@@ -90,13 +90,15 @@ int rsis_global_maxpool_fwd(const float* x, float* y, int* argmax, long BC, int 
 int rsis_global_maxpool_bwd(const float* dy, const int* argmax, float* dx, long BC, int HW, void* stream);
 
 /* ---- nn.BatchNorm2d (+ residual add + ReLU of the bottleneck) (model.py:50-54,59-63; torchvision trunk) ----
- * train != 0: batch statistics, running-stat update (momentum, unbiased var), saves mean / rstd for the backward.
- * stats: scratch of 2*C doubles. res may be NULL. */
+ * train bit0: batch statistics, running-stat update (momentum, unbiased var), saves mean / rstd for the backward;
+ * train bit1: `stats` (scratch of 2*C doubles) was zeroed by the caller (one memset for a whole arena instead of one per
+ * layer). res may be NULL. */
 int rsis_bn_fwd(const float* x, const float* res, float* y, double* stats, const float* gamma, const float* beta,
                 float* running_mean, float* running_var, float* save_mean, float* save_rstd, int B, int C, int HW,
                 float eps, float momentum, int relu, int train, void* stream);
-/* train-mode backward. y (the forward output) is only read when relu != 0. dres (grad of the residual input = masked
- * dy) may be NULL. */
+/* train-mode backward. relu bit0: the forward applied ReLU (y, the forward output, is read for the mask); bit1: `stats`
+ * was zeroed by the caller; bit2: ACCUMULATE into dgamma / dbeta instead of overwriting. dres (grad of the residual
+ * input = masked dy) may be NULL. */
 int rsis_bn_bwd(const float* dy, const float* x, const float* y, const float* save_mean, const float* save_rstd,
                 const float* gamma, double* stats, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C,
                 int HW, int relu, void* stream);

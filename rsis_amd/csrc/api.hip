@@ -219,7 +219,7 @@ int rsis_bn_fwd(const float* x, const float* res, float* y, double* stats, const
                 float* running_mean, float* running_var, float* save_mean, float* save_rstd, int B, int C, int HW,
                 float eps, float momentum, int relu, int train, void* stream) {
   if (!x || !y || !gamma || !beta || !running_mean || !running_var) return RSIS_ERR_ARG;
-  if (train && (!stats || !save_mean || !save_rstd)) return RSIS_ERR_ARG;
+  if ((train & 1) && (!stats || !save_mean || !save_rstd)) return RSIS_ERR_ARG;
   return rsis_l_bn_fwd(x, res, y, stats, gamma, beta, running_mean, running_var, save_mean, save_rstd, B, C, HW, eps,
                        momentum, relu, train, (hipStream_t)stream);
 }
@@ -227,7 +227,7 @@ int rsis_bn_bwd(const float* dy, const float* x, const float* y, const float* sa
                 const float* gamma, double* stats, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C,
                 int HW, int relu, void* stream) {
   if (!dy || !x || !save_mean || !save_rstd || !gamma || !stats || !dx || !dgamma || !dbeta) return RSIS_ERR_ARG;
-  if (relu && !y) return RSIS_ERR_ARG;
+  if ((relu & 1) && !y) return RSIS_ERR_ARG;
   return rsis_l_bn_bwd(dy, x, y, save_mean, save_rstd, gamma, stats, dx, dres, dgamma, dbeta, B, C, HW, relu,
                        (hipStream_t)stream);
 }

@@ -257,12 +257,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const double* __restrict__ stats, float* __restrict__ dx,
                                                            float* __restrict__ dres, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int C, int HW, long N, int relu) {
+                                                           float* __restrict__ dbeta, int C, int HW, long N, int relu,
+                                                           int accum) {
   const int c = blockIdx.x;
   const float m = mean[c], r = rstd[c];
   const float mg = (float)(stats[2 * c] / (double)N), mgx = (float)(stats[2 * c + 1] / (double)N);
   const float kk = gamma[c] * r;
-  if (blockIdx.y == 0 && threadIdx.x == 0) { dgamma[c] = (float)stats[2 * c + 1]; dbeta[c] = (float)stats[2 * c]; }
+  if (blockIdx.y == 0 && threadIdx.x == 0) {
+    const float dg = (float)stats[2 * c + 1], db = (float)stats[2 * c];
+    dgamma[c] = accum ? dgamma[c] + dg : dg;
+    dbeta[c] = accum ? dbeta[c] + db : db;
+  }
   if ((HW & 3) == 0) {
     BN_FOREACH(4, {
       f32x4 g = *reinterpret_cast<const f32x4*>(dy + idx);
@@ -425,11 +430,12 @@ int rsis_l_gmax_bwd(const float* dy, const int* arg, float* dx, long BC, int HW,
 }
 int rsis_l_bn_fwd(const float* x, const float* res, float* y, double* stats, const float* gamma, const float* beta,
                   float* run_mean, float* run_var, float* save_mean, float* save_rstd, int B, int C, int HW, float eps,
-                  float momentum, int relu, int train, hipStream_t st) {
+                  float momentum, int relu, int train_flags, hipStream_t st) {
   const long N = (long)B * HW;
   const int S = chan_splits(C, N);
+  const int train = train_flags & 1;
   if (train) {
-    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, st) != hipSuccess) return RSIS_ERR_LAUNCH;
+    if (!(train_flags & 2) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, st) != hipSuccess) return RSIS_ERR_LAUNCH;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, S), dim3(256), 0, st, x, stats, C, HW, N);
   }
   hipLaunchKernelGGL(bn_apply_kernel, dim3(C, S), dim3(256), 0, st, x, res, y, stats, gamma, beta, run_mean, run_var, save_mean,
@@ -437,14 +443,15 @@ int rsis_l_bn_fwd(const float* x, const float* res, float* y, double* stats, con
   return rsis_check_launch();
 }
 int rsis_l_bn_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, const float* gamma,
-                  double* stats, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C, int HW, int relu,
+                  double* stats, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C, int HW, int relu_flags,
                   hipStream_t st) {
   const long N = (long)B * HW;
   const int S = chan_splits(C, N);
-  if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, st) != hipSuccess) return RSIS_ERR_LAUNCH;
+  const int relu = relu_flags & 1, accum = (relu_flags >> 2) & 1;
+  if (!(relu_flags & 2) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, st) != hipSuccess) return RSIS_ERR_LAUNCH;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, mean, rstd, stats, C, HW, N, relu);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, mean, rstd, gamma, stats, dx, dres, dgamma,
-                     dbeta, C, HW, N, relu);
+                     dbeta, C, HW, N, relu, accum);
   return rsis_check_launch();
 }
 int rsis_l_maxpool_fwd(const float* x, float* y, unsigned char* arg, long BC, int H, int W, int Ho, int Wo, hipStream_t st) {

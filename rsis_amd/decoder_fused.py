@@ -76,6 +76,7 @@ class _HoistFn(torch.autograd.Function):
         check(L.rsis_conv2d_fwd(ptr_array([skip]), int_array([Cs]), 1, B, H, W, ptr(wp), 4 * tl.hid, tl.ks, 1, tl.pad,
                                 ptr(hoist.bias_p), None, ptr(G), H, W, ops.FORCE_TILE[0], stream()), "rsis_conv2d_fwd(hoist)")
         ctx.tl = tl
+        ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(skip, weight)
         return G
 
@@ -94,12 +95,18 @@ class _HoistFn(torch.autograd.Function):
             check(L.rsis_conv2d_dgrad(ptr(dG), B, 4 * tl.hid, H, W, ptr(wd), hoist.cin, tl.ks, 1, tl.pad, ptr_array([dskip]),
                                       int_array([Cs]), 1, H, W, ops.FORCE_TILE[0], stream()), "rsis_conv2d_dgrad(hoist)")
         if ctx.needs_input_grad[2]:
-            dW = torch.zeros_like(weight)
+            tgt = ops._direct_target(ctx.wparam)
+            dW = tgt if tgt is not None else torch.zeros_like(weight)
             check(L.rsis_conv2d_wgrad(ptr(dG), ptr(skip), ptr(dW), B, Cs, H, W, 4 * tl.hid, H, W, tl.ks, 1, tl.pad, weight.shape[1],
                                       tl.c_up, tl.hid, stream()), "rsis_conv2d_wgrad(hoist)")
+            if tgt is not None:
+                dW = None
         if ctx.needs_input_grad[3]:
-            db = torch.zeros(4 * tl.hid, dtype=torch.float32, device=dG.device)
+            tgt = ops._direct_target(ctx.bparam)
+            db = tgt if tgt is not None else torch.zeros(4 * tl.hid, dtype=torch.float32, device=dG.device)
             check(L.rsis_bias_grad(ptr(dG), ptr(db), B, 4 * tl.hid, H * W, tl.hid, stream()), "rsis_bias_grad(hoist)")
+            if tgt is not None:
+                db = None
         return None, dskip, dW, db
 
 
@@ -134,6 +141,7 @@ class _StepFn(torch.autograd.Function):
         check(L.rsis_convlstm_fwd(pa, ia, len(srcs), B, H, W, ptr(wp), None, ptr(G), ptr(c_prev) if h_prev is not None else None,
                                   ptr(h), ptr(c), ptr(act), hid, tl.ks, tl.pad, ops.FORCE_TILE[0], stream()), "rsis_convlstm_fwd(step)")
         ctx.tl, ctx.t, ctx.stacked = tl, t, stacked
+        ctx.wparam = weight
         ctx.has_up, ctx.has_state = up is not None, h_prev is not None
         if need_grad:
             if stacked:
@@ -188,9 +196,10 @@ class _StepFn(torch.autograd.Function):
         dW = dG = None
         Ctot = weight.shape[1]
         h_off = tl.c_up + tl.c_skip
+        tgt = ops._direct_target(ctx.wparam) if ctx.needs_input_grad[6] else None
         if not ctx.stacked:
             # un-batched fallback: this step's own weight gradient
-            dW = torch.zeros_like(weight)
+            dW = tgt if tgt is not None else torch.zeros_like(weight)
             off = [0] if ctx.has_up else []
             off += [h_off] if ctx.has_state else []
             for s, o in zip(srcs, off):
@@ -203,13 +212,16 @@ class _StepFn(torch.autograd.Function):
                 n = tl.n_fwd
                 if tl.n_bwd < n:   # steps that never received a gradient contribute zero
                     raise RuntimeError("fused RSIS decoder: %d of %d timesteps were back-propagated" % (tl.n_bwd, n))
-                dW = torch.zeros_like(weight) if dW is None else dW
+                if dW is None:
+                    dW = tgt if tgt is not None else torch.zeros_like(weight)
                 if tl.c_up > 0:
                     check(L.rsis_conv2d_wgrad(ptr(tl.DA), ptr(tl.UP), ptr(dW), n * B, tl.c_up, H, W, 4 * hid, H, W, ks, 1, pad, Ctot, 0,
                                               hid, stream()), "rsis_conv2d_wgrad(batched up)")
                 if n > 1:
                     check(L.rsis_conv2d_wgrad(ptr(tl.DA[1]), ptr(tl.H), ptr(dW), (n - 1) * B, hid, H, W, 4 * hid, H, W, ks, 1, pad, Ctot,
                                               h_off, hid, stream()), "rsis_conv2d_wgrad(batched h)")
+        if tgt is not None:
+            dW = None   # accumulated straight into weight.grad
         return None, None, d_up, dh_prev, dc_prev, dG, dW
 
 

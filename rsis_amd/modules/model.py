@@ -41,8 +41,24 @@ class FeatureExtractor(nn.Module):
         self.bn3 = HipBatchNorm2d(hs // 2)
         self.bn2 = HipBatchNorm2d(hs // 4)
         self.bn1 = HipBatchNorm2d(hs // 8)
+        self._bns = None
+
+    def _arm_bn_arena(self, device):
+        """one zeroed float64 arena per iteration for the batch statistics of all 109 BN layers (forward + backward
+        partial sums) instead of two memsets per layer"""
+        if self._bns is None:
+            self._bns = [m for m in self.modules() if isinstance(m, HipBatchNorm2d)]
+            self._bn_total = sum(2 * m.num_features for m in self._bns)
+        arena = torch.zeros(2 * self._bn_total, dtype=torch.float64, device=device)
+        off = 0
+        for m in self._bns:
+            n = 2 * m.num_features
+            m._arena = (arena[off:off + n], arena[self._bn_total + off:self._bn_total + off + n])
+            off += n
 
     def forward(self, x, semseg=False, raw=False):
+        if self.training and x.is_cuda:
+            self._arm_bn_arena(x.device)
         x5, x4, x3, x2, x1 = self.base(x)            # model.py:57
         if semseg:
             return x5

@@ -47,19 +47,31 @@ class HipBatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(self.num_features))
         self.register_buffer("running_var", torch.ones(self.num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._nbt_pending = 0     # increments of num_batches_tracked not yet written to the buffer (flushed by state_dict())
+        self._arena = None        # (fwd, bwd) slices of a zeroed float64 stats arena, set per iteration by the owner
+        self._register_state_dict_hook(HipBatchNorm2d._flush_nbt_hook)
+
+    @staticmethod
+    def _flush_nbt_hook(module, state_dict, prefix, local_metadata):
+        if module._nbt_pending:
+            module.num_batches_tracked += module._nbt_pending
+            module._nbt_pending = 0
+            state_dict[prefix + "num_batches_tracked"] = module.num_batches_tracked
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         # torch-0.2 era checkpoints (the reference's) have no num_batches_tracked
         key = prefix + "num_batches_tracked"
         if key not in state_dict:
             state_dict[key] = torch.tensor(0, dtype=torch.long)
+        self._nbt_pending = 0
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     def forward(self, x, res=None, relu=False):
         if self.training:
-            self.num_batches_tracked += 1
+            self._nbt_pending += 1      # host-side counter: no device launch per layer per step
+        arena, self._arena = self._arena, None
         return ops.batchnorm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu=relu, res=res,
-                             eps=self.eps, momentum=self.momentum)
+                             eps=self.eps, momentum=self.momentum, arena=arena if self.training else None)
 
 
 class Bottleneck(nn.Module):

@@ -18,6 +18,19 @@ _WEIGHT_EPOCH = [0]
 FORCE_TILE = [0]
 
 
+# Accumulate weight / bias / BN-affine gradients straight into a pre-zeroed, contiguous `param.grad` (the flat gradient
+# buffer of rsis_amd.optim.FlatGroup) instead of materialising a zero-filled tensor per parameter and letting autograd add
+# it: ~3 small launches less per parameter per step.  Off by default (plain autograd semantics); the training driver turns it
+# on.  Autograd still runs the parameter's AccumulateGrad node (with an undefined gradient), so post-accumulate hooks --
+# the bucketed all-reduce -- keep firing in the right order.
+DIRECT_GRAD = [False]
+
+
+def _direct_target(param):
+    g = param.grad if DIRECT_GRAD[0] and param is not None else None
+    return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.is_cuda) else None
+
+
 def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
@@ -98,10 +111,10 @@ def _dgrad_all(L, dy, wd, cin_packed, ks, stride, pad, srcs, Hx, Wx):
     return dxs
 
 
-def _wgrad_all(L, dy, srcs, w_shape, ks, stride, pad, lstm_hid):
+def _wgrad_all(L, dy, srcs, w_shape, ks, stride, pad, lstm_hid, out=None):
     B, Cout, Ho, Wo = dy.shape
     Ctot = w_shape[1]
-    dW = torch.zeros(w_shape, dtype=torch.float32, device=dy.device)
+    dW = out if out is not None else torch.zeros(w_shape, dtype=torch.float32, device=dy.device)
     c_off = 0
     for s in srcs:
         _, Cs, H, W = s.shape
@@ -130,6 +143,7 @@ class _Conv2dFn(torch.autograd.Function):
               "rsis_conv2d_fwd")
         ctx.pack, ctx.stride, ctx.pad, ctx.nsrc = pack, stride, pad, nsrc
         ctx.has_bias = bias is not None
+        ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(weight, *srcs)
         return out
 
@@ -149,12 +163,15 @@ class _Conv2dFn(torch.autograd.Function):
                 if ctx.needs_input_grad[4 + i]:
                     grads[i] = dxs[i]
         if ctx.needs_input_grad[4 + nsrc]:
-            grads[nsrc] = _wgrad_all(L, dy, srcs, tuple(weight.shape), ks, ctx.stride, ctx.pad, 0)
+            tgt = _direct_target(ctx.wparam)
+            dW = _wgrad_all(L, dy, srcs, tuple(weight.shape), ks, ctx.stride, ctx.pad, 0, out=tgt)
+            grads[nsrc] = None if tgt is not None else dW
         if ctx.has_bias and ctx.needs_input_grad[5 + nsrc]:
-            db = torch.zeros(weight.shape[0], dtype=torch.float32, device=dy.device)
+            tgt = _direct_target(ctx.bparam)
+            db = tgt if tgt is not None else torch.zeros(weight.shape[0], dtype=torch.float32, device=dy.device)
             check(L.rsis_bias_grad(ptr(dy), ptr(db), dy.shape[0], dy.shape[1], dy.shape[2] * dy.shape[3], 0, stream()),
                   "rsis_bias_grad")
-            grads[nsrc + 1] = db
+            grads[nsrc + 1] = None if tgt is not None else db
         return (None, None, None, None) + tuple(grads)
 
 
@@ -295,22 +312,27 @@ def global_maxpool(x):
 
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, train, relu, eps, momentum):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, train, relu, eps, momentum, arena):
         x = _contig(x)
         res = _contig(res) if res is not None else None
         require_cuda_f32(x, res, gamma, beta, running_mean, running_var)
         B, C, H, W = x.shape
         y = torch.empty_like(x)
+        flags = int(train)
         if train:
-            stats = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+            if arena is not None:      # (fwd stats, bwd stats) slices of an arena the caller zeroed for this iteration
+                stats, flags = arena[0], flags | 2
+            else:
+                stats = torch.empty(2 * C, dtype=torch.float64, device=x.device)
             mean = torch.empty(C, dtype=torch.float32, device=x.device)
             rstd = torch.empty_like(mean)
         else:
             stats = mean = rstd = None
         check(lib().rsis_bn_fwd(ptr(x), ptr(res), ptr(y), ptr(stats), ptr(gamma.detach()), ptr(beta.detach()), ptr(running_mean),
                                 ptr(running_var), ptr(mean), ptr(rstd), B, C, H * W, float(eps), float(momentum), int(relu),
-                                int(train), stream()), "rsis_bn_fwd")
+                                flags, stream()), "rsis_bn_fwd")
         ctx.train, ctx.relu, ctx.has_res, ctx.eps = train, relu, res is not None, eps
+        ctx.arena, ctx.gparam, ctx.bparam = arena, gamma, beta
         if train:
             ctx.save_for_backward(x, y if relu else None, gamma, mean, rstd)
         else:
@@ -328,23 +350,35 @@ class _BatchNormFn(torch.autograd.Function):
             scale = gamma.detach() / torch.sqrt(rstd + ctx.eps)  # here `rstd` holds running_var
             dx = g * scale.view(1, C, 1, 1)
             xh = (x - mean.view(1, C, 1, 1)) / torch.sqrt(rstd + ctx.eps).view(1, C, 1, 1)
-            return dx, (g if ctx.has_res else None), (g * xh).sum((0, 2, 3)), g.sum((0, 2, 3)), None, None, None, None, None, None
-        stats = torch.empty(2 * C, dtype=torch.float64, device=dy.device)
+            return dx, (g if ctx.has_res else None), (g * xh).sum((0, 2, 3)), g.sum((0, 2, 3)), None, None, None, None, None, None, None
+        flags = int(ctx.relu)
+        if ctx.arena is not None:
+            stats, flags = ctx.arena[1], flags | 2
+        else:
+            stats = torch.empty(2 * C, dtype=torch.float64, device=dy.device)
         dx = torch.empty_like(x)
         need_dres = ctx.has_res and ctx.relu
         dres = torch.empty_like(x) if need_dres else None
-        dgamma = torch.empty(C, dtype=torch.float32, device=dy.device)
-        dbeta = torch.empty_like(dgamma)
+        tg, tb = _direct_target(ctx.gparam), _direct_target(ctx.bparam)
+        direct = tg is not None and tb is not None
+        if direct:
+            dgamma, dbeta, flags = tg, tb, flags | 4
+        else:
+            dgamma = torch.empty(C, dtype=torch.float32, device=dy.device)
+            dbeta = torch.empty_like(dgamma)
         check(lib().rsis_bn_bwd(ptr(dy), ptr(x), ptr(y), ptr(mean), ptr(rstd), ptr(gamma.detach()), ptr(stats), ptr(dx), ptr(dres),
-                                ptr(dgamma), ptr(dbeta), B, C, H * W, int(ctx.relu), stream()), "rsis_bn_bwd")
+                                ptr(dgamma), ptr(dbeta), B, C, H * W, flags, stream()), "rsis_bn_bwd")
         if ctx.has_res and not need_dres:
             dres = dy
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+        if direct:
+            dgamma = dbeta = None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def batchnorm(x, gamma, beta, running_mean, running_var, train, relu=False, res=None, eps=1e-5, momentum=0.1):
-    """nn.BatchNorm2d (+ residual add) (+ ReLU): y = act(bn(x) + res)."""
-    return _BatchNormFn.apply(x, res, gamma, beta, running_mean, running_var, bool(train), bool(relu), eps, momentum)
+def batchnorm(x, gamma, beta, running_mean, running_var, train, relu=False, res=None, eps=1e-5, momentum=0.1, arena=None):
+    """nn.BatchNorm2d (+ residual add) (+ ReLU): y = act(bn(x) + res).  arena: optional (fwd, bwd) float64 [2*C] scratch
+    slices that the caller zeroed for this iteration (saves one memset per layer per pass)."""
+    return _BatchNormFn.apply(x, res, gamma, beta, running_mean, running_var, bool(train), bool(relu), eps, momentum, arena)
 
 
 class _MaxPool3x3s2Fn(torch.autograd.Function):

@@ -111,7 +111,13 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
     if train:
         if reducer is not None:
             reducer.reset()
-        loss.backward()                                               # :184
+        # FlatAdam keeps every .grad as a zeroed view of one flat buffer: let the wgrad kernels accumulate into it directly
+        direct = isinstance(enc_opt, FlatAdam) and isinstance(dec_opt, FlatAdam)
+        prev, ops.DIRECT_GRAD[0] = ops.DIRECT_GRAD[0], direct
+        try:
+            loss.backward()                                           # :184
+        finally:
+            ops.DIRECT_GRAD[0] = prev
         gscale = reducer.finish() if reducer is not None else 1.0
         dec_opt.gscale = gscale
         enc_opt.gscale = gscale

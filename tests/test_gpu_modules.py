@@ -285,3 +285,34 @@ def test_fused_decoder_equals_unfused(tcap):
     for k in res[0][2]:
         p, q = res[0][2][k], res[1][2][k]
         assert_close("grad." + k, q, p, 1e-4 * max(1.0, float(p.abs().max())), 1e-4)
+
+
+def test_direct_grad_accumulation_equals_autograd():
+    """ops.DIRECT_GRAD (wgrad kernels accumulate straight into the zeroed flat .grad views) == plain autograd grads."""
+    from rsis_amd import ops
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.optim import FlatGroup
+    torch.manual_seed(3)
+    a = mk_args(hidden_size=32, maxseqlen=2)
+    enc, dec = FeatureExtractor(a).cuda().train(), RSIS(a).cuda().train()
+    grp = FlatGroup([p for k, p in enc.named_parameters() if not k.startswith("base.fc")] + list(dec.parameters()), lr=0.0)
+    x = torch.randn(2, 3, 64, 64, device="cuda")
+    flats = []
+    for direct in (False, True):
+        grp.zero_grad()
+        prev, ops.DIRECT_GRAD[0] = ops.DIRECT_GRAD[0], direct
+        try:
+            torch.manual_seed(4)
+            feats = enc(x)
+            hidden, loss = None, 0.0
+            for _t in range(2):
+                m, c, s, hidden = dec(feats, hidden)
+                loss = loss + m.square().mean() + c.square().sum() + s.mean()
+            loss.backward()
+        finally:
+            ops.DIRECT_GRAD[0] = prev
+        flats.append(grp.flat_g.clone())
+    scale = float(flats[0].abs().max())
+    assert scale > 0
+    # identical kernels in both modes except where fp32 atomics reorder sums
+    assert_close("flat grads", flats[1], flats[0], 2e-4 * scale, 1e-3)
