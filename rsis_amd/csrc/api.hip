@@ -127,9 +127,21 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
   a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = pad; a.sshift = 0;
   a.wp = Wp; a.ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN); a.Cout = Cout; a.bias = bias; a.addend = addend;
   a.dst[0] = out; a.Cd[0] = Cout; a.ndst = 1;
+  a.ostride = 1; a.oH = Ho; a.oW = Wo; a.ksplit = 1;
   if (use_direct(ks, stride, pad) && Cout == 1 && nsrc == 1 && !addend && rsis_c1_supported(Csrc[0]))   // conv_out: HBM-bound VALU kernel
     return rsis_l_c1_fwd(src[0], Wp, a.ldw, bias, out, B, Csrc[0], H, W, (hipStream_t)stream);
-  if (use_direct(ks, stride, pad)) return rsis_launch_conv3x3_direct(a, 0, direct_variant(tile), (hipStream_t)stream);
+  if (use_direct(ks, stride, pad)) {
+    // deep-K convs on tiny maps (sk5: 2048x9 deep, 64 blocks) are split over the channel chunks: zero the output here and let
+    // the launcher decide (a.ksplit = 0 means "split allowed, output is zeroed")
+    int nq = 0;
+    for (int s = 0; s < nsrc; ++s) nq += (Csrc[s] + RSIS_CK - 1) / RSIS_CK;
+    const long px_tiles = (long)B * rsis_cdiv(H, 8) * rsis_cdiv(W, W <= 8 ? 8 : 16);
+    if (nq >= 32 && px_tiles * rsis_cdiv(Cout, 64) < 160) {
+      if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * Cout * Ho * Wo, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
+      a.ksplit = 0;
+    }
+    return rsis_launch_conv3x3_direct(a, 0, direct_variant(tile), (hipStream_t)stream);
+  }
   return rsis_launch_conv_igemm(a, ks, false, 0, tile, (hipStream_t)stream);
 }
 
@@ -147,12 +159,21 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const fl
   a.ndst = ndst;
   a.B = B; a.H = Hy; a.W = Wy; a.Ho = Hx; a.Wo = Wx; a.stride = stride; a.pad = pad; a.sshift = log2i(stride);
   if (ctot > Cin_packed) return RSIS_ERR_ARG;
+  a.ostride = 1; a.oH = Hx; a.oW = Wx; a.ksplit = 1;
   a.wp = Wd; a.ldw = rsis_roundup(Cin_packed, RSIS_LDW_ALIGN); a.Cout = ctot; a.bias = nullptr; a.addend = nullptr;
   if (use_direct(ks, stride, pad)) {
     if (Hx != Hy || Wx != Wy) return RSIS_ERR_ARG;
     if (Cout == 1 && ndst == 1 && Cin_packed == Cdx[0] && rsis_c1_supported(Cdx[0]))
       return rsis_l_c1_dgrad(dy, Wd, a.ldw, dx[0], B, Cdx[0], Hx, Wx, (hipStream_t)stream);
     return rsis_launch_conv3x3_direct(a, 0, direct_variant(tile), (hipStream_t)stream);
+  }
+  if (ks == 1 && pad == 0 && stride > 1) {
+    // 1x1 / stride-s data gradient: only the (s*ho, s*wo) input pixels receive a gradient -> zero dx, then run the plain
+    // 1x1 GEMM over the dy grid and scatter its rows to those pixels (instead of gathering with 1/s^2 useful taps)
+    for (int i = 0; i < ndst; ++i)
+      if (hipMemsetAsync(dx[i], 0, sizeof(float) * (size_t)B * Cdx[i] * Hx * Wx, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
+    a.Ho = Hy; a.Wo = Wy; a.stride = 1; a.sshift = 0; a.ostride = stride;
+    return rsis_launch_conv_igemm(a, ks, false, 0, tile, (hipStream_t)stream);
   }
   return rsis_launch_conv_igemm(a, ks, true, 0, tile, (hipStream_t)stream);
 }
@@ -189,6 +210,7 @@ int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B,
   a.wp = Wp; a.ldw = rsis_roundup(4 * hid, RSIS_LDW_ALIGN); a.Cout = 4 * hid; a.bias = bias_packed; a.addend = addend;
   a.ndst = 1; a.dst[0] = nullptr; a.Cd[0] = 4 * hid;
   a.hid = hid; a.c_prev = c_prev; a.h_out = h_out; a.c_out = c_out; a.act_out = act_out;
+  a.ostride = 1; a.oH = H; a.oW = W; a.ksplit = 1;
   if (use_direct(ks, 1, pad)) return rsis_launch_conv3x3_direct(a, 1, direct_variant(tile), (hipStream_t)stream);
   return rsis_launch_conv_igemm(a, ks, false, 1, tile, (hipStream_t)stream);
 }

@@ -45,6 +45,8 @@ struct ConvArgs {
   int Cd[RSIS_MAX_SRC];
   int ndst;
   int n_co_tiles, n_px_tiles;
+  int ostride, oH, oW;             // EPI_PLAIN of the igemm kernel: output pixel (ho,wo) is stored at (ho*ostride, wo*ostride) of an oH x oW map
+  int ksplit;                      // direct 3x3 kernel: split the channel chunks over gridDim.y blocks (atomics into a zeroed output)
   // ConvLSTM epilogue (EPI_LSTM): rows are gate-interleaved, row = 4*j + gate, gate in (i,f,o,g)
   int hid;
   const float* c_prev;             // [B][hid][Ho][Wo] or null (zero state)

@@ -44,7 +44,12 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   const gcf_t src0 = (gcf_t)p.src[0], src1 = (gcf_t)p.src[1], src2 = (gcf_t)p.src[2];
   const int C0 = p.C[0], C1 = p.C[1], C2 = p.C[2];
   const int q0 = (C0 + CK - 1) / CK, q1 = (C1 + CK - 1) / CK, q2 = (C2 + CK - 1) / CK;   // chunks per source
-  const int nq = q0 + q1 + q2;
+  const int nq_all = q0 + q1 + q2;
+  // split-K over the channel chunks (deep-K / few-pixel layers such as sk5: 2048 channels on an 8x8 map): gridDim.y blocks
+  // each take a contiguous chunk range and finish with fp32 atomics into the (zeroed) output
+  const int ksplit = gridDim.y, kz = blockIdx.y;
+  const int q_begin = (int)((long)nq_all * kz / ksplit), q_end = (int)((long)nq_all * (kz + 1) / ksplit);
+  const int nq = q_end - q_begin;
   const int H = p.H, W = p.W, HW = H * W, B = p.B;
   const int ldw = p.ldw;
 
@@ -103,8 +108,10 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   f32x4 rw[NW];
   const gcf_t wbase = (gcf_t)p.wp + co_t * BM;
 
-  // scalar chunk cursor
-  int cs = 0, cq = 0;   // source index, chunk index inside the source
+  // scalar chunk cursor, positioned on this block's first chunk
+  int cs = 0, cq = q_begin;   // source index, chunk index inside the source
+  if (cs == 0 && cq >= q0 && q0 < nq_all) { cq -= q0; cs = 1; }
+  if (cs == 1 && cq >= q1 && q0 + q1 < nq_all) { cq -= q1; cs = 2; }
 
 #define DIRECT_LOAD(QG)                                                                                   \
   {                                                                                                       \
@@ -146,14 +153,14 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   }
 
   if (nq > 0) {   // nq == 0: no dynamic source at all (ConvLSTM level 0 at t = 0 with the hoisted skip term): gates = addend
-    DIRECT_LOAD(0)
+    DIRECT_LOAD(q_begin)
     DIRECT_STORE(0)
   }
   __syncthreads();
   for (int t = 0; t < nq; ++t) {
     const int cur = t & 1;
     const bool more = t + 1 < nq;
-    if (more) DIRECT_LOAD(t + 1)
+    if (more) DIRECT_LOAD(q_begin + t + 1)
     {
       const float* Xs = Xs0 + cur * XS;
       const float* Ws = Ws0 + cur * WS + woff;
@@ -196,14 +203,15 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
         const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (co >= Cout) continue;
         float v = acc[j][r];
-        if (bias) v += bias[co];
+        if (bias && kz == 0) v += bias[co];
         gf_t d = d0;
         int cl = co, Cd = Cd0;
         if (co >= e1) { d = d1; cl = co - e1; Cd = Cd1; }
         if (co >= e2) { d = d2; cl = co - e2; Cd = Cd2; }
         const size_t idx = ((size_t)ob * Cd + cl) * HW + osp;
-        if (addend) v += addend[idx];
-        d[idx] = v;
+        if (addend && kz == 0) v += addend[idx];
+        if (ksplit > 1) atomicAdd((float*)(d + idx), v);
+        else d[idx] = v;
       }
     } else {
       const int hid = p.hid;
@@ -243,7 +251,19 @@ static int launch_direct_cfg(ConvArgs& a, hipStream_t st) {
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
   a.n_px_tiles = rsis_cdiv(a.W, TW) * rsis_cdiv(a.H, TH) * rsis_cdiv(a.B, NI);
   const int grid = a.n_co_tiles * 8 * rsis_cdiv(a.n_px_tiles, 8);
-  hipLaunchKernelGGL((conv3x3_direct_kernel<BM, TW, TH, NI, EPI>), dim3(grid), dim3(256), 0, st, a);
+  int ksplit = 1;
+  if (EPI == EPI_PLAIN && a.ksplit == 0) {    // ksplit == 0: the caller zeroed the output and allows split-K
+    int nq = 0;
+    for (int s = 0; s < a.nsrc; ++s) nq += (a.C[s] + RSIS_CK - 1) / RSIS_CK;
+    const int blocks = a.n_co_tiles * a.n_px_tiles;
+    if (blocks < 160 && nq >= 32) {
+      ksplit = rsis_cdiv(512, blocks);
+      if (ksplit > nq / 8) ksplit = nq / 8;
+      if (ksplit > 16) ksplit = 16;
+      if (ksplit < 1) ksplit = 1;
+    }
+  }
+  hipLaunchKernelGGL((conv3x3_direct_kernel<BM, TW, TH, NI, EPI>), dim3(grid, ksplit), dim3(256), 0, st, a);
   return rsis_check_launch();
 }
 

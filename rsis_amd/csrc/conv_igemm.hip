@@ -222,12 +222,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const gf_t d0 = (gf_t)p.dst[0], d1 = (gf_t)p.dst[1], d2 = (gf_t)p.dst[2];
     const int Cd0 = p.Cd[0], Cd1 = p.Cd[1], Cd2 = p.Cd[2], Cout = p.Cout;
     const int e1 = Cd0, e2 = Cd0 + Cd1;
+    const int ostride = p.ostride, oHW = p.oH * p.oW;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int opx = px_t * BN + wn * TN * 32 + j * 32 + l31;
       if (opx >= Npx) continue;
       const int ob = opx / HoWo;
-      const int osp = opx - ob * HoWo;
+      int osp = opx - ob * HoWo;
+      if (ostride > 1) { const int oho = osp / Wo; osp = (oho * ostride) * p.oW + (osp - oho * Wo) * ostride; }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
           int cl = co, Cd = Cd0;
           if (co >= e1) { d = d1; cl = co - e1; Cd = Cd1; }
           if (co >= e2) { d = d2; cl = co - e2; Cd = Cd2; }
-          const size_t idx = ((size_t)ob * Cd + cl) * HoWo + osp;
+          const size_t idx = ((size_t)ob * Cd + cl) * oHW + osp;
           if (addend) v += addend[idx];
           d[idx] = v;
         }
