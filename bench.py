@@ -80,7 +80,7 @@ def gate_kernel_roofline(B, iters, imsize):
         total_flops += flops
         total_ms += ms
     achieved = total_flops / total_ms / 1e9
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel<EPI_LSTM> (rsis_convlstm_fwd), 5 scales of one decoder timestep",
+    return {"bound": "mfma", "kernel": "conv3x3_direct_kernel<..., EPI_LSTM> (rsis_convlstm_fwd), the 5 pyramid levels of one decoder timestep, full K",
             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": None, "algorithmic_gflop_per_timestep": round(total_flops / 1e9, 3), "ms_per_timestep": round(total_ms, 4),
             "per_scale": per_layer}

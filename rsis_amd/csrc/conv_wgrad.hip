@@ -13,7 +13,8 @@
 #define LDK (BKW + 1)
 
 
-template <int BM, int BN, int WGM, int WGN, int KS>
+// V4 (1x1 / stride 1 / H*W % 4 == 0): both operands are contiguous along the reduction (pixel) axis -> float4 global loads.
+template <int BM, int BN, int WGM, int WGN, int KS, bool V4>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int KK = KS * KS;
@@ -45,8 +46,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float ra[A_LOADS], rb[B_LOADS];
+  // V4 mapping: 8 float4 groups per 32-pixel tile row; thread -> (group kg, first row r4), rows step by 32
+  const int kg = tid & 7, r4 = tid >> 3;
 
   auto load_tile = [&](int t) {
+    if constexpr (V4) {
+      const int px = px_begin + t * BKW + kg * 4;
+      const bool pv = px < px_end;
+      const int b = pv ? px / HoWo : 0;
+      const int sp = pv ? px - b * HoWo : 0;
+      const float* __restrict__ dyb = p.dy + (size_t)b * p.Cout * HoWo + sp;
+      const float* __restrict__ xb = p.x + (size_t)b * p.Cs * HW + sp;
+#pragma unroll
+      for (int i = 0; i < A_LOADS / 4; ++i) {
+        const int co = co_t * BM + r4 + i * 32;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pv && co < p.Cout) v = *reinterpret_cast<const f32x4*>(dyb + (size_t)co * HoWo);
+        ra[4 * i] = v[0]; ra[4 * i + 1] = v[1]; ra[4 * i + 2] = v[2]; ra[4 * i + 3] = v[3];
+      }
+#pragma unroll
+      for (int i = 0; i < B_LOADS / 4; ++i) {
+        const int n = n_t * BN + r4 + i * 32;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pv && n < Nn) v = *reinterpret_cast<const f32x4*>(xb + (size_t)n * HW);
+        rb[4 * i] = v[0]; rb[4 * i + 1] = v[1]; rb[4 * i + 2] = v[2]; rb[4 * i + 3] = v[3];
+      }
+      return;
+    }
     const int px = px_begin + t * BKW + kl;
     const bool pv = px < px_end;
     const int b = pv ? px / HoWo : 0;
@@ -74,6 +100,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   auto store_tile = [&](int buf) {
     float* As = As0 + buf * BM * LDK;
     float* Bs = Bs0 + buf * BN * LDK;
+    if constexpr (V4) {
+#pragma unroll
+      for (int i = 0; i < A_LOADS / 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) As[(r4 + i * 32) * LDK + kg * 4 + k] = ra[4 * i + k];
+#pragma unroll
+      for (int i = 0; i < B_LOADS / 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Bs[(r4 + i * 32) * LDK + kg * 4 + k] = rb[4 * i + k];
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) As[(row0 + i * 8) * LDK + kl] = ra[i];
 #pragma unroll
@@ -139,7 +176,13 @@ static int launch_wgrad_cfg(WgradArgs& a, hipStream_t st) {
   if (nsplit < 1) nsplit = 1;
   a.chunk = rsis_roundup(rsis_cdiv(Npx, nsplit), BKW);
   nsplit = rsis_cdiv(Npx, a.chunk);
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WGM, WGN, KS>), dim3(ntile, nsplit), dim3(256), 0, st, a);
+  if constexpr (KS == 1 && BM % 32 == 0 && BN % 32 == 0) {
+    if (a.stride == 1 && a.pad == 0 && (a.H * a.W) % 4 == 0 && a.H == a.Ho && a.W == a.Wo) {
+      hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WGM, WGN, KS, true>), dim3(ntile, nsplit), dim3(256), 0, st, a);
+      return rsis_check_launch();
+    }
+  }
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WGM, WGN, KS, false>), dim3(ntile, nsplit), dim3(256), 0, st, a);
   return rsis_check_launch();
 }
 
