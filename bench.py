@@ -92,7 +92,7 @@ def cpu_baseline(imsize, T, budget_s=25.0):
     from rsis_amd.synthetic import synthetic_batch
     cores = min(os.cpu_count() or 1, 32)     # a 256-core host oversubscribes a B=2 step; 32 threads are what is timed
     torch.set_num_threads(cores)
-    B = 2
+    B = 4
     a = bench_args(B, imsize, T)
     a.use_gpu = False
     torch.manual_seed(0)
@@ -108,7 +108,7 @@ def cpu_baseline(imsize, T, budget_s=25.0):
     step()                       # warm-up
     warm = time.time() - t0
     n, t0 = 0, time.time()
-    while n < 1 or (time.time() - t0 + warm) < budget_s and n < 8:
+    while n < 1 or (time.time() - t0 + warm) < budget_s and n < 12:
         step()
         n += 1
     dt = (time.time() - t0) / n
@@ -155,8 +155,12 @@ def main():
     crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
     batch = synthetic_batch(a.seed + 1000 * rank, o.batch, o.imsize, o.imsize, a.gt_maxseqlen, 12, a.num_classes, "cuda")
 
+    from rsis_amd.train import steps_to_run
+    t_run = steps_to_run(a, batch[3])      # early-stop rule evaluated once for the resident batch (it is all T steps here)
+
     def step():
-        return runIter(a, encoder, decoder, *batch, crits, [enc_opt, dec_opt], mode="train", reducer=reducer, sync_losses=False)
+        return runIter(a, encoder, decoder, *batch, crits, [enc_opt, dec_opt], mode="train", reducer=reducer, sync_losses=False,
+                       t_run=t_run)
 
     def fence():
         torch.cuda.synchronize()
@@ -177,10 +181,13 @@ def main():
     fence()
     note("warmup done %.2f s" % (time.time() - tw))
     t0 = time.time()
+    marks = []
     for _ in range(o.steps):
         losses = step()[0]
+        marks.append(time.time() - t0)      # host enqueue progress (no sync): shows a host-bound step at a glance
     fence()
     dt = time.time() - t0
+    note("host enqueue marks (s): %s | end %.3f" % (" ".join("%.3f" % m for m in marks), dt))
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -8,6 +8,7 @@
 // Both operands are contiguous along px in NCHW, so global loads run along px and the LDS tiles are [row][BKW+1]
 // (padded) which makes both the stores and the MFMA operand ds_read_b32 conflict-free.
 #include "common.h"
+#include <type_traits>
 
 #define BKW 32
 #define LDK (BKW + 1)
@@ -46,6 +47,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float ra[A_LOADS], rb[B_LOADS];
+  typedef typename std::conditional<(KK > 31), unsigned long long, unsigned>::type mask_t;
+  // loop-invariant decode of this thread's B rows: n -> (ci, r, s) -> element offset from the (hi0, wi0) corner + tap bit
+  int noff[B_LOADS], nbit[B_LOADS];
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) {
+    const int n = n_t * BN + row0 + i * 8;
+    const int ci = n / KK;
+    const int rs = n - ci * KK;
+    const int r = rs / KS, s2 = rs - r * KS;
+    noff[i] = ci * HW + r * p.W + s2;
+    nbit[i] = n < Nn ? rs : (int)(8 * sizeof(mask_t) - 1);   // the top bit of vmask is never set
+  }
   // V4 mapping: 8 float4 groups per 32-pixel tile row; thread -> (group kg, first row r4), rows step by 32
   const int kg = tid & 7, r4 = tid >> 3;
 
@@ -85,16 +98,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       const int co = co_t * BM + row0 + i * 8;
       ra[i] = (pv && co < p.Cout) ? dyb[(size_t)co * HoWo] : 0.f;
     }
-    const float* __restrict__ xb = p.x + (size_t)b * p.Cs * HW;
+    // per-pixel validity bit of every filter tap (once per tile); the tap / channel offsets of this thread's B rows are
+    // loop invariant (noff / nbit, computed before the K loop)
+    mask_t vmask = 0;
+    if (pv) {
+#pragma unroll
+      for (int r = 0; r < KS; ++r)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+          if (((unsigned)(hi0 + r) < (unsigned)p.H) && ((unsigned)(wi0 + s) < (unsigned)p.W)) vmask |= (mask_t)1 << (r * KS + s);
+    }
+    const float* __restrict__ xb = p.x + (size_t)b * p.Cs * HW + hi0 * p.W + wi0;
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
-      const int n = n_t * BN + row0 + i * 8;
-      const int ci = n / KK;
-      const int rs = n - ci * KK;
-      const int r = rs / KS, s = rs - r * KS;
-      const int ih = hi0 + r, iw = wi0 + s;
-      const bool ok = pv && (n < Nn) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-      rb[i] = ok ? xb[ci * HW + ih * p.W + iw] : 0.f;
+      const bool ok = (vmask >> nbit[i]) & 1;
+      rb[i] = ok ? xb[noff[i]] : 0.f;
     }
   };
   auto store_tile = [&](int buf) {

@@ -45,6 +45,15 @@ class SyntheticLoader(object):
                                         getattr(args, "synthetic_instances", 12), args.num_classes, device)
                         for i in range(distinct)]
         self.n = n_batches
+        self._t_run = {}
+
+    def steps_to_run(self, args, sw_mask):
+        """early-stop rule of train.py:80-92 for a resident batch, evaluated once (no per-iteration host sync)"""
+        from .train import steps_to_run
+        key = (sw_mask.data_ptr(), getattr(args, "limit_seqlen_to", None), args.maxseqlen)
+        if key not in self._t_run:
+            self._t_run[key] = steps_to_run(args, sw_mask)
+        return self._t_run[key]
 
     def __len__(self):
         return self.n

@@ -49,7 +49,7 @@ def steps_to_run(args, sw_mask):
 
 
 def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits, optims, mode="train", reducer=None,
-            sync_losses=True):
+            sync_losses=True, t_run=None):
     """Runs forward, computes loss and (if train mode) updates parameters for the provided batch (train.py:54-197).
     Returns (losses [total, iou, stop, class], outs [sigmoid(masks), class probs], perms [y_mask_perm, y_class_perm])."""
     from .utils.hungarian import MaskedNLL, StableBalancedMaskedBCE, softIoU
@@ -61,7 +61,8 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
     y_mask = y_mask.float()
     sw_mask = sw_mask.float()
     sw_class = sw_class.float()
-    t_run = steps_to_run(args, sw_mask)
+    if t_run is None:       # callers that know the batch (data loader / resident synthetic batch) pass it: no sync here
+        t_run = steps_to_run(args, sw_mask)
 
     hidden = None
     out_masks, out_classes, out_stops = [], [], []
@@ -264,8 +265,9 @@ def trainIters(args):
         for split in ("train", "val"):                                    # :341
             n_img, t_split = 0, time.time()
             for batch_idx, (x, y_mask, y_class, sw_mask, sw_class) in enumerate(loaders[split]):
+                t_run = loaders[split].steps_to_run(args, sw_mask) if hasattr(loaders[split], "steps_to_run") else None
                 losses, _outs, _perm = runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits, optims,
-                                               mode=split, reducer=reducer, sync_losses=False)
+                                               mode=split, reducer=reducer, sync_losses=False, t_run=t_run)
                 for k, v in zip(("total", "iou", "stop", "class"), losses):
                     epoch_losses[split][k].append(v)
                 n_img += x.size(0) * world
