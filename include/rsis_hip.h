@@ -114,6 +114,12 @@ int rsis_maxpool3x3s2_bwd(const float* dy, const unsigned char* argmax, float* d
 int rsis_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, float gscale, void* stream);
 
+/* ---- Hungarian matching of predictions to ground-truth slots (hungarian.py:91-125, munkres.Munkres().compute per
+ * sample): scores[B][G][T] fp32 (rows = GT slots, columns = predictions, T <= G <= 64) -> perm[B][G] int64 with
+ * perm[b][t] = GT slot of prediction t for t < T and 0 elsewhere.  Minimum total cost; runs on the device so the training
+ * iteration needs no host synchronisation. ---- */
+int rsis_assign_min_cost(const float* scores, long long* perm, int B, int G, int T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

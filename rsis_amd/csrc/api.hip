@@ -28,6 +28,7 @@ int rsis_l_maxpool_fwd(const float*, float*, unsigned char*, long, int, int, int
 int rsis_l_maxpool_bwd(const float*, const unsigned char*, float*, long, int, int, int, int, hipStream_t);
 int rsis_l_channel_sum(const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_adam(float*, const float*, float*, float*, long, float, float, float, float, float, int, float, hipStream_t);
+int rsis_l_assign(const float*, long long*, int, int, int, hipStream_t);
 
 static inline int krows_of(int C, int ks) { return rsis_roundup(C * ks * ks, RSIS_KPAD); }
 static inline int log2i(int s) { int l = 0; while ((1 << l) < s) ++l; return l; }
@@ -268,6 +269,11 @@ int rsis_adam_step(float* p, const float* g, float* m, float* v, long n, float l
   if (!p || !g || !m || !v || n < 0 || step < 1) return RSIS_ERR_ARG;
   if (n == 0) return RSIS_OK;
   return rsis_l_adam(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, gscale, (hipStream_t)stream);
+}
+
+int rsis_assign_min_cost(const float* scores, long long* perm, int B, int G, int T, void* stream) {
+  if (!scores || !perm || B < 1 || T < 1 || G < T || G > 64) return RSIS_ERR_ARG;
+  return rsis_l_assign(scores, perm, B, G, T, (hipStream_t)stream);
 }
 
 }  // extern "C"

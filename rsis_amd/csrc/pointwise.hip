@@ -383,6 +383,57 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Minimum-cost assignment of predictions to ground-truth slots (reference src/utils/hungarian.py:91-125: Munkres per
+// sample on the host, with a D2H copy of the scores and a host sync in the middle of every iteration).  One thread per
+// sample runs the O(T^2 G) shortest-augmenting-path Hungarian algorithm with potentials in fp64 on the device, so the
+// training step has no host synchronisation at all.  scores[b][g][t]: rows = GT slots, columns = predictions (G >= T);
+// perm[b][t] = GT slot assigned to prediction t, perm[b][t >= T] = 0 (what hungarian.py leaves in unassigned columns).
+// ------------------------------------------------------------------------------------------------
+#define RSIS_ASSIGN_MAX 64
+__global__ void assign_kernel(const float* __restrict__ scores, long long* __restrict__ perm, int B, int G, int T) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* a = scores + (size_t)b * G * T;   // a[g*T + t]
+  double u[RSIS_ASSIGN_MAX + 1], v[RSIS_ASSIGN_MAX + 1], minv[RSIS_ASSIGN_MAX + 1];
+  int p[RSIS_ASSIGN_MAX + 1], way[RSIS_ASSIGN_MAX + 1];
+  bool used[RSIS_ASSIGN_MAX + 1];
+  const int n = T, m = G;                          // n "rows" (predictions) <= m "columns" (GT slots)
+  for (int j = 0; j <= m; ++j) { v[j] = 0.0; p[j] = 0; way[j] = 0; }
+  for (int i = 0; i <= n; ++i) u[i] = 0.0;
+  for (int i = 1; i <= n; ++i) {
+    p[0] = i;
+    int j0 = 0;
+    for (int j = 0; j <= m; ++j) { minv[j] = 1e300; used[j] = false; }
+    do {
+      used[j0] = true;
+      const int i0 = p[j0];
+      double delta = 1e300;
+      int j1 = 0;
+      for (int j = 1; j <= m; ++j) {
+        if (used[j]) continue;
+        const double cur = (double)a[(size_t)(j - 1) * T + (i0 - 1)] - u[i0] - v[j];
+        if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+        if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+      }
+      for (int j = 0; j <= m; ++j) {
+        if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
+        else minv[j] -= delta;
+      }
+      j0 = j1;
+    } while (p[j0] != 0);
+    do {
+      const int j1 = way[j0];
+      p[j0] = p[j1];
+      j0 = j1;
+    } while (j0 != 0);
+  }
+  long long* out = perm + (size_t)b * G;
+  for (int g = 0; g < G; ++g) out[g] = 0;
+  for (int j = 1; j <= m; ++j)
+    if (p[j] != 0) out[p[j] - 1] = j - 1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers (called from api.hip)
 // ------------------------------------------------------------------------------------------------
 static inline int ew_grid(long total) {
@@ -475,5 +526,10 @@ int rsis_l_adam(float* p, const float* g, float* m, float* v, long n, float lr, 
   const float bc1 = 1.f - powf(b1, (float)step);
   const float bc2s = sqrtf(1.f - powf(b2, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, gscale);
+  return rsis_check_launch();
+}
+
+int rsis_l_assign(const float* scores, long long* perm, int B, int G, int T, hipStream_t st) {
+  hipLaunchKernelGGL(assign_kernel, dim3((B + 63) / 64), dim3(64), 0, st, scores, perm, B, G, T);
   return rsis_check_launch();
 }

@@ -416,3 +416,14 @@ def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gscale
     check(lib().rsis_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
                                float(weight_decay), int(step), float(gscale), stream()), "rsis_adam_step")
     bump_weight_epoch()
+
+
+def assign_min_cost(scores):
+    """Device-side Hungarian matching (reference hungarian.py:91-125): scores (B, G, T) fp32, rows = GT slots, columns =
+    predictions -> perm (B, G) int64, perm[b, t] = GT slot matched to prediction t (0 in the unassigned tail)."""
+    scores = _contig(scores)
+    require_cuda_f32(scores)
+    B, G, T = scores.shape
+    perm = torch.empty((B, G), dtype=torch.int64, device=scores.device)
+    check(lib().rsis_assign_min_cost(ptr(scores), ptr(perm), B, G, T, stream()), "rsis_assign_min_cost")
+    return perm

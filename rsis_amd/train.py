@@ -85,7 +85,10 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
         scores[:, :, :t] = args.iou_weight * softIoU_matrix(y_mask, out_masks)
         valid = (sw_mask.unsqueeze(-1) * sw_mask[:, 0:args.maxseqlen].unsqueeze(1) > 0).float()   # :127-130
         scores = scores * valid + (1 - valid) * 10                                                 # :131
-        perm = torch.from_numpy(match_indices(scores)).to(x.device)                               # :137 (ONE D2H)
+        if scores.is_cuda and scores.size(1) <= 64 and scores.size(1) >= scores.size(2):
+            perm = ops.assign_min_cost(scores)                                                     # :137 on the device: no sync
+        else:
+            perm = torch.from_numpy(match_indices(scores)).to(x.device)                           # more than 64 GT slots: host assignment (scipy), as the reference does
         idx = perm[:, 0:t]
         y_mask_perm = torch.gather(y_mask, 1, idx.unsqueeze(-1).expand(-1, -1, y_mask.size(2)))   # :140
         y_class_perm = torch.gather(y_class, 1, idx)                                               # :141

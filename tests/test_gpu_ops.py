@@ -212,3 +212,44 @@ def test_adam_matches_torch():
         opt.step()
         ops.adam_step_flat(pd, g.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-6, step)
     assert_close("adam", pd, ref_p, 1e-6, 1e-5)
+
+
+@pytest.mark.parametrize("B,G,T", [(3, 20, 10), (32, 20, 10), (5, 7, 7), (4, 64, 20), (2, 3, 1)])
+def test_assign_min_cost_matches_scipy(B, G, T):
+    """device Hungarian == scipy.optimize.linear_sum_assignment (what the oracle uses for munkres) on generic costs"""
+    from scipy.optimize import linear_sum_assignment
+    from rsis_amd import ops
+    rng = np.random.default_rng(B * 1000 + G * 10 + T)
+    scores = rng.uniform(0, 1, (B, G, T)).astype(np.float32)
+    perm = ops.assign_min_cost(torch.from_numpy(scores).cuda()).cpu().numpy()
+    for b in range(B):
+        r, c = linear_sum_assignment(scores[b].astype(np.float64))
+        want = np.zeros(G, dtype=np.int64)
+        want[c] = r
+        assert (perm[b] == want).all(), (b, perm[b], want)
+
+
+def test_assign_min_cost_with_masked_ties_and_golden():
+    """the reference's score structure (invalid pairs = 10 -> ties among unused slots): the assignment must have the
+    optimal total cost and agree with the golden permutation wherever the loss looks (valid predictions)."""
+    from scipy.optimize import linear_sum_assignment
+    from helpers import gold
+    from rsis_amd import ops
+    g = gold("losses")
+    scores = np.random.default_rng(56).uniform(0, 1, (3, 20, 10)).astype(np.float32)
+    perm = ops.assign_min_cost(torch.from_numpy(scores).cuda()).cpu().numpy()
+    assert (perm == g["match_perm"]).all()
+    B, G, T, n_inst = 4, 20, 10, 6
+    sc = np.random.default_rng(1).uniform(0, 1, (B, G, T)).astype(np.float32)
+    sw = np.zeros(G, np.float32)
+    sw[:n_inst] = 1
+    valid = sw[None, :, None] * sw[None, None, :T]
+    sc = sc * valid + (1 - valid) * 10
+    perm = ops.assign_min_cost(torch.from_numpy(sc).cuda()).cpu().numpy()
+    for b in range(B):
+        r, c = linear_sum_assignment(sc[b].astype(np.float64))
+        assert abs(sc[b][perm[b, :T], np.arange(T)].sum() - sc[b][r, c].sum()) < 1e-4
+        assert len(set(perm[b, :T].tolist())) == T
+        want = np.zeros(G, dtype=np.int64)
+        want[c] = r
+        assert (perm[b, :n_inst] == want[:n_inst]).all()
