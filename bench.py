@@ -12,6 +12,9 @@ Prints ONE JSON line on rank 0 with the contract fields plus
   "cpu_baseline": the CPU oracle (port of the reference op graph, oracle/rsis_oracle.py) timed on this box's host cores
                   on a bounded sample of the same workload (rank 0, N=1 only).
 
+After the W warm-up steps an untimed "settle" phase keeps stepping until the step time is stable (cold-box power
+management; see main()); the timed region is still EXACTLY K steps between barrier + synchronize.
+
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
@@ -128,6 +131,9 @@ def main():
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
+    ap.add_argument("--no-settle", action="store_true", help="skip the untimed settle phase after the warm-up steps")
+    ap.add_argument("--settle-min", type=float, default=2.0, help="minimum seconds of the untimed settle phase")
+    ap.add_argument("--settle-cap", type=float, default=8.0, help="maximum seconds of the untimed settle phase")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     o = ap.parse_args()
     if o.cpu_baseline_only:
@@ -172,22 +178,49 @@ def main():
         if rank == 0:
             print("[bench] %s" % msg, file=sys.stderr, flush=True)
 
+    roof = None
+    if rank == 0 and not o.skip_roofline:
+        roof = gate_kernel_roofline(o.batch, o.kernel_iters, o.imsize)
+        note("gate kernel roofline: %s TFLOP/s" % roof["achieved"])
     tw = time.time()
     for i in range(o.warmup):
         losses = step()[0]
         if i == 0:
             torch.cuda.synchronize()
             note("first step %.2f s" % (time.time() - tw))
+    # Untimed settle phase (still warm-up): on a cold box the GPU's power management overshoots and throttles for about a
+    # second some 1-2 s after sustained load starts (observed: 62 ms steps turning into 150 ms steps, then back).  Keep
+    # stepping, untimed, until the step time is stable, so that the K timed steps measure steady state.
+    if not o.no_settle:
+        hist, t_settle = [], time.time()
+        while time.time() - t_settle < o.settle_cap:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            losses = step()[0]
+            e1.record()
+            e1.synchronize()
+            hist.append(e0.elapsed_time(e1))
+            done = len(hist) >= 4 and time.time() - t_settle > o.settle_min and max(hist[-3:]) < 1.05 * min(hist)
+            if world > 1:     # every rank must leave the loop in the same iteration
+                flag = torch.tensor([1.0 if done else 0.0], device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                done = bool(flag.item() > 0.5)
+            if done:
+                break
+        note("settle: %d extra untimed steps, last %s ms" % (len(hist), " ".join("%.1f" % h for h in hist[-4:])))
     fence()
     note("warmup done %.2f s" % (time.time() - tw))
     t0 = time.time()
-    marks = []
-    for _ in range(o.steps):
+    marks, evs = [], [torch.cuda.Event(enable_timing=True) for _ in range(o.steps + 1)]
+    evs[0].record()
+    for i in range(o.steps):
         losses = step()[0]
+        evs[i + 1].record()
         marks.append(time.time() - t0)      # host enqueue progress (no sync): shows a host-bound step at a glance
     fence()
     dt = time.time() - t0
     note("host enqueue marks (s): %s | end %.3f" % (" ".join("%.3f" % m for m in marks), dt))
+    note("GPU ms per step (events): %s" % " ".join("%.1f" % evs[i].elapsed_time(evs[i + 1]) for i in range(o.steps)))
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -195,12 +228,9 @@ def main():
     loss_val = float(losses[0])
     assert loss_val == loss_val, "loss is NaN"
 
-    roof = cpu = None
+    cpu = None
     if rank == 0:
         note("timed region %.3f s for %d steps" % (dt, o.steps))
-        if not o.skip_roofline:
-            roof = gate_kernel_roofline(o.batch, o.kernel_iters, o.imsize)
-            note("gate kernel roofline: %s TFLOP/s" % roof["achieved"])
         if world == 1 and not o.skip_cpu:
             # own process + hard timeout: the CPU leg can never stall the GPU bench
             import subprocess

@@ -390,47 +390,64 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 // perm[b][t] = GT slot assigned to prediction t, perm[b][t >= T] = 0 (what hungarian.py leaves in unassigned columns).
 // ------------------------------------------------------------------------------------------------
 #define RSIS_ASSIGN_MAX 64
-__global__ void assign_kernel(const float* __restrict__ scores, long long* __restrict__ perm, int B, int G, int T) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// One 64-lane wave per sample: lane j owns GT slot ("column") j+1 of the classical algorithm -- its potential v, the
+// running minimum minv, used / way / p -- and lane i owns the potential u of prediction ("row") i+1; the inner scan over
+// columns is a wave-wide arg-min (first minimum wins, as in the sequential scan), row lookups are lane shuffles.
+__global__ __launch_bounds__(64) void assign_kernel(const float* __restrict__ scores, long long* __restrict__ perm, int B, int G,
+                                                    int T) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
   const float* a = scores + (size_t)b * G * T;   // a[g*T + t]
-  double u[RSIS_ASSIGN_MAX + 1], v[RSIS_ASSIGN_MAX + 1], minv[RSIS_ASSIGN_MAX + 1];
-  int p[RSIS_ASSIGN_MAX + 1], way[RSIS_ASSIGN_MAX + 1];
-  bool used[RSIS_ASSIGN_MAX + 1];
-  const int n = T, m = G;                          // n "rows" (predictions) <= m "columns" (GT slots)
-  for (int j = 0; j <= m; ++j) { v[j] = 0.0; p[j] = 0; way[j] = 0; }
-  for (int i = 0; i <= n; ++i) u[i] = 0.0;
+  const int n = T, m = G;
+  const bool col = lane < m;
+  double u = 0.0, v = 0.0;
+  int p = 0;                                       // row assigned to my column (0 = free)
   for (int i = 1; i <= n; ++i) {
-    p[0] = i;
+    const int p0 = i;                              // row of the virtual column 0
     int j0 = 0;
-    for (int j = 0; j <= m; ++j) { minv[j] = 1e300; used[j] = false; }
-    do {
-      used[j0] = true;
-      const int i0 = p[j0];
-      double delta = 1e300;
-      int j1 = 0;
-      for (int j = 1; j <= m; ++j) {
-        if (used[j]) continue;
-        const double cur = (double)a[(size_t)(j - 1) * T + (i0 - 1)] - u[i0] - v[j];
-        if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
-        if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+    double minv = 1e300;
+    bool used = false, in_tree = false;
+    int way = 0;
+    while (true) {
+      if (j0 > 0 && lane == j0 - 1) used = true;
+      const int i0 = j0 == 0 ? p0 : __shfl(p, j0 - 1, 64);
+      if (lane == i0 - 1) in_tree = true;
+      const double ui0 = __shfl(u, i0 - 1, 64);
+      double cand = 1e300;
+      if (col && !used) {
+        const double cur = (double)a[(size_t)lane * T + (i0 - 1)] - ui0 - v;
+        if (cur < minv) { minv = cur; way = j0; }
+        cand = minv;
       }
-      for (int j = 0; j <= m; ++j) {
-        if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
-        else minv[j] -= delta;
+      // wave arg-min, smallest lane on ties
+      double best = cand;
+      int bj = lane;
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oj = __shfl_xor(bj, o, 64);
+        if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
       }
+      const double delta = best;
+      if (in_tree) u += delta;
+      if (col) { if (used) v -= delta; else minv -= delta; }
+      j0 = bj + 1;
+      if (__shfl(p, j0 - 1, 64) == 0) break;
+    }
+    // augment along the alternating path
+    while (j0 != 0) {
+      const int j1 = __shfl(way, j0 - 1, 64);
+      const int pj1 = j1 == 0 ? p0 : __shfl(p, j1 - 1, 64);
+      if (lane == j0 - 1) p = pj1;
       j0 = j1;
-    } while (p[j0] != 0);
-    do {
-      const int j1 = way[j0];
-      p[j0] = p[j1];
-      j0 = j1;
-    } while (j0 != 0);
+    }
   }
-  long long* out = perm + (size_t)b * G;
-  for (int g = 0; g < G; ++g) out[g] = 0;
-  for (int j = 1; j <= m; ++j)
-    if (p[j] != 0) out[p[j] - 1] = j - 1;
+  // perm[b][t] = column of row t+1; zeros elsewhere
+  __shared__ long long outp[RSIS_ASSIGN_MAX];
+  if (lane < G) outp[lane] = 0;
+  __syncthreads();
+  if (col && p != 0) outp[p - 1] = lane;
+  __syncthreads();
+  if (lane < G) perm[(size_t)b * G + lane] = outp[lane];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -530,6 +547,6 @@ int rsis_l_adam(float* p, const float* g, float* m, float* v, long n, float lr, 
 }
 
 int rsis_l_assign(const float* scores, long long* perm, int B, int G, int T, hipStream_t st) {
-  hipLaunchKernelGGL(assign_kernel, dim3((B + 63) / 64), dim3(64), 0, st, scores, perm, B, G, T);
+  hipLaunchKernelGGL(assign_kernel, dim3(B), dim3(64), 0, st, scores, perm, B, G, T);
   return rsis_check_launch();
 }
