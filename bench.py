@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--no-settle", action="store_true", help="skip the untimed settle phase after the warm-up steps")
     ap.add_argument("--settle-min", type=float, default=2.0, help="minimum seconds of the untimed settle phase")
-    ap.add_argument("--settle-cap", type=float, default=8.0, help="maximum seconds of the untimed settle phase")
+    ap.add_argument("--settle-cap", type=float, default=10.0, help="maximum seconds of the untimed settle phase")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     o = ap.parse_args()
     if o.cpu_baseline_only:
@@ -188,9 +188,8 @@ def main():
         if i == 0:
             torch.cuda.synchronize()
             note("first step %.2f s" % (time.time() - tw))
-    # Untimed settle phase (still warm-up): on a cold box the GPU's power management overshoots and throttles for about a
-    # second some 1-2 s after sustained load starts (observed: 62 ms steps turning into 150 ms steps, then back).  Keep
-    # stepping, untimed, until the step time is stable, so that the K timed steps measure steady state.
+    # Untimed settle phase (still warm-up): keep stepping until the step time has been stable for a while (cold-box clock
+    # ramp, allocator growth, first-use code loading), so that the K timed steps measure steady state.
     if not o.no_settle:
         hist, t_settle = [], time.time()
         while time.time() - t_settle < o.settle_cap:
@@ -200,7 +199,7 @@ def main():
             e1.record()
             e1.synchronize()
             hist.append(e0.elapsed_time(e1))
-            done = len(hist) >= 4 and time.time() - t_settle > o.settle_min and max(hist[-3:]) < 1.05 * min(hist)
+            done = len(hist) >= 10 and time.time() - t_settle > o.settle_min and max(hist[-10:]) < 1.05 * min(hist)
             if world > 1:     # every rank must leave the loop in the same iteration
                 flag = torch.tensor([1.0 if done else 0.0], device="cuda")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)

@@ -36,6 +36,13 @@ class LevelTape(object):
         self.last_h = self.last_c = None
         self.need_grad = False
 
+    def release(self):
+        """Drop every tensor the level holds.  tl -> G / last_h -> grad_fn -> ctx -> tl is a reference CYCLE: without this
+        the whole iteration (stacked buffers + the encoder graph hanging off G) is only reclaimed by Python's cyclic GC,
+        i.e. tens of GB per step pile up until a gen-2 collection stalls the host for seconds."""
+        self.H = self.C = self.ACT = self.UP = self.DA = self.da_sum = None
+        self.G = self.last_h = self.last_c = None
+
     def alloc_forward(self, B, Hh, Ww, device, need_grad):
         hid, cap = self.hid, self.cap
         self.need_grad = need_grad
@@ -222,6 +229,8 @@ class _StepFn(torch.autograd.Function):
                                               h_off, hid, stream()), "rsis_conv2d_wgrad(batched h)")
         if tgt is not None:
             dW = None   # accumulated straight into weight.grad
+        if t == 0:
+            tl.release()   # last use of this level's tape: break the tape <-> autograd-node reference cycle now
         return None, None, d_up, dh_prev, dc_prev, dG, dW
 
 
@@ -281,6 +290,9 @@ def decoder_levels(decoder, skip_feats, prev_hidden_list):
                                             any(p.requires_grad for p in decoder.clstm_list.parameters()))
     tape = decoder._tape
     if prev_hidden_list is None:
+        if tape is not None:           # a previous sequence that was never back-propagated: drop its cycles explicitly
+            for old in tape.levels:
+                old.release()
         tape = decoder._tape = DecoderTape(decoder, skip_feats, need_grad)
     elif tape is None or not tape.matches(skip_feats, prev_hidden_list):
         return None

@@ -322,3 +322,33 @@ def test_direct_grad_accumulation_equals_autograd():
     assert_close("decoder + skip grads", flats[1][0], flats[0][0], 2e-4 * scale, 1e-3)
     rel = float((flats[1][1] - flats[0][1]).norm() / flats[0][1].norm())
     assert rel < 0.2, "trunk grads rel-L2 %.3e" % rel
+
+
+def test_training_step_leaves_no_cyclic_garbage():
+    """with Python's cyclic GC disabled, device memory must not grow from step to step (the decoder tape / autograd
+    nodes used to form reference cycles that kept a whole iteration alive until a gen-2 collection)."""
+    import gc
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import build_optimizers, runIter
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    a = mk_args(hidden_size=32, maxseqlen=3, optim="adam", optim_cnn="adam", lr=1e-3, lr_cnn=1e-6, weight_decay=1e-6,
+                weight_decay_cnn=1e-6)
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    batch = synthetic_batch(5, 2, 64, 64, 20, 3, 21, "cuda")
+    opts = list(build_optimizers(a, enc, dec))
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(0.5)]
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(3):
+            runIter(a, enc, dec, *batch, crits, opts, mode="train", sync_losses=False, t_run=3)
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        for _ in range(5):
+            runIter(a, enc, dec, *batch, crits, opts, mode="train", sync_losses=False, t_run=3)
+        torch.cuda.synchronize()
+        grown = torch.cuda.memory_allocated() - base
+    finally:
+        gc.enable()
+    assert grown <= 1 << 20, "device memory grew by %.1f MB over 5 steps with the cyclic GC off" % (grown / 2 ** 20)
