@@ -46,7 +46,9 @@ int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, 
 
 /* ---- nn.Conv2d forward (model.py:59-63 skip convs, :167 conv_out, vision.py:12-19 trunk convs) ----
  * out[B][Cout][Ho][Wo] = conv(cat(src[0..nsrc-1], dim=1), W, stride, pad) + bias (+ addend, same shape as out).
- * torch.cat (model.py:153) is folded in: up to 3 sources.  tile = 0 lets the library choose the MFMA tiling. */
+ * torch.cat (model.py:153) is folded in: up to 3 sources.  tile = 0 lets the library choose the MFMA tiling; tile + 100
+ * additionally allows a split-K schedule (fp32 atomics: faster on deep-K / few-pixel layers such as sk5, but the summation
+ * order is not reproducible -- the Python binding allows it only while training). */
 int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const float* Wp, int Cout,
                     int ks, int stride, int pad, const float* bias, const float* addend, float* out, int Ho, int Wo,
                     int tile, void* stream);

@@ -120,6 +120,8 @@ static int fill_sources(ConvArgs& a, const float* const* src, const int* Csrc, i
 int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const float* Wp, int Cout,
                     int ks, int stride, int pad, const float* bias, const float* addend, float* out, int Ho, int Wo,
                     int tile, void* stream) {
+  const bool allow_splitk = tile >= 100;     // tile + 100: the caller accepts a split-K (atomic, order-nondeterministic) sum
+  tile %= 100;
   ConvArgs a = {};
   int rc = fill_sources(a, src, Csrc, nsrc, ks);
   if (rc) return rc;
@@ -137,7 +139,8 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
     int nq = 0;
     for (int s = 0; s < nsrc; ++s) nq += (Csrc[s] + RSIS_CK - 1) / RSIS_CK;
     const long px_tiles = (long)B * rsis_cdiv(H, 8) * rsis_cdiv(W, W <= 8 ? 8 : 16);
-    if (nq >= 32 && px_tiles * rsis_cdiv(Cout, 64) < 160) {
+    static const bool splitk_ok = !(getenv("RSIS_CONV_SPLITK") && getenv("RSIS_CONV_SPLITK")[0] == '0');   // A/B switch
+    if (allow_splitk && splitk_ok && nq >= 32 && px_tiles * rsis_cdiv(Cout, 64) < 160) {
       if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * Cout * Ho * Wo, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
       a.ksplit = 0;
     }

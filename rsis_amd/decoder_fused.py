@@ -127,8 +127,8 @@ class _StepFn(torch.autograd.Function):
         _hoist, dyn = _packs(tl.cell, tl.c_up, tl.c_skip)
         B, _, H, W = G.shape
         hid = tl.hid
-        need_grad = any(ctx.needs_input_grad)
-        stacked = need_grad and tl.need_grad and t < tl.cap
+        need_grad = any(ctx.needs_input_grad) and tl.need_grad   # (needs_input_grad is True for parameters even under no_grad)
+        stacked = need_grad and t < tl.cap
         srcs = []
         if up is not None:
             srcs.append(up if up.is_contiguous() else up.contiguous())
