@@ -63,9 +63,62 @@ __global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restri
 }
 
 // backward as a GATHER (no atomics, deterministic): dx[hi][wi] = sum over the few output pixels whose 2x2 stencil touches
-// (hi, wi).  Membership is decided by re-evaluating ac_coord for every candidate, so it is bit-consistent with the forward.
-__global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Hi, int Wi, int Ho, int Wo,
-                                    float sh, float sw, long total) {
+// (hi, wi).  A block owns one (b, c) plane tile of UT x UT input pixels; the 1-D interpolation weights of the candidate output
+// rows / columns of the tile are evaluated ONCE per block into LDS (with the forward's own ac_coord, so membership is
+// bit-consistent with it), and each thread then does a UK x UK weighted gather.
+#define UT 16
+#define UK 8   // candidate outputs per input index: covers scale factors >= 1/3 (checked by the launcher)
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Hi, int Wi,
+                                                           int Ho, int Wo, float sh, float sw, int tiles_x, int tiles_y) {
+  __shared__ float wgt[2][UT][UK];
+  __shared__ int lo[2][UT];
+  const int tid = threadIdx.x;
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y;
+  const long bc = blockIdx.x / (tiles_x * tiles_y);
+  // ---- per-block tables: threads 0..255 -> (axis, local index, candidate) ----
+  {
+    const int axis = tid >> 7, li = (tid >> 3) & 15, k = tid & 7;
+    const int in = axis ? Wi : Hi, out = axis ? Wo : Ho;
+    const float sc = axis ? sw : sh;
+    const int i = (axis ? tx : ty) * UT + li;
+    int l = 0;
+    if (sc > 0.f) l = max(0, (int)floorf((i - 1) / sc) - 1);
+    const int o = l + k;
+    float w = 0.f;
+    if (i < in && o < out) {
+      int i0, i1; float l1;
+      ac_coord(o, sc, in, i0, i1, l1);
+      w = (i0 == i ? 1.f - l1 : 0.f) + (i1 == i ? l1 : 0.f);
+    }
+    wgt[axis][li][k] = w;
+    if (k == 0) lo[axis][li] = l;
+  }
+  __syncthreads();
+  const int ly = tid >> 4, lx = tid & 15;
+  const int hi = ty * UT + ly, wi = tx * UT + lx;
+  if (hi >= Hi || wi >= Wi) return;
+  const float* yb = dy + bc * Ho * Wo;
+  const int ho0 = lo[0][ly], wo0 = lo[1][lx];
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < UK; ++a) {
+    const float wh = wgt[0][ly][a];
+    if (wh == 0.f) continue;
+    const float* row = yb + (size_t)(ho0 + a) * Wo + wo0;
+    float r = 0.f;
+#pragma unroll
+    for (int c = 0; c < UK; ++c) {
+      const float ww = wgt[1][lx][c];
+      if (ww != 0.f) r = fmaf(ww, row[c], r);
+    }
+    acc = fmaf(wh, r, acc);
+  }
+  dx[bc * Hi * Wi + (size_t)hi * Wi + wi] = acc;
+}
+
+// general fallback (any scale): per-thread candidate scan
+__global__ void upsample_bwd_generic_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Hi, int Wi, int Ho, int Wo,
+                                            float sh, float sw, long total) {
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int wi = (int)(e % Wi);
     const long t = e / Wi;
@@ -482,9 +535,17 @@ int rsis_l_upsample_fwd(const float* x, float* y, long BC, int Hi, int Wi, int H
   return rsis_check_launch();
 }
 int rsis_l_upsample_bwd(const float* dy, float* dx, long BC, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
-  const long total = BC * Hi * Wi;
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, ac_scale(Hi, Ho),
-                     ac_scale(Wi, Wo), total);
+  const float sh = ac_scale(Hi, Ho), sw = ac_scale(Wi, Wo);
+  // the tiled kernel scans UK = 8 candidate outputs per input index: enough when at most ~2/scale + 3 outputs touch it
+  const bool tiled = sh > 0.f && sw > 0.f && (2.f / sh + 3.5f <= UK) && (2.f / sw + 3.5f <= UK);
+  if (tiled) {
+    const int tiles_x = (Wi + UT - 1) / UT, tiles_y = (Hi + UT - 1) / UT;
+    const long blocks = BC * tiles_x * tiles_y;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, tiles_x, tiles_y);
+  } else {
+    const long total = BC * Hi * Wi;
+    hipLaunchKernelGGL(upsample_bwd_generic_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, total);
+  }
   return rsis_check_launch();
 }
 int rsis_l_gmax_fwd(const float* x, float* y, int* arg, long BC, int HW, hipStream_t st) {
