@@ -187,13 +187,16 @@ static int launch_wgrad_cfg(WgradArgs& a, hipStream_t st) {
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
   a.n_n_tiles = rsis_cdiv((long)a.Cs * KS * KS, BN);
   const int ntile = a.n_co_tiles * a.n_n_tiles;
-  // split-K so that the launch has >= ~2 blocks per CU, at least 4 K-tiles (128 px) per split
-  int nsplit = rsis_cdiv(512, ntile);
+  // split-K: fill the resident block slots of the chip in ONE round (blocks/CU from the kernel's LDS/VGPR budget: 2 for the
+  // 128x128 tile, 3 otherwise) -- a few blocks more than the slot count would cost a whole extra round -- while keeping at
+  // least 4 K-tiles (128 px) per split
+  const int slots = 256 * (BM * BN >= 128 * 128 ? 2 : 3);
+  int nsplit = ntile >= slots ? 1 : slots / ntile;
   const int max_split = (int)((Npx + 4 * BKW - 1) / (4 * BKW));
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
   a.chunk = rsis_roundup(rsis_cdiv(Npx, nsplit), BKW);
-  nsplit = rsis_cdiv(Npx, a.chunk);
+  nsplit = rsis_cdiv(Npx, a.chunk);   // (rounding the chunk up can only lower the split count)
   if constexpr (KS == 1 && BM % 32 == 0 && BN % 32 == 0) {
     if (a.stride == 1 && a.pad == 0 && (a.H * a.W) % 4 == 0 && a.H == a.Ho && a.W == a.Wo) {
       hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WGM, WGN, KS, true>), dim3(ntile, nsplit), dim3(256), 0, st, a);
