@@ -169,6 +169,16 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const fl
     if (Hx != Hy || Wx != Wy) return RSIS_ERR_ARG;
     if (Cout == 1 && ndst == 1 && Cin_packed == Cdx[0] && rsis_c1_supported(Cdx[0]))
       return rsis_l_c1_dgrad(dy, Wd, a.ldw, dx[0], B, Cdx[0], Hx, Wx, (hipStream_t)stream);
+    {  // deep-K data gradients on tiny maps (ConvLSTM level 0: 512 gate rows x 9 taps on 8x8): split over the channel chunks
+      static const bool splitk_ok = !(getenv("RSIS_CONV_SPLITK") && getenv("RSIS_CONV_SPLITK")[0] == '0');
+      const int nq = (Cout + RSIS_CK - 1) / RSIS_CK;
+      const long px_tiles = (long)B * rsis_cdiv(Hx, 8) * rsis_cdiv(Wx, Wx <= 8 ? 8 : 16);
+      if (splitk_ok && nq >= 32 && px_tiles * rsis_cdiv(ctot, 64) < 160) {
+        for (int i = 0; i < ndst; ++i)
+          if (hipMemsetAsync(dx[i], 0, sizeof(float) * (size_t)B * Cdx[i] * Hx * Wx, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
+        a.ksplit = 0;
+      }
+    }
     return rsis_launch_conv3x3_direct(a, 0, direct_variant(tile), (hipStream_t)stream);
   }
   if (ks == 1 && pad == 0 && stride > 1) {
