@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librsis_hip.so")
+# RSIS_HIP_LIB selects another build of the same C ABI (a replacement .so must export every symbol of include/rsis_hip.h)
+LIB_PATH = os.environ.get("RSIS_HIP_LIB") or os.path.join(_HERE, "lib", "librsis_hip.so")
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 _ip = ctypes.POINTER(ctypes.c_int)

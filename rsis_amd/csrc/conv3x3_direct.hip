@@ -17,6 +17,10 @@
 #include "common.h"
 
 enum { EPI_PLAIN = 0, EPI_LSTM = 1 };
+#ifndef DIRECT_DMA
+#define DIRECT_DMA 1   // 1: stage global -> LDS with buffer_load ... lds (LDS-DMA); 0: through registers + ds_write
+#endif
+typedef __attribute__((address_space(3))) void* lds_vp_t;
 #define CK RSIS_CK
 
 typedef const float __attribute__((address_space(1)))* gcf_t;
@@ -25,6 +29,7 @@ typedef const f32x4 __attribute__((address_space(1)))* gcf4_t;
 
 template <int BM, int TW, int TH, int NI, int EPI>
 __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
+#if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; the buffer-resource builtins do not exist there)
   constexpr int BN = TW * TH * NI;
   constexpr int WGM = BM / 32, WGN = 4 / WGM;      // BM=64: 2x2 waves, BM=32: 1x4
   constexpr int TN = BN / WGN / 32;                 // 32-pixel MFMA column tiles per wave (TM == 1)
@@ -32,14 +37,15 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   constexpr int IMS = PH * PW;                      // one image of the patch
   constexpr int CHS = NI * IMS;                     // channel stride of the patch
   constexpr int XS = CK * CHS, WS = CK * 9 * BM;    // floats per LDS stage
+  constexpr int XSP = DIRECT_DMA ? (XS + 255) / 256 * 256 : XS;   // the DMA writes whole 64-lane rows: pad the stage
   constexpr int NX = (XS + 255) / 256;              // patch loads per thread per chunk
   constexpr int W_F4 = WS / 4;
   constexpr int NW = (W_F4 + 255) / 256;            // weight float4 loads per thread per chunk
   static_assert(TN >= 1 && BN % (WGN * 32) == 0, "tile");
 
-  __shared__ __attribute__((aligned(16))) float lds[2 * (XS + WS)];
+  __shared__ __attribute__((aligned(16))) float lds[2 * (XSP + WS)];
   float* const Xs0 = lds;
-  float* const Ws0 = lds + 2 * XS;
+  float* const Ws0 = lds + 2 * XSP;
 
   const gcf_t src0 = (gcf_t)p.src[0], src1 = (gcf_t)p.src[1], src2 = (gcf_t)p.src[2];
   const int C0 = p.C[0], C1 = p.C[1], C2 = p.C[2];
@@ -70,6 +76,28 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
 
+#if DIRECT_DMA
+  // ---- loop-invariant byte offset of this thread's patch elements inside the [CK][H][W] slab of one chunk of image b0;
+  // halo / out-of-image elements get an offset beyond the buffer range, which the buffer load turns into a zero ----
+  static_assert(NI == 1, "LDS-DMA staging addresses one image per block");
+  unsigned xvo[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int e = tid + i * 256;
+    const int cl = e / CHS, rem2 = e - cl * CHS;
+    const int py = rem2 / PW, pxx = rem2 - py * PW;
+    const int gy = y0 + py - 1, gx = x0 + pxx - 1;
+    const bool ok = (e < XS) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+    xvo[i] = ok ? (unsigned)(cl * HW + gy * W + gx) * 4u : 0x7FFFFFF0u;
+  }
+  unsigned wvo[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+    wvo[i] = (unsigned)(row * ldw + c4 * 4) * 4u;
+  }
+#else
   // ---- loop-invariant decode of this thread's patch elements: element e -> (channel-in-chunk, image, row, col) ----
   int goff[NX];      // offset inside one channel plane set: img*Cs*HW is added per source (NI > 1 only)
   int gimg[NX];
@@ -88,6 +116,8 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
     gcl[i] = cl;
   }
 
+#endif
+
   // ---- per-lane LDS read bases (bytes are immediates in the unrolled loop) ----
   int xoff[TN];
 #pragma unroll
@@ -104,8 +134,6 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  float rx[NX];
-  f32x4 rw[NW];
   const gcf_t wbase = (gcf_t)p.wp + co_t * BM;
 
   // scalar chunk cursor, positioned on this block's first chunk
@@ -113,6 +141,35 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   if (cs == 0 && cq >= q0 && q0 < nq_all) { cq -= q0; cs = 1; }
   if (cs == 1 && cq >= q1 && q0 + q1 < nq_all) { cq -= q1; cs = 2; }
 
+#if DIRECT_DMA
+  // One chunk = NX dword + NW dwordx4 `buffer_load ... lds` per thread: no staging registers, no ds_write pass, no per-lane
+  // 64-bit addresses or predicates (the descriptor's range check zero-fills the halo and the channel tail).
+#define DIRECT_ISSUE(QG, BUF)                                                                             \
+  {                                                                                                       \
+    gcf_t src = src0; int Cs = C0;                                                                        \
+    if (cs == 1) { src = src1; Cs = C1; }                                                                 \
+    if (cs == 2) { src = src2; Cs = C2; }                                                                 \
+    const int c0 = cq * CK;                                                                               \
+    const int cn = min(CK, Cs - c0);                                                                      \
+    const float* xb = (const float*)src + ((size_t)b0 * Cs + c0) * HW;                                    \
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, cn * HW * 4, 0x00020000); \
+    float* Xs = Xs0 + (BUF) * XSP + wave * 64;                                                            \
+    _Pragma("unroll") for (int i = 0; i < NX; ++i)                                                        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_vp_t)(Xs + i * 256), 4, xvo[i], 0, 0, 0);        \
+    const float* wrow = (const float*)wbase + (size_t)(QG) * (CK * 9) * ldw;                              \
+    const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)wrow, 0, CK * 9 * ldw * 4, 0x00020000); \
+    float* Ws = Ws0 + (BUF) * WS + wave * 256;                                                            \
+    _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                        \
+      if (W_F4 % 256 == 0 || i * 256 + wave * 64 < W_F4)                                                  \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_, (lds_vp_t)(Ws + i * 1024), 16, wvo[i], 0, 0, 0);    \
+    if (++cq == (cs == 0 ? q0 : (cs == 1 ? q1 : q2))) { cq = 0; ++cs; if (cs == 1 && q1 == 0) ++cs; }     \
+  }
+#define DIRECT_LAND() __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): this wave's DMA has landed in LDS */
+  if (nq > 0) DIRECT_ISSUE(q_begin, 0)
+  DIRECT_LAND()
+#else
+  float rx[NX];
+  f32x4 rw[NW];
 #define DIRECT_LOAD(QG)                                                                                   \
   {                                                                                                       \
     gcf_t src = src0; int Cs = C0;                                                                        \
@@ -137,10 +194,9 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
     }                                                                                                     \
     if (++cq == (cs == 0 ? q0 : (cs == 1 ? q1 : q2))) { cq = 0; ++cs; if (cs == 1 && q1 == 0) ++cs; }     \
   }
-
 #define DIRECT_STORE(BUF)                                                                                 \
   {                                                                                                       \
-    float* Xs = Xs0 + (BUF) * XS;                                                                         \
+    float* Xs = Xs0 + (BUF) * XSP;                                                                        \
     float* Ws = Ws0 + (BUF) * WS;                                                                         \
     _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                      \
       const int e = tid + i * 256;                                                                        \
@@ -151,18 +207,22 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
       if (W_F4 % 256 == 0 || idx < W_F4) *reinterpret_cast<f32x4*>(Ws + idx * 4) = rw[i];                 \
     }                                                                                                     \
   }
-
   if (nq > 0) {   // nq == 0: no dynamic source at all (ConvLSTM level 0 at t = 0 with the hoisted skip term): gates = addend
     DIRECT_LOAD(q_begin)
     DIRECT_STORE(0)
   }
+#endif
   __syncthreads();
   for (int t = 0; t < nq; ++t) {
     const int cur = t & 1;
     const bool more = t + 1 < nq;
+#if DIRECT_DMA
+    if (more) DIRECT_ISSUE(q_begin + t + 1, cur ^ 1)   // stage cur^1 was last read before the barrier that ended step t-1
+#else
     if (more) DIRECT_LOAD(q_begin + t + 1)
+#endif
     {
-      const float* Xs = Xs0 + cur * XS;
+      const float* Xs = Xs0 + cur * XSP;
       const float* Ws = Ws0 + cur * WS + woff;
 #pragma unroll
       for (int c2 = 0; c2 < CK / 2; ++c2)
@@ -178,9 +238,15 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
             for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
           }
     }
+#if DIRECT_DMA
+    DIRECT_LAND()
+#else
     if (more) DIRECT_STORE(cur ^ 1)
+#endif
     __syncthreads();
   }
+#undef DIRECT_ISSUE
+#undef DIRECT_LAND
 #undef DIRECT_LOAD
 #undef DIRECT_STORE
 
@@ -243,6 +309,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
       }
     }
   }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
