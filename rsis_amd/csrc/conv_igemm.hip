@@ -25,10 +25,14 @@ typedef const char __attribute__((address_space(1)))* gcc_t;
 typedef float __attribute__((address_space(1)))* gf_t;
 typedef const f32x4 __attribute__((address_space(1)))* gcf4_t;
 
-// V4: 1x1 / stride 1 / single source with H*W % 4 == 0 (the bottleneck 1x1 convs and their data gradients): the pixel
-// operand is loaded as float4 runs along W (a plain GEMM B-tile), 4x fewer load instructions and no per-tap masks.
+// V4: 1x1 / stride 1 / single source with H*W % 4 == 0 and C % BK == 0 (the bottleneck 1x1 convs and their data gradients):
+// a plain GEMM whose two operand tiles are copied global -> LDS by the LDS-DMA (`buffer_load_dwordx4 ... lds`): the k-major
+// tiles are lane-linear images of what the threads fetch, so there are no staging registers, no ds_write pass and no
+// per-lane predicates (pixels beyond the tensor get an out-of-range offset, which the descriptor turns into zeros).
+typedef __attribute__((address_space(3))) void* lds_vp_t;
 template <int BM, int BN, int BK, int WGM, int WGN, int KS, bool DGRAD, int EPI, bool V4>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+#if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; the buffer-resource builtins do not exist there)
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int KK = KS * KS;
   constexpr int B_ROWS = 256 / BN;       // k rows covered by one load pass of the pixel operand
@@ -114,28 +118,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float rb[V4 ? 1 : B_LOADS];
-  f32x4 rbv[BV_LOADS];
-  f32x4 ra[A_LOADS];
+  f32x4 ra[V4 ? 1 : A_LOADS];
   // V4 mapping: thread -> (float4 column, first k row); the 4 pixels share an image because H*W % 4 == 0
   const int v_col = tid % BV_COLS, v_row0 = tid / BV_COLS;
-  int v_px = px_t * BN + v_col * 4;
-  const bool v_ok = v_px < Npx;
-  if (!v_ok) v_px = 0;
+  const int v_px = px_t * BN + v_col * 4;
   const int v_b = v_px / HoWo;
-  const int v_base = v_b * C0 * HW + (v_px - v_b * HoWo);   // V4 => H == Ho, W == Wo, one source
+  unsigned v_bo[BV_LOADS], v_ao[A_LOADS];   // loop-invariant byte offsets of this thread's float4s inside a K-tile
+#pragma unroll
+  for (int i = 0; i < BV_LOADS; ++i)       // V4 => H == Ho, W == Wo, one source
+    v_bo[i] = v_px < Npx ? (unsigned)(v_b * C0 * HW + (v_px - v_b * HoWo) + (v_row0 + i * BV_ROWS) * HW) * 4u : 0x7FFFFFF0u;
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int idx = tid + i * 256;
+    v_ao[i] = (unsigned)((idx / (BM / 4)) * ldw + (idx % (BM / 4)) * 4) * 4u;
+  }
   const int ntiles = (p.K + BK - 1) / BK;
   const gcf_t wbase = (gcf_t)p.wp + co_t * BM;
+  const unsigned x_bytes = (unsigned)p.B * C0 * HW * 4u;   // V4 only (the host routes tensors >= 2 GiB to the generic path)
+
+  // V4: issue the LDS-DMA of K-tile T into LDS stage BUF (stage BUF was last read before the previous barrier)
+#define RSIS_DMA_TILE(T, BUF)                                                                                      \
+  {                                                                                                                \
+    const unsigned xo = (unsigned)(T) * BK * HW * 4u;                                                              \
+    const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)src0 + xo), 0, x_bytes - xo, 0x00020000); \
+    float* Bs = Bs0 + (BUF) * BK * BN + wave * 256;                                                                \
+    _Pragma("unroll") for (int i = 0; i < BV_LOADS; ++i)                                                           \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_vp_t)(Bs + i * 1024), 16, v_bo[i], 0, 0, 0);              \
+    const float* wrow = (const float*)wbase + (size_t)(T) * BK * ldw;                                              \
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)wrow, 0, BK * ldw * 4, 0x00020000); \
+    float* As = As0 + (BUF) * BK * BM + wave * 256;                                                                \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                                            \
+      if (A_F4 % 256 == 0 || i * 256 + wave * 64 < A_F4)                                                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_vp_t)(As + i * 1024), 16, v_ao[i], 0, 0, 0);             \
+  }
 
 #define RSIS_LOAD_TILE(T)                                                                                          \
   {                                                                                                                \
-    if constexpr (V4) {                                                                                            \
-      _Pragma("unroll") for (int i = 0; i < BV_LOADS; ++i) {                                                       \
-        const int ci = (T) * BK + v_row0 + i * BV_ROWS;                                                            \
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                            \
-        if (v_ok && ci < C0) v = *(gcf4_t)((gcf_t)src0 + (size_t)(v_base + ci * HW));                              \
-        rbv[i] = v;                                                                                                \
-      }                                                                                                            \
-    } else                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) {                                                          \
       const int kl = __builtin_amdgcn_readfirstlane((T) * BK + krow0 + i * B_ROWS); /* scalar from here on */      \
       const int cg = kl / KK;                                                                                      \
@@ -167,10 +185,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   {                                                                                                                \
     float* As = As0 + (BUF) * BK * BM;                                                                             \
     float* Bs = Bs0 + (BUF) * BK * BN;                                                                             \
-    if constexpr (V4) {                                                                                            \
-      _Pragma("unroll") for (int i = 0; i < BV_LOADS; ++i)                                                         \
-        *reinterpret_cast<f32x4*>(Bs + (v_row0 + i * BV_ROWS) * BN + v_col * 4) = rbv[i];                          \
-    } else                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) Bs[(krow0 + i * B_ROWS) * BN + px_local] = rb[i];          \
     _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                                          \
       const int idx = tid + i * 256;                                                                               \
@@ -183,14 +197,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 
   // ---- software pipeline: global->regs for tile t+1 overlaps MFMA on tile t; one barrier per tile ----
   if (ntiles > 0) {
-    RSIS_LOAD_TILE(0)
-    RSIS_STORE_TILE(0)
+    if constexpr (V4) {
+      RSIS_DMA_TILE(0, 0)
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA has landed
+    } else {
+      RSIS_LOAD_TILE(0)
+      RSIS_STORE_TILE(0)
+    }
   }
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     const bool more = t + 1 < ntiles;
-    if (more) RSIS_LOAD_TILE(t + 1)
+    if constexpr (V4) {
+      if (more) RSIS_DMA_TILE(t + 1, cur ^ 1)
+    } else {
+      if (more) RSIS_LOAD_TILE(t + 1)
+    }
     {
       const float* As = As0 + cur * BK * BM + wm * TM * 32 + l31;
       const float* Bs = Bs0 + cur * BK * BN + wn * TN * 32 + l31;
@@ -209,11 +232,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (more) RSIS_STORE_TILE(cur ^ 1)
+    if constexpr (V4) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    } else {
+      if (more) RSIS_STORE_TILE(cur ^ 1)
+    }
     __syncthreads();
   }
 #undef RSIS_LOAD_TILE
 #undef RSIS_STORE_TILE
+#undef RSIS_DMA_TILE
 
   // ---- epilogue ----
   const int co_base = co_t * BM + wm * TM * 32;
@@ -288,6 +316,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       }
     }
   }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -300,7 +329,8 @@ static int launch_cfg(ConvArgs& a, hipStream_t st) {
   a.n_px_tiles = rsis_cdiv(Npx, BN);
   const int grid = a.n_co_tiles * 8 * rsis_cdiv(a.n_px_tiles, 8);
   if constexpr (KS == 1 && !DGRAD && EPI == EPI_PLAIN) {
-    if (a.stride == 1 && a.pad == 0 && a.nsrc == 1 && (a.H * a.W) % 4 == 0) {
+    if (a.stride == 1 && a.pad == 0 && a.nsrc == 1 && (a.H * a.W) % 4 == 0 && a.C[0] % BK == 0 &&
+        (long)a.B * a.C[0] * a.H * a.W * 4 < (1L << 31)) {
       hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, KS, DGRAD, EPI, true>), dim3(grid), dim3(256), 0, st, a);
       return rsis_check_launch();
     }
