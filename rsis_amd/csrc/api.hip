@@ -7,7 +7,8 @@
 int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_tile, hipStream_t st);
 int rsis_launch_conv_wgrad(WgradArgs& a, int ks, hipStream_t st);
 int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st);
-int rsis_launch_conv3x3_wgrad_direct(const WgradArgs& w, hipStream_t st);
+bool rsis_wgrad_tiled_supported(const WgradArgs& w, int ks);
+int rsis_launch_conv_wgrad_tiled(const WgradArgs& w, int ks, hipStream_t st);
 bool rsis_c1_supported(int Cin);
 int rsis_l_c1_fwd(const float*, const float*, int, const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_c1_dgrad(const float*, const float*, int, float*, int, int, int, int, hipStream_t);
@@ -200,10 +201,10 @@ int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs,
   a.stride = stride; a.pad = pad; a.ldo = Ctot * ks * ks; a.n_off = c_off * ks * ks; a.interleave_hid = lstm_hid;
   if (use_direct(ks, stride, pad) && Cout == 1 && lstm_hid == 0 && rsis_c1_supported(Cs) && H == Ho && W == Wo)
     return rsis_l_c1_wgrad(dy, x, dW + a.n_off, B, Cs, H, W, (hipStream_t)stream);
-  // experimental LDS-patch wgrad (conv3x3_wgrad_direct.hip): measured no faster than the split-K implicit GEMM on this
-  // round's shapes (staging is not overlapped, atomics double), so it is opt-in: RSIS_WGRAD_DIRECT=1
-  static const bool direct_ok = getenv("RSIS_WGRAD_DIRECT") && getenv("RSIS_WGRAD_DIRECT")[0] == '1';
-  if (direct_ok && use_direct(ks, stride, pad) && H == Ho && W == Wo) return rsis_launch_conv3x3_wgrad_direct(a, (hipStream_t)stream);
+  // stride-1 "same" convs on tile-aligned maps: the LDS-DMA tiled kernel (conv_wgrad_tiled.hip); RSIS_WGRAD_TILED=0 forces the
+  // generic split-K implicit GEMM (conv_wgrad.hip), which also covers every other shape
+  static const bool tiled_ok = !(getenv("RSIS_WGRAD_TILED") && getenv("RSIS_WGRAD_TILED")[0] == '0');
+  if (tiled_ok && rsis_wgrad_tiled_supported(a, ks)) return rsis_launch_conv_wgrad_tiled(a, ks, (hipStream_t)stream);
   return rsis_launch_conv_wgrad(a, ks, (hipStream_t)stream);
 }
 

@@ -1,0 +1,290 @@
+// Weight gradient of the stride-1 "same" convolutions (3x3/p1 and 1x1/p0) for gfx950 on the exact-f32 MFMA
+// (v_mfma_f32_32x32x2_f32), NCHW fp32, fed entirely by the LDS-DMA:
+//     dW[co][ci][r][s] += sum_{b,y,x} dy[b][co][y][x] * x[b][ci][y+r-pad][x+s-pad]
+// (autograd of nn.Conv2d in reference src/modules/clstm.py:17,44 -- the ConvLSTM gates, time-batched over T*B images --
+//  model.py:43-47 and the 1x1 / 3x3 convs of the torchvision bottlenecks).
+//
+// GEMM view D[co][n], n = ci*ks*ks + rs (the reference's weight layout, so the result is accumulated straight into dW),
+// the PIXELS are the reduction axis.  A block owns a BM x BN tile of D and walks a range of 8 x TH spatial tiles
+// (split-K over tiles and images, fp32 atomics at the end).  Per spatial tile it copies into LDS, with
+// `buffer_load ... lds` only (no staging registers, no ds_write pass, double buffered):
+//   * the dy tile  As[BM][TP]  as float4 runs along W.  Row r keeps its 16-byte group G at slot G ^ (r & 7): the LDS image
+//     stays lane-linear for the DMA (the swizzle is applied to the SOURCE offset) and the MFMA A operand of lane (r, h) is
+//     ONE conflict-free ds_read_b128 per tile row y: group 2y+h = pixels (y, 4h..4h+3).  The K index of the MFMA is only
+//     a summation index, so "lanes 0-31 take pixels x=0..3, lanes 32-63 take x=4..7 of row y" is as good as any order,
+//     provided B uses the same one;
+//   * 3x3: the input patch WITH halo  Xs[CI_P][TH+2][10]  as dwords (each input element once instead of 9 times; halo
+//     outside the image gets an out-of-range offset, which the buffer descriptor turns into zeros).  The B operand of lane
+//     n = (ci, r, s) is Xs[base(n) + 4h + y*10 + e]: a bare ds_read_b32 with an immediate offset;
+//   * 1x1: the x tile Bs[BN][TP], same layout / same reads as dy.
+// Per MFMA the wave issues <= 1 ds_read_b32 and 1/8..1/4 ds_read_b128; the DMA costs ~15 VMEM + ~25 VALU per thread per
+// tile (128 MFMAs per wave for 3x3).  The spatial tile is as wide as the map allows (32x2 / 16x4 / 8x8 pixels for 3x3,
+// 32x1 / 16x2 / 8x4 for 1x1) so that dy / x rows are read as full 128-byte lines; maps that no tile shape divides use
+// conv_wgrad.hip.
+#include "common.h"
+
+typedef __attribute__((address_space(3))) void* lds_vp_t;
+
+struct WgradTiledArgs {
+  const float* dy;   // [B][CoutDy][H][W]
+  const float* x;    // [B][Cs][H][W]
+  float* dw;         // [Cout][ldo]
+  int B, Cs, H, W, Cout;
+  int ldo, n_off, interleave_hid;
+  int n_co_tiles, n_n_tiles, n_sp_tiles, tiles_per_split;
+};
+
+#define RSIS_OOB 0x7FFFFFF0u
+
+template <int BM, int BN, int WGM, int WGN, int KS, int TW>
+__global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(const WgradTiledArgs p) {
+#if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; the buffer-resource builtins do not exist there)
+  constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+  constexpr int KK = KS * KS, HALO = KS / 2;
+  constexpr int TP = KS == 1 ? 32 : 64;       // pixels per spatial tile = reduction depth per LDS stage
+  constexpr int TH = TP / TW;                 // tile = TW x TH pixels: 32x2 / 16x4 / 8x8 (3x3), 32x1 / 16x2 / 8x4 (1x1)
+  constexpr int NG = TP / 4;                  // 16-byte groups per dy row
+  constexpr int GPR = TW / 4;                 // groups per tile row
+  constexpr int PW = TW + 2 * HALO, PH = TH + 2 * HALO, IMS = PW * PH;
+  constexpr int CI_P = KS == 1 ? BN : (BN + KK - 2) / KK + 1;   // input channels whose taps cover BN consecutive n
+  constexpr int AS = BM * TP;                                   // floats per dy stage
+  constexpr int XS = KS == 1 ? BN * TP : (CI_P * IMS + 255) / 256 * 256;
+  constexpr int NA = BM * NG / 256;           // dwordx4 DMA per thread per tile (dy)
+  constexpr int NB4 = KS == 1 ? BN * NG / 256 : 0;   // dwordx4 DMA per thread per tile (x, 1x1)
+  constexpr int NB1 = KS == 1 ? 0 : XS / 256;        // dword DMA per thread per tile (x patch, 3x3)
+  static_assert(WGM * WGN == 4 && (BM * NG) % 256 == 0 && (KS == 3 || (BN * NG) % 256 == 0), "config");
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * (AS + XS)];
+  float* const As0 = lds;
+  float* const Xs0 = lds + 2 * AS;
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int H = p.H, W = p.W, HW = H * W, Cs = p.Cs, Cout = p.Cout;
+  const int co_t = blockIdx.x % p.n_co_tiles, n_t = blockIdx.x / p.n_co_tiles;
+  const int co0 = co_t * BM, n0 = n_t * BN;
+  const int ci0 = n0 / KK;                     // first input channel of this block's patch / x tile
+  const int Nn = Cs * KK;
+  const int tiles_x = W / TW, tiles_y = H / TH;
+  const int t_begin = blockIdx.y * p.tiles_per_split;
+  const int t_end = min(t_begin + p.tiles_per_split, p.n_sp_tiles);
+  if (t_begin >= t_end) return;
+
+  // ---- loop-invariant DMA offsets (bytes, relative to the tile's scalar base) ----
+  unsigned voa[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx / NG, sl = idx % NG;
+    const int G = (sl & ~7) | ((sl & 7) ^ (row & 7));     // group held by this slot
+    const int y = G / GPR, x4 = G % GPR;
+    voa[i] = co0 + row < Cout ? (unsigned)((co0 + row) * HW + y * W + x4 * 4) * 4u : RSIS_OOB;
+  }
+  unsigned vob4[NB4 ? NB4 : 1];
+  unsigned vob1[NB1 ? NB1 : 1];
+  unsigned cls1[NB1 ? NB1 : 1];   // halo class of a patch element: 1 top row, 2 bottom row, 4 left column, 8 right column
+  if constexpr (KS == 1) {
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / NG, sl = idx % NG;
+      const int G = (sl & ~7) | ((sl & 7) ^ (row & 7));
+      const int y = G / GPR, x4 = G % GPR;
+      vob4[i] = n0 + row < Cs ? (unsigned)((n0 + row) * HW + y * W + x4 * 4) * 4u : RSIS_OOB;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NB1; ++i) {
+      const int e = tid + i * 256;
+      const int cl = e / IMS, rem = e - cl * IMS;
+      const int py = rem / PW, pxx = rem - py * PW;
+      const bool ok = cl < CI_P && ci0 + cl < Cs;
+      // relative to the element one row above / one column left of the tile origin in channel ci0 (+ (W+1)*4 so that it is >= 0)
+      vob1[i] = ok ? (unsigned)(cl * HW + py * W + pxx) * 4u : RSIS_OOB;
+      cls1[i] = (py == 0 ? 1u : 0u) | (py == PH - 1 ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx == PW - 1 ? 8u : 0u);
+    }
+  }
+
+  // ---- per-lane LDS read offsets ----
+  // A (and 1x1 B): lanes 0-31 take group 2g, lanes 32-63 group 2g+1 of MFMA step block g; the group's slot in this lane's
+  // row is (2g+h) ^ (row & 7), and row & 7 == l31 & 7 for every 32-row tile
+  int sg[NG / 2];
+#pragma unroll
+  for (int g = 0; g < NG / 2; ++g) sg[g] = ((2 * g + hi) ^ (l31 & 7)) * 4;
+  const int arow = (wm * TM * 32 + l31) * TP;
+  int xb[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nl = wn * TN * 32 + j * 32 + l31;          // column inside the block tile
+    if constexpr (KS == 1) {
+      xb[j] = nl * TP;
+    } else {
+      const int n = n0 + nl;
+      const int cl = n / KK - ci0, rs = n - (n / KK) * KK;
+      xb[j] = cl * IMS + (rs / KS) * PW + (rs % KS) + 4 * hi;
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // scalar tile cursor
+  int tb = t_begin / (tiles_x * tiles_y);
+  int trem = t_begin - tb * (tiles_x * tiles_y);
+  int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+
+#define WG_ISSUE(BUF)                                                                                          \
+  {                                                                                                            \
+    const int y0 = ty * TH, x0 = tx * TW;                                                                      \
+    const float* ab = p.dy + ((size_t)tb * Cout * HW + y0 * W + x0);                                           \
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, 0x7FFFFFF0, 0x00020000); \
+    float* As = As0 + (BUF) * AS + wave * 256;                                                                 \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                             \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_vp_t)(As + i * 1024), 16, voa[i], 0, 0, 0);           \
+    if constexpr (KS == 1) {                                                                                   \
+      const float* bb = p.x + ((size_t)tb * Cs * HW + y0 * W + x0);                                            \
+      const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)bb, 0, 0x7FFFFFF0, 0x00020000); \
+      float* Xs = Xs0 + (BUF) * XS + wave * 256;                                                               \
+      _Pragma("unroll") for (int i = 0; i < NB4; ++i)                                                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_vp_t)(Xs + i * 1024), 16, vob4[i], 0, 0, 0);        \
+    } else {                                                                                                   \
+      const float* bb = p.x + (((size_t)tb * Cs + ci0) * HW + (y0 - 1) * W + (x0 - 1));                        \
+      const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)bb, 0, 0x7FFFFFF0, 0x00020000); \
+      const unsigned edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + TW == W ? 8u : 0u); \
+      float* Xs = Xs0 + (BUF) * XS + wave * 64;                                                                \
+      _Pragma("unroll") for (int i = 0; i < NB1; ++i) {                                                        \
+        const unsigned vo = (cls1[i] & edge) ? RSIS_OOB : vob1[i];                                             \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_vp_t)(Xs + i * 256), 4, vo, 0, 0, 0);               \
+      }                                                                                                        \
+    }                                                                                                          \
+    if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++tb; } }                                    \
+  }
+#define WG_LAND() __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): this wave's DMA has landed in LDS */
+
+  WG_ISSUE(0)
+  WG_LAND()
+  __syncthreads();
+  const int ntl = t_end - t_begin;
+  for (int t = 0; t < ntl; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntl) WG_ISSUE(cur ^ 1)   // stage cur^1 was last read before the barrier that ended step t-1
+    {
+      const float* As = As0 + cur * AS + arow;
+      const float* Xs = Xs0 + cur * XS;
+#pragma unroll
+      for (int g = 0; g < NG / 2; ++g) {
+        f32x4 a4[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a4[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * TP + sg[g]);
+        if constexpr (KS == 1) {
+          f32x4 b4[TN];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const f32x4*>(Xs + xb[j] + sg[g]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][e], b4[j][e], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float b[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Xs[xb[j] + (g / (TW / 8)) * PW + (g % (TW / 8)) * 8 + e];   // pixel (y, x) of group 2g+h, element e
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][e], b[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    WG_LAND()
+    __syncthreads();
+  }
+#undef WG_ISSUE
+#undef WG_LAND
+
+  // ---- epilogue: fp32 atomics into dW (reference layout) ----
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * TN * 32 + j * 32 + l31;
+    if (n >= Nn) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (co >= Cout) continue;
+        const int row = p.interleave_hid > 0 ? (co & 3) * p.interleave_hid + (co >> 2) : co;
+        atomicAdd(p.dw + (size_t)row * p.ldo + p.n_off + n, acc[i][j][r]);
+      }
+    }
+  }
+#endif
+}
+
+template <int BM, int BN, int WGM, int WGN, int KS, int TW>
+static int launch_tiled_cfg(WgradTiledArgs& a, hipStream_t st) {
+  constexpr int TH = (KS == 1 ? 32 : 64) / TW;
+  a.n_co_tiles = rsis_cdiv(a.Cout, BM);
+  a.n_n_tiles = rsis_cdiv((long)a.Cs * KS * KS, BN);
+  a.n_sp_tiles = a.B * (a.H / TH) * (a.W / TW);
+  const int ntile = a.n_co_tiles * a.n_n_tiles;
+  // split-K over the spatial tiles: fill the resident block slots (2 blocks per CU for the 128-wide tiles, 3 otherwise) in one
+  // round, keeping >= 2 spatial tiles per split
+  const int slots = 256 * (BM * BN >= 128 * 128 ? 2 : 3);
+  int nsplit = ntile >= slots ? 1 : slots / ntile;
+  if (nsplit > a.n_sp_tiles / 2) nsplit = a.n_sp_tiles / 2;
+  if (nsplit < 1) nsplit = 1;
+  a.tiles_per_split = rsis_cdiv(a.n_sp_tiles, nsplit);
+  nsplit = rsis_cdiv(a.n_sp_tiles, a.tiles_per_split);
+  hipLaunchKernelGGL((conv_wgrad_tiled_kernel<BM, BN, WGM, WGN, KS, TW>), dim3(ntile, nsplit), dim3(256), 0, st, a);
+  return rsis_check_launch();
+}
+
+template <int KS, int TW>
+static int launch_tiled_tw(WgradTiledArgs& a, hipStream_t st) {
+  if (a.Cout <= 32) return launch_tiled_cfg<32, 128, 1, 4, KS, TW>(a, st);
+  if (a.Cout <= 64) return launch_tiled_cfg<64, 128, 2, 2, KS, TW>(a, st);
+  return launch_tiled_cfg<128, 128, 2, 2, KS, TW>(a, st);
+}
+
+// widest tile the map allows: full 128-byte lines of dy / x per tile row on the wide maps, whole rows on the narrow ones
+static int tiled_tw(int H, int W, int ks) {
+  const int tp = ks == 1 ? 32 : 64;
+  // 3x3: the 32x2 tile's halo patch pushes the 128x128 configuration past 80 KB of LDS (1 block per CU); 16x4 measured equal
+  // or better on every trunk / gate shape.  1x1 has no patch and prefers full 128-byte rows.
+  for (int tw = ks == 1 ? 32 : 16; tw >= 8; tw >>= 1)
+    if (W % tw == 0 && H % (tp / tw) == 0) return tw;
+  return 0;
+}
+
+// true when the LDS-DMA tiled kernel covers this weight gradient (stride 1, "same" padding, tile-aligned map, 32-bit offsets)
+bool rsis_wgrad_tiled_supported(const WgradArgs& w, int ks) {
+  if (!(ks == 1 || ks == 3) || w.stride != 1 || w.pad != ks / 2 || w.H != w.Ho || w.W != w.Wo) return false;
+  if (tiled_tw(w.H, w.W, ks) == 0) return false;
+  const long img = (long)w.H * w.W * 4;
+  return (long)w.Cout * img < (1L << 30) && (long)w.Cs * img < (1L << 30);
+}
+
+int rsis_launch_conv_wgrad_tiled(const WgradArgs& w, int ks, hipStream_t st) {
+  WgradTiledArgs a = {};
+  a.dy = w.dy; a.x = w.x; a.dw = w.dw; a.B = w.B; a.Cs = w.Cs; a.H = w.H; a.W = w.W; a.Cout = w.Cout;
+  a.ldo = w.ldo; a.n_off = w.n_off; a.interleave_hid = w.interleave_hid;
+  const int tw = tiled_tw(w.H, w.W, ks);
+  if (ks == 1) {
+    if (tw == 32) return launch_tiled_tw<1, 32>(a, st);
+    if (tw == 16) return launch_tiled_tw<1, 16>(a, st);
+    return launch_tiled_tw<1, 8>(a, st);
+  }
+  if (tw == 16) return launch_tiled_tw<3, 16>(a, st);
+  return launch_tiled_tw<3, 8>(a, st);
+}

@@ -39,6 +39,9 @@ CONV_CASES = [
     (2, [6], 8, 8, 1, 3, 1, 1, False),          # Cout = 1 with an unsupported Cin -> MFMA path
     (1, [130], 7, 7, 129, 3, 1, 1, True),       # ragged channels
     (2, [2048], 4, 4, 128, 3, 1, 1, True),      # sk5-like deep K
+    (2, [20, 12], 16, 24, 40, 3, 1, 1, True),   # tile-aligned map, 2 sources, ragged channels (LDS-DMA tiled wgrad, 64-row tile)
+    (2, [72], 8, 16, 200, 3, 1, 1, False),      # tiled wgrad, 128-row tile, several co / n tiles
+    (3, [40], 12, 16, 24, 1, 1, 0, False),      # tiled 1x1 wgrad (8x4 tiles), ragged channels
 ]
 
 
