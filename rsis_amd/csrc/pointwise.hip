@@ -62,58 +62,115 @@ __global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
+// Wo % 4 == 0 and < 2^31 outputs: one thread = 4 consecutive outputs of a row (float4 store), 32-bit index math.  Same
+// arithmetic per element as upsample_fwd_kernel (bit-identical results).
+__global__ __launch_bounds__(256) void upsample_fwd_v4_kernel(const float* __restrict__ x, float* __restrict__ y, int Hi, int Wi,
+                                                              int Ho, int Wo, float sh, float sw, int items) {
+  const int Wq = Wo >> 2;
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) {
+    const int wq = it % Wq;
+    const int t = it / Wq;
+    const int ho = t % Ho;
+    const int bc = t / Ho;
+    int h0, h1; float lh;
+    ac_coord(ho, sh, Hi, h0, h1, lh);
+    const float* r0 = x + (size_t)bc * Hi * Wi + h0 * Wi;
+    const float* r1 = x + (size_t)bc * Hi * Wi + h1 * Wi;
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int w0, w1; float lw;
+      ac_coord(wq * 4 + k, sw, Wi, w0, w1, lw);
+      o[k] = (1.f - lh) * ((1.f - lw) * r0[w0] + lw * r0[w1]) + lh * ((1.f - lw) * r1[w0] + lw * r1[w1]);
+    }
+    *reinterpret_cast<f32x4*>(y + (size_t)it * 4) = o;
+  }
+}
+
 // backward as a GATHER (no atomics, deterministic): dx[hi][wi] = sum over the few output pixels whose 2x2 stencil touches
-// (hi, wi).  A block owns one (b, c) plane tile of UT x UT input pixels; the 1-D interpolation weights of the candidate output
-// rows / columns of the tile are evaluated ONCE per block into LDS (with the forward's own ac_coord, so membership is
-// bit-consistent with it), and each thread then does a UK x UK weighted gather.
-#define UT 16
-#define UK 8   // candidate outputs per input index: covers scale factors >= 1/3 (checked by the launcher)
+// (hi, wi).  A block owns a UT x UT tile of input pixels of one (b, c) plane.  The 1-D interpolation weights of the (<= UK)
+// consecutive output rows / columns that touch each input row / column are evaluated ONCE per block (with the forward's own
+// ac_coord, so membership is bit-consistent with it); the block then stages the dy region the tile needs in LDS with
+// row-coalesced loads and reduces it separably: rows first (tmp[hi][wo]), then columns.
+#define UK 6   // consecutive candidate outputs per input index: covers scale factors >= ~0.46 (checked by the launcher)
+template <int UT, int RM>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Hi, int Wi,
                                                            int Ho, int Wo, float sh, float sw, int tiles_x, int tiles_y) {
+  constexpr int RP = RM + 1;
   __shared__ float wgt[2][UT][UK];
-  __shared__ int lo[2][UT];
+  __shared__ int st[2][UT];          // first candidate of each input index, relative to the region origin
+  __shared__ int org[2], ext[2];     // region origin / extent (rows, cols)
+  __shared__ float reg[RM * RP];
+  __shared__ float tmp[UT * RP];
   const int tid = threadIdx.x;
   const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y;
   const long bc = blockIdx.x / (tiles_x * tiles_y);
-  // ---- per-block tables: threads 0..255 -> (axis, local index, candidate) ----
-  {
-    const int axis = tid >> 7, li = (tid >> 3) & 15, k = tid & 7;
+  // ---- per-block tables: threads -> (axis, local index) ----
+  if (tid < 2 * UT) {
+    const int axis = tid / UT, li = tid % UT;
     const int in = axis ? Wi : Hi, out = axis ? Wo : Ho;
     const float sc = axis ? sw : sh;
     const int i = (axis ? tx : ty) * UT + li;
-    int l = 0;
-    if (sc > 0.f) l = max(0, (int)floorf((i - 1) / sc) - 1);
-    const int o = l + k;
-    float w = 0.f;
-    if (i < in && o < out) {
-      int i0, i1; float l1;
-      ac_coord(o, sc, in, i0, i1, l1);
-      w = (i0 == i ? 1.f - l1 : 0.f) + (i1 == i ? l1 : 0.f);
+    int l = max(0, (int)floorf((i - 1) / sc) - 1);
+    // advance to the first output that really touches i (at most a few steps)
+    int first = -1;
+    float w[UK];
+#pragma unroll
+    for (int k = 0; k < UK; ++k) w[k] = 0.f;
+    if (i < in) {
+      for (int o = l; o < out && o < l + 4 + UK; ++o) {
+        int i0, i1; float l1;
+        ac_coord(o, sc, in, i0, i1, l1);
+        const float wv = (i0 == i ? 1.f - l1 : 0.f) + (i1 == i ? l1 : 0.f);
+        if (first < 0 && (i0 == i || i1 == i)) first = o;
+        if (first >= 0 && o - first < UK) w[o - first] = wv;
+      }
     }
-    wgt[axis][li][k] = w;
-    if (k == 0) lo[axis][li] = l;
+    if (first < 0) first = min(l, out - 1);
+#pragma unroll
+    for (int k = 0; k < UK; ++k) wgt[axis][li][k] = w[k];
+    st[axis][li] = first;   // absolute for now
   }
   __syncthreads();
-  const int ly = tid >> 4, lx = tid & 15;
-  const int hi = ty * UT + ly, wi = tx * UT + lx;
-  if (hi >= Hi || wi >= Wi) return;
-  const float* yb = dy + bc * Ho * Wo;
-  const int ho0 = lo[0][ly], wo0 = lo[1][lx];
-  float acc = 0.f;
-#pragma unroll
-  for (int a = 0; a < UK; ++a) {
-    const float wh = wgt[0][ly][a];
-    if (wh == 0.f) continue;
-    const float* row = yb + (size_t)(ho0 + a) * Wo + wo0;
-    float r = 0.f;
-#pragma unroll
-    for (int c = 0; c < UK; ++c) {
-      const float ww = wgt[1][lx][c];
-      if (ww != 0.f) r = fmaf(ww, row[c], r);
-    }
-    acc = fmaf(wh, r, acc);
+  if (tid < 2) {
+    const int o0 = st[tid][0];
+    int last = 0;
+    for (int li = 0; li < UT; ++li) last = max(last, st[tid][li] + UK - 1);
+    const int out = tid ? Wo : Ho;
+    org[tid] = o0;
+    ext[tid] = min(min(last, out - 1) - o0 + 1, RM);
   }
-  dx[bc * Hi * Wi + (size_t)hi * Wi + wi] = acc;
+  __syncthreads();
+  const int oy = org[0], ox = org[1], ey = ext[0], ex = ext[1];   // ey, ex <= RM (launcher)
+  const float* yb = dy + bc * Ho * Wo;
+  for (int e = tid; e < ey * RM; e += 256) {
+    const int r = e / RM, c = e - r * RM;
+    reg[r * RP + c] = c < ex ? yb[(size_t)(oy + r) * Wo + ox + c] : 0.f;
+  }
+  __syncthreads();
+  // rows: tmp[ly][c] = sum_k wgt_y[ly][k] * reg[st_y[ly] - oy + k][c]
+  for (int e = tid; e < UT * RM; e += 256) {
+    const int ly = e / RM, c = e - ly * RM;
+    const int r0 = st[0][ly] - oy;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < UK; ++k) {
+      const int r = min(r0 + k, ey - 1);          // weights beyond the region are zero
+      acc = fmaf(wgt[0][ly][k], reg[r * RP + c], acc);
+    }
+    tmp[ly * RP + c] = acc;
+  }
+  __syncthreads();
+  for (int e = tid; e < UT * UT; e += 256) {
+    const int ly = e / UT, lx = e - ly * UT;
+    const int hi = ty * UT + ly, wi = tx * UT + lx;
+    if (hi >= Hi || wi >= Wi) continue;
+    const int c0 = st[1][lx] - ox;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < UK; ++k) acc = fmaf(wgt[1][lx][k], tmp[ly * RP + min(c0 + k, ex - 1)], acc);
+    dx[bc * Hi * Wi + (size_t)hi * Wi + wi] = acc;
+  }
 }
 
 // general fallback (any scale): per-thread candidate scan
@@ -530,18 +587,31 @@ int rsis_l_lstm_bwd(const float* dh, const float* dc_next, const float* act, con
 static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 int rsis_l_upsample_fwd(const float* x, float* y, long BC, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
   const long total = BC * Ho * Wo;
-  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, Hi, Wi, Ho, Wo, ac_scale(Hi, Ho),
-                     ac_scale(Wi, Wo), total);
+  if (Wo % 4 == 0 && total < (1L << 31)) {
+    const int items = (int)(total / 4);
+    hipLaunchKernelGGL(upsample_fwd_v4_kernel, dim3(ew_grid(items)), dim3(256), 0, st, x, y, Hi, Wi, Ho, Wo, ac_scale(Hi, Ho),
+                       ac_scale(Wi, Wo), items);
+  } else {
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, Hi, Wi, Ho, Wo, ac_scale(Hi, Ho),
+                       ac_scale(Wi, Wo), total);
+  }
   return rsis_check_launch();
 }
 int rsis_l_upsample_bwd(const float* dy, float* dx, long BC, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
   const float sh = ac_scale(Hi, Ho), sw = ac_scale(Wi, Wo);
-  // the tiled kernel scans UK = 8 candidate outputs per input index: enough when at most ~2/scale + 3 outputs touch it
-  const bool tiled = sh > 0.f && sw > 0.f && (2.f / sh + 3.5f <= UK) && (2.f / sw + 3.5f <= UK);
-  if (tiled) {
-    const int tiles_x = (Wi + UT - 1) / UT, tiles_y = (Hi + UT - 1) / UT;
+  // the tiled kernel keeps UK = 6 consecutive candidate outputs per input index (< 2/scale + 1 touch it) and a dy region of
+  // at most (UT + 1)/scale + UK outputs per axis in LDS
+  const float smin = sh < sw ? sh : sw;
+  const bool tiled = smin > 0.f && (2.f / smin + 1.f <= UK);
+  const int ut = (Hi > 16 || Wi > 16) ? 32 : 16;
+  const bool fits = tiled && ((ut - 1) / smin + UK + 3 <= (ut == 32 ? 80 : 44));
+  if (fits) {
+    const int tiles_x = (Wi + ut - 1) / ut, tiles_y = (Hi + ut - 1) / ut;
     const long blocks = BC * tiles_x * tiles_y;
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, tiles_x, tiles_y);
+    if (ut == 32)
+      hipLaunchKernelGGL((upsample_bwd_kernel<32, 80>), dim3((unsigned)blocks), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, tiles_x, tiles_y);
+    else
+      hipLaunchKernelGGL((upsample_bwd_kernel<16, 44>), dim3((unsigned)blocks), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, tiles_x, tiles_y);
   } else {
     const long total = BC * Hi * Wi;
     hipLaunchKernelGGL(upsample_bwd_generic_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, total);

@@ -125,7 +125,9 @@ def test_convlstm_fwd_bwd(case, tile):
 
 
 @pytest.mark.parametrize("shape,size", [((2, 3, 4, 5), (7, 9)), ((2, 8, 8, 8), (16, 16)), ((1, 2, 13, 25), (25, 50)),
-                                        ((2, 1, 5, 7), (5, 7)), ((2, 4, 1, 1), (3, 3)), ((2, 1, 64, 64), (100, 132))])
+                                        ((2, 1, 5, 7), (5, 7)), ((2, 4, 1, 1), (3, 3)), ((2, 1, 64, 64), (100, 132)),
+                                        ((2, 3, 64, 64), (128, 128)), ((1, 2, 40, 72), (80, 144)), ((1, 2, 128, 128), (256, 256)),
+                                        ((2, 2, 16, 16), (32, 32)), ((1, 2, 33, 20), (66, 40))])
 def test_upsample(shape, size):
     from rsis_amd import ops
     x = _rng_t(3, shape).requires_grad_()
@@ -135,8 +137,9 @@ def test_upsample(shape, size):
     xd = _dev(x.detach().clone().requires_grad_())
     y = ops.upsample_bilinear_ac(xd, size)
     y.backward(gy.cuda())
-    assert_close("fwd", y, ref, 1e-5)
-    assert_close("bwd", xd.grad, x.grad, 2e-5, 1e-5)
+    # 1 ulp of the fp32 source coordinate (|coord| up to ~130 here -> 1.5e-5) times the local slope of O(1) data
+    assert_close("fwd", y, ref, 3e-5)
+    assert_close("bwd", xd.grad, x.grad, 4e-5, 1e-5)
 
 
 @pytest.mark.parametrize("shape", [(2, 5, 7, 9), (3, 8, 16, 16), (1, 3, 1, 1), (2, 2, 40, 33)])
