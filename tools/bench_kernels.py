@@ -82,9 +82,11 @@ def main():
             ms = timeit(wg, o.iters)
             print("gate wgrad %3dx%-3d %38s %8.1f us  %6.1f TF/s" % (H, W, "", ms * 1e3, fl / ms / 1e9))
         print("gates fwd total: %.1f us/timestep, %.1f TF/s" % (tot_ms * 1e3, tot_f / tot_ms / 1e9))
-    if o.what in ("trunk", "all"):
+    if o.what in ("trunk", "all", "depth"):
         tf = tm = 0.0
-        for cin, cout, ks, stride, hw, count in TRUNK:
+        # "depth": the same 3x3 / 1x1 layer at growing input depth -> the intercept is the kernel's fixed cost
+        shapes = TRUNK if o.what != "depth" else [(c, 256, k, 1, 16, 1) for k in (3, 1) for c in (8, 32, 64, 128, 256, 512, 1024)]
+        for cin, cout, ks, stride, hw, count in shapes:
             pad = ks // 2
             Hi = hw * stride
             x = torch.randn(B, cin, Hi, Hi, device="cuda")
