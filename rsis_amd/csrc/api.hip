@@ -132,7 +132,7 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
   a.wp = Wp; a.ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN); a.Cout = Cout; a.bias = bias; a.addend = addend;
   a.dst[0] = out; a.Cd[0] = Cout; a.ndst = 1;
   a.ostride = 1; a.oH = Ho; a.oW = Wo; a.ksplit = 1;
-  if (use_direct(ks, stride, pad) && Cout == 1 && nsrc == 1 && !addend && rsis_c1_supported(Csrc[0]))   // conv_out: HBM-bound VALU kernel
+  if (use_direct(ks, stride, pad) && Cout == 1 && nsrc == 1 && !addend && rsis_c1_supported(Csrc[0]) && W % 4 == 0)   // conv_out: HBM-bound VALU kernel
     return rsis_l_c1_fwd(src[0], Wp, a.ldw, bias, out, B, Csrc[0], H, W, (hipStream_t)stream);
   if (use_direct(ks, stride, pad)) {
     // deep-K convs on tiny maps (sk5: 2048x9 deep, 64 blocks) are split over the channel chunks: zero the output here and let
@@ -199,7 +199,7 @@ int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs,
   WgradArgs a = {};
   a.dy = dy; a.x = x; a.dw = dW; a.B = B; a.Cs = Cs; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.stride = stride; a.pad = pad; a.ldo = Ctot * ks * ks; a.n_off = c_off * ks * ks; a.interleave_hid = lstm_hid;
-  if (use_direct(ks, stride, pad) && Cout == 1 && lstm_hid == 0 && rsis_c1_supported(Cs) && H == Ho && W == Wo)
+  if (use_direct(ks, stride, pad) && Cout == 1 && lstm_hid == 0 && rsis_c1_supported(Cs) && H == Ho && W == Wo && W % 4 == 0)
     return rsis_l_c1_wgrad(dy, x, dW + a.n_off, B, Cs, H, W, (hipStream_t)stream);
   // stride-1 "same" convs on tile-aligned maps: the LDS-DMA tiled kernel (conv_wgrad_tiled.hip); RSIS_WGRAD_TILED=0 forces the
   // generic split-K implicit GEMM (conv_wgrad.hip), which also covers every other shape
