@@ -57,9 +57,31 @@ class FlatGroup(object):
                 "weight_decay": self.weight_decay, "betas": self.betas, "eps": self.eps}
 
     def load_state_dict(self, sd):
+        if "param_groups" in sd:
+            return self._load_torch_adam(sd)
         self.step_count = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+    def _load_torch_adam(self, sd):
+        """torch.optim.Adam.state_dict() as the reference saved it (utils/utils.py:93-94): per-parameter moments in
+        param_groups order.  They are adopted when they line up with this group's parameters one to one; otherwise
+        (e.g. the reference's trunk group lists tensors several times) the moments restart at zero."""
+        ids = [i for g in sd.get("param_groups", []) for i in g["params"]]
+        st = sd.get("state", {})
+        ok = len(ids) == len(self.params) and all(i in st and tuple(st[i]["exp_avg"].shape) == tuple(p.shape)
+                                                  for i, p in zip(ids, self.params))
+        if not ok:
+            if st:
+                print("FlatGroup(%s): optimizer state does not match the parameter list; moments restart at zero" % self.name)
+            return False
+        steps = []
+        for i, (off, k) in zip(ids, self.offsets):
+            self.exp_avg[off:off + k].copy_(st[i]["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + k].copy_(st[i]["exp_avg_sq"].reshape(-1))
+            steps.append(int(st[i]["step"]))
+        self.step_count = max(steps) if steps else 0
+        return True
 
 
 class FlatAdam(object):
