@@ -122,6 +122,18 @@ int rsis_adam_step(float* p, const float* g, float* m, float* v, long n, float l
  * iteration needs no host synchronisation. ---- */
 int rsis_assign_min_cost(const float* scores, long long* perm, int B, int G, int T, void* stream);
 
+/* ---- soft-IoU matching scores and matched-loss gradient (train.py:98-110,127-131,162-163; hungarian.py:62-89 softIoU) ----
+ * rsis_softiou_sums: logits[B][T][N] (mask logits of the T predictions), y[B][G][N] (ground-truth masks, 0/1 floats) ->
+ *   S[B][T+1][G+1]:  S[t][g] = sum_n sigmoid(logits[t][n]) * y[g][n],  S[t][G] = sum_n sigmoid(logits[t][n]),
+ *   S[T][g] = sum_n y[g][n]  (S[T][G] is left 0).  One pass over both tensors; requires T < 32, G < 32, N % 8 == 0.
+ *   The reference's cost is then 1 - S[t][g] / (S[t][G] + S[T][g] - S[t][g] + 1e-6) for every pair.
+ * rsis_softiou_bwd: gradient of the matched costs w.r.t. the logits,
+ *   dlogits[b][t][n] = (ca[b][t]*y + cb[b][t]*(1-y)) * p*(1-p),  y = y[b][perm[b*perm_ld + t]][n], p = sigmoid(logits[b][t][n]);
+ *   the caller supplies ca = -g/U, cb = g*I/U^2 (g = upstream gradient of the cost, U = the cost's denominator). N % 4 == 0. */
+int rsis_softiou_sums(const float* logits, const float* y, float* S, int B, int T, int G, long N, void* stream);
+int rsis_softiou_bwd(const float* logits, const float* y, const long long* perm, int perm_ld, const float* ca, const float* cb,
+                     float* dlogits, int B, int T, int G, long N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

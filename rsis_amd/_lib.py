@@ -39,6 +39,8 @@ SIGNATURES = {
     "rsis_maxpool3x3s2_fwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "rsis_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "rsis_assign_min_cost": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "rsis_softiou_sums": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _vp]),
+    "rsis_softiou_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _l, _vp]),
     "rsis_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp]),
 }
 

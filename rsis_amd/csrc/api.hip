@@ -30,6 +30,9 @@ int rsis_l_maxpool_bwd(const float*, const unsigned char*, float*, long, int, in
 int rsis_l_channel_sum(const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_adam(float*, const float*, float*, float*, long, float, float, float, float, float, int, float, hipStream_t);
 int rsis_l_assign(const float*, long long*, int, int, int, hipStream_t);
+int rsis_l_softiou_sums(const float*, const float*, float*, int, int, int, long, hipStream_t);
+int rsis_l_softiou_bwd(const float*, const float*, const long long*, int, const float*, const float*, float*, int, int, int, long,
+                       hipStream_t);
 
 static inline int krows_of(int C, int ks) { return rsis_roundup(C * ks * ks, RSIS_KPAD); }
 static inline int log2i(int s) { int l = 0; while ((1 << l) < s) ++l; return l; }
@@ -291,3 +294,15 @@ int rsis_assign_min_cost(const float* scores, long long* perm, int B, int G, int
 }
 
 }  // extern "C"
+
+int rsis_softiou_sums(const float* logits, const float* y, float* S, int B, int T, int G, long N, void* stream) {
+  if (!logits || !y || !S || B < 1 || T < 1 || G < 1 || T >= 32 || G >= 32 || N < 8 || N % 8 != 0) return RSIS_ERR_ARG;
+  return rsis_l_softiou_sums(logits, y, S, B, T, G, N, (hipStream_t)stream);
+}
+
+int rsis_softiou_bwd(const float* logits, const float* y, const long long* perm, int perm_ld, const float* ca, const float* cb,
+                     float* dlogits, int B, int T, int G, long N, void* stream) {
+  if (!logits || !y || !perm || !ca || !cb || !dlogits || B < 1 || T < 1 || G < 1 || perm_ld < T || N < 4 || N % 4 != 0)
+    return RSIS_ERR_ARG;
+  return rsis_l_softiou_bwd(logits, y, perm, perm_ld, ca, cb, dlogits, B, T, G, N, (hipStream_t)stream);
+}

@@ -1,0 +1,98 @@
+// Soft-IoU matching scores and loss gradient of the RSIS training step on the device (gfx950).
+//
+// reference: src/train.py:98-110 builds, per timestep, the all-pairs cost  softIoU(y_mask[b, g], sigmoid(out_mask_t[b]))  by
+// repeating every prediction gt_T times; src/utils/hungarian.py:62-89 (softIoU) reduces each pair; after the assignment the
+// same sums are recomputed for the matched pairs (train.py:162-163) and autograd differentiates them.
+//
+// Here ONE pass over the logits and the ground-truth masks produces every sum at once as a [T+1] x [G+1] GEMM per image on
+// the exact-f32 MFMA:   S[b][i][j] = sum_n A[i][n] * Bm[j][n],   A = [sigmoid(P[b, 0..T-1]); ones],  Bm = [Y[b, 0..G-1]; ones]
+//   S[t][g] = intersection,  S[t][G] = sum_n p_t,  S[T][g] = sum_n y_g.
+// The matched loss needs nothing else (its forward is a gather of S), and its backward is one elementwise kernel:
+//   d cost / d logit_n = (ca * y_n + cb * (1 - y_n)) * p_n (1 - p_n),  ca = -g / U,  cb = g * I / U^2,  U = sum p + sum y - I + e.
+// Both kernels are HBM-bound (252 MB in / 84 MB out at B=32, T=10, G=20, 256x256): bytes ~ (T + G) * N * 4 per image.
+#include "common.h"
+
+typedef const f32x4 __attribute__((address_space(1)))* gcf4_t;
+typedef f32x4 __attribute__((address_space(1)))* gf4_t;
+
+// grid = (nsplit, B), 256 threads = 4 waves; wave w of split s walks the pixels [k0, k1) in steps of 8 (N % 8 == 0):
+// lanes 0-31 take pixels +0..3, lanes 32-63 pixels +4..7 of each step (the MFMA K index is only a summation index).
+__global__ __launch_bounds__(256) void softiou_sums_kernel(const float* __restrict__ logits, const float* __restrict__ y,
+                                                           float* __restrict__ S, int T, int G, long N, long per_wave) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long k0 = wid * per_wave, k1 = min(N, k0 + per_wave);
+  if (k0 >= k1) return;
+  const bool arow = l31 < T, aone = l31 == T;      // A rows: predictions, then the all-ones row
+  const bool brow = l31 < G, bone = l31 == G;
+  const float* pa = logits + ((size_t)b * T + (arow ? l31 : 0)) * N + 4 * hi;
+  const float* pb = y + ((size_t)b * G + (brow ? l31 : 0)) * N + 4 * hi;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (long k = k0; k < k1; k += 8) {
+    f32x4 a = aone ? one4 : zero4, bv = bone ? one4 : zero4;
+    if (arow) {
+      const f32x4 v = *(gcf4_t)(pa + k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = rsis_sigmoid(v[e]);
+    }
+    if (brow) bv = *(gcf4_t)(pb + k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bv[e], acc, 0, 0, 0);
+  }
+  float* Sb = S + (size_t)b * (T + 1) * (G + 1);
+  if (l31 <= G) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (i <= T && !(i == T && l31 == G)) atomicAdd(Sb + i * (G + 1) + l31, acc[r]);
+    }
+  }
+}
+
+// dlogits[b][t][n] = (ca[b][t] * y + cb[b][t] * (1 - y)) * p (1 - p),  y = Y[b][perm[b][t]][n],  p = sigmoid(logits[b][t][n])
+__global__ __launch_bounds__(256) void softiou_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ y,
+                                                          const long long* __restrict__ perm, int perm_ld,
+                                                          const float* __restrict__ ca, const float* __restrict__ cb,
+                                                          float* __restrict__ dlogits, int T, int G, long N4, long total) {
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long bt = e / N4, n4 = e - bt * N4;
+    const int b = (int)(bt / T), t = (int)(bt - (long)b * T);
+    const int g = (int)perm[(size_t)b * perm_ld + t];
+    const f32x4 v = *(gcf4_t)(logits + (size_t)e * 4);
+    const f32x4 yy = *(gcf4_t)(y + (((size_t)b * G + g) * N4 + n4) * 4);
+    const float a = ca[bt], c = cb[bt];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float p = rsis_sigmoid(v[k]);
+      o[k] = (a * yy[k] + c * (1.f - yy[k])) * p * (1.f - p);
+    }
+    *(gf4_t)(dlogits + (size_t)e * 4) = o;
+  }
+}
+
+int rsis_l_softiou_sums(const float* logits, const float* y, float* S, int B, int T, int G, long N, hipStream_t st) {
+  if (hipMemsetAsync(S, 0, sizeof(float) * (size_t)B * (T + 1) * (G + 1), st) != hipSuccess) return RSIS_ERR_LAUNCH;
+  // ~4 blocks per CU over the whole batch; each wave gets a multiple of 8 pixels
+  int nsplit = (int)((1024 + B - 1) / B);
+  long per_wave = (N + (long)nsplit * 4 - 1) / ((long)nsplit * 4);
+  per_wave = (per_wave + 7) / 8 * 8;
+  if (per_wave < 64) per_wave = 64;
+  nsplit = (int)((N + per_wave * 4 - 1) / (per_wave * 4));
+  hipLaunchKernelGGL(softiou_sums_kernel, dim3(nsplit, B), dim3(256), 0, st, logits, y, S, T, G, N, per_wave);
+  return rsis_check_launch();
+}
+
+int rsis_l_softiou_bwd(const float* logits, const float* y, const long long* perm, int perm_ld, const float* ca, const float* cb,
+                       float* dlogits, int B, int T, int G, long N, hipStream_t st) {
+  const long total = (long)B * T * (N / 4);
+  long grid = (total + 255) / 256;
+  if (grid > 256L * 32) grid = 256L * 32;
+  hipLaunchKernelGGL(softiou_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, st, logits, y, perm, perm_ld, ca, cb, dlogits, T, G,
+                     N / 4, total);
+  return rsis_check_launch();
+}

@@ -434,3 +434,62 @@ def assign_min_cost(scores):
     perm = torch.empty((B, G), dtype=torch.int64, device=scores.device)
     check(lib().rsis_assign_min_cost(ptr(scores), ptr(perm), B, G, T, stream()), "rsis_assign_min_cost")
     return perm
+
+
+def softiou_supported(out_masks, y_mask):
+    """the fused soft-IoU kernels cover T < 32 predictions, G < 32 ground-truth slots and N % 8 == 0 pixels"""
+    return (out_masks.is_cuda and out_masks.dtype == torch.float32 and y_mask.dtype == torch.float32 and
+            out_masks.size(1) < 32 and y_mask.size(1) < 32 and out_masks.size(2) % 8 == 0)
+
+
+def softiou_sums(out_masks, y_mask):
+    """S (B, T+1, G+1): intersections sigmoid(out_masks[b,t]) . y_mask[b,g], plus the row / column of plain sums
+    (include/rsis_hip.h: rsis_softiou_sums).  No gradient."""
+    out_masks, y_mask = _contig(out_masks.detach()), _contig(y_mask)
+    require_cuda_f32(out_masks, y_mask)
+    B, T, N = out_masks.shape
+    G = y_mask.shape[1]
+    S = torch.empty((B, T + 1, G + 1), dtype=torch.float32, device=out_masks.device)
+    check(lib().rsis_softiou_sums(ptr(out_masks), ptr(y_mask), ptr(S), B, T, G, N, stream()), "rsis_softiou_sums")
+    return S
+
+
+def softiou_cost_matrix(S, e=1e-6):
+    """all-pairs cost (B, G, T) of reference train.py:102-110 from the sums: 1 - I / (sum p + sum y - I + e)"""
+    inter = S[:, :-1, :-1]                                   # (B, T, G)
+    den = S[:, :-1, -1:] + S[:, -1:, :-1] - inter + e
+    return (1 - inter / den).transpose(1, 2)
+
+
+class _SoftIoUMatchedFn(torch.autograd.Function):
+    """cost[b, t] = softIoU(y_mask[b, perm[b, t]], out_masks[b, t]) (hungarian.py:62-89) from the precomputed sums S;
+    the backward is one elementwise kernel over the logits."""
+
+    @staticmethod
+    def forward(ctx, out_masks, y_mask, perm, S, e):
+        B, T, N = out_masks.shape
+        idx = perm[:, :T]
+        inter = torch.gather(S[:, :T, :-1], 2, idx.unsqueeze(-1)).squeeze(-1)          # (B, T)
+        ysum = torch.gather(S[:, -1, :-1], 1, idx)
+        den = S[:, :T, -1] + ysum - inter + e
+        ctx.save_for_backward(out_masks, y_mask, perm, inter, den)
+        return 1 - inter / den
+
+    @staticmethod
+    def backward(ctx, g):
+        out_masks, y_mask, perm, inter, den = ctx.saved_tensors
+        B, T, N = out_masks.shape
+        g = g.contiguous().float()
+        ca = (-g / den).contiguous()
+        cb = (g * inter / (den * den)).contiguous()
+        logits = _contig(out_masks.detach())
+        d = torch.empty_like(logits)
+        check(lib().rsis_softiou_bwd(ptr(logits), ptr(y_mask), ptr(perm), perm.shape[1], ptr(ca), ptr(cb), ptr(d), B, T,
+                                     y_mask.shape[1], N, stream()), "rsis_softiou_bwd")
+        return d, None, None, None, None
+
+
+def softiou_matched(out_masks, y_mask, perm, S, e=1e-6):
+    """(B, T) soft-IoU cost of every prediction against its matched ground-truth mask; differentiable w.r.t. out_masks."""
+    y_mask, perm = _contig(y_mask), _contig(perm)
+    return _SoftIoUMatchedFn.apply(out_masks, y_mask, perm, S, float(e))

@@ -80,9 +80,14 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
         out_stops = torch.stack(out_stops, 1)                        # (B, t, 1)   :120
 
     # ---- scores + matching (no grad) : train.py:78,102-110,127-137 ----
+    fused_iou = ops.softiou_supported(out_masks, y_mask)    # one pass over logits + GT masks gives every soft-IoU sum
     with torch.no_grad():
         scores = torch.ones(y_mask.size(0), args.gt_maxseqlen, args.maxseqlen, device=x.device)
-        scores[:, :, :t] = args.iou_weight * softIoU_matrix(y_mask, out_masks)
+        if fused_iou:
+            iou_sums = ops.softiou_sums(out_masks, y_mask)
+            scores[:, :, :t] = args.iou_weight * ops.softiou_cost_matrix(iou_sums)
+        else:
+            scores[:, :, :t] = args.iou_weight * softIoU_matrix(y_mask, out_masks)
         valid = (sw_mask.unsqueeze(-1) * sw_mask[:, 0:args.maxseqlen].unsqueeze(1) > 0).float()   # :127-130
         scores = scores * valid + (1 - valid) * 10                                                 # :131
         if scores.is_cuda and scores.size(1) <= 64 and scores.size(1) >= scores.size(2):
@@ -100,7 +105,10 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
         N, C = out_masks.size(-1), out_classes.size(-1)
         nll = MaskedNLL(y_class_perm.reshape(-1, 1), out_classes.reshape(-1, C), getattr(class_crit, "balance_weight", None))
         loss_class = _masked_mean(nll.reshape(-1, 1), sw_mask_t.reshape(-1, 1))                   # :159-161
-        siou = softIoU(y_mask_perm.reshape(-1, N), out_masks.reshape(-1, N))
+        if fused_iou:
+            siou = ops.softiou_matched(out_masks, y_mask, perm, iou_sums)                          # same sums, no second pass
+        else:
+            siou = softIoU(y_mask_perm.reshape(-1, N), out_masks.reshape(-1, N))
         loss_mask_iou = _masked_mean(siou.reshape(-1, 1), sw_mask_t.reshape(-1, 1))               # :162-163
         bce = StableBalancedMaskedBCE(sw_mask_t, out_stops.squeeze(-1), getattr(stop_xentropy, "balance_weight", None))
         loss_stop = _masked_mean(bce.reshape(-1, 1), sw_class_t.reshape(-1, 1))                   # :167-168

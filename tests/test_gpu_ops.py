@@ -259,3 +259,30 @@ def test_assign_min_cost_with_masked_ties_and_golden():
         want = np.zeros(G, dtype=np.int64)
         want[c] = r
         assert (perm[b, :n_inst] == want[:n_inst]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,G,N", [(2, 3, 5, 64), (3, 10, 20, 4096), (1, 31, 31, 520), (2, 1, 1, 8), (2, 7, 12, 65536)])
+def test_softiou_sums_and_matched_loss(B, T, G, N):
+    """fused soft-IoU (rsis_softiou_sums / rsis_softiou_bwd) against the oracle's softIoU (hungarian.py:62-89) on every
+    pair, and against autograd of the oracle's matched loss"""
+    from rsis_amd import ops
+    from oracle import rsis_oracle as O
+    rng = np.random.default_rng(5)
+    logits = torch.from_numpy(rng.normal(0, 2.0, (B, T, N)).astype(np.float32))
+    y = torch.from_numpy((rng.random((B, G, N)) < 0.3).astype(np.float32))
+    y[:, -1] = 0                                                     # an empty ground-truth slot
+    S = ops.softiou_sums(logits.cuda(), y.cuda())
+    cost = ops.softiou_cost_matrix(S).cpu()                          # (B, G, T)
+    ref = torch.stack([torch.stack([O.softIoU(y[:, g], logits[:, t]).reshape(B) for t in range(T)], 1) for g in range(G)], 1)
+    assert_close("cost", cost, ref, 2e-6, 1e-5)
+    perm = torch.stack([torch.from_numpy(rng.permutation(G)) for _ in range(B)]).long()
+    lg = logits.clone().requires_grad_()
+    ref_cost = O.softIoU(torch.gather(y, 1, perm[:, :T].unsqueeze(-1).expand(-1, -1, N)).reshape(-1, N), lg.reshape(-1, N)).reshape(B, T)
+    w = torch.from_numpy(rng.normal(0, 1, (B, T)).astype(np.float32))
+    (ref_cost * w).sum().backward()
+    ld = logits.cuda().requires_grad_()
+    got = ops.softiou_matched(ld, y.cuda(), perm.cuda(), S)
+    (got * w.cuda()).sum().backward()
+    assert_close("matched", got, ref_cost, 2e-6, 1e-5)
+    assert_close("dlogits", ld.grad, lg.grad, 1e-6 * max(1.0, float(lg.grad.abs().max()) * 1e3), 1e-4)
