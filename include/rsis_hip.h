@@ -134,6 +134,21 @@ int rsis_softiou_sums(const float* logits, const float* y, float* S, int B, int 
 int rsis_softiou_bwd(const float* logits, const float* y, const long long* perm, int perm_ld, const float* ca, const float* cb,
                      float* dlogits, int B, int T, int G, long N, void* stream);
 
+/* ---- inference post-processing of predicted masks (eval.py:96-127 resize_mask + pycocotools mask.encode; RLE semantics of
+ * src/coco/common/maskApi.c:32-41,196-209) ----
+ * rsis_mask_resize_threshold: prob[n][Hm][Wm] fp32 -> seg[n][w][h] uint8 (COLUMN-major h x w masks: align-corners bilinear
+ *   resample == scipy.ndimage.zoom(order=1), `> th`, pixels with ignore[h][w] == 1 cleared (ignore may be null)), the same
+ *   without the ignore mask in raw (may be null), area[n] = number of set pixels of seg.
+ * rsis_rle_encode: masks[n][len] uint8 column-major -> counts[n][cap] uint32 = lengths of the alternating runs starting with
+ *   the (possibly empty) run of zeros; nruns[n] = number of runs, or -(number of runs) when cap is too small (counts then
+ *   undefined for that mask).
+ * rsis_rle_to_string: HOST function (host pointers): the COCO text form of `m` counts into out[cap]; returns its length
+ *   (NUL-terminated) or -1 when cap is too small. */
+int rsis_mask_resize_threshold(const float* prob, int n, int Hm, int Wm, const unsigned char* ignore, float th, unsigned char* seg,
+                               unsigned char* raw, unsigned int* area, int h, int w, void* stream);
+int rsis_rle_encode(const unsigned char* masks, int n, long len, unsigned int* counts, int cap, int* nruns, void* stream);
+int rsis_rle_to_string(const unsigned int* counts, int m, char* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,10 @@ int rsis_l_maxpool_bwd(const float*, const unsigned char*, float*, long, int, in
 int rsis_l_channel_sum(const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_adam(float*, const float*, float*, float*, long, float, float, float, float, float, int, float, hipStream_t);
 int rsis_l_assign(const float*, long long*, int, int, int, hipStream_t);
+int rsis_l_mask_resize_threshold(const float*, int, int, int, const unsigned char*, float, unsigned char*, unsigned char*, unsigned int*,
+                                 int, int, hipStream_t);
+int rsis_l_rle_encode(const unsigned char*, int, long, unsigned int*, int, int*, hipStream_t);
+int rsis_l_rle_to_string(const unsigned int*, int, char*, int);
 int rsis_l_softiou_sums(const float*, const float*, float*, int, int, int, long, hipStream_t);
 int rsis_l_softiou_bwd(const float*, const float*, const long long*, int, const float*, const float*, float*, int, int, int, long,
                        hipStream_t);
@@ -305,4 +309,20 @@ int rsis_softiou_bwd(const float* logits, const float* y, const long long* perm,
   if (!logits || !y || !perm || !ca || !cb || !dlogits || B < 1 || T < 1 || G < 1 || perm_ld < T || N < 4 || N % 4 != 0)
     return RSIS_ERR_ARG;
   return rsis_l_softiou_bwd(logits, y, perm, perm_ld, ca, cb, dlogits, B, T, G, N, (hipStream_t)stream);
+}
+
+int rsis_mask_resize_threshold(const float* prob, int n, int Hm, int Wm, const unsigned char* ignore, float th, unsigned char* seg,
+                               unsigned char* raw, unsigned int* area, int h, int w, void* stream) {
+  if (!prob || !seg || !area || n < 1 || Hm < 1 || Wm < 1 || h < 1 || w < 1) return RSIS_ERR_ARG;
+  return rsis_l_mask_resize_threshold(prob, n, Hm, Wm, ignore, th, seg, raw, area, h, w, (hipStream_t)stream);
+}
+
+int rsis_rle_encode(const unsigned char* masks, int n, long len, unsigned int* counts, int cap, int* nruns, void* stream) {
+  if (!masks || !counts || !nruns || n < 1 || len < 1 || cap < 1 || len >= (1L << 32)) return RSIS_ERR_ARG;
+  return rsis_l_rle_encode(masks, n, len, counts, cap, nruns, (hipStream_t)stream);
+}
+
+int rsis_rle_to_string(const unsigned int* counts, int m, char* out, int cap) {
+  if (!counts || !out || m < 0 || cap < 1) return -1;
+  return rsis_l_rle_to_string(counts, m, out, cap);
 }

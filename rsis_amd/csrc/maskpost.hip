@@ -1,0 +1,162 @@
+// Inference post-processing of the predicted instance masks on the device (gfx950): what the reference does per mask on the
+// host with scipy + pycocotools (reference src/eval.py:96-127 resize_mask: scipy.ndimage.zoom(order=1) to the image size,
+// `> mask_th`, ignore pixels cleared, area test, pycocotools mask.encode; RLE semantics from src/coco/common/maskApi.c).
+//   mask_resize_threshold_kernel: align-corners bilinear resample (== zoom order 1) of n probability maps + threshold, written
+//     directly in COLUMN-major order (the order the run-length encoding walks), plus the per-mask area.  HBM-bound: one byte
+//     out per pixel (two with the raw copy), the small probability map stays in cache.
+//   rle_encode_kernel: run lengths of one column-major mask per block: per chunk the threads count value changes, a block scan
+//     turns the counts into output slots for the change positions, and a last pass differences the positions in place.
+//   rsis_rle_to_string (host): the 6-bit varint text form of the counts.
+#include "common.h"
+
+__device__ __forceinline__ void mp_coord(int o, float scale, int in, int& i0, int& i1, float& l1) {
+  const float src = scale * o;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - i0;
+}
+
+// grid = (ceil(h*w / 256), n); element e of mask k is column-major: e = x * h + y
+__global__ __launch_bounds__(256) void mask_resize_threshold_kernel(const float* __restrict__ prob, int Hm, int Wm,
+                                                                    const unsigned char* __restrict__ ignore, float th,
+                                                                    unsigned char* __restrict__ seg, unsigned char* __restrict__ raw,
+                                                                    unsigned int* __restrict__ area, int h, int w, float sh,
+                                                                    float sw) {
+  const int k = blockIdx.y;
+  const long hw = (long)h * w;
+  const long e = blockIdx.x * 256L + threadIdx.x;
+  unsigned int on = 0;
+  if (e < hw) {
+    const int x = (int)(e / h), y = (int)(e - (long)x * h);
+    int y0, y1, x0, x1; float ly, lx;
+    mp_coord(y, sh, Hm, y0, y1, ly);
+    mp_coord(x, sw, Wm, x0, x1, lx);
+    const float* p = prob + (size_t)k * Hm * Wm;
+    const float v = (1.f - ly) * ((1.f - lx) * p[y0 * Wm + x0] + lx * p[y0 * Wm + x1]) +
+                    ly * ((1.f - lx) * p[y1 * Wm + x0] + lx * p[y1 * Wm + x1]);
+    const unsigned char r = v > th ? 1 : 0;
+    unsigned char s = r;
+    if (ignore && ignore[(size_t)y * w + x] == 1) s = 0;
+    seg[(size_t)k * hw + e] = s;
+    if (raw) raw[(size_t)k * hw + e] = r;
+    on = s;
+  }
+  // block reduction of the area
+  __shared__ unsigned int red[4];
+  unsigned int v = on;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = red[0] + red[1] + red[2] + red[3];
+    if (t) atomicAdd(area + k, t);
+  }
+}
+
+#define RLE_T 1024   // threads per block
+#define RLE_E 16     // consecutive elements per thread per chunk
+__global__ __launch_bounds__(RLE_T) void rle_encode_kernel(const unsigned char* __restrict__ masks, long len,
+                                                           unsigned int* __restrict__ counts, int cap, int* __restrict__ nruns) {
+  const int k = blockIdx.x;
+  const unsigned char* m = masks + (size_t)k * len;
+  unsigned int* out = counts + (size_t)k * cap;
+  __shared__ unsigned int wsum[RLE_T / 64];
+  __shared__ unsigned int running;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) running = 0;
+  __syncthreads();
+  // ---- pass 1: positions of the value changes (the mask is preceded by an implicit 0) ----
+  for (long base = 0; base < len; base += (long)RLE_T * RLE_E) {
+    const long j0 = base + (long)tid * RLE_E;
+    unsigned char v[RLE_E + 1];
+    v[0] = (j0 > 0 && j0 - 1 < len) ? m[j0 - 1] : 0;
+    int nvalid = 0;
+#pragma unroll
+    for (int i = 0; i < RLE_E; ++i) {
+      const bool ok = j0 + i < len;
+      v[i + 1] = ok ? m[j0 + i] : v[i];
+      nvalid += ok ? 1 : 0;
+    }
+    unsigned int c = 0;
+#pragma unroll
+    for (int i = 0; i < RLE_E; ++i) c += (v[i + 1] != v[i]) ? 1u : 0u;
+    // exclusive scan over the block: wave scan by shuffles, wave totals through LDS
+    unsigned int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    unsigned int woff = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < RLE_T / 64; ++i) {
+      const unsigned int s = wsum[i];
+      if (i < wv) woff += s;
+      total += s;
+    }
+    unsigned int slot = running + woff + inc - c;
+#pragma unroll
+    for (int i = 0; i < RLE_E; ++i)
+      if (v[i + 1] != v[i]) {
+        if (slot < (unsigned)cap) out[slot] = (unsigned int)(j0 + i);
+        ++slot;
+      }
+    __syncthreads();
+    if (tid == 0) running += total;
+    __syncthreads();
+  }
+  const unsigned int nchg = running;          // runs = nchg + 1 (the first run counts zeros, possibly 0 of them)
+  if (tid == 0) nruns[k] = nchg + 1 <= (unsigned)cap ? (int)(nchg + 1) : -(int)(nchg + 1);
+  if (nchg + 1 > (unsigned)cap) return;
+  // ---- pass 2: positions -> run lengths, in place, from the last chunk down (chunk c needs the last position of chunk c-1) ----
+  if (tid == 0) out[nchg] = (unsigned int)len - (nchg ? out[nchg - 1] : 0u);
+  __syncthreads();
+  for (long hi = nchg; hi > 0; hi -= RLE_T) {
+    const long i = hi - 1 - tid;              // this chunk covers indices (hi - RLE_T, hi - 1]
+    unsigned int cur = 0, prev = 0;
+    if (i >= 0) { cur = out[i]; prev = i > 0 ? out[i - 1] : 0u; }
+    __syncthreads();
+    if (i >= 0) out[i] = cur - prev;
+    __syncthreads();
+  }
+}
+
+int rsis_l_mask_resize_threshold(const float* prob, int n, int Hm, int Wm, const unsigned char* ignore, float th, unsigned char* seg,
+                                 unsigned char* raw, unsigned int* area, int h, int w, hipStream_t st) {
+  if (hipMemsetAsync(area, 0, sizeof(unsigned int) * (size_t)n, st) != hipSuccess) return RSIS_ERR_LAUNCH;
+  const float sh = h > 1 ? (float)(Hm - 1) / (float)(h - 1) : 0.f, sw = w > 1 ? (float)(Wm - 1) / (float)(w - 1) : 0.f;
+  const long hw = (long)h * w;
+  hipLaunchKernelGGL(mask_resize_threshold_kernel, dim3((unsigned)((hw + 255) / 256), n), dim3(256), 0, st, prob, Hm, Wm, ignore, th,
+                     seg, raw, area, h, w, sh, sw);
+  return rsis_check_launch();
+}
+
+int rsis_l_rle_encode(const unsigned char* masks, int n, long len, unsigned int* counts, int cap, int* nruns, hipStream_t st) {
+  hipLaunchKernelGGL(rle_encode_kernel, dim3(n), dim3(RLE_T), 0, st, masks, len, counts, cap, nruns);
+  return rsis_check_launch();
+}
+
+// host: counts -> text (each count, for i > 2 minus counts[i-2], as a base-32 varint, 5 payload bits + continuation bit per
+// character, least significant group first, sign-extended, offset 48); returns the string length or -1 if `cap` is too small
+int rsis_l_rle_to_string(const unsigned int* counts, int m, char* out, int cap) {
+  int p = 0;
+  for (int i = 0; i < m; ++i) {
+    long x = (long)counts[i];
+    if (i > 2) x -= (long)counts[i - 2];
+    bool more = true;
+    while (more) {
+      char c = (char)(x & 0x1f);
+      x >>= 5;
+      more = (c & 0x10) ? x != -1 : x != 0;
+      if (more) c |= 0x20;
+      if (p + 1 >= cap) return -1;
+      out[p++] = (char)(c + 48);
+    }
+  }
+  out[p] = 0;
+  return p;
+}

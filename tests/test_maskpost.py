@@ -1,0 +1,118 @@
+"""Inference post-processing: run-length encoding and resize + threshold of predicted masks.
+CPU: the numpy restatement (oracle/rle_numpy.py) against the golden vectors produced by the reference's own maskApi.c
+(tests/golden/rle.npz, oracle/make_golden_rle.py) and, when the compiled reference library is present, against it directly.
+GPU: librsis_hip.so (rsis_rle_encode / rsis_rle_to_string / rsis_mask_resize_threshold) against the oracle, bit-exact for
+the integer / byte work."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import maskapi_ref, rle_numpy
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rle.npz")
+
+
+def _golden():
+    g = np.load(GOLD)
+    return [(g["mask%d" % i], g["counts%d" % i], g["string%d" % i].tobytes()) for i in range(int(g["n"]))]
+
+
+def test_oracle_rle_matches_golden():
+    for m, counts, s in _golden():
+        c = rle_numpy.rle_counts(m)
+        assert np.array_equal(c, counts)
+        assert rle_numpy.rle_string(c) == s
+        assert rle_numpy.rle_area(c) == int(m.sum())
+
+
+@pytest.mark.skipif(not maskapi_ref.available(), reason="oracle/_ref/libmaskapi_ref.so not built (make -C oracle)")
+def test_oracle_rle_matches_reference_library():
+    rng = np.random.default_rng(7)
+    for it in range(60):
+        h, w = int(rng.integers(1, 50)), int(rng.integers(1, 50))
+        blob = int(rng.integers(1, 6))
+        m = np.kron((rng.random((-(-h // blob), -(-w // blob))) < rng.random()).astype(np.uint8), np.ones((blob, blob), np.uint8))[:h, :w]
+        c, s = maskapi_ref.encode(m)
+        c2 = rle_numpy.rle_counts(m)
+        assert np.array_equal(c, c2) and s == rle_numpy.rle_string(c2)
+
+
+def test_host_rle_to_string_matches_golden():
+    """rsis_rle_to_string is a host function of the library: checked without a GPU"""
+    import ctypes
+    from rsis_amd._lib import lib
+    L = lib()
+    for _m, counts, s in _golden():
+        c = np.ascontiguousarray(counts.astype(np.uint32))
+        buf = ctypes.create_string_buffer(6 * len(c) + 8)
+        n = L.rsis_rle_to_string(c.ctypes.data_as(ctypes.c_void_p), len(c), buf, len(buf))
+        assert n == len(s) and buf.raw[:n] == s
+    assert L.rsis_rle_to_string(c.ctypes.data_as(ctypes.c_void_p), len(c), buf, 2) == -1       # too small a buffer is an error
+
+
+@pytest.mark.gpu
+def test_device_rle_matches_oracle():
+    from rsis_amd import eval_post
+    from rsis_amd._lib import lib
+    L = lib()
+    rng = np.random.default_rng(11)
+    cases = [m for m, _c, _s in _golden()]
+    big = np.zeros((1024, 2048), np.uint8)
+    big[100:900, 300:1800] = 1
+    big[500, 1000] = 0
+    cases += [big, np.ones((37, 1025), np.uint8), np.zeros((300, 17), np.uint8),
+              (rng.random((257, 129)) < 0.5).astype(np.uint8)]      # worst case: a change at almost every pixel
+    for m in cases:
+        h, w = m.shape
+        col = torch.from_numpy(np.ascontiguousarray(m.T.reshape(1, -1))).cuda()          # column-major, as the kernel expects
+        dicts = eval_post._rle_dicts(L, col, 1, h * w, h, w)
+        c = rle_numpy.rle_counts(m)
+        assert dicts[0]["size"] == [h, w]
+        assert dicts[0]["counts"] == rle_numpy.rle_string(c), (h, w)
+    # several masks of one image in one launch
+    ms = [(rng.random((40, 56)) < p).astype(np.uint8) for p in (0.0, 0.2, 0.9, 1.0)]
+    col = torch.from_numpy(np.stack([m.T.reshape(-1) for m in ms])).cuda()
+    dicts = eval_post._rle_dicts(L, col, len(ms), 40 * 56, 40, 56)
+    for d, m in zip(dicts, ms):
+        assert d["counts"] == rle_numpy.rle_string(rle_numpy.rle_counts(m))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Hm,Wm,h,w", [(16, 16, 16, 16), (64, 64, 100, 132), (32, 48, 21, 35), (256, 256, 375, 500), (8, 8, 1, 1)])
+def test_device_resize_threshold_matches_oracle(Hm, Wm, h, w):
+    """resample + threshold + ignore + area + encoding against scipy.ndimage.zoom(order=1) in float64 (oracle restatement of
+    eval.py:96-117); pixels whose interpolated value is within 1e-5 of the threshold may legitimately differ (fp32 vs fp64)"""
+    from rsis_amd import eval_post
+    rng = np.random.default_rng(3)
+    n = 3
+    prob = rng.random((n, Hm, Wm)).astype(np.float32)
+    ignore = (rng.random((h, w)) < 0.1).astype(np.uint8)
+    th = 0.5
+    segs, areas, raws = eval_post.encode_masks(torch.from_numpy(prob).cuda(), h, w, th, ignore)
+    from scipy.ndimage import zoom
+    for k in range(n):
+        seg, raw = rle_numpy.resize_threshold(prob[k], h, w, th, ignore)
+        z = zoom(prob[k].astype(np.float64).reshape(Hm, Wm, 1), [float(h) / Hm, float(w) / Wm, 1], order=1).reshape(h, w)
+        near = np.abs(z - th) < 1e-5
+        if not near.any():
+            assert segs[k]["counts"] == rle_numpy.rle_string(rle_numpy.rle_counts(seg))
+            assert raws[k]["counts"] == rle_numpy.rle_string(rle_numpy.rle_counts(raw))
+            assert int(areas[k]) == int(seg.sum())
+        else:                                                       # decode ours and compare away from the threshold
+            assert abs(int(areas[k]) - int(seg.sum())) <= int(near.sum())
+
+
+@pytest.mark.gpu
+def test_resize_mask_reference_signature():
+    import argparse
+    from rsis_amd import eval_post
+    rng = np.random.default_rng(9)
+    a = argparse.Namespace(mask_th=0.5, min_size=0.001)
+    p = rng.random((64, 64)).astype(np.float32)
+    seg, ok, raw = eval_post.resize_mask(a, p, 120, 90)
+    want, _ = rle_numpy.resize_threshold(p, 120, 90, 0.5)
+    assert ok and seg["size"] == [120, 90] and seg["counts"] == rle_numpy.rle_string(rle_numpy.rle_counts(want)) and raw["counts"] == seg["counts"]
+    _seg, ok2, _ = eval_post.resize_mask(a, np.zeros((64, 64), np.float32), 120, 90)
+    assert not ok2                                                  # eval.py:113-114: fewer than min_size * h * w pixels
