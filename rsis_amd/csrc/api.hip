@@ -42,6 +42,8 @@ static inline int krows_of(int C, int ks) { return rsis_roundup(C * ks * ks, RSI
 static inline int log2i(int s) { int l = 0; while ((1 << l) < s) ++l; return l; }
 // 3x3 / stride 1 / pad 1 convs (and their data gradients) run on the direct LDS-patch kernel with its own packed layout
 static inline bool use_direct(int ks, int stride, int pad) { return ks == 3 && stride == 1 && pad == 1; }
+// 3x3 / stride 2 / pad 1 data gradients run on the same kernel (EPI_S2: parity classes of the input pixel)
+static inline bool use_direct_s2(int ks, int stride, int pad) { return ks == 3 && stride == 2 && pad == 1; }
 static inline int direct_rows(int nseg, const int* Cseg) {
   int q = 0;
   for (int s = 0; s < nseg; ++s) q += (Cseg[s] + RSIS_CK - 1) / RSIS_CK;
@@ -74,7 +76,7 @@ long rsis_conv_packed_floats_fwd(int Cout, int ks, int stride, int pad, int nseg
 
 long rsis_conv_packed_floats_dgrad(int Cout, int ks, int stride, int pad, int c_count) {
   const long ldw = rsis_roundup(c_count, RSIS_LDW_ALIGN);
-  if (use_direct(ks, stride, pad)) return (long)direct_rows(1, &Cout) * ldw;
+  if (use_direct(ks, stride, pad) || use_direct_s2(ks, stride, pad)) return (long)direct_rows(1, &Cout) * ldw;
   return (long)krows_of(Cout, ks) * ldw;
 }
 
@@ -110,6 +112,8 @@ int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, 
   const int ldw = rsis_roundup(csum, RSIS_LDW_ALIGN);
   if (use_direct(ks, stride, pad))
     return rsis_l_pack(3, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, direct_rows(1, &Cout), lstm_hid, (hipStream_t)stream);
+  if (use_direct_s2(ks, stride, pad))
+    return rsis_l_pack(4, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, direct_rows(1, &Cout), lstm_hid, (hipStream_t)stream);
   return rsis_l_pack(1, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, krows_of(Cout, ks), lstm_hid, (hipStream_t)stream);
 }
 
@@ -188,6 +192,12 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const fl
       }
     }
     return rsis_launch_conv3x3_direct(a, 0, direct_variant(tile), (hipStream_t)stream);
+  }
+  if (use_direct_s2(ks, stride, pad) && ndst == 1 && Hy == (Hx + 1) / 2 && Wy == (Wx + 1) / 2) {
+    // 3x3 / stride 2: the direct kernel walks the dy grid and scatters the four input-pixel parity classes (every dx pixel is
+    // written exactly once: no memset)
+    a.Ho = Hy; a.Wo = Wy; a.oH = Hx; a.oW = Wx;
+    return rsis_launch_conv3x3_direct(a, 2, direct_variant(tile), (hipStream_t)stream);
   }
   if (ks == 1 && pad == 0 && stride > 1) {
     // 1x1 / stride-s data gradient: only the (s*ho, s*wo) input pixels receive a gradient -> zero dx, then run the plain

@@ -14,9 +14,15 @@
 // 32-63 the odd one), i.e. a bare `ds_read_b32 v, v_base offset:imm`; the A-operand likewise.  Per MFMA (64 cycles) the
 // wave issues 1.25-2 LDS reads and nothing else, which is what makes the exact-f32 MFMA the bound.
 // Channel concat (torch.cat at clstm.py:43 / model.py:153) is by pointer: chunks never straddle a source.
+//
+// EPI_S2: data gradient of the 3x3 / stride 2 / pad 1 convs (the first block of ResNet layers 2-4).  The four parity classes
+// of the input pixel (2y+ph, 2x+pw) each receive the taps with r = 1 (ph = 0) or r in {0, 2} (ph = 1), likewise s: every tap
+// belongs to exactly one class, reads dy at (y + (r == 0), x + (s == 0)) and accumulates into that class's accumulator.  So
+// the block walks the dy grid exactly like a stride-1 conv (9 taps per channel pair, no wasted MFMAs -- the gather
+// formulation multiplies 3/4 zeros) and the epilogue scatters the 4 accumulators to the 2x larger dx tile.
 #include "common.h"
 
-enum { EPI_PLAIN = 0, EPI_LSTM = 1 };
+enum { EPI_PLAIN = 0, EPI_LSTM = 1, EPI_S2 = 2 };
 #ifndef DIRECT_DMA
 #define DIRECT_DMA 1   // 1: stage global -> LDS with buffer_load ... lds (LDS-DMA); 0: through registers + ds_write
 #endif
@@ -128,11 +134,15 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   }
   const int woff = hi * BM + wm * 32 + l31;
 
-  f32x16 acc[TN];
+  constexpr int NACC = EPI == EPI_S2 ? 4 : 1;   // EPI_S2: one accumulator set per parity class of the input pixel
+  f32x16 accs[NACC][TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
+  for (int c = 0; c < NACC; ++c)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accs[c][j][r] = 0.f;
+  f32x16 (&acc)[TN] = accs[0];
 
   const gcf_t wbase = (gcf_t)p.wp + co_t * BM;
 
@@ -233,9 +243,11 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
             const float a = Ws[((c2 * 9 + r * 3 + s) * 2) * BM];
             float b[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Xs[xoff[j] + (2 * c2) * CHS + r * PW + s];
+            for (int j = 0; j < TN; ++j)
+              b[j] = Xs[xoff[j] + (2 * c2) * CHS + (EPI == EPI_S2 ? ((r == 0) + 1) * PW + (s == 0) + 1 : r * PW + s)];
+            const int cls = EPI == EPI_S2 ? (r != 1) * 2 + (s != 1) : 0;   // compile time after unrolling
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) accs[cls][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], accs[cls][j], 0, 0, 0);
           }
     }
 #if DIRECT_DMA
@@ -260,7 +272,20 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
     const int ob = b0 + img, oy = y0 + y, ox = x0 + x;
     if (ob >= B || oy >= H || ox >= W) continue;
     const int osp = oy * W + ox;
-    if (EPI == EPI_PLAIN) {
+    if (EPI == EPI_S2) {
+      const gf_t d0 = (gf_t)p.dst[0];
+      const int Cd0 = p.Cd[0], oH = p.oH, oW = p.oW;
+#pragma unroll
+      for (int c = 0; c < NACC; ++c) {
+        const int py = 2 * oy + (c >> 1), px = 2 * ox + (c & 1);
+        if (py >= oH || px >= oW) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (co < Cd0) d0[((size_t)ob * Cd0 + co) * ((size_t)oH * oW) + py * oW + px] = accs[c][j][r];
+        }
+      }
+    } else if (EPI == EPI_PLAIN) {
       const gf_t d0 = (gf_t)p.dst[0], d1 = (gf_t)p.dst[1], d2 = (gf_t)p.dst[2];
       const int Cd0 = p.Cd[0], Cd1 = p.Cd[1], Cd2 = p.Cd[2], Cout = p.Cout;
       const int e1 = Cd0, e2 = Cd0 + Cd1;
@@ -356,10 +381,11 @@ static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
       if (blocks < 512) v = v == 2 ? 4 : 5;
     }
   }
+  if (EPI == EPI_S2 && v == 3) v = 5;   // 4 accumulator sets: the 256-pixel x 64-row tile would need 256 accumulator registers
   switch (v) {
     case 1: return launch_direct_cfg<64, 8, 8, 1, EPI>(a, st);
     case 2: return launch_direct_cfg<64, 16, 8, 1, EPI>(a, st);
-    case 3: return launch_direct_cfg<64, 32, 8, 1, EPI>(a, st);
+    case 3: if constexpr (EPI != EPI_S2) return launch_direct_cfg<64, 32, 8, 1, EPI>(a, st); else return RSIS_ERR_ARG;
     case 4: return launch_direct_cfg<32, 16, 8, 1, EPI>(a, st);
     case 5: return launch_direct_cfg<32, 32, 8, 1, EPI>(a, st);
     default: return RSIS_ERR_ARG;
@@ -369,5 +395,6 @@ static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
 int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st) {
   if (a.nsrc < 0 || a.nsrc > RSIS_MAX_SRC) return RSIS_ERR_ARG;
   if (epi == EPI_LSTM) return launch_direct_epi<EPI_LSTM>(a, st, force_variant);
+  if (epi == EPI_S2) return launch_direct_epi<EPI_S2>(a, st, force_variant);
   return launch_direct_epi<EPI_PLAIN>(a, st, force_variant);
 }

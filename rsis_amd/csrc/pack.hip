@@ -81,8 +81,10 @@ __global__ void pack_direct_fwd_kernel(const float* __restrict__ W, float* __res
   }
 }
 
+// flip: stride-1 dgrad reads tap 8-rs (the transposed conv); the stride-2 dgrad (EPI_S2 of conv3x3_direct.hip) keeps the
+// original tap order (each tap is routed to its parity class by the kernel)
 __global__ void pack_direct_dgrad_kernel(const float* __restrict__ W, float* __restrict__ Wd, int Cout, int Ctot, SegMap m, int ldw,
-                                         int krows, int hid) {
+                                         int krows, int hid, int flip) {
   const long total = (long)krows * ldw;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int row = (int)(e / ldw), cg = (int)(e - (long)row * ldw);
@@ -92,7 +94,7 @@ __global__ void pack_direct_dgrad_kernel(const float* __restrict__ W, float* __r
     const int cc = pair / 9, rs = pair - cc * 9;
     const int c = qg * RSIS_CK + 2 * cc + h;      // channel of dy (packed row order for ConvLSTM)
     const int ci = seg_channel(m, cg);
-    if (c < Cout && ci >= 0) v = W[((long)ref_row(c, hid) * Ctot + ci) * 9 + (8 - rs)];
+    if (c < Cout && ci >= 0) v = W[((long)ref_row(c, hid) * Ctot + ci) * 9 + (flip ? 8 - rs : rs)];
     Wd[e] = v;
   }
 }
@@ -103,7 +105,7 @@ static inline int pack_grid(long total) {
   return (int)(g < 1 ? 1 : g);
 }
 
-// mode: 0 igemm fwd, 1 igemm dgrad, 2 direct fwd, 3 direct dgrad
+// mode: 0 igemm fwd, 1 igemm dgrad, 2 direct fwd, 3 direct dgrad (stride 1), 4 direct dgrad (stride 2: taps not flipped)
 int rsis_l_pack(int mode, const float* W, float* out, int Cout, int Ctot, int ks, int nseg, const int* Cseg, const int* Coff,
                 int ldw, int krows, int hid, hipStream_t st) {
   SegMap m = {};
@@ -116,7 +118,8 @@ int rsis_l_pack(int mode, const float* W, float* out, int Cout, int Ctot, int ks
     case 0: hipLaunchKernelGGL(pack_fwd_kernel, g, b, 0, st, W, out, Cout, Ctot, ks * ks, m, ldw, krows, hid); break;
     case 1: hipLaunchKernelGGL(pack_dgrad_kernel, g, b, 0, st, W, out, Cout, Ctot, ks * ks, m, ldw, krows, hid); break;
     case 2: hipLaunchKernelGGL(pack_direct_fwd_kernel, g, b, 0, st, W, out, Cout, Ctot, m, ldw, krows, hid); break;
-    case 3: hipLaunchKernelGGL(pack_direct_dgrad_kernel, g, b, 0, st, W, out, Cout, Ctot, m, ldw, krows, hid); break;
+    case 3: hipLaunchKernelGGL(pack_direct_dgrad_kernel, g, b, 0, st, W, out, Cout, Ctot, m, ldw, krows, hid, 1); break;
+    case 4: hipLaunchKernelGGL(pack_direct_dgrad_kernel, g, b, 0, st, W, out, Cout, Ctot, m, ldw, krows, hid, 0); break;
     default: return RSIS_ERR_ARG;
   }
   return rsis_check_launch();

@@ -42,6 +42,8 @@ CONV_CASES = [
     (2, [20, 12], 16, 24, 40, 3, 1, 1, True),   # tile-aligned map, 2 sources, ragged channels (LDS-DMA tiled wgrad, 64-row tile)
     (2, [72], 8, 16, 200, 3, 1, 1, False),      # tiled wgrad, 128-row tile, several co / n tiles
     (3, [40], 12, 16, 24, 1, 1, 0, False),      # tiled 1x1 wgrad (8x4 tiles), ragged channels
+    (2, [24], 32, 48, 40, 3, 2, 1, True),       # strided 3x3, even size, several tiles (parity-class dgrad)
+    (1, [16], 9, 64, 72, 3, 2, 1, False),       # strided 3x3, odd height, wide map
 ]
 
 
