@@ -122,6 +122,22 @@ int rsis_adam_step(float* p, const float* g, float* m, float* v, long n, float l
  * iteration needs no host synchronisation. ---- */
 int rsis_assign_min_cost(const float* scores, long long* perm, int B, int G, int T, void* stream);
 
+/* ---- batched repack: every packed weight copy of a model in ONE launch (after an optimizer step).  `jobs` is a DEVICE array
+ * of njobs descriptors, sorted by block_begin; job i is processed by the blocks [block_begin_i, block_begin_{i+1}) of a grid
+ * of total_blocks blocks, rsis_conv_pack_job_blocks() blocks each.  rsis_conv_pack_job_fill() fills the derived fields
+ * (imode, ldw, krows) of a host-side descriptor exactly as rsis_conv_pack_fwd / _dgrad would choose them and returns the
+ * job's block count (< 0: invalid). ---- */
+typedef struct rsis_pack_job {
+  const float* W;      /* reference-layout weight [Cout][Ctot][ks][ks] (device) */
+  float* out;          /* packed copy (device), rsis_conv_packed_floats_fwd / _dgrad floats */
+  int dgrad;           /* 0: forward copy, 1: data-gradient copy */
+  int Cout, Ctot, ks, stride, pad, nseg, Cseg[3], Coff[3], lstm_hid;
+  int imode, ldw, krows;   /* derived (rsis_conv_pack_job_fill) */
+  int block_begin;     /* first block of this job in the batch grid */
+} rsis_pack_job;
+int rsis_conv_pack_job_fill(rsis_pack_job* job);
+int rsis_conv_pack_batch(const rsis_pack_job* jobs_dev, int njobs, int total_blocks, void* stream);
+
 /* ---- soft-IoU matching scores and matched-loss gradient (train.py:98-110,127-131,162-163; hungarian.py:62-89 softIoU) ----
  * rsis_softiou_sums: logits[B][T][N] (mask logits of the T predictions), y[B][G][N] (ground-truth masks, 0/1 floats) ->
  *   S[B][T+1][G+1]:  S[t][g] = sum_n sigmoid(logits[t][n]) * y[g][n],  S[t][G] = sum_n sigmoid(logits[t][n]),

@@ -16,6 +16,14 @@ _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 _ip = ctypes.POINTER(ctypes.c_int)
 _vpp = ctypes.POINTER(ctypes.c_void_p)
 
+class PackJob(ctypes.Structure):
+    """struct rsis_pack_job of include/rsis_hip.h"""
+    _fields_ = [("W", ctypes.c_void_p), ("out", ctypes.c_void_p), ("dgrad", ctypes.c_int), ("Cout", ctypes.c_int),
+                ("Ctot", ctypes.c_int), ("ks", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int),
+                ("nseg", ctypes.c_int), ("Cseg", ctypes.c_int * 3), ("Coff", ctypes.c_int * 3), ("lstm_hid", ctypes.c_int),
+                ("imode", ctypes.c_int), ("ldw", ctypes.c_int), ("krows", ctypes.c_int), ("block_begin", ctypes.c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/rsis_hip.h
 SIGNATURES = {
     "rsis_version": (_i, []),
@@ -24,6 +32,8 @@ SIGNATURES = {
     "rsis_conv_packed_floats_dgrad": (_l, [_i, _i, _i, _i, _i]),
     "rsis_conv_pack_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ip, _ip, _i, _vp]),
     "rsis_conv_pack_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ip, _ip, _i, _vp]),
+    "rsis_conv_pack_job_fill": (_i, [ctypes.POINTER(PackJob)]),
+    "rsis_conv_pack_batch": (_i, [_vp, _i, _i, _vp]),
     "rsis_conv2d_fwd": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "rsis_conv2d_dgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vpp, _ip, _i, _i, _i, _i, _vp]),
     "rsis_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -30,6 +30,8 @@ int rsis_l_maxpool_bwd(const float*, const unsigned char*, float*, long, int, in
 int rsis_l_channel_sum(const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_adam(float*, const float*, float*, float*, long, float, float, float, float, float, int, float, hipStream_t);
 int rsis_l_assign(const float*, long long*, int, int, int, hipStream_t);
+int rsis_l_pack_batch(const rsis_pack_job*, int, int, hipStream_t);
+int rsis_l_pack_chunk();
 int rsis_l_mask_resize_threshold(const float*, int, int, int, const unsigned char*, float, unsigned char*, unsigned char*, unsigned int*,
                                  int, int, hipStream_t);
 int rsis_l_rle_encode(const unsigned char*, int, long, unsigned int*, int, int*, hipStream_t);
@@ -115,6 +117,29 @@ int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, 
   if (use_direct_s2(ks, stride, pad))
     return rsis_l_pack(4, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, direct_rows(1, &Cout), lstm_hid, (hipStream_t)stream);
   return rsis_l_pack(1, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, krows_of(Cout, ks), lstm_hid, (hipStream_t)stream);
+}
+
+int rsis_conv_pack_job_fill(rsis_pack_job* j) {
+  if (!j || check_segments(j->Ctot, j->nseg, j->Cseg, j->Coff)) return -1;
+  if (j->lstm_hid > 0 && j->Cout != 4 * j->lstm_hid) return -1;
+  int csum = 0;
+  for (int s = 0; s < j->nseg; ++s) csum += j->Cseg[s];
+  if (!j->dgrad) {
+    j->ldw = rsis_roundup(j->Cout, RSIS_LDW_ALIGN);
+    if (use_direct(j->ks, j->stride, j->pad)) { j->imode = 2; j->krows = direct_rows(j->nseg, j->Cseg); }
+    else { j->imode = 0; j->krows = krows_of(csum, j->ks); }
+  } else {
+    j->ldw = rsis_roundup(csum, RSIS_LDW_ALIGN);
+    if (use_direct(j->ks, j->stride, j->pad)) { j->imode = 3; j->krows = direct_rows(1, &j->Cout); }
+    else if (use_direct_s2(j->ks, j->stride, j->pad)) { j->imode = 4; j->krows = direct_rows(1, &j->Cout); }
+    else { j->imode = 1; j->krows = krows_of(j->Cout, j->ks); }
+  }
+  return rsis_cdiv((long)j->krows * j->ldw, rsis_l_pack_chunk());
+}
+
+int rsis_conv_pack_batch(const rsis_pack_job* jobs_dev, int njobs, int total_blocks, void* stream) {
+  if (!jobs_dev || njobs < 1 || total_blocks < 1) return RSIS_ERR_ARG;
+  return rsis_l_pack_batch(jobs_dev, njobs, total_blocks, (hipStream_t)stream);
 }
 
 static int fill_sources(ConvArgs& a, const float* const* src, const int* Csrc, int nsrc, int ks, bool allow_empty = false) {

@@ -10,6 +10,7 @@
 //                          c0 + 2*c2 + h, tap rs.  FWD columns = co_p; DGRAD rows = chunks of co_p, columns = cg, tap 8-rs.
 // co_p -> reference row: (co_p&3)*hid + (co_p>>2) for gate-interleaved ConvLSTM rows (clstm.py:47), identity otherwise.
 #include "common.h"
+#include "../../include/rsis_hip.h"
 
 struct SegMap { int n; int C[3]; int off[3]; };
 
@@ -26,78 +27,83 @@ __device__ __forceinline__ int seg_channel(const SegMap& m, int cg) {   // conca
 }
 __device__ __forceinline__ int ref_row(int cop, int hid) { return hid > 0 ? (cop & 3) * hid + (cop >> 2) : cop; }
 
-__global__ void pack_fwd_kernel(const float* __restrict__ W, float* __restrict__ Wp, int Cout, int Ctot, int KK, SegMap m,
-                                int ldw, int krows, int hid) {
-  const long total = (long)krows * ldw;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(e / ldw), cop = (int)(e - (long)k * ldw);
-    float v = 0.f;
-    if (cop < Cout) {
-      const int cg = k / KK, rs = k - cg * KK;
-      const int ci = seg_channel(m, cg);
-      if (ci >= 0) v = W[((long)ref_row(cop, hid) * Ctot + ci) * KK + rs];
-    }
-    Wp[e] = v;
-  }
-}
-
-__global__ void pack_dgrad_kernel(const float* __restrict__ W, float* __restrict__ Wd, int Cout, int Ctot, int KK, SegMap m,
-                                  int ldw, int krows, int hid) {
-  const long total = (long)krows * ldw;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(e / ldw), cg = (int)(e - (long)k * ldw);
-    float v = 0.f;
-    const int cop = k / KK, rs = k - cop * KK;
+// ---- one element of each packed layout (shared by the per-conv kernels and the batched repack) ----
+__device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ W, long e, int Cout, int Ctot, int KK, const SegMap& m,
+                                           int ldw, int hid) {
+  const int row = (int)(e / ldw), col = (int)(e - (long)row * ldw);
+  if (mode == 0) {                 // igemm fwd: Wp[cg*KK + rs][co_p]
+    if (col >= Cout) return 0.f;
+    const int cg = row / KK, rs = row - cg * KK;
     const int ci = seg_channel(m, cg);
-    if (cop < Cout && ci >= 0) v = W[((long)ref_row(cop, hid) * Ctot + ci) * KK + rs];
-    Wd[e] = v;
+    return ci >= 0 ? W[((long)ref_row(col, hid) * Ctot + ci) * KK + rs] : 0.f;
   }
-}
-
-__global__ void pack_direct_fwd_kernel(const float* __restrict__ W, float* __restrict__ Wp, int Cout, int Ctot, SegMap m, int ldw,
-                                       int krows, int hid) {
-  const long total = (long)krows * ldw;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int row = (int)(e / ldw), col = (int)(e - (long)row * ldw);
-    float v = 0.f;
-    if (col < Cout) {
-      const int qg = row / (RSIS_CK * 9), kin = row - qg * (RSIS_CK * 9);
-      const int pair = kin >> 1, h = kin & 1;
-      const int cc = pair / 9, rs = pair - cc * 9;
-      int qs = 0;
+  if (mode == 1) {                 // igemm dgrad: Wd[co_p*KK + rs][cg]
+    const int cop = row / KK, rs = row - cop * KK;
+    const int ci = seg_channel(m, col);
+    return (cop < Cout && ci >= 0) ? W[((long)ref_row(cop, hid) * Ctot + ci) * KK + rs] : 0.f;
+  }
+  const int qg = row / (RSIS_CK * 9), kin = row - qg * (RSIS_CK * 9);
+  const int pair = kin >> 1, h = kin & 1;
+  const int cc = pair / 9, rs = pair - cc * 9;
+  if (mode == 2) {                 // direct fwd: 8-channel chunks per segment, columns = co_p
+    if (col >= Cout) return 0.f;
+    int qs = 0;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        if (s < m.n) {
-          const int nq = (m.C[s] + RSIS_CK - 1) / RSIS_CK;
-          if (qg >= qs && qg < qs + nq) {
-            const int c = (qg - qs) * RSIS_CK + 2 * cc + h;
-            if (c < m.C[s]) v = W[((long)ref_row(col, hid) * Ctot + m.off[s] + c) * 9 + rs];
-          }
-          qs += nq;
+    for (int s = 0; s < 3; ++s) {
+      if (s < m.n) {
+        const int nq = (m.C[s] + RSIS_CK - 1) / RSIS_CK;
+        if (qg >= qs && qg < qs + nq) {
+          const int c = (qg - qs) * RSIS_CK + 2 * cc + h;
+          return c < m.C[s] ? W[((long)ref_row(col, hid) * Ctot + m.off[s] + c) * 9 + rs] : 0.f;
         }
+        qs += nq;
       }
     }
-    Wp[e] = v;
+    return 0.f;
+  }
+  // direct dgrad: rows = chunks of co_p, columns = cg.  mode 3 (stride 1) reads tap 8-rs (the transposed conv); mode 4 (stride 2,
+  // EPI_S2 of conv3x3_direct.hip) keeps the original tap order (each tap is routed to its parity class by the kernel)
+  const int c = qg * RSIS_CK + 2 * cc + h;      // channel of dy (packed row order for ConvLSTM)
+  const int ci = seg_channel(m, col);
+  return (c < Cout && ci >= 0) ? W[((long)ref_row(c, hid) * Ctot + ci) * 9 + (mode == 3 ? 8 - rs : rs)] : 0.f;
+}
+
+__global__ void pack_kernel(int mode, const float* __restrict__ W, float* __restrict__ out, int Cout, int Ctot, int KK, SegMap m, int ldw,
+                            int krows, int hid) {
+  const long total = (long)krows * ldw;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    out[e] = pack_elem(mode, W, e, Cout, Ctot, KK, m, ldw, hid);
+}
+
+// ---- batched repack: every packed copy of every conv weight in ONE launch (after an optimizer step ~240 tiny pack launches
+// per training step otherwise).  jobs[] lives in device memory; job i owns the blocks [block_begin_i, block_begin_{i+1}). ----
+#define PACK_CHUNK 4096   // elements per block
+__global__ __launch_bounds__(256) void pack_batch_kernel(const rsis_pack_job* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {                       // last job whose block_begin <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_begin <= b) lo = mid; else hi = mid - 1;
+  }
+  const rsis_pack_job j = jobs[lo];
+  SegMap m;
+  m.n = j.nseg;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) { m.C[s] = j.Cseg[s]; m.off[s] = j.Coff[s]; }
+  const long total = (long)j.krows * j.ldw;
+  const long base = (long)(b - j.block_begin) * PACK_CHUNK;
+#pragma unroll 4
+  for (int i = 0; i < PACK_CHUNK / 256; ++i) {
+    const long e = base + i * 256 + threadIdx.x;
+    if (e < total) j.out[e] = pack_elem(j.imode, j.W, e, j.Cout, j.Ctot, j.ks * j.ks, m, j.ldw, j.lstm_hid);
   }
 }
 
-// flip: stride-1 dgrad reads tap 8-rs (the transposed conv); the stride-2 dgrad (EPI_S2 of conv3x3_direct.hip) keeps the
-// original tap order (each tap is routed to its parity class by the kernel)
-__global__ void pack_direct_dgrad_kernel(const float* __restrict__ W, float* __restrict__ Wd, int Cout, int Ctot, SegMap m, int ldw,
-                                         int krows, int hid, int flip) {
-  const long total = (long)krows * ldw;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int row = (int)(e / ldw), cg = (int)(e - (long)row * ldw);
-    float v = 0.f;
-    const int qg = row / (RSIS_CK * 9), kin = row - qg * (RSIS_CK * 9);
-    const int pair = kin >> 1, h = kin & 1;
-    const int cc = pair / 9, rs = pair - cc * 9;
-    const int c = qg * RSIS_CK + 2 * cc + h;      // channel of dy (packed row order for ConvLSTM)
-    const int ci = seg_channel(m, cg);
-    if (c < Cout && ci >= 0) v = W[((long)ref_row(c, hid) * Ctot + ci) * 9 + (flip ? 8 - rs : rs)];
-    Wd[e] = v;
-  }
+int rsis_l_pack_batch(const rsis_pack_job* jobs, int njobs, int total_blocks, hipStream_t st) {
+  hipLaunchKernelGGL(pack_batch_kernel, dim3(total_blocks), dim3(256), 0, st, jobs, njobs);
+  return rsis_check_launch();
 }
+int rsis_l_pack_chunk() { return PACK_CHUNK; }
 
 static inline int pack_grid(long total) {
   long g = (total + 255) / 256;
@@ -114,13 +120,7 @@ int rsis_l_pack(int mode, const float* W, float* out, int Cout, int Ctot, int ks
   for (int s = 0; s < nseg; ++s) { m.C[s] = Cseg[s]; m.off[s] = Coff ? Coff[s] : base; base += Cseg[s]; }
   const long total = (long)krows * ldw;
   const dim3 g(pack_grid(total)), b(256);
-  switch (mode) {
-    case 0: hipLaunchKernelGGL(pack_fwd_kernel, g, b, 0, st, W, out, Cout, Ctot, ks * ks, m, ldw, krows, hid); break;
-    case 1: hipLaunchKernelGGL(pack_dgrad_kernel, g, b, 0, st, W, out, Cout, Ctot, ks * ks, m, ldw, krows, hid); break;
-    case 2: hipLaunchKernelGGL(pack_direct_fwd_kernel, g, b, 0, st, W, out, Cout, Ctot, m, ldw, krows, hid); break;
-    case 3: hipLaunchKernelGGL(pack_direct_dgrad_kernel, g, b, 0, st, W, out, Cout, Ctot, m, ldw, krows, hid, 1); break;
-    case 4: hipLaunchKernelGGL(pack_direct_dgrad_kernel, g, b, 0, st, W, out, Cout, Ctot, m, ldw, krows, hid, 0); break;
-    default: return RSIS_ERR_ARG;
-  }
+  if (mode < 0 || mode > 4) return RSIS_ERR_ARG;
+  hipLaunchKernelGGL(pack_kernel, g, b, 0, st, mode, W, out, Cout, Ctot, ks * ks, m, ldw, krows, hid);
   return rsis_check_launch();
 }

@@ -4,6 +4,9 @@ PyTorch is plumbing here (device memory, streams, the autograd tape); every arit
 the hand-written gfx950 kernels.  There is no CPU/eager fallback: the ops raise if the library is missing or a
 tensor is not a CUDA fp32 tensor.
 """
+import ctypes
+import weakref
+
 import torch
 
 from . import _lib
@@ -29,6 +32,49 @@ DIRECT_GRAD = [False]
 def _direct_target(param):
     g = param.grad if DIRECT_GRAD[0] and param is not None else None
     return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.is_cuda) else None
+
+
+_PACKS = weakref.WeakSet()       # every PackedConv that holds a packed copy
+_BATCH = {"sig": None, "jobs": None, "n": 0, "blocks": 0}
+
+
+def repack_all():
+    """Rebuild every packed weight copy in ONE launch (rsis_conv_pack_batch) -- call after the optimizer step.  Without it
+    each PackedConv repacks lazily at its next use: ~240 launches of ~5 us per training step."""
+    L = lib()
+    todo = []
+    for p in list(_PACKS):
+        w = p._refs[0]() if p._refs is not None else None
+        if w is None or not w.is_cuda:
+            continue
+        b = p._refs[1]() if p._refs[1] is not None else None
+        if p.wp is not None and p._key_f is not None:
+            todo.append((p, w, b, p.wp, 0))
+        if p.wd is not None and p._key_d is not None:
+            todo.append((p, w, b, p.wd, 1))
+    if not todo:
+        return
+    sig = tuple((id(p), w.data_ptr(), out.data_ptr(), d) for p, w, _b, out, d in todo)
+    if _BATCH["sig"] != sig:                       # (re)build the device-side job table: pointers are stable across steps
+        jobs = (_lib.PackJob * len(todo))()
+        blocks = 0
+        for i, (p, w, _b, out, d) in enumerate(todo):
+            jobs[i] = p._job(w, out, d)
+            nb = L.rsis_conv_pack_job_fill(ctypes.byref(jobs[i]))
+            if nb < 0:
+                raise _lib.RsisHipError("rsis_conv_pack_job_fill rejected a pack job")
+            jobs[i].block_begin = blocks
+            blocks += nb
+        raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(todo[0][1].device)
+        _BATCH.update(sig=sig, jobs=raw, n=len(todo), blocks=blocks)
+    check(L.rsis_conv_pack_batch(ptr(_BATCH["jobs"]), _BATCH["n"], _BATCH["blocks"], stream()), "rsis_conv_pack_batch")
+    for p, w, b, _out, d in todo:
+        if d == 0:
+            p._key_f = p._key(w) + ((b._version, b.data_ptr()) if b is not None else ())
+            if b is not None and p.lstm_hid > 0:
+                p.bias_p = b.detach().view(4, p.lstm_hid).t().contiguous().view(-1)
+        else:
+            p._key_d = p._key(w)
 
 
 def bump_weight_epoch():
@@ -57,9 +103,22 @@ class PackedConv(object):
         self.wp = None
         self.wd = None
         self.bias_p = None
+        self._refs = None
 
     def _key(self, w):
         return (_WEIGHT_EPOCH[0], w._version, w.data_ptr())
+
+    def _job(self, w, out, dgrad):
+        j = _lib.PackJob()
+        j.W, j.out, j.dgrad = w.data_ptr(), out.data_ptr(), int(dgrad)
+        j.Cout, j.Ctot, j.ks, j.stride, j.pad = w.shape[0], w.shape[1], self.ks, self.stride, self.pad
+        j.nseg, j.lstm_hid = len(self.segs), self.lstm_hid
+        off = 0
+        for i, c in enumerate(self.segs):
+            j.Cseg[i] = c
+            j.Coff[i] = self.offs[i] if self.offs is not None else off
+            off += c
+        return j
 
     def _seg_args(self):
         return len(self.segs), int_array(self.segs), (int_array(self.offs) if self.offs is not None else None)
@@ -78,6 +137,8 @@ class PackedConv(object):
             if bias is not None and self.lstm_hid > 0:
                 self.bias_p = bias.detach().view(4, self.lstm_hid).t().contiguous().view(-1)
             self._key_f = key
+            self._refs = (weakref.ref(w), weakref.ref(bias) if bias is not None else None)
+            _PACKS.add(self)
         return self.wp
 
     def dgrad(self, w):
@@ -92,6 +153,9 @@ class PackedConv(object):
             check(L.rsis_conv_pack_dgrad(ptr(w.detach()), ptr(self.wd), Cout, Ctot, self.ks, self.stride, self.pad, nseg, segs, offs,
                                          self.lstm_hid, stream()), "rsis_conv_pack_dgrad")
             self._key_d = key
+            if self._refs is None:
+                self._refs = (weakref.ref(w), None)
+            _PACKS.add(self)
         return self.wd
 
 

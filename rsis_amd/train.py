@@ -136,6 +136,8 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
         dec_opt.step()                                                # :185
         if args.update_encoder:
             enc_opt.step()                                            # :186-187
+        if x.is_cuda:
+            ops.repack_all()                                          # every packed weight copy in one launch
 
     losses = [loss.detach(), loss_mask_iou.detach(), loss_stop.detach(), loss_class.detach()]
     if sync_losses:

@@ -288,3 +288,35 @@ def test_softiou_sums_and_matched_loss(B, T, G, N):
     (got * w.cuda()).sum().backward()
     assert_close("matched", got, ref_cost, 2e-6, 1e-5)
     assert_close("dlogits", ld.grad, lg.grad, 1e-6 * max(1.0, float(lg.grad.abs().max()) * 1e3), 1e-4)
+
+
+@pytest.mark.gpu
+def test_repack_all_equals_lazy_packs():
+    """rsis_conv_pack_batch (one launch for every packed copy) must write exactly what the per-conv pack entry points write"""
+    from rsis_amd import ops
+    cfgs = [  # (Cout, Ctot, ks, stride, pad, segs, offs, lstm_hid)
+        (64, 48, 3, 1, 1, [16, 32], None, 0), (256, 64, 1, 1, 0, [64], None, 0), (64, 3, 7, 2, 3, [3], None, 0),
+        (40, 24, 3, 2, 1, [24], None, 0), (128, 56, 3, 1, 1, [24, 8], [0, 48], 32), (130, 129, 3, 1, 1, [129], None, 0),
+        (512, 256, 1, 2, 0, [256], None, 0)]
+    rng = np.random.default_rng(17)
+    packs, weights, biases = [], [], []
+    for Cout, Ctot, ks, stride, pad, segs, offs, hid in cfgs:
+        w = torch.from_numpy(rng.normal(0, 1, (Cout, Ctot, ks, ks)).astype(np.float32)).cuda()
+        b = torch.from_numpy(rng.normal(0, 1, (Cout,)).astype(np.float32)).cuda() if hid else None
+        p = ops.PackedConv(ks, segs, lstm_hid=hid, stride=stride, pad=pad, offs=offs)
+        p.fwd(w, b)
+        p.dgrad(w)
+        packs.append(p); weights.append(w); biases.append(b)
+    for w in weights:
+        w.mul_(-1.5).add_(0.25)                      # "optimizer step"
+    ops.bump_weight_epoch()
+    ops.repack_all()
+    torch.cuda.synchronize()
+    for (Cout, Ctot, ks, stride, pad, segs, offs, hid), p, w, b in zip(cfgs, packs, weights, biases):
+        key_f, key_d = p._key_f, p._key_d
+        got_f, got_d = p.fwd(w, b).clone(), p.dgrad(w).clone()
+        assert p._key_f == key_f and p._key_d == key_d, "repack_all must leave the caches valid (no lazy repack afterwards)"
+        q = ops.PackedConv(ks, segs, lstm_hid=hid, stride=stride, pad=pad, offs=offs)
+        assert torch.equal(got_f, q.fwd(w, b)) and torch.equal(got_d, q.dgrad(w)), (Cout, Ctot, ks, stride)
+        if hid:
+            assert torch.equal(p.bias_p, q.bias_p)
