@@ -150,6 +150,17 @@ int rsis_softiou_sums(const float* logits, const float* y, float* S, int B, int 
 int rsis_softiou_bwd(const float* logits, const float* y, const long long* perm, int perm_ld, const float* ca, const float* cb,
                      float* dlogits, int B, int T, int G, long N, void* stream);
 
+/* ---- class / stop heads of one decoder timestep (model.py:169-182): side = channel concat (by pointer) of nside <= 5 vectors
+ * side[i][B][Cside[i]] (the global max-pools of the hidden states); class_probs[B][ncls] = softmax(Wc side + bc) with
+ * Wc[ncls][K], K = sum Cside; stop[B] = Ws . side + bs (a logit).  rsis_heads_bwd: dside[i][B][Cside[i]] (any pointer may be
+ * null) from dprobs[B][ncls] / dstop[B] (either may be null = zero), and dWc, dbc, dWs, dbs are ACCUMULATED into (null = skip).
+ * K <= 2048, ncls <= 64. ---- */
+int rsis_heads_fwd(const float* const* side, const int* Cside, int nside, int B, const float* Wc, const float* bc, int ncls,
+                   const float* Ws, const float* bs, float* class_probs, float* stop, void* stream);
+int rsis_heads_bwd(const float* const* side, const int* Cside, int nside, int B, const float* Wc, int ncls, const float* Ws,
+                   const float* class_probs, const float* dprobs, const float* dstop, float* const* dside, float* dWc, float* dbc,
+                   float* dWs, float* dbs, void* stream);
+
 /* ---- inference post-processing of predicted masks (eval.py:96-127 resize_mask + pycocotools mask.encode; RLE semantics of
  * src/coco/common/maskApi.c:32-41,196-209) ----
  * rsis_mask_resize_threshold: prob[n][Hm][Wm] fp32 -> seg[n][w][h] uint8 (COLUMN-major h x w masks: align-corners bilinear

@@ -49,6 +49,8 @@ SIGNATURES = {
     "rsis_maxpool3x3s2_fwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "rsis_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "rsis_assign_min_cost": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "rsis_heads_fwd": (_i, [_vpp, _ip, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rsis_heads_bwd": (_i, [_vpp, _ip, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vpp, _vp, _vp, _vp, _vp, _vp]),
     "rsis_softiou_sums": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _vp]),
     "rsis_softiou_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _l, _vp]),
     "rsis_mask_resize_threshold": (_i, [_vp, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _i, _i, _vp]),
@@ -99,7 +101,7 @@ def stream():
 def ptr_array(tensors):
     arr = (ctypes.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
-        arr[i] = t.data_ptr()
+        arr[i] = t.data_ptr() if t is not None else None
     return arr
 
 

@@ -36,6 +36,10 @@ int rsis_l_mask_resize_threshold(const float*, int, int, int, const unsigned cha
                                  int, int, hipStream_t);
 int rsis_l_rle_encode(const unsigned char*, int, long, unsigned int*, int, int*, hipStream_t);
 int rsis_l_rle_to_string(const unsigned int*, int, char*, int);
+int rsis_l_heads_fwd(const float* const*, const int*, int, int, const float*, const float*, int, const float*, const float*, float*, float*,
+                     hipStream_t);
+int rsis_l_heads_bwd(const float* const*, const int*, int, int, const float*, int, const float*, const float*, const float*, const float*,
+                     float* const*, float*, float*, float*, float*, hipStream_t);
 int rsis_l_softiou_sums(const float*, const float*, float*, int, int, int, long, hipStream_t);
 int rsis_l_softiou_bwd(const float*, const float*, const long long*, int, const float*, const float*, float*, int, int, int, long,
                        hipStream_t);
@@ -360,4 +364,17 @@ int rsis_rle_encode(const unsigned char* masks, int n, long len, unsigned int* c
 int rsis_rle_to_string(const unsigned int* counts, int m, char* out, int cap) {
   if (!counts || !out || m < 0 || cap < 1) return -1;
   return rsis_l_rle_to_string(counts, m, out, cap);
+}
+
+int rsis_heads_fwd(const float* const* side, const int* Cside, int nside, int B, const float* Wc, const float* bc, int ncls,
+                   const float* Ws, const float* bs, float* class_probs, float* stop, void* stream) {
+  if (!side || !Cside || !Wc || !bc || !Ws || !bs || !class_probs || !stop || B < 1) return RSIS_ERR_ARG;
+  return rsis_l_heads_fwd(side, Cside, nside, B, Wc, bc, ncls, Ws, bs, class_probs, stop, (hipStream_t)stream);
+}
+
+int rsis_heads_bwd(const float* const* side, const int* Cside, int nside, int B, const float* Wc, int ncls, const float* Ws,
+                   const float* class_probs, const float* dprobs, const float* dstop, float* const* dside, float* dWc, float* dbc,
+                   float* dWs, float* dbs, void* stream) {
+  if (!side || !Cside || !Wc || !Ws || !class_probs || B < 1) return RSIS_ERR_ARG;
+  return rsis_l_heads_bwd(side, Cside, nside, B, Wc, ncls, Ws, class_probs, dprobs, dstop, dside, dWc, dbc, dWs, dbs, (hipStream_t)stream);
 }

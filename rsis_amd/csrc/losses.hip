@@ -96,3 +96,118 @@ int rsis_l_softiou_bwd(const float* logits, const float* y, const long long* per
                      N / 4, total);
   return rsis_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Class / stop heads of one decoder timestep (reference src/modules/model.py:169-182): side = cat of the five global-max-pool
+// vectors (248 features at hidden 128) -> class_probs = softmax(fc_class(side)), stop = fc_stop(side).  ~20 tiny launches
+// per timestep in eager form (cat, 2 addmm, softmax; backward: softmax_backward, 4 mm, 5 slice copies, 4 parameter adds): one
+// block per image here, the concatenation is by pointer, the backward accumulates the parameter gradients with atomics.
+// ------------------------------------------------------------------------------------------------
+#define HEADS_MAXK 2048
+#define HEADS_MAXC 64
+struct HeadSides { const float* p[5]; float* d[5]; int C[5]; int n; };
+
+__device__ __forceinline__ void heads_load_side(const HeadSides& s, int b, float* sv) {
+  int base = 0;
+  for (int i = 0; i < s.n; ++i) {
+    for (int k = threadIdx.x; k < s.C[i]; k += blockDim.x) sv[base + k] = s.p[i][(size_t)b * s.C[i] + k];
+    base += s.C[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void heads_fwd_kernel(HeadSides s, int K, const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                        int ncls, const float* __restrict__ Ws, const float* __restrict__ bs,
+                                                        float* __restrict__ probs, float* __restrict__ stop) {
+  __shared__ float sv[HEADS_MAXK];
+  __shared__ float lg[HEADS_MAXC + 1];
+  const int b = blockIdx.x;
+  heads_load_side(s, b, sv);
+  __syncthreads();
+  // one wave-quarter (16 lanes) per output row: rows 0..ncls-1 = fc_class, row ncls = fc_stop
+  const int row = threadIdx.x >> 4, sub = threadIdx.x & 15;
+  for (int r = row; r <= ncls; r += 16) {
+    const float* w = r < ncls ? Wc + (size_t)r * K : Ws;
+    float acc = 0.f;
+    for (int k = sub; k < K; k += 16) acc = fmaf(w[k], sv[k], acc);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_down(acc, o, 16);
+    if (sub == 0) lg[r] = acc + (r < ncls ? bc[r] : bs[0]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = lg[0];
+    for (int c = 1; c < ncls; ++c) m = fmaxf(m, lg[c]);
+    float z = 0.f;
+    for (int c = 0; c < ncls; ++c) { const float e = expf(lg[c] - m); lg[c] = e; z += e; }
+    for (int c = 0; c < ncls; ++c) probs[(size_t)b * ncls + c] = lg[c] / z;
+    stop[b] = lg[ncls];
+  }
+}
+
+__global__ __launch_bounds__(256) void heads_bwd_kernel(HeadSides s, int K, const float* __restrict__ Wc, int ncls,
+                                                        const float* __restrict__ Ws, const float* __restrict__ probs,
+                                                        const float* __restrict__ dprobs, const float* __restrict__ dstop,
+                                                        float* __restrict__ dWc, float* __restrict__ dbc, float* __restrict__ dWs,
+                                                        float* __restrict__ dbs) {
+  __shared__ float sv[HEADS_MAXK];
+  __shared__ float dl[HEADS_MAXC + 1];     // d logits of fc_class, then d stop
+  const int b = blockIdx.x;
+  heads_load_side(s, b, sv);
+  if (threadIdx.x == 0) {
+    float dot = 0.f;
+    if (dprobs)
+      for (int c = 0; c < ncls; ++c) dot += dprobs[(size_t)b * ncls + c] * probs[(size_t)b * ncls + c];
+    for (int c = 0; c < ncls; ++c)          // softmax backward: p * (g - sum g p)
+      dl[c] = dprobs ? probs[(size_t)b * ncls + c] * (dprobs[(size_t)b * ncls + c] - dot) : 0.f;
+    dl[ncls] = dstop ? dstop[b] : 0.f;
+  }
+  __syncthreads();
+  // d side[k] = sum_c dl[c] * Wc[c][k] + dstop * Ws[k]   (coalesced along k), and the parameter gradients
+  int base = 0;
+  for (int i = 0; i < s.n; ++i) {
+    for (int k = threadIdx.x; k < s.C[i]; k += blockDim.x) {
+      const int kk = base + k;
+      float acc = dl[ncls] * Ws[kk];
+      for (int c = 0; c < ncls; ++c) acc = fmaf(dl[c], Wc[(size_t)c * K + kk], acc);
+      if (s.d[i]) s.d[i][(size_t)b * s.C[i] + k] = acc;
+    }
+    base += s.C[i];
+  }
+  for (int e = threadIdx.x; e < (ncls + 1) * K; e += blockDim.x) {
+    const int r = e / K, k = e - r * K;
+    const float g = dl[r] * sv[k];
+    if (r < ncls) { if (dWc) atomicAdd(dWc + (size_t)r * K + k, g); }
+    else if (dWs) atomicAdd(dWs + k, g);
+  }
+  if (threadIdx.x <= ncls) {
+    if (threadIdx.x < ncls) { if (dbc) atomicAdd(dbc + threadIdx.x, dl[threadIdx.x]); }
+    else if (dbs) atomicAdd(dbs, dl[ncls]);
+  }
+}
+
+static int heads_sides(HeadSides& s, const float* const* side, float* const* dside, const int* C, int n) {
+  if (n < 1 || n > 5) return -1;
+  int K = 0;
+  s.n = n;
+  for (int i = 0; i < 5; ++i) { s.p[i] = i < n ? side[i] : nullptr; s.d[i] = (i < n && dside) ? dside[i] : nullptr; s.C[i] = i < n ? C[i] : 0; K += s.C[i]; }
+  return K;
+}
+
+int rsis_l_heads_fwd(const float* const* side, const int* C, int n, int B, const float* Wc, const float* bc, int ncls, const float* Ws,
+                     const float* bs, float* probs, float* stop, hipStream_t st) {
+  HeadSides s;
+  const int K = heads_sides(s, side, nullptr, C, n);
+  if (K < 1 || K > HEADS_MAXK || ncls < 1 || ncls > HEADS_MAXC) return RSIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(heads_fwd_kernel, dim3(B), dim3(256), 0, st, s, K, Wc, bc, ncls, Ws, bs, probs, stop);
+  return rsis_check_launch();
+}
+
+int rsis_l_heads_bwd(const float* const* side, const int* C, int n, int B, const float* Wc, int ncls, const float* Ws,
+                     const float* probs, const float* dprobs, const float* dstop, float* const* dside, float* dWc, float* dbc,
+                     float* dWs, float* dbs, hipStream_t st) {
+  HeadSides s;
+  const int K = heads_sides(s, side, dside, C, n);
+  if (K < 1 || K > HEADS_MAXK || ncls < 1 || ncls > HEADS_MAXC) return RSIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(heads_bwd_kernel, dim3(B), dim3(256), 0, st, s, K, Wc, ncls, Ws, probs, dprobs, dstop, dWc, dbc, dWs, dbs);
+  return rsis_check_launch();
+}

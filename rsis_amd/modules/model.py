@@ -108,6 +108,9 @@ class RSIS(nn.Module):
 
     def _heads(self, clstm_in, side_feats, hidden_list):
         out_mask = self.conv_out(clstm_in)                               # model.py:167
+        if self.dropout_cls == 0 and self.dropout_stop == 0 and ops.heads_supported(side_feats, self.fc_class, self.fc_stop):
+            class_probs, stop_probs = ops.heads(side_feats, self.fc_class, self.fc_stop)   # model.py:169-182 in one launch
+            return out_mask, class_probs, stop_probs, hidden_list
         side_feats = torch.cat(side_feats, 1).squeeze()                  # model.py:169 (drops the batch dim at B == 1)
         if self.dropout_cls > 0:
             class_feats = nn.functional.dropout(side_feats, self.dropout_cls, training=True)

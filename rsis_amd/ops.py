@@ -557,3 +557,59 @@ def softiou_matched(out_masks, y_mask, perm, S, e=1e-6):
     """(B, T) soft-IoU cost of every prediction against its matched ground-truth mask; differentiable w.r.t. out_masks."""
     y_mask, perm = _contig(y_mask), _contig(perm)
     return _SoftIoUMatchedFn.apply(out_masks, y_mask, perm, S, float(e))
+
+
+class _HeadsFn(torch.autograd.Function):
+    """class_probs, stop = softmax(fc_class(cat(sides))), fc_stop(cat(sides))  (reference model.py:169-182) in one launch each
+    way; the concatenation is by pointer and the parameter gradients accumulate in place when DIRECT_GRAD is on."""
+
+    @staticmethod
+    def forward(ctx, n, *tensors):
+        sides = [_contig(t).reshape(t.shape[0], -1) for t in tensors[:n]]
+        Wc, bc, Ws, bs = tensors[n:n + 4]
+        require_cuda_f32(Wc, bc, Ws, bs, *sides)
+        B, ncls = sides[0].shape[0], Wc.shape[0]
+        probs = torch.empty((B, ncls), dtype=torch.float32, device=Wc.device)
+        stop = torch.empty((B, 1), dtype=torch.float32, device=Wc.device)
+        check(lib().rsis_heads_fwd(ptr_array(sides), int_array([s.shape[1] for s in sides]), n, B, ptr(Wc.detach()), ptr(bc.detach()),
+                                   ncls, ptr(Ws.detach()), ptr(bs.detach()), ptr(probs), ptr(stop), stream()), "rsis_heads_fwd")
+        ctx.n = n
+        ctx.shapes = [tuple(t.shape) for t in tensors[:n]]
+        ctx.params = (Wc, bc, Ws, bs)
+        ctx.save_for_backward(probs, Wc, Ws, *sides)
+        return probs, stop
+
+    @staticmethod
+    def backward(ctx, dprobs, dstop):
+        probs, Wc, Ws = ctx.saved_tensors[:3]
+        sides = list(ctx.saved_tensors[3:])
+        n = ctx.n
+        B, ncls = probs.shape
+        dprobs = _contig(dprobs) if dprobs is not None else None
+        dstop = _contig(dstop) if dstop is not None else None
+        dsides = [torch.empty_like(s) if ctx.needs_input_grad[1 + i] else None for i, s in enumerate(sides)]
+        outs, tgts = [], []
+        for j, p in enumerate(ctx.params):
+            if ctx.needs_input_grad[1 + n + j]:
+                t = _direct_target(p)
+                tgts.append(t)
+                outs.append(t if t is not None else torch.zeros_like(p))
+            else:
+                tgts.append(None)
+                outs.append(None)
+        check(lib().rsis_heads_bwd(ptr_array(sides), int_array([s.shape[1] for s in sides]), n, B, ptr(Wc.detach()), ncls,
+                                   ptr(Ws.detach()), ptr(probs), ptr(dprobs), ptr(dstop), ptr_array(dsides), ptr(outs[0]),
+                                   ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), stream()), "rsis_heads_bwd")
+        grads = [d.reshape(sh) if d is not None else None for d, sh in zip(dsides, ctx.shapes)]
+        grads += [None if t is not None else o for t, o in zip(tgts, outs)]
+        return (None,) + tuple(grads)
+
+
+def heads_supported(sides, fc_class, fc_stop):
+    return (sides[0].is_cuda and sides[0].shape[0] >= 2 and len(sides) <= 5 and fc_class.weight.shape[1] <= 2048 and
+            fc_class.weight.shape[0] <= 64 and fc_stop.weight.shape[0] == 1 and fc_class.bias is not None and fc_stop.bias is not None)
+
+
+def heads(sides, fc_class, fc_stop):
+    """(class_probs (B, ncls), stop logits (B, 1)) of reference RSIS.forward's tail from the list of pooled side features"""
+    return _HeadsFn.apply(len(sides), *sides, fc_class.weight, fc_class.bias, fc_stop.weight, fc_stop.bias)

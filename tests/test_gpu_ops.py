@@ -320,3 +320,33 @@ def test_repack_all_equals_lazy_packs():
         assert torch.equal(got_f, q.fwd(w, b)) and torch.equal(got_d, q.dgrad(w)), (Cout, Ctot, ks, stride)
         if hid:
             assert torch.equal(p.bias_p, q.bias_p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Cs,ncls", [(2, [32, 16, 8, 4, 2], 7), (32, [128, 64, 32, 16, 8], 21), (3, [5], 2), (4, [100, 3, 9], 64)])
+def test_heads_fwd_bwd(B, Cs, ncls):
+    """fused class / stop heads (rsis_heads_fwd / _bwd) against model.py:169-182 in plain torch"""
+    from rsis_amd import ops
+    rng = np.random.default_rng(13)
+    K = sum(Cs)
+    sides = [torch.from_numpy(rng.normal(0, 1, (B, c, 1, 1)).astype(np.float32)).requires_grad_() for c in Cs]
+    fc_c, fc_s = torch.nn.Linear(K, ncls), torch.nn.Linear(K, 1)
+    side = torch.cat(sides, 1).squeeze(-1).squeeze(-1)
+    ref_p, ref_s = torch.softmax(fc_c(side), dim=1), fc_s(side)
+    gp = torch.from_numpy(rng.normal(0, 1, (B, ncls)).astype(np.float32))
+    gs = torch.from_numpy(rng.normal(0, 1, (B, 1)).astype(np.float32))
+    ((ref_p * gp).sum() + (ref_s * gs).sum()).backward()
+    import copy
+    dc, ds = copy.deepcopy(fc_c).cuda(), copy.deepcopy(fc_s).cuda()
+    for m in (dc, ds):
+        for p in m.parameters():
+            p.grad = None
+    sd = [_dev(s.detach().clone().requires_grad_()) for s in sides]
+    p, s = ops.heads(sd, dc, ds)
+    ((p * gp.cuda()).sum() + (s * gs.cuda()).sum()).backward()
+    assert_close("probs", p, ref_p, 1e-6, 1e-5)
+    assert_close("stop", s, ref_s, 2e-6, 1e-5)
+    for a, b in zip(sd, sides):
+        assert_close("dside", a.grad, b.grad, 2e-6, 1e-4)
+    for a, b in ((dc.weight, fc_c.weight), (dc.bias, fc_c.bias), (ds.weight, fc_s.weight), (ds.bias, fc_s.bias)):
+        assert_close("dparam", a.grad, b.grad, 5e-6, 1e-4)
