@@ -90,6 +90,8 @@ int rsis_upsample_bilinear_ac_bwd(const float* dy, float* dx, long BC, int Hi, i
 /* ---- nn.MaxPool2d(full map) side features (model.py:143): y[BC], argmax[BC] (int32 flat index) ---- */
 int rsis_global_maxpool_fwd(const float* x, float* y, int* argmax, long BC, int HW, void* stream);
 int rsis_global_maxpool_bwd(const float* dy, const int* argmax, float* dx, long BC, int HW, void* stream);
+/* dx[bc][argmax[bc]] += dy[bc] (dx already holds the gradient of another consumer of the same tensor) */
+int rsis_global_maxpool_bwd_add(const float* dy, const int* argmax, float* dx, long BC, int HW, void* stream);
 
 /* ---- nn.BatchNorm2d (+ residual add + ReLU of the bottleneck) (model.py:50-54,59-63; torchvision trunk) ----
  * train bit0: batch statistics, running-stat update (momentum, unbiased var), saves mean / rstd for the backward;

@@ -44,6 +44,7 @@ SIGNATURES = {
     "rsis_upsample_bilinear_ac_bwd": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "rsis_global_maxpool_fwd": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "rsis_global_maxpool_bwd": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
+    "rsis_global_maxpool_bwd_add": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "rsis_bn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp]),
     "rsis_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_maxpool3x3s2_fwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),

@@ -30,6 +30,7 @@ int rsis_l_maxpool_bwd(const float*, const unsigned char*, float*, long, int, in
 int rsis_l_channel_sum(const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_adam(float*, const float*, float*, float*, long, float, float, float, float, float, int, float, hipStream_t);
 int rsis_l_assign(const float*, long long*, int, int, int, hipStream_t);
+int rsis_l_gmax_bwd_add(const float*, const int*, float*, long, int, hipStream_t);
 int rsis_l_pack_batch(const rsis_pack_job*, int, int, hipStream_t);
 int rsis_l_pack_chunk();
 int rsis_l_mask_resize_threshold(const float*, int, int, int, const unsigned char*, float, unsigned char*, unsigned char*, unsigned int*,
@@ -297,6 +298,10 @@ int rsis_global_maxpool_fwd(const float* x, float* y, int* argmax, long BC, int 
 int rsis_global_maxpool_bwd(const float* dy, const int* argmax, float* dx, long BC, int HW, void* stream) {
   if (!dy || !dx || !argmax) return RSIS_ERR_ARG;
   return rsis_l_gmax_bwd(dy, argmax, dx, BC, HW, (hipStream_t)stream);
+}
+int rsis_global_maxpool_bwd_add(const float* dy, const int* argmax, float* dx, long BC, int HW, void* stream) {
+  if (!dy || !dx || !argmax) return RSIS_ERR_ARG;
+  return rsis_l_gmax_bwd_add(dy, argmax, dx, BC, HW, (hipStream_t)stream);
 }
 int rsis_bn_fwd(const float* x, const float* res, float* y, double* stats, const float* gamma, const float* beta,
                 float* running_mean, float* running_var, float* save_mean, float* save_rstd, int B, int C, int HW,

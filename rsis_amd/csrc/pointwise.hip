@@ -238,6 +238,13 @@ __global__ void global_maxpool_bwd_kernel(const float* __restrict__ dy, const in
   }
 }
 
+// dx[bc][argmax[bc]] += dy[bc]: the max-pool gradient added into a gradient that already holds another path's contribution
+__global__ void global_maxpool_bwd_add_kernel(const float* __restrict__ dy, const int* __restrict__ arg, float* __restrict__ dx,
+                                              int HW, long BC) {
+  const long bc = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (bc < BC) dx[bc * HW + arg[bc]] += dy[bc];
+}
+
 // ------------------------------------------------------------------------------------------------
 // BatchNorm2d (stock semantics: eps, momentum, biased var for normalisation, unbiased for running_var)
 //   fused with the optional residual add and ReLU of the ResNet bottleneck.
@@ -651,6 +658,10 @@ int rsis_l_bn_bwd(const float* dy, const float* x, const float* y, const float* 
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, mean, rstd, stats, C, HW, N, relu);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, mean, rstd, gamma, stats, dx, dres, dgamma,
                      dbeta, C, HW, N, relu, accum);
+  return rsis_check_launch();
+}
+int rsis_l_gmax_bwd_add(const float* dy, const int* arg, float* dx, long BC, int HW, hipStream_t st) {
+  hipLaunchKernelGGL(global_maxpool_bwd_add_kernel, dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, st, dy, arg, dx, HW, BC);
   return rsis_check_launch();
 }
 int rsis_l_maxpool_fwd(const float* x, float* y, unsigned char* arg, long BC, int H, int W, int Ho, int Wo, hipStream_t st) {

@@ -283,6 +283,50 @@ class _UpsampleIntoFn(torch.autograd.Function):
         return None, None, dx
 
 
+class _SideUpFn(torch.autograd.Function):
+    """The two consumers of a level's hidden state besides the recurrence (model.py:143,149-150,163-164): the global max-pool
+    side feature and the align-corners upsample into the next level, as ONE autograd node -- the backward writes the upsample
+    gradient and adds the pooled gradient at the arg-max pixel in place, instead of materialising a mostly-zero map and
+    letting autograd add the two."""
+
+    @staticmethod
+    def forward(ctx, tl, t, x, size):
+        x = x if x.is_contiguous() else x.contiguous()
+        B, C, Hi, Wi = x.shape
+        L = lib()
+        side = torch.empty((B, C, 1, 1), dtype=torch.float32, device=x.device)
+        arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
+        check(L.rsis_global_maxpool_fwd(ptr(x), ptr(side), ptr(arg), B * C, Hi * Wi, stream()), "rsis_global_maxpool_fwd")
+        if tl is not None:
+            y = tl.UP[t]                      # straight into the next level's stacked buffer
+        else:
+            y = torch.empty((B, C, size[0], size[1]), dtype=torch.float32, device=x.device)
+        Ho, Wo = y.shape[-2], y.shape[-1]
+        check(L.rsis_upsample_bilinear_ac_fwd(ptr(x), ptr(y), B * C, Hi, Wi, Ho, Wo, stream()), "rsis_upsample_fwd")
+        ctx.dims = (B, C, Hi, Wi, Ho, Wo)
+        ctx.save_for_backward(arg)
+        return side, y
+
+    @staticmethod
+    def backward(ctx, dside, dy):
+        (arg,) = ctx.saved_tensors
+        B, C, Hi, Wi, Ho, Wo = ctx.dims
+        L = lib()
+        dx = None
+        if dy is not None:
+            dy = dy if dy.is_contiguous() else dy.contiguous()
+            dx = torch.empty((B, C, Hi, Wi), dtype=torch.float32, device=dy.device)
+            check(L.rsis_upsample_bilinear_ac_bwd(ptr(dy), ptr(dx), B * C, Hi, Wi, Ho, Wo, stream()), "rsis_upsample_bwd")
+        if dside is not None:
+            dside = dside if dside.is_contiguous() else dside.contiguous()
+            if dx is None:
+                dx = torch.empty((B, C, Hi, Wi), dtype=torch.float32, device=dside.device)
+                check(L.rsis_global_maxpool_bwd(ptr(dside), ptr(arg), ptr(dx), B * C, Hi * Wi, stream()), "rsis_global_maxpool_bwd")
+            else:
+                check(L.rsis_global_maxpool_bwd_add(ptr(dside), ptr(arg), ptr(dx), B * C, Hi * Wi, stream()), "rsis_global_maxpool_bwd_add")
+        return None, None, dx, None
+
+
 def decoder_levels(decoder, skip_feats, prev_hidden_list):
     """The 5-level ConvLSTM pyramid of RSIS.forward (model.py:129-165) with hoisting; returns (hidden_list, side_feats,
     last up-sampled hidden) or None when the fused path does not apply to this call."""
@@ -306,14 +350,12 @@ def decoder_levels(decoder, skip_feats, prev_hidden_list):
         h, c = _StepFn.apply(tl, t, up, h_prev, c_prev, tl.G, cell.Gates.weight)
         tl.last_h, tl.last_c = h, c
         hidden_list.append([h, c])                                       # model.py:137
-        side_feats.append(ops.global_maxpool(h))                         # model.py:143
         if i + 1 < n_levels:
             nxt = tape.levels[i + 1]
-            if nxt.UP is not None and t < nxt.cap:
-                up = _UpsampleIntoFn.apply(nxt, t, h)                    # model.py:149-150 (into the stacked buffer)
-            else:
-                up = ops.upsample_bilinear_ac(h, skip_feats[i + 1].shape[-2:])
+            into = nxt if (nxt.UP is not None and t < nxt.cap) else None
+            side, up = _SideUpFn.apply(into, t, h, tuple(skip_feats[i + 1].shape[-2:]))     # model.py:143,149-150
         else:
-            up = ops.upsample_bilinear_ac(h, (h.shape[-2] * 2, h.shape[-1] * 2))   # model.py:163-164
+            side, up = _SideUpFn.apply(None, t, h, (h.shape[-2] * 2, h.shape[-1] * 2))      # model.py:143,163-164
+        side_feats.append(side)
     tape.t += 1
     return hidden_list, side_feats, up
