@@ -78,10 +78,11 @@ int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B,
                       const float* bias_packed, const float* addend, const float* c_prev, float* h_out, float* c_out,
                       float* act_out, int hid, int ks, int pad, int tile, void* stream);
 
-/* ---- ConvLSTMCell pointwise backward: (dh, dc_next, saved act, c_prev, c) -> da (gate pre-activation grads,
- * interleaved rows) and dc_prev.  dh / dc_next / c_prev / dc_prev / da_sum may be NULL. da_sum += da if given. ---- */
-int rsis_convlstm_bwd_gates(const float* dh, const float* dc_next, const float* act, const float* c_prev, const float* c,
-                            float* da, float* dc_prev, float* da_sum, int B, int hid, int HW, void* stream);
+/* ---- ConvLSTMCell pointwise backward: (dh + dh2, dc_next, saved act, c_prev, c) -> da (gate pre-activation grads,
+ * interleaved rows) and dc_prev.  dh / dh2 / dc_next / c_prev / dc_prev / da_sum may be NULL. da_sum += da if given.
+ * dh2: the gradient reaching h through a second consumer (the next timestep's recurrence), summed in the kernel. ---- */
+int rsis_convlstm_bwd_gates(const float* dh, const float* dh2, const float* dc_next, const float* act, const float* c_prev,
+                            const float* c, float* da, float* dc_prev, float* da_sum, int B, int hid, int HW, void* stream);
 
 /* ---- nn.UpsamplingBilinear2d(size) = bilinear, align_corners=True (model.py:149,163; train.py:96; test.py:39) ---- */
 int rsis_upsample_bilinear_ac_fwd(const float* x, float* y, long BC, int Hi, int Wi, int Ho, int Wo, void* stream);

@@ -39,7 +39,7 @@ SIGNATURES = {
     "rsis_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsis_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_convlstm_fwd": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "rsis_convlstm_bwd_gates": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "rsis_convlstm_bwd_gates": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "rsis_upsample_bilinear_ac_fwd": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "rsis_upsample_bilinear_ac_bwd": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "rsis_global_maxpool_fwd": (_i, [_vp, _vp, _vp, _l, _i, _vp]),

@@ -15,7 +15,7 @@ int rsis_l_c1_dgrad(const float*, const float*, int, float*, int, int, int, int,
 int rsis_l_c1_wgrad(const float*, const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_pack(int, const float*, float*, int, int, int, int, const int*, const int*, int, int, int, hipStream_t);
 
-int rsis_l_lstm_bwd(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
+int rsis_l_lstm_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
                     hipStream_t);
 int rsis_l_upsample_fwd(const float*, float*, long, int, int, int, int, hipStream_t);
 int rsis_l_upsample_bwd(const float*, float*, long, int, int, int, int, hipStream_t);
@@ -277,10 +277,10 @@ int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B,
   return rsis_launch_conv_igemm(a, ks, false, 1, tile, (hipStream_t)stream);
 }
 
-int rsis_convlstm_bwd_gates(const float* dh, const float* dc_next, const float* act, const float* c_prev, const float* c,
-                            float* da, float* dc_prev, float* da_sum, int B, int hid, int HW, void* stream) {
+int rsis_convlstm_bwd_gates(const float* dh, const float* dh2, const float* dc_next, const float* act, const float* c_prev,
+                            const float* c, float* da, float* dc_prev, float* da_sum, int B, int hid, int HW, void* stream) {
   if (!act || !c || !da) return RSIS_ERR_ARG;
-  return rsis_l_lstm_bwd(dh, dc_next, act, c_prev, c, da, dc_prev, da_sum, B, hid, HW, (hipStream_t)stream);
+  return rsis_l_lstm_bwd(dh, dh2, dc_next, act, c_prev, c, da, dc_prev, da_sum, B, hid, HW, (hipStream_t)stream);
 }
 
 int rsis_upsample_bilinear_ac_fwd(const float* x, float* y, long BC, int Hi, int Wi, int Ho, int Wo, void* stream) {

@@ -11,7 +11,7 @@
 // act / da use gate-interleaved rows (4*j+gate).  Optionally accumulates da into da_sum (for the hoisted,
 // time-invariant skip channels: sum_t da_t feeds ONE dgrad/wgrad per iteration).
 // ------------------------------------------------------------------------------------------------
-__global__ void lstm_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc_next,
+__global__ void lstm_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dh2, const float* __restrict__ dc_next,
                                 const float* __restrict__ act, const float* __restrict__ c_prev,
                                 const float* __restrict__ c, float* __restrict__ da, float* __restrict__ dc_prev,
                                 float* __restrict__ da_sum, int hid, int HW, long total) {
@@ -21,7 +21,7 @@ __global__ void lstm_bwd_kernel(const float* __restrict__ dh, const float* __res
     const long g0 = bj * 4 * HW + sp;     // (b*4*hid + 4*j)*HW + sp
     const float gi = act[g0], gf = act[g0 + HW], go = act[g0 + 2L * HW], gg = act[g0 + 3L * HW];
     const float tc = tanhf(c[e]);
-    const float dhv = dh ? dh[e] : 0.f;
+    const float dhv = (dh ? dh[e] : 0.f) + (dh2 ? dh2[e] : 0.f);   // dh2: a second consumer's gradient (the recurrence)
     float dcv = dhv * go * (1.f - tc * tc);
     if (dc_next) dcv += dc_next[e];
     const float cp = c_prev ? c_prev[e] : 0.f;
@@ -584,11 +584,11 @@ static inline int chan_splits(int C, long N) {
   return (int)s;
 }
 
-int rsis_l_lstm_bwd(const float* dh, const float* dc_next, const float* act, const float* c_prev, const float* c, float* da,
+int rsis_l_lstm_bwd(const float* dh, const float* dh2, const float* dc_next, const float* act, const float* c_prev, const float* c, float* da,
                     float* dc_prev, float* da_sum, int B, int hid, int HW, hipStream_t st) {
   const long total = (long)B * hid * HW;
-  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dh, dc_next, act, c_prev, c, da, dc_prev, da_sum,
-                     hid, HW, total);
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dh, dh2, dc_next, act, c_prev, c, da, dc_prev,
+                     da_sum, hid, HW, total);
   return rsis_check_launch();
 }
 static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }

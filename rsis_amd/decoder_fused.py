@@ -30,6 +30,7 @@ class LevelTape(object):
         self.hid = cell.hidden_size
         self.ks, self.pad = cell.kernel_size, cell.padding
         self.H = self.C = self.ACT = self.UP = self.DA = self.da_sum = None
+        self.DHP, self.dhp_t = None, -1      # gradient of h[dhp_t] through the recurrence, handed from step dhp_t+1 to step dhp_t
         self.G = None
         self.n_fwd = 0
         self.n_bwd = 0
@@ -41,6 +42,7 @@ class LevelTape(object):
         the whole iteration (stacked buffers + the encoder graph hanging off G) is only reclaimed by Python's cyclic GC,
         i.e. tens of GB per step pile up until a gen-2 collection stalls the host for seconds."""
         self.H = self.C = self.ACT = self.UP = self.DA = self.da_sum = None
+        self.DHP, self.dhp_t = None, -1
         self.G = self.last_h = self.last_c = None
 
     def alloc_forward(self, B, Hh, Ww, device, need_grad):
@@ -150,6 +152,9 @@ class _StepFn(torch.autograd.Function):
         ctx.tl, ctx.t, ctx.stacked = tl, t, stacked
         ctx.wparam = weight
         ctx.has_up, ctx.has_state = up is not None, h_prev is not None
+        # the recurrent input is the tape's own previous output: its gradient is handed over through tl.DHP and summed inside
+        # the next (earlier) step's gate-backward kernel instead of by an autograd add
+        ctx.handover = bool(stacked and h_prev is not None and t > 0 and h_prev.data_ptr() == tl.H[t - 1].data_ptr())
         if need_grad:
             if stacked:
                 tl.n_fwd = max(tl.n_fwd, t + 1)
@@ -184,13 +189,19 @@ class _StepFn(torch.autograd.Function):
                 tl.da_sum = torch.zeros_like(act)
         B, _, H, W = c.shape
         dc_prev = torch.empty_like(c) if ctx.has_state else None
-        check(L.rsis_convlstm_bwd_gates(ptr(dh), ptr(dc), ptr(act), ptr(c_prev), ptr(c), ptr(da), ptr(dc_prev), ptr(tl.da_sum), B, hid,
-                                        H * W, stream()), "rsis_convlstm_bwd_gates(step)")
+        dh2 = tl.DHP if (ctx.stacked and tl.dhp_t == t) else None
+        tl.dhp_t = -1
+        check(L.rsis_convlstm_bwd_gates(ptr(dh), ptr(dh2), ptr(dc), ptr(act), ptr(c_prev), ptr(c), ptr(da), ptr(dc_prev), ptr(tl.da_sum),
+                                        B, hid, H * W, stream()), "rsis_convlstm_bwd_gates(step)")
         tl.n_bwd += 1
         d_up = dh_prev = None
         if srcs:
             wd = dyn.dgrad(weight)
             dxs = [torch.empty_like(s) for s in srcs]
+            if ctx.handover:
+                if tl.DHP is None:
+                    tl.DHP = torch.empty_like(srcs[-1])
+                dxs[-1] = tl.DHP
             check(L.rsis_conv2d_dgrad(ptr(da), B, 4 * hid, H, W, ptr(wd), dyn.cin, ks, 1, pad, ptr_array(dxs),
                                       int_array([s.shape[1] for s in srcs]), len(srcs), H, W, ops.FORCE_TILE[0], stream()),
                   "rsis_conv2d_dgrad(step)")
@@ -199,7 +210,10 @@ class _StepFn(torch.autograd.Function):
                 d_up = dxs[k]
                 k += 1
             if ctx.has_state:
-                dh_prev = dxs[k]
+                if ctx.handover:
+                    tl.dhp_t = t - 1          # consumed (and summed in-kernel) by step t-1's backward, which autograd runs next for this level
+                else:
+                    dh_prev = dxs[k]
         dW = dG = None
         Ctot = weight.shape[1]
         h_off = tl.c_up + tl.c_skip

@@ -294,7 +294,7 @@ class _ConvLSTMFn(torch.autograd.Function):
         dc = _contig(dc) if dc is not None else None
         da = torch.empty_like(act)
         dc_prev = torch.empty_like(c) if has_state else None
-        check(L.rsis_convlstm_bwd_gates(ptr(dh), ptr(dc), ptr(act), ptr(c_prev), ptr(c), ptr(da), ptr(dc_prev), None, B, hid, H * W,
+        check(L.rsis_convlstm_bwd_gates(ptr(dh), None, ptr(dc), ptr(act), ptr(c_prev), ptr(c), ptr(da), ptr(dc_prev), None, B, hid, H * W,
                                         stream()), "rsis_convlstm_bwd_gates")
         grads = [None] * (nx + 4)
         need_src = list(ctx.needs_input_grad[4:4 + nx]) + ([ctx.needs_input_grad[4 + nx]] if has_state else [])
