@@ -55,9 +55,12 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
 
 /* ---- nn.Conv2d backward-data (autograd of the above): dx for input channels [c_lo,c_hi) of the conv input, written
  * to ndst tensors dx[i] = [B][Cdx[i]][Hx][Wx] (the inverse of the channel concat). dy = [B][Cout][Hy][Wy].
- * Cin_packed = sum(Cseg) given to rsis_conv_pack_dgrad; sum(Cdx) <= Cin_packed (leading channels are produced). ---- */
+ * Cin_packed = sum(Cseg) given to rsis_conv_pack_dgrad; sum(Cdx) <= Cin_packed (leading channels are produced).
+ * addend (optional, ndst == 1, stride 1 only): dx[0] = dgrad + addend -- the gradient the same tensor receives through another
+ * consumer (the identity branch of a residual block), summed in the epilogue instead of by a separate pass. ---- */
 int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const float* Wd, int Cin_packed, int ks, int stride,
-                      int pad, float* const* dx, const int* Cdx, int ndst, int Hx, int Wx, int tile, void* stream);
+                      int pad, float* const* dx, const int* Cdx, int ndst, int Hx, int Wx, const float* addend, int tile,
+                      void* stream);
 
 /* ---- nn.Conv2d backward-weight: dW[Cout][Ctot][ks][ks] (reference layout) += corr(x, dy) for the source tensor
  * x = [B][Cs][H][W] that occupies input channels [c_off, c_off+Cs).  ACCUMULATES (fp32 atomics): zero dW first.

@@ -192,8 +192,10 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
 }
 
 int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const float* Wd, int Cin_packed, int ks, int stride,
-                      int pad, float* const* dx, const int* Cdx, int ndst, int Hx, int Wx, int tile, void* stream) {
+                      int pad, float* const* dx, const int* Cdx, int ndst, int Hx, int Wx, const float* addend, int tile,
+                      void* stream) {
   if (!dy || !Wd || !dx || !Cdx || ndst < 1 || ndst > RSIS_MAX_SRC) return RSIS_ERR_ARG;
+  if (addend && (ndst != 1 || stride != 1)) return RSIS_ERR_UNSUPPORTED;
   if (stride != 1 && stride != 2 && stride != 4) return RSIS_ERR_UNSUPPORTED;
   ConvArgs a = {};
   const float* srcs[1] = {dy};
@@ -206,16 +208,16 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const fl
   a.B = B; a.H = Hy; a.W = Wy; a.Ho = Hx; a.Wo = Wx; a.stride = stride; a.pad = pad; a.sshift = log2i(stride);
   if (ctot > Cin_packed) return RSIS_ERR_ARG;
   a.ostride = 1; a.oH = Hx; a.oW = Wx; a.ksplit = 1;
-  a.wp = Wd; a.ldw = rsis_roundup(Cin_packed, RSIS_LDW_ALIGN); a.Cout = ctot; a.bias = nullptr; a.addend = nullptr;
+  a.wp = Wd; a.ldw = rsis_roundup(Cin_packed, RSIS_LDW_ALIGN); a.Cout = ctot; a.bias = nullptr; a.addend = addend;
   if (use_direct(ks, stride, pad)) {
     if (Hx != Hy || Wx != Wy) return RSIS_ERR_ARG;
-    if (Cout == 1 && ndst == 1 && Cin_packed == Cdx[0] && rsis_c1_supported(Cdx[0]))
+    if (Cout == 1 && ndst == 1 && Cin_packed == Cdx[0] && rsis_c1_supported(Cdx[0]) && !addend)
       return rsis_l_c1_dgrad(dy, Wd, a.ldw, dx[0], B, Cdx[0], Hx, Wx, (hipStream_t)stream);
     {  // deep-K data gradients on tiny maps (ConvLSTM level 0: 512 gate rows x 9 taps on 8x8): split over the channel chunks
       static const bool splitk_ok = !(getenv("RSIS_CONV_SPLITK") && getenv("RSIS_CONV_SPLITK")[0] == '0');
       const int nq = (Cout + RSIS_CK - 1) / RSIS_CK;
       const long px_tiles = (long)B * rsis_cdiv(Hx, 8) * rsis_cdiv(Wx, Wx <= 8 ? 8 : 16);
-      if (splitk_ok && nq >= 32 && px_tiles * rsis_cdiv(ctot, 64) < 160) {
+      if (splitk_ok && !addend && nq >= 32 && px_tiles * rsis_cdiv(ctot, 64) < 160) {
         for (int i = 0; i < ndst; ++i)
           if (hipMemsetAsync(dx[i], 0, sizeof(float) * (size_t)B * Cdx[i] * Hx * Wx, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
         a.ksplit = 0;

@@ -260,6 +260,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       if (ostride > 1) { const int oho = osp / Wo; osp = (oho * ostride) * p.oW + (osp - oho * Wo) * ostride; }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
+        if (addend) {
+          // gradient hand-over (rsis_conv2d_dgrad addend) / fused add: all addend loads of the tile first, then the stores --
+          // a load -> add -> store chain per element would expose one memory round trip per accumulator register
+          float av[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            av[r] = co < Cout ? addend[((size_t)ob * Cd0 + co) * oHW + osp] : 0.f;     // (addend: single destination only)
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (co < Cout) d0[((size_t)ob * Cd0 + co) * oHW + osp] = acc[i][j][r] + av[r] + (bias ? bias[co] : 0.f);
+          }
+          continue;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -270,9 +286,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
           int cl = co, Cd = Cd0;
           if (co >= e1) { d = d1; cl = co - e1; Cd = Cd1; }
           if (co >= e2) { d = d2; cl = co - e2; Cd = Cd2; }
-          const size_t idx = ((size_t)ob * Cd + cl) * oHW + osp;
-          if (addend) v += addend[idx];
-          d[idx] = v;
+          d[((size_t)ob * Cd + cl) * oHW + osp] = v;
         }
       }
     }

@@ -102,7 +102,7 @@ class _HoistFn(torch.autograd.Function):
             wd = hoist.dgrad(weight)
             dskip = torch.empty_like(skip)
             check(L.rsis_conv2d_dgrad(ptr(dG), B, 4 * tl.hid, H, W, ptr(wd), hoist.cin, tl.ks, 1, tl.pad, ptr_array([dskip]),
-                                      int_array([Cs]), 1, H, W, ops.FORCE_TILE[0], stream()), "rsis_conv2d_dgrad(hoist)")
+                                      int_array([Cs]), 1, H, W, None, ops.FORCE_TILE[0], stream()), "rsis_conv2d_dgrad(hoist)")
         if ctx.needs_input_grad[2]:
             tgt = ops._direct_target(ctx.wparam)
             dW = tgt if tgt is not None else torch.zeros_like(weight)
@@ -203,7 +203,7 @@ class _StepFn(torch.autograd.Function):
                     tl.DHP = torch.empty_like(srcs[-1])
                 dxs[-1] = tl.DHP
             check(L.rsis_conv2d_dgrad(ptr(da), B, 4 * hid, H, W, ptr(wd), dyn.cin, ks, 1, pad, ptr_array(dxs),
-                                      int_array([s.shape[1] for s in srcs]), len(srcs), H, W, ops.FORCE_TILE[0], stream()),
+                                      int_array([s.shape[1] for s in srcs]), len(srcs), H, W, None, ops.FORCE_TILE[0], stream()),
                   "rsis_conv2d_dgrad(step)")
             k = 0
             if ctx.has_up:

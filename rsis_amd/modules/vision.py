@@ -31,8 +31,8 @@ class HipConv2d(nn.Module):
             self.register_parameter("bias", None)
         self._pack = ops.PackedConv(self.kernel_size, [self.in_channels], stride=self.stride, pad=self.padding)
 
-    def forward(self, x):
-        return ops.conv2d([x], self.weight, self.bias, self.stride, self.padding, self._pack)
+    def forward(self, x, grad_slot=None):
+        return ops.conv2d([x], self.weight, self.bias, self.stride, self.padding, self._pack, grad_slot=grad_slot)
 
 
 class HipBatchNorm2d(nn.Module):
@@ -66,12 +66,12 @@ class HipBatchNorm2d(nn.Module):
         self._nbt_pending = 0
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
-    def forward(self, x, res=None, relu=False):
+    def forward(self, x, res=None, relu=False, res_slot=None):
         if self.training:
             self._nbt_pending += 1      # host-side counter: no device launch per layer per step
         arena, self._arena = self._arena, None
         return ops.batchnorm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu=relu, res=res,
-                             eps=self.eps, momentum=self.momentum, arena=arena if self.training else None)
+                             eps=self.eps, momentum=self.momentum, arena=arena if self.training else None, res_slot=res_slot)
 
 
 class Bottleneck(nn.Module):
@@ -87,12 +87,16 @@ class Bottleneck(nn.Module):
         self.bn3 = HipBatchNorm2d(planes * 4)
         self.downsample = downsample
         self.stride = stride
+        self._slot = ops.GradSlot()
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
+        # identity blocks in training: x feeds conv1 AND the residual add; the residual gradient is handed to conv1's
+        # data-gradient kernel (ops.GradSlot) instead of being added by autograd
+        slot = self._slot if (self.downsample is None and self.training and torch.is_grad_enabled() and x.requires_grad) else None
+        out = self.bn1(self.conv1(x, grad_slot=slot), relu=True)
         out = self.bn2(self.conv2(out), relu=True)
         residual = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
-        return self.bn3(self.conv3(out), res=residual, relu=True)
+        return self.bn3(self.conv3(out), res=residual, relu=True, res_slot=slot)
 
 
 class ResNet101(nn.Module):

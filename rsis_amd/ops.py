@@ -167,13 +167,28 @@ def _conv_out_size(n, ks, stride, pad):
     return (n + 2 * pad - ks) // stride + 1
 
 
-def _dgrad_all(L, dy, wd, cin_packed, ks, stride, pad, srcs, Hx, Wx):
-    """One dgrad launch producing the gradient of every concat source."""
+def _dgrad_all(L, dy, wd, cin_packed, ks, stride, pad, srcs, Hx, Wx, addend=None):
+    """One dgrad launch producing the gradient of every concat source (+ addend: another consumer's gradient of the input)."""
     B, Cout, Hy, Wy = dy.shape
     dxs = [torch.empty_like(s) for s in srcs]
     check(L.rsis_conv2d_dgrad(ptr(dy), B, Cout, Hy, Wy, ptr(wd), cin_packed, ks, stride, pad, ptr_array(dxs),
-                              int_array([s.shape[1] for s in srcs]), len(srcs), Hx, Wx, FORCE_TILE[0], stream()), "rsis_conv2d_dgrad")
+                              int_array([s.shape[1] for s in srcs]), len(srcs), Hx, Wx, ptr(addend), FORCE_TILE[0], stream()),
+          "rsis_conv2d_dgrad")
     return dxs
+
+
+class GradSlot(object):
+    """Hand-over of a gradient between two autograd nodes that consume the SAME tensor (the input of a residual block feeds
+    conv1 and, as the identity branch, the block's last BatchNorm): the BatchNorm backward -- which autograd necessarily runs
+    first -- parks its identity-branch gradient here and returns None for it; conv1's data-gradient kernel then adds it in
+    its epilogue.  One full-size `add` pass per residual block less than letting autograd accumulate the two."""
+
+    def __init__(self):
+        self.grad = None
+
+    def take(self):
+        g, self.grad = self.grad, None
+        return g
 
 
 def _wgrad_all(L, dy, srcs, w_shape, ks, stride, pad, lstm_hid, out=None):
@@ -191,9 +206,10 @@ def _wgrad_all(L, dy, srcs, w_shape, ks, stride, pad, lstm_hid, out=None):
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pack, stride, pad, nsrc, *tensors):
+    def forward(ctx, pack, stride, pad, nsrc, slot, *tensors):
         srcs = [_contig(t) for t in tensors[:nsrc]]
         weight, bias = tensors[nsrc], tensors[nsrc + 1]
+        ctx.slot = slot
         require_cuda_f32(weight, bias, *srcs)
         L = lib()
         B, _, H, W = srcs[0].shape
@@ -224,31 +240,36 @@ class _Conv2dFn(torch.autograd.Function):
         ks = weight.shape[2]
         nsrc = ctx.nsrc
         grads = [None] * (nsrc + 2)
-        if any(ctx.needs_input_grad[4:4 + nsrc]):
+        addend = ctx.slot.take() if ctx.slot is not None else None
+        if any(ctx.needs_input_grad[5:5 + nsrc]):
             wd = ctx.pack.dgrad(weight)
-            dxs = _dgrad_all(L, dy, wd, ctx.pack.cin, ks, ctx.stride, ctx.pad, srcs, srcs[0].shape[2], srcs[0].shape[3])
+            if addend is not None and (nsrc != 1 or ctx.stride != 1 or addend.shape != srcs[0].shape):
+                raise _lib.RsisHipError("GradSlot: the parked gradient does not belong to this conv's input")
+            dxs = _dgrad_all(L, dy, wd, ctx.pack.cin, ks, ctx.stride, ctx.pad, srcs, srcs[0].shape[2], srcs[0].shape[3], addend)
             for i in range(nsrc):
-                if ctx.needs_input_grad[4 + i]:
+                if ctx.needs_input_grad[5 + i]:
                     grads[i] = dxs[i]
-        if ctx.needs_input_grad[4 + nsrc]:
+        if ctx.needs_input_grad[5 + nsrc]:
             tgt = _direct_target(ctx.wparam)
             dW = _wgrad_all(L, dy, srcs, tuple(weight.shape), ks, ctx.stride, ctx.pad, 0, out=tgt)
             grads[nsrc] = None if tgt is not None else dW
-        if ctx.has_bias and ctx.needs_input_grad[5 + nsrc]:
+        if ctx.has_bias and ctx.needs_input_grad[6 + nsrc]:
             tgt = _direct_target(ctx.bparam)
             db = tgt if tgt is not None else torch.zeros(weight.shape[0], dtype=torch.float32, device=dy.device)
             check(L.rsis_bias_grad(ptr(dy), ptr(db), dy.shape[0], dy.shape[1], dy.shape[2] * dy.shape[3], 0, stream()),
                   "rsis_bias_grad")
             grads[nsrc + 1] = None if tgt is not None else db
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)
 
 
-def conv2d(srcs, weight, bias, stride, pad, pack):
-    """nn.Conv2d over the channel concat of `srcs` (list of NCHW tensors)."""
+def conv2d(srcs, weight, bias, stride, pad, pack, grad_slot=None):
+    """nn.Conv2d over the channel concat of `srcs` (list of NCHW tensors).  grad_slot: see GradSlot."""
     # (ctx.needs_input_grad is True for parameters even under no_grad, and grad mode is off inside Function.forward, so the
     #  "is this a training call" decision is taken here)
     pack.training_call = torch.is_grad_enabled() and (weight.requires_grad or any(s.requires_grad for s in srcs))
-    return _Conv2dFn.apply(pack, int(stride), int(pad), len(srcs), *srcs, weight, bias)
+    if grad_slot is not None:
+        grad_slot.grad = None
+    return _Conv2dFn.apply(pack, int(stride), int(pad), len(srcs), grad_slot, *srcs, weight, bias)
 
 
 class _ConvLSTMFn(torch.autograd.Function):
@@ -383,8 +404,9 @@ def global_maxpool(x):
 
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, train, relu, eps, momentum, arena):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, train, relu, eps, momentum, arena, res_slot=None):
         x = _contig(x)
+        ctx.res_slot = res_slot
         res = _contig(res) if res is not None else None
         require_cuda_f32(x, res, gamma, beta, running_mean, running_var)
         B, C, H, W = x.shape
@@ -421,7 +443,7 @@ class _BatchNormFn(torch.autograd.Function):
             scale = gamma.detach() / torch.sqrt(rstd + ctx.eps)  # here `rstd` holds running_var
             dx = g * scale.view(1, C, 1, 1)
             xh = (x - mean.view(1, C, 1, 1)) / torch.sqrt(rstd + ctx.eps).view(1, C, 1, 1)
-            return dx, (g if ctx.has_res else None), (g * xh).sum((0, 2, 3)), g.sum((0, 2, 3)), None, None, None, None, None, None, None
+            return dx, (g if ctx.has_res else None), (g * xh).sum((0, 2, 3)), g.sum((0, 2, 3)), None, None, None, None, None, None, None, None
         flags = int(ctx.relu)
         if ctx.arena is not None:
             stats, flags = ctx.arena[1], flags | 2
@@ -443,13 +465,17 @@ class _BatchNormFn(torch.autograd.Function):
             dres = dy
         if direct:
             dgamma = dbeta = None
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
+        if ctx.res_slot is not None and dres is not None:
+            ctx.res_slot.grad, dres = dres, None       # picked up by the data-gradient kernel of the block's first conv
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
-def batchnorm(x, gamma, beta, running_mean, running_var, train, relu=False, res=None, eps=1e-5, momentum=0.1, arena=None):
+def batchnorm(x, gamma, beta, running_mean, running_var, train, relu=False, res=None, eps=1e-5, momentum=0.1, arena=None,
+              res_slot=None):
     """nn.BatchNorm2d (+ residual add) (+ ReLU): y = act(bn(x) + res).  arena: optional (fwd, bwd) float64 [2*C] scratch
     slices that the caller zeroed for this iteration (saves one memset per layer per pass)."""
-    return _BatchNormFn.apply(x, res, gamma, beta, running_mean, running_var, bool(train), bool(relu), eps, momentum, arena)
+    return _BatchNormFn.apply(x, res, gamma, beta, running_mean, running_var, bool(train), bool(relu), eps, momentum, arena,
+                              res_slot if (train and res is not None) else None)
 
 
 class _MaxPool3x3s2Fn(torch.autograd.Function):

@@ -69,7 +69,7 @@ def main():
             dxs = [torch.empty_like(s) for s in srcs]
             pd, idd = ptr_array(dxs), int_array(segs + [hid])
             ms = timeit(lambda: check(L.rsis_conv2d_dgrad(ptr(da), B, 4 * hid, H, W, ptr(wd), cin, 3, 1, 1, pd, idd, len(dxs), H, W,
-                                                          o.tile, stream()), "dgrad"), o.iters)
+                                                          None, o.tile, stream()), "dgrad"), o.iters)
             print("gate dgrad %3dx%-3d %38s %8.1f us  %6.1f TF/s" % (H, W, "", ms * 1e3, fl / ms / 1e9))
             dW = torch.zeros_like(w)
 
@@ -101,7 +101,7 @@ def main():
             dx = torch.empty_like(x)
             pd = ptr_array([dx])
             ms_d = timeit(lambda: check(L.rsis_conv2d_dgrad(ptr(y), B, cout, hw, hw, ptr(wd), cin, ks, stride, pad, pd, ia, 1, Hi, Hi,
-                                                            o.tile, stream()), "dgrad"), o.iters)
+                                                            None, o.tile, stream()), "dgrad"), o.iters)
             dW = torch.zeros_like(w)
             ms_w = timeit(lambda: check(L.rsis_conv2d_wgrad(ptr(y), ptr(x), ptr(dW), B, cin, Hi, Hi, cout, hw, hw, ks, stride, pad, cin, 0, 0,
                                                             stream()), "wgrad"), o.iters)
