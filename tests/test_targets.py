@@ -1,0 +1,44 @@
+"""Target-tensor construction against golden vectors produced by the reference's own
+MyDataset.sequence_from_masks (tests/golden/targets.npz, oracle/make_golden_targets.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from rsis_amd.dataloader import sequence_from_masks, targets_from_maps
+from rsis_amd.utils.utils import batch_to_var
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "targets.npz")
+
+
+def _cases():
+    g = np.load(GOLD)
+    return [(g["ins%d" % i], g["seg%d" % i], int(g["T%d" % i]), g["target%d" % i]) for i in range(int(g["n"]))]
+
+
+def test_sequence_from_masks_matches_reference():
+    for ins, seg, T, want in _cases():
+        got = sequence_from_masks(ins, seg, T)
+        assert got.shape == want.shape and got.dtype == np.float64
+        assert np.array_equal(got, want)
+
+
+def _check_device_targets(device):
+    import argparse
+    a = argparse.Namespace(use_gpu=False)
+    for ins, seg, T, want in _cases():
+        ym, yc, swm, swc = targets_from_maps(ins[None], seg[None], T, device=device)
+        x = torch.zeros(1, 3, 2, 2)
+        _x, rm, rc, rsm, rsc = batch_to_var(a, x, torch.from_numpy(want)[None])      # the reference's own split of the target
+        assert torch.equal(ym.cpu(), rm) and torch.equal(yc.cpu(), rc)
+        assert torch.equal(swm.cpu().double(), rsm.double()) and torch.equal(swc.cpu().double(), rsc.double())
+
+
+def test_targets_from_maps_cpu_matches_reference():
+    _check_device_targets("cpu")
+
+
+@pytest.mark.gpu
+def test_targets_from_maps_gpu_matches_reference():
+    _check_device_targets("cuda")
