@@ -3,6 +3,7 @@
 // 3x3/2 max-pool fwd/bwd, per-channel bias-grad reduction and the flat fused Adam step (weight repacking: pack.hip).
 // All are HBM-roofline kernels: coalesced along W, grid-stride, float4 where the row length allows it.
 #include "common.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 // ConvLSTM pointwise backward (derivative of reference clstm.py:47-58; formulas in SURVEY.md 8(a))
@@ -411,6 +412,127 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #undef BN_FOREACH
 
 // ------------------------------------------------------------------------------------------------
+// Register-resident BatchNorm for the layers whose channel plane set fits one block (B*HW/4 <= NT*VPT float4 groups: layers
+// 2-4 of the trunk and the deep skip BNs at batch 32): ONE launch and ONE read of each input per pass instead of a reduce
+// launch + an apply launch that re-reads everything.  Block c holds channel c's values in registers, reduces them
+// (fp64 partial sums), then normalises / back-propagates from the registers.  Same arithmetic as the split kernels above.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void block_allreduce2(double& a, double& b) {
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
+  __shared__ double sa[NT / 64], sb[NT / 64];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sa[w] = a; sb[w] = b; }
+  __syncthreads();
+  a = 0.0; b = 0.0;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) { a += sa[i]; b += sb[i]; }
+}
+
+template <int NT, int VPT>
+__global__ __launch_bounds__(NT) void bn_fwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                          float* __restrict__ y, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                          float* __restrict__ run_var, float* __restrict__ save_mean,
+                                                          float* __restrict__ save_rstd, int C, int HW, long N, float eps,
+                                                          float momentum, int relu) {
+  const int c = blockIdx.x;
+  const int ng = (int)(N / 4), hwg = HW / 4;
+  f32x4 v[VPT];
+  double s = 0.0, ss = 0.0;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int g = threadIdx.x + i * NT;
+    if (g < ng) {
+      const int b = g / hwg, sp = (g - b * hwg) * 4;
+      v[i] = *reinterpret_cast<const f32x4*>(x + ((size_t)b * C + c) * HW + sp);
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      ss += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+    }
+  }
+  block_allreduce2<NT>(s, ss);
+  const double m = s / (double)N;
+  double var = ss / (double)N - m * m;
+  if (var < 0) var = 0;
+  const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) {
+    save_mean[c] = mean; save_rstd[c] = rstd;
+    const double unb = N > 1 ? var * (double)N / (double)(N - 1) : var;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+  }
+  const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int g = threadIdx.x + i * NT;
+    if (g < ng) {
+      const int b = g / hwg, sp = (g - b * hwg) * 4;
+      const size_t idx = ((size_t)b * C + c) * HW + sp;
+      f32x4 r = {0.f, 0.f, 0.f, 0.f};
+      if (res) r = *reinterpret_cast<const f32x4*>(res + idx);
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float t = v[i][k] * sc + sh + r[k]; o[k] = relu ? fmaxf(t, 0.f) : t; }
+      *reinterpret_cast<f32x4*>(y + idx) = o;
+    }
+  }
+}
+
+template <int NT, int VPT>
+__global__ __launch_bounds__(NT) void bn_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ y, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                          float* __restrict__ dx, float* __restrict__ dres,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int HW,
+                                                          long N, int relu, int accum) {
+  const int c = blockIdx.x;
+  const int ng = (int)(N / 4), hwg = HW / 4;
+  const float m = mean[c], r = rstd[c];
+  f32x4 g[VPT], xh[VPT];
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int gi = threadIdx.x + i * NT;
+    if (gi < ng) {
+      const int b = gi / hwg, sp = (gi - b * hwg) * 4;
+      const size_t idx = ((size_t)b * C + c) * HW + sp;
+      g[i] = *reinterpret_cast<const f32x4*>(dy + idx);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + idx);
+      if (relu) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + idx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (!(yv[k] > 0.f)) g[i][k] = 0.f;
+      }
+      float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { xh[i][k] = (xv[k] - m) * r; p1 += g[i][k]; p2 += g[i][k] * xh[i][k]; }
+      s1 += p1; s2 += p2;
+    }
+  }
+  block_allreduce2<NT>(s1, s2);
+  const float mg = (float)(s1 / (double)N), mgx = (float)(s2 / (double)N);
+  const float kk = gamma[c] * r;
+  if (threadIdx.x == 0) {
+    const float dg = (float)s2, db = (float)s1;
+    dgamma[c] = accum ? dgamma[c] + dg : dg;
+    dbeta[c] = accum ? dbeta[c] + db : db;
+  }
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int gi = threadIdx.x + i * NT;
+    if (gi < ng) {
+      const int b = gi / hwg, sp = (gi - b * hwg) * 4;
+      const size_t idx = ((size_t)b * C + c) * HW + sp;
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = kk * (g[i][k] - mg - xh[i][k] * mgx);
+      *reinterpret_cast<f32x4*>(dx + idx) = o;
+      if (dres) *reinterpret_cast<f32x4*>(dres + idx) = g[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // MaxPool2d(3, stride 2, pad 1) of the ResNet stem (torchvision; reference vision.py:15)
 // ------------------------------------------------------------------------------------------------
 __global__ void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ arg,
@@ -576,6 +698,12 @@ static inline int ew_grid(long total) {
   if (g < 1) g = 1;
   return (int)g;
 }
+// register-resident single-launch BatchNorm: float4-able planes, the whole channel (B*HW values) in one block's registers, and
+// enough channels to fill the chip (RSIS_BN_FUSED=0 forces the split kernels)
+static inline bool bn_fused_ok(int C, int HW, long N) {
+  static const bool on = !(getenv("RSIS_BN_FUSED") && getenv("RSIS_BN_FUSED")[0] == '0');
+  return on && (HW & 3) == 0 && N / 4 <= 1024 * 8 && C >= 64;
+}
 static inline int chan_splits(int C, long N) {
   long s = (2048 + C - 1) / C;
   const long maxs = (N + 1023) / 1024;
@@ -640,6 +768,15 @@ int rsis_l_bn_fwd(const float* x, const float* res, float* y, double* stats, con
   const long N = (long)B * HW;
   const int S = chan_splits(C, N);
   const int train = train_flags & 1;
+  if (train && bn_fused_ok(C, HW, N)) {      // channel fits one block: one launch, one read of x
+    if (N / 4 <= 256 * 8)
+      hipLaunchKernelGGL((bn_fwd_fused_kernel<256, 8>), dim3(C), dim3(256), 0, st, x, res, y, gamma, beta, run_mean, run_var, save_mean,
+                         save_rstd, C, HW, N, eps, momentum, relu);
+    else
+      hipLaunchKernelGGL((bn_fwd_fused_kernel<1024, 8>), dim3(C), dim3(1024), 0, st, x, res, y, gamma, beta, run_mean, run_var,
+                         save_mean, save_rstd, C, HW, N, eps, momentum, relu);
+    return rsis_check_launch();
+  }
   if (train) {
     if (!(train_flags & 2) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, st) != hipSuccess) return RSIS_ERR_LAUNCH;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, S), dim3(256), 0, st, x, stats, C, HW, N);
@@ -654,6 +791,15 @@ int rsis_l_bn_bwd(const float* dy, const float* x, const float* y, const float* 
   const long N = (long)B * HW;
   const int S = chan_splits(C, N);
   const int relu = relu_flags & 1, accum = (relu_flags >> 2) & 1;
+  if (bn_fused_ok(C, HW, N)) {
+    if (N / 4 <= 256 * 8)
+      hipLaunchKernelGGL((bn_bwd_fused_kernel<256, 8>), dim3(C), dim3(256), 0, st, dy, x, y, mean, rstd, gamma, dx, dres, dgamma, dbeta,
+                         C, HW, N, relu, accum);
+    else
+      hipLaunchKernelGGL((bn_bwd_fused_kernel<1024, 8>), dim3(C), dim3(1024), 0, st, dy, x, y, mean, rstd, gamma, dx, dres, dgamma,
+                         dbeta, C, HW, N, relu, accum);
+    return rsis_check_launch();
+  }
   if (!(relu_flags & 2) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, st) != hipSuccess) return RSIS_ERR_LAUNCH;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, mean, rstd, stats, C, HW, N, relu);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, mean, rstd, gamma, stats, dx, dres, dgamma,

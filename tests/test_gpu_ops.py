@@ -172,7 +172,8 @@ def test_maxpool3x3s2(shape):
     assert_close("bwd", xd.grad, x.grad, 1e-6)
 
 
-@pytest.mark.parametrize("shape", [(4, 6, 5, 7), (2, 64, 16, 16), (3, 3, 33, 17), (8, 130, 4, 4)])
+@pytest.mark.parametrize("shape", [(4, 6, 5, 7), (2, 64, 16, 16), (3, 3, 33, 17), (8, 130, 4, 4),
+                                   (32, 96, 16, 16), (16, 64, 32, 32), (32, 64, 32, 32), (2, 64, 64, 68)])   # register-resident / split paths
 @pytest.mark.parametrize("train,relu,res", [(True, False, False), (True, True, False), (True, True, True), (True, False, True),
                                             (False, True, True), (False, False, False)])
 def test_batchnorm(shape, train, relu, res):
