@@ -181,6 +181,11 @@ int rsis_mask_resize_threshold(const float* prob, int n, int Hm, int Wm, const u
                                unsigned char* raw, unsigned int* area, int h, int w, void* stream);
 int rsis_rle_encode(const unsigned char* masks, int n, long len, unsigned int* counts, int cap, int* nruns, void* stream);
 int rsis_rle_to_string(const unsigned int* counts, int m, char* out, int cap);
+/* largest 8-connected component of n binary masks [n][h][w] (row-major, 0/1) -> out [n][h][w] (eval_cityscapes.py:131-150:
+ * skimage.measure.label + most frequent label; ties: the component first in raster order).  Caller-owned workspaces:
+ * labels[n*h*w], counts[n*h*w] int32, best[n] int32.  h*w < 2^31. */
+int rsis_largest_component(const unsigned char* mask, unsigned char* out, int* labels, int* counts, int* best, int n, int h, int w,
+                           void* stream);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,7 @@ SIGNATURES = {
     "rsis_softiou_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _l, _vp]),
     "rsis_mask_resize_threshold": (_i, [_vp, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _i, _i, _vp]),
     "rsis_rle_encode": (_i, [_vp, _i, _l, _vp, _i, _vp, _vp]),
+    "rsis_largest_component": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "rsis_rle_to_string": (_i, [_vp, _i, ctypes.c_char_p, _i]),
     "rsis_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp]),
 }

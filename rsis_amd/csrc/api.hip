@@ -37,6 +37,7 @@ int rsis_l_mask_resize_threshold(const float*, int, int, int, const unsigned cha
                                  int, int, hipStream_t);
 int rsis_l_rle_encode(const unsigned char*, int, long, unsigned int*, int, int*, hipStream_t);
 int rsis_l_rle_to_string(const unsigned int*, int, char*, int);
+int rsis_l_largest_component(const unsigned char*, unsigned char*, int*, int*, int*, int, int, int, hipStream_t);
 int rsis_l_heads_fwd(const float* const*, const int*, int, int, const float*, const float*, int, const float*, const float*, float*, float*,
                      hipStream_t);
 int rsis_l_heads_bwd(const float* const*, const int*, int, int, const float*, int, const float*, const float*, const float*, const float*,
@@ -384,4 +385,10 @@ int rsis_heads_bwd(const float* const* side, const int* Cside, int nside, int B,
                    float* dWs, float* dbs, void* stream) {
   if (!side || !Cside || !Wc || !Ws || !class_probs || B < 1) return RSIS_ERR_ARG;
   return rsis_l_heads_bwd(side, Cside, nside, B, Wc, ncls, Ws, class_probs, dprobs, dstop, dside, dWc, dbc, dWs, dbs, (hipStream_t)stream);
+}
+
+int rsis_largest_component(const unsigned char* mask, unsigned char* out, int* labels, int* counts, int* best, int n, int h, int w,
+                           void* stream) {
+  if (!mask || !out || !labels || !counts || !best || n < 1 || h < 1 || w < 1 || (long)h * w >= (1L << 31)) return RSIS_ERR_ARG;
+  return rsis_l_largest_component(mask, out, labels, counts, best, n, h, w, (hipStream_t)stream);
 }

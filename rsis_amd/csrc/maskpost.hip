@@ -160,3 +160,102 @@ int rsis_l_rle_to_string(const unsigned int* counts, int m, char* out, int cap) 
   out[p] = 0;
   return p;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Largest 8-connected component of a binary mask (reference src/eval_cityscapes.py:131-150: skimage.measure.label with the
+// default full connectivity, then the most frequent non-background label).  Union-find on the device, no host loop:
+//   init (every foreground pixel is its own root) -> merge (each pixel unites with its W / NW / N / NE foreground neighbours;
+//   roots are linked larger -> smaller with atomicMin, so the structure stays a forest and the result does not depend on
+//   the order of the unions) -> flatten -> per-root pixel counts -> arg-max (ties: the component that comes first in raster
+//   order; the reference's tie order is that of a python-2 dict, i.e. unspecified) -> select.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cc_find(const int* L, int x) {
+  int p = L[x];
+  while (p != x) { x = p; p = L[x]; }
+  return x;
+}
+__device__ __forceinline__ void cc_union(int* L, int a, int b) {
+  while (true) {
+    a = cc_find(L, a);
+    b = cc_find(L, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }      // link the larger root a under the smaller root b
+    const int old = atomicMin(&L[a], b);
+    if (old == a) return;                                // a was still a root: linked
+    a = old;                                             // someone re-parented a meanwhile: retry from its new parent
+  }
+}
+
+__global__ void cc_init_kernel(const unsigned char* __restrict__ m, int* __restrict__ L, int* __restrict__ cnt, long total, int hw) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    L[e] = m[e] ? (int)(e % hw) : -1;
+    cnt[e] = 0;
+  }
+}
+__global__ void cc_merge_kernel(const unsigned char* __restrict__ m, int* __restrict__ L, long total, int h, int w) {
+  const int hw = h * w;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    if (!m[e]) continue;
+    const long k = e / hw;
+    const int i = (int)(e - k * hw), y = i / w, x = i - y * w;
+    const unsigned char* mk = m + k * hw;
+    int* Lk = L + k * hw;
+    if (x > 0 && mk[i - 1]) cc_union(Lk, i, i - 1);
+    if (y > 0) {
+      if (mk[i - w]) cc_union(Lk, i, i - w);
+      if (x > 0 && mk[i - w - 1]) cc_union(Lk, i, i - w - 1);
+      if (x + 1 < w && mk[i - w + 1]) cc_union(Lk, i, i - w + 1);
+    }
+  }
+}
+__global__ void cc_count_kernel(const unsigned char* __restrict__ m, int* __restrict__ L, int* __restrict__ cnt, long total, int hw) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    if (!m[e]) continue;
+    const long k = e / hw;
+    const int r = cc_find(L + k * hw, (int)(e - k * hw));
+    L[e] = r;                                            // (a pixel's own entry is only read by finds that pass through it: any root-ward value is valid)
+    atomicAdd(&cnt[k * hw + r], 1);
+  }
+}
+// one block per mask: best[k] = root with the largest count (ties: smallest root index)
+__global__ __launch_bounds__(256) void cc_argmax_kernel(const int* __restrict__ cnt, int* __restrict__ best, int hw) {
+  const int k = blockIdx.x;
+  int bc = 0, bi = -1;
+  for (int i = threadIdx.x; i < hw; i += 256) {
+    const int c = cnt[(size_t)k * hw + i];
+    if (c > bc) { bc = c; bi = i; }                      // ascending i per thread: the first maximum wins
+  }
+  __shared__ int sc[256], si[256];
+  sc[threadIdx.x] = bc; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const int c2 = sc[threadIdx.x + o], i2 = si[threadIdx.x + o];
+      if (c2 > sc[threadIdx.x] || (c2 == sc[threadIdx.x] && c2 > 0 && i2 < si[threadIdx.x])) { sc[threadIdx.x] = c2; si[threadIdx.x] = i2; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) best[k] = si[0];
+}
+__global__ void cc_select_kernel(const unsigned char* __restrict__ m, const int* __restrict__ L, const int* __restrict__ best,
+                                 unsigned char* __restrict__ out, long total, int hw) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long k = e / hw;
+    out[e] = (m[e] && L[e] == best[k]) ? 1 : 0;
+  }
+}
+
+int rsis_l_largest_component(const unsigned char* mask, unsigned char* out, int* labels, int* counts, int* best, int n, int h, int w,
+                             hipStream_t st) {
+  const int hw = h * w;
+  const long total = (long)n * hw;
+  long g = (total + 255) / 256;
+  if (g > 256L * 32) g = 256L * 32;
+  const dim3 grid((unsigned)g), blk(256);
+  hipLaunchKernelGGL(cc_init_kernel, grid, blk, 0, st, mask, labels, counts, total, hw);
+  hipLaunchKernelGGL(cc_merge_kernel, grid, blk, 0, st, mask, labels, total, h, w);
+  hipLaunchKernelGGL(cc_count_kernel, grid, blk, 0, st, mask, labels, counts, total, hw);
+  hipLaunchKernelGGL(cc_argmax_kernel, dim3(n), blk, 0, st, counts, best, hw);
+  hipLaunchKernelGGL(cc_select_kernel, grid, blk, 0, st, mask, labels, best, out, total, hw);
+  return rsis_check_launch();
+}

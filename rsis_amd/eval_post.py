@@ -61,6 +61,22 @@ def _rle_dicts(L, masks, n, hw, height, width):
     return out
 
 
+def largest_component(masks):
+    """masks: (n, h, w) CUDA uint8 / bool binary masks -> (n, h, w) uint8 mask of each one's largest 8-connected component
+    (reference src/eval_cityscapes.py:131-150: skimage.measure.label + the most frequent label)."""
+    m = masks.detach().to(torch.uint8).contiguous()
+    if not m.is_cuda:
+        raise ValueError("largest_component: masks must be a CUDA tensor")
+    n, h, w = m.shape
+    out = torch.empty_like(m)
+    labels = torch.empty((n, h * w), dtype=torch.int32, device=m.device)
+    counts = torch.empty_like(labels)
+    best = torch.empty((n,), dtype=torch.int32, device=m.device)
+    check(lib().rsis_largest_component(ptr(m), ptr(out), ptr(labels), ptr(counts), ptr(best), n, h, w, stream()),
+          "rsis_largest_component")
+    return out
+
+
 def resize_mask(args, pred_mask, height, width, ignore_pixels=None):
     """reference src/eval.py:96-127, same arguments and return value: (segmentation, is_valid, segmentation_raw) with the two
     segmentations as COCO RLE dicts.  pred_mask: (Hm, Wm) numpy array or tensor of mask probabilities."""

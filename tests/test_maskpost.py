@@ -116,3 +116,39 @@ def test_resize_mask_reference_signature():
     assert ok and seg["size"] == [120, 90] and seg["counts"] == rle_numpy.rle_string(rle_numpy.rle_counts(want)) and raw["counts"] == seg["counts"]
     _seg, ok2, _ = eval_post.resize_mask(a, np.zeros((64, 64), np.float32), 120, 90)
     assert not ok2                                                  # eval.py:113-114: fewer than min_size * h * w pixels
+
+
+@pytest.mark.gpu
+def test_largest_component_matches_scipy():
+    """rsis_largest_component against scipy.ndimage.label with the full 3x3 structure (== skimage.measure.label's default
+    connectivity for 2-D, eval_cityscapes.py:139) + the most frequent label; ties resolved towards the first label in raster
+    order on both sides"""
+    from scipy import ndimage
+    from rsis_amd import eval_post
+    rng = np.random.default_rng(21)
+    cases = []
+    for (h, w, p, blob) in [(1, 1, 1.0, 1), (7, 9, 0.5, 1), (64, 48, 0.45, 2), (100, 132, 0.55, 3), (256, 512, 0.6, 4), (33, 65, 0.0, 1),
+                            (40, 40, 1.0, 1), (128, 128, 0.5, 1)]:
+        m = np.kron((rng.random((-(-h // blob), -(-w // blob))) < p).astype(np.uint8), np.ones((blob, blob), np.uint8))[:h, :w]
+        cases.append(np.ascontiguousarray(m))
+    spiral = np.zeros((41, 41), np.uint8)                 # a long thin component: deep union-find chains
+    for k in range(0, 20, 2):
+        spiral[k, k:41 - k] = 1; spiral[k:41 - k, 40 - k] = 1; spiral[40 - k, k:41 - k] = 1; spiral[k + 2:41 - k, k] = 1
+    cases.append(spiral)
+    diag = np.eye(30, dtype=np.uint8)                     # only diagonal contacts: 8-connectivity matters
+    cases.append(diag)
+    for m in cases:
+        lab, nlab = ndimage.label(m, structure=np.ones((3, 3)))
+        want = np.zeros_like(m)
+        if nlab:
+            cnt = np.bincount(lab.reshape(-1))[1:]
+            want = (lab == (int(np.argmax(cnt)) + 1)).astype(np.uint8)        # argmax: first maximum = first in raster order
+        got = eval_post.largest_component(torch.from_numpy(m[None]).cuda())[0].cpu().numpy()
+        assert np.array_equal(got, want), m.shape
+    # a batch in one call
+    batch = np.stack([cases[2], cases[2][::-1].copy(), np.zeros_like(cases[2])])
+    got = eval_post.largest_component(torch.from_numpy(batch).cuda()).cpu().numpy()
+    for k in range(3):
+        lab, nlab = ndimage.label(batch[k], structure=np.ones((3, 3)))
+        want = (lab == (int(np.argmax(np.bincount(lab.reshape(-1))[1:])) + 1)).astype(np.uint8) if nlab else np.zeros_like(batch[k])
+        assert np.array_equal(got[k], want)
