@@ -99,6 +99,21 @@ __global__ __launch_bounds__(256) void k_lds_sync(float* out, int iters) {
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// shader clock during a kernel: clock64() ticks (shader clock) per wall_clock64() tick (constant 100 MHz)
+__global__ void k_clock_probe(long long* out, int iters) {
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float a = threadIdx.x * 1e-3f, b = threadIdx.x * 2e-3f;
+  const long long c0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  const long long c1 = clock64(), w1 = wall_clock64();
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += acc[r];
+  if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = (long long)s; }
+}
+
 template <typename F>
 static void run(const char* name, F launch, double mfma_per_wave_iter, int blocks, int iters) {
   hipEvent_t e0, e1;
@@ -119,6 +134,16 @@ static void run(const char* name, F launch, double mfma_per_wave_iter, int block
 int main() {
   float* out;
   hipMalloc(&out, 4096 * 256 * sizeof(float));
+  {
+    long long* d; long long h[3];
+    hipMalloc(&d, 3 * sizeof(long long));
+    for (int blocks : {1, 256, 1024}) {
+      hipLaunchKernelGGL(k_clock_probe, dim3(blocks), dim3(256), 0, 0, d, 20000);
+      hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+      printf("clock probe, %4d blocks of MFMA work: %.0f MHz shader clock (clock64 / wall_clock64 @100 MHz), 16 MFMA per %.1f clk\n", blocks,
+             100.0 * (double)h[0] / (double)h[1], (double)h[0] / 20000.0);
+    }
+  }
   const int it = 2000;
   for (int bpc : {1, 2, 3, 4}) {
     const int blocks = 256 * bpc;
