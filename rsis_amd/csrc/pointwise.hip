@@ -63,29 +63,36 @@ __global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
-// Wo % 4 == 0 and < 2^31 outputs: one thread = 4 consecutive outputs of a row (float4 store), 32-bit index math.  Same
-// arithmetic per element as upsample_fwd_kernel (bit-identical results).
+// Wo % 4 == 0: one thread = 4 consecutive outputs of a row (float4 store).  A block covers 256 / (Wo/4) consecutive output
+// rows of the flattened (bc, ho) row space (or a 256-thread slice of one long row); the only division left is one per thread
+// (row -> bc, ho).  Same arithmetic per element as upsample_fwd_kernel (bit-identical results).
 __global__ __launch_bounds__(256) void upsample_fwd_v4_kernel(const float* __restrict__ x, float* __restrict__ y, int Hi, int Wi,
-                                                              int Ho, int Wo, float sh, float sw, int items) {
-  const int Wq = Wo >> 2;
-  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) {
-    const int wq = it % Wq;
-    const int t = it / Wq;
-    const int ho = t % Ho;
-    const int bc = t / Ho;
-    int h0, h1; float lh;
-    ac_coord(ho, sh, Hi, h0, h1, lh);
-    const float* r0 = x + (size_t)bc * Hi * Wi + h0 * Wi;
-    const float* r1 = x + (size_t)bc * Hi * Wi + h1 * Wi;
-    f32x4 o;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      int w0, w1; float lw;
-      ac_coord(wq * 4 + k, sw, Wi, w0, w1, lw);
-      o[k] = (1.f - lh) * ((1.f - lw) * r0[w0] + lw * r0[w1]) + lh * ((1.f - lw) * r1[w0] + lw * r1[w1]);
-    }
-    *reinterpret_cast<f32x4*>(y + (size_t)it * 4) = o;
+                                                              int Ho, int Wo, float sh, float sw, long rows, int Wq, int wq_shift) {
+  // wq_shift >= 0: Wq is a power of two <= 256 and a block spans 256 >> wq_shift rows; otherwise blockIdx.y walks the row
+  long row;
+  int wq;
+  if (wq_shift >= 0) {
+    row = (long)blockIdx.x * (256 >> wq_shift) + (threadIdx.x >> wq_shift);
+    wq = threadIdx.x & (Wq - 1);
+  } else {
+    row = blockIdx.x;
+    wq = blockIdx.y * 256 + threadIdx.x;
   }
+  if (row >= rows || wq >= Wq) return;
+  const long bc = row / Ho;
+  const int ho = (int)(row - bc * Ho);
+  int h0, h1; float lh;
+  ac_coord(ho, sh, Hi, h0, h1, lh);
+  const float* r0 = x + (size_t)bc * Hi * Wi + h0 * Wi;
+  const float* r1 = x + (size_t)bc * Hi * Wi + h1 * Wi;
+  f32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int w0, w1; float lw;
+    ac_coord(wq * 4 + k, sw, Wi, w0, w1, lw);
+    o[k] = (1.f - lh) * ((1.f - lw) * r0[w0] + lw * r0[w1]) + lh * ((1.f - lw) * r1[w0] + lw * r1[w1]);
+  }
+  *reinterpret_cast<f32x4*>(y + ((size_t)row * Wq + wq) * 4) = o;
 }
 
 // backward as a GATHER (no atomics, deterministic): dx[hi][wi] = sum over the few output pixels whose 2x2 stencil touches
@@ -96,24 +103,24 @@ __global__ __launch_bounds__(256) void upsample_fwd_v4_kernel(const float* __res
 #define UK 6   // consecutive candidate outputs per input index: covers scale factors >= ~0.46 (checked by the launcher)
 template <int UT, int RM>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Hi, int Wi,
-                                                           int Ho, int Wo, float sh, float sw, int tiles_x, int tiles_y) {
+                                                           int Ho, int Wo, float sh, float sw, int tiles_x, int tiles_y, long BC,
+                                                           int planes_per_block) {
   constexpr int RP = RM + 1;
   __shared__ float wgt[2][UT][UK];
-  __shared__ int st[2][UT];          // first candidate of each input index, relative to the region origin
+  __shared__ int st[2][UT];          // first candidate of each input index (absolute output index)
   __shared__ int org[2], ext[2];     // region origin / extent (rows, cols)
   __shared__ float reg[RM * RP];
   __shared__ float tmp[UT * RP];
   const int tid = threadIdx.x;
   const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y;
-  const long bc = blockIdx.x / (tiles_x * tiles_y);
-  // ---- per-block tables: threads -> (axis, local index) ----
+  const long bc0 = (long)(blockIdx.x / (tiles_x * tiles_y)) * planes_per_block;
+  // ---- per-block tables (shared by all planes of the block): threads -> (axis, local index) ----
   if (tid < 2 * UT) {
     const int axis = tid / UT, li = tid % UT;
     const int in = axis ? Wi : Hi, out = axis ? Wo : Ho;
     const float sc = axis ? sw : sh;
     const int i = (axis ? tx : ty) * UT + li;
     int l = max(0, (int)floorf((i - 1) / sc) - 1);
-    // advance to the first output that really touches i (at most a few steps)
     int first = -1;
     float w[UK];
 #pragma unroll
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
     if (first < 0) first = min(l, out - 1);
 #pragma unroll
     for (int k = 0; k < UK; ++k) wgt[axis][li][k] = w[k];
-    st[axis][li] = first;   // absolute for now
+    st[axis][li] = first;
   }
   __syncthreads();
   if (tid < 2) {
@@ -143,34 +150,37 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   }
   __syncthreads();
   const int oy = org[0], ox = org[1], ey = ext[0], ex = ext[1];   // ey, ex <= RM (launcher)
-  const float* yb = dy + bc * Ho * Wo;
-  for (int e = tid; e < ey * RM; e += 256) {
-    const int r = e / RM, c = e - r * RM;
-    reg[r * RP + c] = c < ex ? yb[(size_t)(oy + r) * Wo + ox + c] : 0.f;
-  }
-  __syncthreads();
-  // rows: tmp[ly][c] = sum_k wgt_y[ly][k] * reg[st_y[ly] - oy + k][c]
-  for (int e = tid; e < UT * RM; e += 256) {
-    const int ly = e / RM, c = e - ly * RM;
-    const int r0 = st[0][ly] - oy;
-    float acc = 0.f;
-#pragma unroll
-    for (int k = 0; k < UK; ++k) {
-      const int r = min(r0 + k, ey - 1);          // weights beyond the region are zero
-      acc = fmaf(wgt[0][ly][k], reg[r * RP + c], acc);
+  for (int pl = 0; pl < planes_per_block; ++pl) {
+    const long bc = bc0 + pl;
+    if (bc >= BC) break;
+    const float* yb = dy + bc * Ho * Wo;
+    for (int e = tid; e < ey * RM; e += 256) {
+      const int r = e / RM, c = e - r * RM;
+      reg[r * RP + c] = c < ex ? yb[(size_t)(oy + r) * Wo + ox + c] : 0.f;
     }
-    tmp[ly * RP + c] = acc;
-  }
-  __syncthreads();
-  for (int e = tid; e < UT * UT; e += 256) {
-    const int ly = e / UT, lx = e - ly * UT;
-    const int hi = ty * UT + ly, wi = tx * UT + lx;
-    if (hi >= Hi || wi >= Wi) continue;
-    const int c0 = st[1][lx] - ox;
-    float acc = 0.f;
+    __syncthreads();
+    // rows: tmp[ly][c] = sum_k wgt_y[ly][k] * reg[st_y[ly] - oy + k][c]
+    for (int e = tid; e < UT * RM; e += 256) {
+      const int ly = e / RM, c = e - ly * RM;
+      const int r0 = st[0][ly] - oy;
+      float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < UK; ++k) acc = fmaf(wgt[1][lx][k], tmp[ly * RP + min(c0 + k, ex - 1)], acc);
-    dx[bc * Hi * Wi + (size_t)hi * Wi + wi] = acc;
+      for (int k = 0; k < UK; ++k) acc = fmaf(wgt[0][ly][k], reg[min(r0 + k, ey - 1) * RP + c], acc);   // weights beyond the region are zero
+      tmp[ly * RP + c] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < UT * UT; e += 256) {
+      const int ly = e / UT, lx = e - ly * UT;
+      const int hi = ty * UT + ly, wi = tx * UT + lx;
+      if (hi >= Hi || wi >= Wi) continue;
+      const int c0 = st[1][lx] - ox;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < UK; ++k) acc = fmaf(wgt[1][lx][k], tmp[ly * RP + min(c0 + k, ex - 1)], acc);
+      dx[bc * Hi * Wi + (size_t)hi * Wi + wi] = acc;
+    }
+    // (the next plane's `reg` fill is ordered after this plane's last `reg` read by the barrier above; `tmp` is rewritten only
+    //  after the next barrier)
   }
 }
 
@@ -592,9 +602,19 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
                                                           long N, int hid) {
   const int c = blockIdx.x;
   double s = 0.0;
-  for (long e = blockIdx.y * 256L + threadIdx.x; e < N; e += gridDim.y * 256L) {
-    const long b = e / HW; const int sp = (int)(e - b * HW);
-    s += dy[(b * C + c) * HW + sp];
+  if ((HW & 3) == 0) {                       // float4 groups never straddle an image
+    const long ng = N / 4;
+    const int hwg = HW / 4;
+    for (long g = blockIdx.y * 256L + threadIdx.x; g < ng; g += gridDim.y * 256L) {
+      const long b = g / hwg; const int sp = (int)(g - b * hwg) * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(dy + (b * C + c) * HW + sp);
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  } else {
+    for (long e = blockIdx.y * 256L + threadIdx.x; e < N; e += gridDim.y * 256L) {
+      const long b = e / HW; const int sp = (int)(e - b * HW);
+      s += dy[(b * C + c) * HW + sp];
+    }
   }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   __shared__ double sa[4];
@@ -722,10 +742,14 @@ int rsis_l_lstm_bwd(const float* dh, const float* dh2, const float* dc_next, con
 static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 int rsis_l_upsample_fwd(const float* x, float* y, long BC, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
   const long total = BC * Ho * Wo;
-  if (Wo % 4 == 0 && total < (1L << 31)) {
-    const int items = (int)(total / 4);
-    hipLaunchKernelGGL(upsample_fwd_v4_kernel, dim3(ew_grid(items)), dim3(256), 0, st, x, y, Hi, Wi, Ho, Wo, ac_scale(Hi, Ho),
-                       ac_scale(Wi, Wo), items);
+  if (Wo % 4 == 0 && BC * Ho < (1L << 31)) {
+    const int Wq = Wo / 4;
+    const long rows = BC * Ho;
+    int shift = -1;
+    if (Wq <= 256 && (Wq & (Wq - 1)) == 0) { shift = 0; while ((1 << shift) < Wq) ++shift; }
+    const dim3 grid = shift >= 0 ? dim3((unsigned)((rows + (256 >> shift) - 1) / (256 >> shift))) : dim3((unsigned)rows, (Wq + 255) / 256);
+    hipLaunchKernelGGL(upsample_fwd_v4_kernel, grid, dim3(256), 0, st, x, y, Hi, Wi, Ho, Wo, ac_scale(Hi, Ho), ac_scale(Wi, Wo), rows,
+                       Wq, shift);
   } else {
     hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, Hi, Wi, Ho, Wo, ac_scale(Hi, Ho),
                        ac_scale(Wi, Wo), total);
@@ -742,11 +766,17 @@ int rsis_l_upsample_bwd(const float* dy, float* dx, long BC, int Hi, int Wi, int
   const bool fits = tiled && ((ut - 1) / smin + UK + 3 <= (ut == 32 ? 80 : 44));
   if (fits) {
     const int tiles_x = (Wi + ut - 1) / ut, tiles_y = (Hi + ut - 1) / ut;
-    const long blocks = BC * tiles_x * tiles_y;
+    // several planes per block (the interpolation tables depend on the tile only), keeping >= ~2048 blocks
+    long ppb = BC * tiles_x * tiles_y / 2048;
+    if (ppb < 1) ppb = 1;
+    if (ppb > 16) ppb = 16;
+    const long blocks = (BC + ppb - 1) / ppb * tiles_x * tiles_y;
     if (ut == 32)
-      hipLaunchKernelGGL((upsample_bwd_kernel<32, 80>), dim3((unsigned)blocks), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, tiles_x, tiles_y);
+      hipLaunchKernelGGL((upsample_bwd_kernel<32, 80>), dim3((unsigned)blocks), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, tiles_x,
+                         tiles_y, BC, (int)ppb);
     else
-      hipLaunchKernelGGL((upsample_bwd_kernel<16, 44>), dim3((unsigned)blocks), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, tiles_x, tiles_y);
+      hipLaunchKernelGGL((upsample_bwd_kernel<16, 44>), dim3((unsigned)blocks), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, tiles_x,
+                         tiles_y, BC, (int)ppb);
   } else {
     const long total = BC * Hi * Wi;
     hipLaunchKernelGGL(upsample_bwd_generic_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, total);
@@ -823,7 +853,9 @@ int rsis_l_maxpool_bwd(const float* dy, const unsigned char* arg, float* dx, lon
 }
 int rsis_l_channel_sum(const float* dy, float* db, int B, int C, int HW, int hid, hipStream_t st) {
   const long N = (long)B * HW;
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, chan_splits(C, N)), dim3(256), 0, st, dy, db, C, HW, N, hid);
+  int S = chan_splits(C, N);
+  if (S > 512) S = 512;                      // (all splits of a channel end in one atomic on the same address)
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, S), dim3(256), 0, st, dy, db, C, HW, N, hid);
   return rsis_check_launch();
 }
 int rsis_l_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
