@@ -167,6 +167,16 @@ int rsis_heads_bwd(const float* const* side, const int* Cside, int nside, int B,
                    const float* class_probs, const float* dprobs, const float* dstop, float* const* dside, float* dWc, float* dbc,
                    float* dWs, float* dbs, void* stream);
 
+/* ---- loss tail of a training iteration (train.py:159-176; hungarian.py:10-59): masked means of the class NLL (probs[n][C],
+ * targets y_class[n] int64, optional per-class weights cls_w[C]), of the matched soft-IoU costs siou[n] and of the balanced stop
+ * BCE (logits stop[n], target = sw_mask, balance weight bw or < 0 = positives / n), n = B*T samples; sw_mask / sw_class are the
+ * 0/1 sample weights.  out[4] = {w_iou*iou + w_cls*cls + w_stop*stop, iou, stop, cls} (pass w_cls / w_stop = 0 for a disabled
+ * loss).  With dprobs / dstop / dsiou non-null the same launch also writes the gradient of out[0] * gout[0] (gout: device
+ * pointer to the upstream gradient, null = 1) w.r.t. the three inputs (out may then be null). ---- */
+int rsis_loss_tail(const float* probs, const long long* y_class, const float* stop, const float* siou, const float* sw_mask,
+                   const float* sw_class, const float* cls_w, int n, int C, float bw, float w_iou, float w_cls, float w_stop,
+                   float* out, float* dprobs, float* dstop, float* dsiou, const float* gout, void* stream);
+
 /* ---- inference post-processing of predicted masks (eval.py:96-127 resize_mask + pycocotools mask.encode; RLE semantics of
  * src/coco/common/maskApi.c:32-41,196-209) ----
  * rsis_mask_resize_threshold: prob[n][Hm][Wm] fp32 -> seg[n][w][h] uint8 (COLUMN-major h x w masks: align-corners bilinear

@@ -42,6 +42,8 @@ int rsis_l_heads_fwd(const float* const*, const int*, int, int, const float*, co
                      hipStream_t);
 int rsis_l_heads_bwd(const float* const*, const int*, int, int, const float*, int, const float*, const float*, const float*, const float*,
                      float* const*, float*, float*, float*, float*, hipStream_t);
+int rsis_l_loss_tail(const float*, const long long*, const float*, const float*, const float*, const float*, const float*, int, int, float,
+                     float, float, float, float*, float*, float*, float*, const float*, hipStream_t);
 int rsis_l_softiou_sums(const float*, const float*, float*, int, int, int, long, hipStream_t);
 int rsis_l_softiou_bwd(const float*, const float*, const long long*, int, const float*, const float*, float*, int, int, int, long,
                        hipStream_t);
@@ -391,4 +393,14 @@ int rsis_largest_component(const unsigned char* mask, unsigned char* out, int* l
                            void* stream) {
   if (!mask || !out || !labels || !counts || !best || n < 1 || h < 1 || w < 1 || (long)h * w >= (1L << 31)) return RSIS_ERR_ARG;
   return rsis_l_largest_component(mask, out, labels, counts, best, n, h, w, (hipStream_t)stream);
+}
+
+int rsis_loss_tail(const float* probs, const long long* y_class, const float* stop, const float* siou, const float* sw_mask,
+                   const float* sw_class, const float* cls_w, int n, int C, float bw, float w_iou, float w_cls, float w_stop,
+                   float* out, float* dprobs, float* dstop, float* dsiou, const float* gout, void* stream) {
+  if (!probs || !y_class || !stop || !siou || !sw_mask || !sw_class || n < 1 || C < 1) return RSIS_ERR_ARG;
+  if ((dprobs || dstop || dsiou) && !(dprobs && dstop && dsiou)) return RSIS_ERR_ARG;
+  if (!out && !dprobs) return RSIS_ERR_ARG;
+  return rsis_l_loss_tail(probs, y_class, stop, siou, sw_mask, sw_class, cls_w, n, C, bw, w_iou, w_cls, w_stop, out, dprobs, dstop, dsiou,
+                          gout, (hipStream_t)stream);
 }

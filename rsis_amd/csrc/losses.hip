@@ -211,3 +211,67 @@ int rsis_l_heads_bwd(const float* const* side, const int* C, int n, int B, const
   hipLaunchKernelGGL(heads_bwd_kernel, dim3(B), dim3(256), 0, st, s, K, Wc, ncls, Ws, probs, dprobs, dstop, dWc, dbc, dWs, dbs);
   return rsis_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Loss tail of a training iteration (reference src/train.py:159-176 with utils/hungarian.py:10-59): the masked means of the
+// class NLL, the matched soft-IoU costs and the balanced stop BCE, and their weighted sum -- ~100 tiny eager launches (gather,
+// log, neg, where, sum, div, mul, ... and their autograd) folded into one single-block kernel each way.  n = B*T samples.
+//   out[0] = total, out[1] = mean soft-IoU, out[2] = mean stop BCE, out[3] = mean class NLL   (train.py:189 order)
+// bw < 0: the BCE balance weight is taken from the targets (positives / total, hungarian.py:45-49); cls_w: optional per-class
+// weights multiplying log p (hungarian.py:24-27).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void loss_tail_kernel(const float* __restrict__ probs, const long long* __restrict__ y_class,
+                                                        const float* __restrict__ stop, const float* __restrict__ siou,
+                                                        const float* __restrict__ sw_mask, const float* __restrict__ sw_class,
+                                                        const float* __restrict__ cls_w, int n, int C, float bw, float w_iou,
+                                                        float w_cls, float w_stop, float* __restrict__ out,
+                                                        float* __restrict__ dprobs, float* __restrict__ dstop,
+                                                        float* __restrict__ dsiou, const float* __restrict__ gout_p) {
+  __shared__ float sh[4];
+  const float gout = gout_p ? gout_p[0] : 1.f;
+  float s_m = 0.f, s_c = 0.f, s_pos = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) { s_m += sw_mask[i]; s_c += sw_class[i]; s_pos += sw_mask[i]; }
+  const float sum_m = block_sum256(s_m, sh), sum_c = block_sum256(s_c, sh), npos = block_sum256(s_pos, sh);
+  if (bw < 0.f) bw = npos / (float)n;                          // target of the stop loss is sw_mask (train.py:167)
+  float a_iou = 0.f, a_cls = 0.f, a_stop = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float wm = sw_mask[i], wc = sw_class[i];
+    const int yc = (int)y_class[i];
+    const float p = probs[(size_t)i * C + yc];
+    const float cw = cls_w ? cls_w[yc] : 1.f;
+    const float nll = -logf(p) * cw;
+    const float x = stop[i], t = sw_mask[i];
+    const float mx = fmaxf(-x, 0.f);
+    const float lv = x - x * t + mx + logf(expf(-mx) + expf(-x - mx));       // hungarian.py:51-52
+    const float bal = (1.f - bw) * t + bw * (1.f - t);
+    if (wm > 0.f) { a_iou += siou[i]; a_cls += nll; }            // masked_select(costs, sw) semantics: unselected rows never enter
+    if (wc > 0.f) a_stop += lv * bal;
+    if (dprobs) {                                                // backward (gout = upstream gradient of the total)
+      dsiou[i] = wm > 0.f ? gout * w_iou / sum_m : 0.f;
+      dstop[i] = wc > 0.f ? gout * w_stop / sum_c * bal * (1.f / (1.f + expf(-x)) - t) : 0.f;
+      for (int c = 0; c < C; ++c) dprobs[(size_t)i * C + c] = 0.f;
+      if (wm > 0.f) dprobs[(size_t)i * C + yc] = -gout * w_cls * cw / (sum_m * p);
+    }
+  }
+  const float l_iou = block_sum256(a_iou, sh) / sum_m, l_cls = block_sum256(a_cls, sh) / sum_m, l_stop = block_sum256(a_stop, sh) / sum_c;
+  if (threadIdx.x == 0 && out) {
+    out[0] = w_iou * l_iou + w_cls * l_cls + w_stop * l_stop;
+    out[1] = l_iou; out[2] = l_stop; out[3] = l_cls;
+  }
+}
+
+int rsis_l_loss_tail(const float* probs, const long long* y_class, const float* stop, const float* siou, const float* sw_mask,
+                     const float* sw_class, const float* cls_w, int n, int C, float bw, float w_iou, float w_cls, float w_stop, float* out,
+                     float* dprobs, float* dstop, float* dsiou, const float* gout, hipStream_t st) {
+  hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(256), 0, st, probs, y_class, stop, siou, sw_mask, sw_class, cls_w, n, C, bw, w_iou,
+                     w_cls, w_stop, out, dprobs, dstop, dsiou, gout);
+  return rsis_check_launch();
+}

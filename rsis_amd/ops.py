@@ -639,3 +639,39 @@ def heads_supported(sides, fc_class, fc_stop):
 def heads(sides, fc_class, fc_stop):
     """(class_probs (B, ncls), stop logits (B, 1)) of reference RSIS.forward's tail from the list of pooled side features"""
     return _HeadsFn.apply(len(sides), *sides, fc_class.weight, fc_class.bias, fc_stop.weight, fc_stop.bias)
+
+
+class _LossTailFn(torch.autograd.Function):
+    """(total, [iou, stop, class]) of reference train.py:159-176 from class probabilities (B, T, C), matched class targets
+    (B, T), stop logits (B, T), matched soft-IoU costs (B, T) and the two sample-weight matrices; one launch each way."""
+
+    @staticmethod
+    def forward(ctx, probs, y_class, stop, siou, sw_mask, sw_class, cls_w, bw, w_iou, w_cls, w_stop):
+        probs, stop, siou = _contig(probs), _contig(stop), _contig(siou)
+        y_class, sw_mask, sw_class = _contig(y_class), _contig(sw_mask), _contig(sw_class)
+        require_cuda_f32(probs, stop, siou, sw_mask, sw_class, cls_w)
+        n, C = y_class.numel(), probs.shape[-1]
+        out = torch.empty(4, dtype=torch.float32, device=probs.device)
+        check(lib().rsis_loss_tail(ptr(probs), ptr(y_class), ptr(stop), ptr(siou), ptr(sw_mask), ptr(sw_class), ptr(cls_w), n, C,
+                                   float(bw), float(w_iou), float(w_cls), float(w_stop), ptr(out), None, None, None, None, stream()),
+              "rsis_loss_tail")
+        ctx.save_for_backward(probs, y_class, stop, siou, sw_mask, sw_class, cls_w)
+        ctx.cfg = (n, C, float(bw), float(w_iou), float(w_cls), float(w_stop))
+        total, parts = out[0], out[1:]
+        ctx.mark_non_differentiable(parts)
+        return total, parts
+
+    @staticmethod
+    def backward(ctx, g, _gparts):
+        probs, y_class, stop, siou, sw_mask, sw_class, cls_w = ctx.saved_tensors
+        n, C, bw, w_iou, w_cls, w_stop = ctx.cfg
+        g = _contig(g.reshape(1).float())
+        dprobs, dstop, dsiou = torch.empty_like(probs), torch.empty_like(stop), torch.empty_like(siou)
+        check(lib().rsis_loss_tail(ptr(probs), ptr(y_class), ptr(stop), ptr(siou), ptr(sw_mask), ptr(sw_class), ptr(cls_w), n, C, bw, w_iou,
+                                   w_cls, w_stop, None, ptr(dprobs), ptr(dstop), ptr(dsiou), ptr(g), stream()), "rsis_loss_tail(bwd)")
+        return dprobs, None, dstop, dsiou, None, None, None, None, None, None, None
+
+
+def loss_tail(probs, y_class, stop, siou, sw_mask, sw_class, cls_w, bw, w_iou, w_cls, w_stop):
+    """bw: BCE balance weight or None (taken from the targets); cls_w: per-class weights tensor or None"""
+    return _LossTailFn.apply(probs, y_class, stop, siou, sw_mask, sw_class, cls_w, -1.0 if bw is None else bw, w_iou, w_cls, w_stop)

@@ -103,20 +103,29 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
     # ---- losses : train.py:159-176 (masked means) ----
     with torch.set_grad_enabled(train):
         N, C = out_masks.size(-1), out_classes.size(-1)
-        nll = MaskedNLL(y_class_perm.reshape(-1, 1), out_classes.reshape(-1, C), getattr(class_crit, "balance_weight", None))
-        loss_class = _masked_mean(nll.reshape(-1, 1), sw_mask_t.reshape(-1, 1))                   # :159-161
         if fused_iou:
             siou = ops.softiou_matched(out_masks, y_mask, perm, iou_sums)                          # same sums, no second pass
         else:
             siou = softIoU(y_mask_perm.reshape(-1, N), out_masks.reshape(-1, N))
-        loss_mask_iou = _masked_mean(siou.reshape(-1, 1), sw_mask_t.reshape(-1, 1))               # :162-163
-        bce = StableBalancedMaskedBCE(sw_mask_t, out_stops.squeeze(-1), getattr(stop_xentropy, "balance_weight", None))
-        loss_stop = _masked_mean(bce.reshape(-1, 1), sw_class_t.reshape(-1, 1))                   # :167-168
-        loss = args.iou_weight * loss_mask_iou                                                      # :171
-        if args.use_class_loss:
-            loss = loss + args.class_weight * loss_class                                            # :173-174
-        if args.use_stop_loss:
-            loss = loss + args.stop_weight * loss_stop                                              # :175-176
+        cls_w, bw = getattr(class_crit, "balance_weight", None), getattr(stop_xentropy, "balance_weight", None)
+        if out_classes.is_cuda and out_classes.dtype == torch.float32:
+            # the three masked means and their weighted sum (:159-176) in one launch each way
+            cw = cls_w.to(out_classes.device, torch.float32) if cls_w is not None else None
+            loss, parts = ops.loss_tail(out_classes, y_class_perm, out_stops.squeeze(-1), siou.reshape(y_class_perm.shape), sw_mask_t,
+                                        sw_class_t, cw, bw, args.iou_weight, args.class_weight if args.use_class_loss else 0.0,
+                                        args.stop_weight if args.use_stop_loss else 0.0)
+            loss_mask_iou, loss_stop, loss_class = parts[0], parts[1], parts[2]
+        else:
+            nll = MaskedNLL(y_class_perm.reshape(-1, 1), out_classes.reshape(-1, C), cls_w)
+            loss_class = _masked_mean(nll.reshape(-1, 1), sw_mask_t.reshape(-1, 1))               # :159-161
+            loss_mask_iou = _masked_mean(siou.reshape(-1, 1), sw_mask_t.reshape(-1, 1))           # :162-163
+            bce = StableBalancedMaskedBCE(sw_mask_t, out_stops.squeeze(-1), bw)
+            loss_stop = _masked_mean(bce.reshape(-1, 1), sw_class_t.reshape(-1, 1))               # :167-168
+            loss = args.iou_weight * loss_mask_iou                                                  # :171
+            if args.use_class_loss:
+                loss = loss + args.class_weight * loss_class                                        # :173-174
+            if args.use_stop_loss:
+                loss = loss + args.stop_weight * loss_stop                                          # :175-176
 
     enc_opt.zero_grad()                                               # :178-181
     dec_opt.zero_grad()

@@ -351,3 +351,35 @@ def test_heads_fwd_bwd(B, Cs, ncls):
         assert_close("dside", a.grad, b.grad, 2e-6, 1e-4)
     for a, b in ((dc.weight, fc_c.weight), (dc.bias, fc_c.bias), (ds.weight, fc_s.weight), (ds.bias, fc_s.bias)):
         assert_close("dparam", a.grad, b.grad, 5e-6, 1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bw,use_w", [(0.5, False), (None, False), (0.3, True)])
+def test_loss_tail_matches_oracle(bw, use_w):
+    """fused loss tail (rsis_loss_tail) against the oracle's MaskedNLL / StableBalancedMaskedBCE + masked means (train.py:159-176)"""
+    from rsis_amd import ops
+    from oracle import rsis_oracle as O
+    rng = np.random.default_rng(23)
+    B, T, C = 6, 5, 9
+    probs = torch.softmax(torch.from_numpy(rng.normal(0, 2, (B, T, C)).astype(np.float32)), -1)
+    y = torch.from_numpy(rng.integers(0, C, (B, T)))
+    stop = torch.from_numpy(rng.normal(0, 3, (B, T)).astype(np.float32))
+    siou = torch.from_numpy(rng.random((B, T)).astype(np.float32))
+    swm = torch.from_numpy((rng.random((B, T)) < 0.6).astype(np.float32)); swm[0, 0] = 1
+    swc = torch.from_numpy((rng.random((B, T)) < 0.7).astype(np.float32)); swc[0, 0] = 1
+    cw = torch.from_numpy(rng.random(C).astype(np.float32) + 0.5) if use_w else None
+    w_iou, w_cls, w_stop = 1.0, 0.1, 0.5
+    leaves = [t.clone().requires_grad_() for t in (probs, stop, siou)]
+    nll = O.MaskedNLL(y.reshape(-1, 1), leaves[0].reshape(-1, C), cw)
+    bce = O.StableBalancedMaskedBCE(swm, leaves[1], bw)
+    mm = lambda c, w: torch.masked_select(c.reshape(-1), w.reshape(-1).bool()).mean()
+    l_cls, l_iou, l_stop = mm(nll, swm), mm(leaves[2], swm), mm(bce, swc)
+    ref = w_iou * l_iou + w_cls * l_cls + w_stop * l_stop
+    (ref * 1.7).backward()
+    dev = [t.detach().cuda().requires_grad_() for t in (probs, stop, siou)]
+    total, parts = ops.loss_tail(dev[0], y.cuda(), dev[1], dev[2], swm.cuda(), swc.cuda(), cw.cuda() if use_w else None, bw, w_iou, w_cls, w_stop)
+    (total * 1.7).backward()
+    assert_close("total", total, ref, 2e-6, 1e-5)
+    assert_close("parts", parts, torch.stack([l_iou, l_stop, l_cls]), 2e-6, 1e-5)
+    for a, b, nm in zip(dev, leaves, ("dprobs", "dstop", "dsiou")):
+        assert_close(nm, a.grad, b.grad, 2e-6, 1e-4)
