@@ -1,0 +1,106 @@
+"""GPU test of the data-parallel training step: two ranks (gloo, both on the one GPU of the test box) run runIter on different
+shards with the bucketed gradient all-reduce hooked into the backward; afterwards the summed gradients and the updated
+parameters must be identical on both ranks, and the all-reduced gradient must equal the sum of the two ranks' local
+gradients.  (nccl = RCCL needs one GPU per rank; the collective path itself is backend-agnostic.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    # RSIS_CONV_SPLITK=0: bit-reproducible forward, so that the two lr = 0 steps below see the same scores / the same assignment
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      RSIS_CONV_SPLITK="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import mk_args
+    from rsis_amd.modules import RSIS, FeatureExtractor
+    from rsis_amd.optim import BucketedAllReduce
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import build_optimizers, runIter
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    torch.cuda.set_device(0)
+    a = mk_args(hidden_size=32, maxseqlen=3, optim="adam", optim_cnn="adam", lr=1e-3, lr_cnn=1e-4, weight_decay=0.0, weight_decay_cnn=0.0)
+    a.gt_maxseqlen, a.num_classes = 5, 7
+    a.use_class_loss = a.use_stop_loss = a.update_encoder = True
+    torch.manual_seed(0)                                   # identical replicas
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    enc_opt, dec_opt = build_optimizers(a, enc, dec)
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(0.5)]
+    batch = synthetic_batch(10 + rank, 2, 64, 64, 5, 3, 7, "cuda")          # a different shard per rank
+    # local gradient of this rank (no reducer, no optimizer effect on the comparison: snapshot params first)
+    p0 = torch.cat([dec_opt.group.flat_p, enc_opt.group.flat_p]).clone()
+    # two steps with lr = 0: the local gradient first (the reducer's hooks are live from its construction on, so it is built
+    # afterwards), then the all-reduced one, to be compared with the sum of the local gradients of both ranks
+    for g in (enc_opt.group, dec_opt.group):
+        g.lr_saved, g.lr = g.lr, 0.0
+    runIter(a, enc, dec, *batch, crits, [enc_opt, dec_opt], mode="train", reducer=None, sync_losses=True)
+    local = torch.cat([dec_opt.group.flat_g, enc_opt.group.flat_g]).clone()
+    red = BucketedAllReduce([dec_opt.group, enc_opt.group], bucket_bytes=8 << 20)
+    assert red.active and len(red.buckets) >= 3
+    runIter(a, enc, dec, *batch, crits, [enc_opt, dec_opt], mode="train", reducer=red, sync_losses=True)
+    summed = torch.cat([dec_opt.group.flat_g, enc_opt.group.flat_g]).clone()
+    both = [torch.empty_like(local).cpu() for _ in range(world)]
+    dist.all_gather(both, local.cpu())
+    want = both[0] + both[1]
+    err = float((summed.cpu() - want).abs().max() / want.abs().max().clamp_min(1e-12))
+    assert float((torch.cat([dec_opt.group.flat_p, enc_opt.group.flat_p]) - p0).abs().max()) == 0.0      # lr 0: parameters untouched
+    # now a real step: parameters must stay identical across ranks
+    for g in (enc_opt.group, dec_opt.group):      # (the lr = 0 step without a reducer fed rank-local gradients to the Adam moments)
+        g.lr = g.lr_saved
+        g.exp_avg.zero_()
+        g.exp_avg_sq.zero_()
+        g.step_count = 0
+    runIter(a, enc, dec, *batch, crits, [enc_opt, dec_opt], mode="train", reducer=red, sync_losses=True)
+    p1 = torch.cat([dec_opt.group.flat_p, enc_opt.group.flat_p]).cpu()
+    # (small summaries only: tensors that travel through an mp.Queue live in shared memory of a process that is about to exit)
+    def digest(t):
+        t = t.double().cpu()
+        return (float(t.sum()), float(t.abs().sum()), t[::997].numpy().copy())
+    q.put((rank, err, digest(summed), digest(p1), float((p1 - p0.cpu()).abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_runiter_world2_gradients_and_parameters_agree():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    res, t0 = [], time.time()
+    while len(res) < 2:                                    # fail fast when a rank dies instead of waiting for the timeout
+        try:
+            res.append(q.get(timeout=5))
+        except queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), "a rank crashed: %s" % [p.exitcode for p in procs]
+            assert time.time() - t0 < 300, "timed out"
+    res.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    # the two launches of the same shard differ only by the order of the fp32 atomics in the backward
+    assert res[0][1] < 1e-3 and res[1][1] < 1e-3, (res[0][1], res[1][1])
+    import numpy as np
+    for i, what in ((2, "all-reduced gradients differ between ranks"), (3, "parameters diverged between ranks")):
+        a, b = res[0][i], res[1][i]
+        assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]), what
+    assert res[0][4] > 0, "the optimizer step did not change the parameters"
