@@ -7,8 +7,6 @@ flat fp32 buffer (so are their grads): the Adam step is a single fused HIP kerne
 bucket, launched from autograd hooks as soon as a bucket's gradients are final (decoder + skip bucket first -- it
 overlaps the whole encoder backward).
 """
-import os
-
 import torch
 import torch.distributed as dist
 
