@@ -135,9 +135,16 @@ def main():
     ap.add_argument("--settle-min", type=float, default=2.0, help="minimum seconds of the untimed settle phase")
     ap.add_argument("--settle-cap", type=float, default=10.0, help="maximum seconds of the untimed settle phase")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the gate-kernel roofline leg and print its object (for `rocprofv3 --kernel-trace --stats`: the "
+                         "profile then holds exactly the launches the `roofline` figure is computed from)")
     o = ap.parse_args()
     if o.cpu_baseline_only:
         print(json.dumps(cpu_baseline(o.imsize, o.T)))
+        return
+    if o.roofline_only:
+        assert torch.cuda.is_available(), "bench.py needs the GPU (there is no CPU path)"
+        print(json.dumps(gate_kernel_roofline(o.batch, o.kernel_iters, o.imsize)))
         return
 
     from rsis_amd.train import build_optimizers, init_distributed, runIter
