@@ -21,6 +21,7 @@ management; see main()); the timed region is still EXACTLY K steps between barri
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -120,6 +121,51 @@ def cpu_baseline(imsize, T, budget_s=25.0):
                       % (B, imsize, imsize, T, n)}
 
 
+def gate_kernel_traffic(batch, imsize, timeout=240):
+    """HBM bytes of the five gate-kernel launches of one timestep from the memory-side PMC counters: two rocprofv3 passes
+    (FETCH_SIZE, then WRITE_SIZE -- they do not fit one pass) over `bench.py --roofline-only` in a child process.
+    FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibrated there for 16 B/lane streaming reads; this
+    kernel's input patch is fetched 4 B/lane, for which the doubling is an upper bound).  Returns (bytes, detail) or (None, why)."""
+    import csv
+    import re
+    import shutil
+    import statistics
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="rsis_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    per_counter = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", counter.lower(), "--",
+                   sys.executable, os.path.abspath(__file__), "--roofline-only", "--kernel-iters", "4", "--batch", str(batch), "--imsize",
+                   str(imsize)]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            path = None
+            for root, _d, files in os.walk(tmp):
+                for f in files:
+                    if f.startswith(counter.lower()) and f.endswith("counter_collection.csv"):
+                        path = os.path.join(root, f)
+            if path is None:
+                return None, "no counter_collection.csv from rocprofv3"
+            vals = {}
+            with open(path) as f:
+                for r in csv.DictReader(f):
+                    k = r["Kernel_Name"]
+                    if "conv3x3_direct_kernel" in k and r["Counter_Name"] == counter and re.search(r", 1>", k):
+                        vals.setdefault((k, r["Grid_Size"]), []).append(float(r["Counter_Value"]))
+            if len(vals) != 5:
+                return None, "expected 5 gate-kernel launch shapes in the counter file, found %d" % len(vals)
+            per_counter[counter] = sum(statistics.median(v) for v in vals.values()) * 1024.0      # counters are in KiB
+    except Exception as e:  # noqa: BLE001  (profiler missing / refused / timed out: the figure stays null)
+        return None, "rocprofv3 pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = 2.0 * per_counter["FETCH_SIZE"], per_counter["WRITE_SIZE"]
+    return fetch + write, {"fetch_bytes_x2": fetch, "write_bytes": write}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +177,7 @@ def main():
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
+    ap.add_argument("--skip-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--no-settle", action="store_true", help="skip the untimed settle phase after the warm-up steps")
     ap.add_argument("--settle-min", type=float, default=2.0, help="minimum seconds of the untimed settle phase")
     ap.add_argument("--settle-cap", type=float, default=10.0, help="maximum seconds of the untimed settle phase")
@@ -189,6 +236,14 @@ def main():
     if rank == 0 and not o.skip_roofline:
         roof = gate_kernel_roofline(o.batch, o.kernel_iters, o.imsize)
         note("gate kernel roofline: %s TFLOP/s" % roof["achieved"])
+        if world == 1 and not o.skip_traffic:
+            t0 = time.time()
+            traffic, detail = gate_kernel_traffic(o.batch, o.imsize)
+            roof["traffic"] = traffic
+            if traffic is not None:
+                roof["traffic_unit"] = "bytes per timestep (5 launches): 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate passes"
+                roof["traffic_detail"] = detail
+            note("gate kernel HBM traffic: %s (%.0f s)" % (traffic if traffic is not None else detail, time.time() - t0))
     tw = time.time()
     for i in range(o.warmup):
         losses = step()[0]
