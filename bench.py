@@ -121,7 +121,7 @@ def cpu_baseline(imsize, T, budget_s=25.0):
                       % (B, imsize, imsize, T, n)}
 
 
-def gate_kernel_traffic(batch, imsize, timeout=240):
+def gate_kernel_traffic(batch, imsize, timeout=150):
     """HBM bytes of the five gate-kernel launches of one timestep from the memory-side PMC counters: two rocprofv3 passes
     (FETCH_SIZE, then WRITE_SIZE -- they do not fit one pass) over `bench.py --roofline-only` in a child process.
     FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibrated there for 16 B/lane streaming reads; this
