@@ -152,3 +152,44 @@ def test_largest_component_matches_scipy():
         lab, nlab = ndimage.label(batch[k], structure=np.ones((3, 3)))
         want = (lab == (int(np.argmax(np.bincount(lab.reshape(-1))[1:])) + 1)).astype(np.uint8) if nlab else np.zeros_like(batch[k])
         assert np.array_equal(got[k], want)
+
+
+@pytest.mark.gpu
+def test_eval_driver_writes_coco_records(tmp_path):
+    """python -m rsis_amd.eval --synthetic: inference + device post-processing + COCO-style records (eval.py:254-345)"""
+    import json
+    from rsis_amd.args import get_parser
+    from rsis_amd.eval import Evaluate
+    a = get_parser().parse_args(["--synthetic", "-model_name", "evtest", "-batch_size", "2", "-maxseqlen", "3", "-hidden_size", "32",
+                                 "-synthetic_batches", "4", "-stop_th", "0.0", "-class_th", "0.0", "-min_size", "0.0"])
+    a.models_root, a.imsize, a.num_classes = str(tmp_path), 64, 5
+    torch.manual_seed(0)
+    preds = Evaluate(a).run_eval()
+    assert len(preds) == 2 * 3 * 4                               # images x timesteps x (classes - eos), nothing filtered at th = 0
+    rec = preds[0]
+    assert set(rec) == {"image_id", "category_id", "category_name", "segmentation", "score"} and rec["segmentation"]["size"] == [64, 64]
+    with open(os.path.join(str(tmp_path), "evtest", "evtest_test_predictions.json")) as f:
+        assert len(json.load(f)) == len(preds)
+    # the record's RLE decodes (oracle side) to as many pixels as the thresholded mask has
+    counts = rle_numpy_decode_area(rec["segmentation"]["counts"].encode("ascii"))
+    assert 0 <= counts <= 64 * 64
+
+
+def rle_numpy_decode_area(s):
+    """area of a COCO compressed RLE string (inverse of rle_string, oracle side)"""
+    cnts, p, m = [], 0, 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            c = s[p] - 48
+            x |= (c & 0x1F) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if m > 2:
+            x += cnts[m - 2]
+        cnts.append(x)
+        m += 1
+    return int(sum(cnts[1::2]))
