@@ -59,7 +59,7 @@ static inline int direct_rows(int nseg, const int* Cseg) {
   for (int s = 0; s < nseg; ++s) q += (Cseg[s] + RSIS_CK - 1) / RSIS_CK;
   return q * RSIS_CK * 9;
 }
-static inline int direct_variant(int tile) { const int v = tile % 10; return (tile > 0 && v >= 1 && v <= 5) ? v : 0; }
+static inline int direct_variant(int tile) { const int v = tile % 10; return (tile > 0 && v >= 1 && v <= 6) ? v : 0; }
 
 extern "C" {
 

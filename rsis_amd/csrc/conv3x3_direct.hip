@@ -33,11 +33,15 @@ typedef const float __attribute__((address_space(1)))* gcf_t;
 typedef float __attribute__((address_space(1)))* gf_t;
 typedef const f32x4 __attribute__((address_space(1)))* gcf4_t;
 
-template <int BM, int TW, int TH, int NI, int EPI>
+// KSP = 2: the 4 waves are 2 K-halves x (BM/32 x BN/32/TN) tiles -- each wave walks every other channel pair of a chunk and the
+// two partial accumulators are summed through LDS before the epilogue.  Used for the 8x8 maps (64 pixels = 2 column tiles):
+// twice the blocks (32 instead of 64 output rows each) and twice the waves per SIMD on a launch that otherwise fills only
+// one wave per SIMD.
+template <int BM, int TW, int TH, int NI, int EPI, int KSP = 1>
 __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
 #if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; the buffer-resource builtins do not exist there)
   constexpr int BN = TW * TH * NI;
-  constexpr int WGM = BM / 32, WGN = 4 / WGM;      // BM=64: 2x2 waves, BM=32: 1x4
+  constexpr int WGM = BM / 32, WGN = 4 / WGM / KSP;      // BM=64: 2x2 waves, BM=32: 1x4 (KSP = 2: 1x2 tiles x 2 K-halves)
   constexpr int TN = BN / WGN / 32;                 // 32-pixel MFMA column tiles per wave (TM == 1)
   constexpr int PW = TW + 2, PH = TH + 2;
   constexpr int IMS = PH * PW;                      // one image of the patch
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   constexpr int NX = (XS + 255) / 256;              // patch loads per thread per chunk
   constexpr int W_F4 = WS / 4;
   constexpr int NW = (W_F4 + 255) / 256;            // weight float4 loads per thread per chunk
-  static_assert(TN >= 1 && BN % (WGN * 32) == 0, "tile");
+  static_assert(TN >= 1 && BN % (WGN * 32) == 0 && WGM * WGN * KSP == 4 && (CK / 2) % KSP == 0 && (KSP == 1 || EPI != EPI_S2), "tile");
 
   __shared__ __attribute__((aligned(16))) float lds[2 * (XSP + WS)];
   float* const Xs0 = lds;
@@ -80,7 +84,8 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
+  const int wk = wave / (WGM * WGN);                 // K-half of this wave (0 when KSP == 1)
+  const int wm = (wave / WGN) % WGM, wn = wave % WGN;
 
 #if DIRECT_DMA
   // ---- loop-invariant byte offset of this thread's patch elements inside the [CK][H][W] slab of one chunk of image b0;
@@ -132,7 +137,10 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
     const int x = pp % TW, y = (pp / TW) % TH, img = pp / (TW * TH);
     xoff[j] = hi * CHS + img * IMS + y * PW + x;
   }
-  const int woff = hi * BM + wm * 32 + l31;
+  // K-split: wave half wk starts at channel pair wk * (CK/2/KSP) of every chunk (folded into the two read bases)
+  constexpr int C2W = CK / 2 / KSP;                 // channel pairs per wave per chunk
+  const int woff = hi * BM + wm * 32 + l31 + wk * (C2W * 9 * 2) * BM;
+  const int xk = wk * (2 * C2W) * CHS;
 
   constexpr int NACC = EPI == EPI_S2 ? 4 : 1;   // EPI_S2: one accumulator set per parity class of the input pixel
   f32x16 accs[NACC][TN];
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
       const float* Xs = Xs0 + cur * XSP;
       const float* Ws = Ws0 + cur * WS + woff;
 #pragma unroll
-      for (int c2 = 0; c2 < CK / 2; ++c2)
+      for (int c2 = 0; c2 < C2W; ++c2)
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
             float b[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              b[j] = Xs[xoff[j] + (2 * c2) * CHS + (EPI == EPI_S2 ? ((r == 0) + 1) * PW + (s == 0) + 1 : r * PW + s)];
+              b[j] = Xs[xk + xoff[j] + (2 * c2) * CHS + (EPI == EPI_S2 ? ((r == 0) + 1) * PW + (s == 0) + 1 : r * PW + s)];
             const int cls = EPI == EPI_S2 ? (r != 1) * 2 + (s != 1) : 0;   // compile time after unrolling
 #pragma unroll
             for (int j = 0; j < TN; ++j) accs[cls][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], accs[cls][j], 0, 0, 0);
@@ -262,6 +270,22 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
 #undef DIRECT_LOAD
 #undef DIRECT_STORE
 
+  if constexpr (KSP > 1) {
+    // sum the K-halves: waves with wk > 0 park their accumulators in LDS (the staging buffers are dead after the last barrier)
+    float* red = lds + ((wm * WGN + wn) * TN) * 16 * 64;
+    if (wk > 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(j * 16 + r) * 64 + lane] = acc[j][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] += red[(j * 16 + r) * 64 + lane];
+  }
   // ---- epilogue ----
   const int co_base = co_t * BM + wm * 32;
   const gcf_t bias = (gcf_t)p.bias, addend = (gcf_t)p.addend;
@@ -338,7 +362,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int BM, int TW, int TH, int NI, int EPI>
+template <int BM, int TW, int TH, int NI, int EPI, int KSP = 1>
 static int launch_direct_cfg(ConvArgs& a, hipStream_t st) {
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
   a.n_px_tiles = rsis_cdiv(a.W, TW) * rsis_cdiv(a.H, TH) * rsis_cdiv(a.B, NI);
@@ -355,17 +379,23 @@ static int launch_direct_cfg(ConvArgs& a, hipStream_t st) {
       if (ksplit < 1) ksplit = 1;
     }
   }
-  hipLaunchKernelGGL((conv3x3_direct_kernel<BM, TW, TH, NI, EPI>), dim3(grid, ksplit), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv3x3_direct_kernel<BM, TW, TH, NI, EPI, KSP>), dim3(grid, ksplit), dim3(256), 0, st, a);
   return rsis_check_launch();
 }
 
-// variant codes: 1 = BM64 8x8x1 (64 px), 2 = BM64 16x8 (128 px), 3 = BM64 32x8 (256 px), 4 = BM32 16x8, 5 = BM32 32x8
+// variant codes: 1 = BM64 8x8x1 (64 px), 2 = BM64 16x8 (128 px), 3 = BM64 32x8 (256 px), 4 = BM32 16x8, 5 = BM32 32x8,
+// 6 = BM32 8x8 with the K range split over two wave pairs
 template <int EPI>
 static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
   int v = force;
   if (v <= 0) {
     const bool small_co = a.Cout <= 32;
-    if (a.W <= 8 && a.H <= 8) v = 1;
+    if (a.W <= 8 && a.H <= 8) {
+      // 8x8 maps: 64-row blocks give at most one wave per SIMD below 1024 blocks; the 32-row K-split variant doubles both
+      const long b64 = (long)rsis_cdiv(a.Cout, 64) * a.B;
+      const bool gsplit = EPI == EPI_PLAIN && a.ksplit == 0 && b64 < 160;   // the grid-level split-K schedule is tuned for v = 1
+      v = (EPI != EPI_S2 && b64 < 1024 && !gsplit) ? 6 : 1;
+    }
     else if (a.W <= 16) v = small_co ? 4 : 2;
     else v = small_co ? 5 : 3;
     // keep >= ~1 block per CU: fall back to the smaller pixel tile when the big one leaves CUs idle
@@ -382,12 +412,14 @@ static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
     }
   }
   if (EPI == EPI_S2 && v == 3) v = 5;   // 4 accumulator sets: the 256-pixel x 64-row tile would need 256 accumulator registers
+  if (EPI == EPI_S2 && v == 6) v = 1;   // (no K-split variant of the 4-accumulator epilogue)
   switch (v) {
     case 1: return launch_direct_cfg<64, 8, 8, 1, EPI>(a, st);
     case 2: return launch_direct_cfg<64, 16, 8, 1, EPI>(a, st);
     case 3: if constexpr (EPI != EPI_S2) return launch_direct_cfg<64, 32, 8, 1, EPI>(a, st); else return RSIS_ERR_ARG;
     case 4: return launch_direct_cfg<32, 16, 8, 1, EPI>(a, st);
     case 5: return launch_direct_cfg<32, 32, 8, 1, EPI>(a, st);
+    case 6: if constexpr (EPI != EPI_S2) return launch_direct_cfg<32, 8, 8, 1, EPI, 2>(a, st); else return RSIS_ERR_ARG;
     default: return RSIS_ERR_ARG;
   }
 }

@@ -97,7 +97,11 @@ def test_encoder_golden(name, train):
         fs = enc(x.cuda())
     if not train:
         for i, f in enumerate(fs):
-            assert_close("%s.skip%d" % (name, 5 - i), f, g["skip%d" % (5 - i)], 1e-4, 1e-4)
+            # eval-mode BN of these (filler-initialised, un-normalised) nets scales activations to O(100): the absolute part of
+            # the tolerance is 1e-4 at unit scale plus 2 ulp-ish of the tensor's largest magnitude (an element that cancels
+            # from +-200 down to 0.007 carries fp32 summation-order noise of ~2e-4)
+            ref = g["skip%d" % (5 - i)]
+            assert_close("%s.skip%d" % (name, 5 - i), f, ref, 1e-4 + 2e-6 * float(np.abs(ref).max()), 1e-4)
         return
     o64 = filler.fill_module(O.FeatureExtractor(mk_args()), seed=33).double().train()
     with torch.no_grad():

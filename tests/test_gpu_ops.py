@@ -88,7 +88,7 @@ LSTM_CASES = [
 
 
 @pytest.mark.parametrize("case", LSTM_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
 def test_convlstm_fwd_bwd(case, tile):
     from oracle import rsis_oracle as O
     from rsis_amd import ops
