@@ -8,6 +8,7 @@ import torch
 
 def synthetic_targets(seed, B, H, W, gt_maxseqlen=20, n_inst=12, num_classes=21):
     r = np.random.default_rng([int(seed), 777])
+    n_inst = min(int(n_inst), int(gt_maxseqlen))      # (the reference keeps the gt_maxseqlen largest instances: dataset.py:126-131)
     y_mask = np.zeros((B, gt_maxseqlen, H * W), np.float32)
     y_class = np.zeros((B, gt_maxseqlen), np.int64)
     sw_mask = np.zeros((B, gt_maxseqlen), np.float32)

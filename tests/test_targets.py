@@ -42,3 +42,10 @@ def test_targets_from_maps_cpu_matches_reference():
 @pytest.mark.gpu
 def test_targets_from_maps_gpu_matches_reference():
     _check_device_targets("cuda")
+
+
+def test_synthetic_targets_clamp_instances_to_gt_slots():
+    """`-synthetic_instances` above `-gt_maxseqlen` must not overflow the target tensor (python -m rsis_amd.train -gt_maxseqlen 8)"""
+    from rsis_amd.synthetic import synthetic_targets
+    ym, yc, swm, swc = synthetic_targets(1, 2, 16, 16, gt_maxseqlen=5, n_inst=12, num_classes=7)
+    assert ym.shape == (2, 5, 256) and float(swm.sum()) == 10 and float(swc.sum()) == 10
