@@ -356,3 +356,39 @@ def test_training_step_leaves_no_cyclic_garbage():
     finally:
         gc.enable()
     assert grown <= 1 << 20, "device memory grew by %.1f MB over 5 steps with the cyclic GC off" % (grown / 2 ** 20)
+
+
+@pytest.mark.parametrize("skip_mode", ["sum", "mul", "none"])
+def test_decoder_other_skip_modes_match_oracle(skip_mode):
+    """model.py:151-158: the non-default skip connections (`-skip_mode sum|mul|none`) run the per-cell (unfused) decoder path;
+    2 timesteps forward + backward against the oracle on the same weights"""
+    from oracle import filler
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules import RSIS
+    hs, B = 32, 2
+    sizes = [(2, 3), (4, 6), (8, 12), (16, 24), (32, 48)]
+    a = mk_args(hidden_size=hs, skip_mode=skip_mode)
+    odec = filler.fill_module(O.RSIS(a), seed=41).train()
+    dec = RSIS(a).cuda().train()
+    dec.load_state_dict(odec.state_dict())
+    chans = [hs, hs, hs // 2, hs // 4, hs // 8]
+    feats = [filler.tensor(41, "skipmode.f%d" % i, (B, chans[i]) + sizes[i]).requires_grad_() for i in range(5)]
+    dfeats = [f.detach().cuda().requires_grad_() for f in feats]
+    res = []
+    for d, fs in ((odec, feats), (dec, dfeats)):
+        hidden, loss, outs = None, 0.0, []
+        for _t in range(2):
+            m, c, s, hidden = d(fs, hidden)
+            outs += [m, c, s]
+            loss = loss + m.square().mean() + c.square().sum() + s.mean()
+        loss.backward()
+        res.append(outs)
+    for i, (p, q) in enumerate(zip(*res)):
+        assert_close("%s.out%d" % (skip_mode, i), q, p.detach(), 1e-4, 1e-4)
+    for i, (f, g) in enumerate(zip(feats, dfeats)):
+        if f.grad is None:                                   # skip_mode none: the skip features of levels 1-4 are unused
+            assert g.grad is None or float(g.grad.abs().max()) == 0.0
+            continue
+        assert_close("%s.dfeat%d" % (skip_mode, i), g.grad, f.grad, 2e-4 * max(1.0, float(f.grad.abs().max())), 1e-4)
+    for (k, p), (_k2, q) in zip(odec.named_parameters(), dec.named_parameters()):
+        assert_close("%s.grad.%s" % (skip_mode, k), q.grad, p.grad, 2e-4 * max(1.0, float(p.grad.abs().max())), 1e-4)
