@@ -383,3 +383,34 @@ def test_loss_tail_matches_oracle(bw, use_w):
     assert_close("parts", parts, torch.stack([l_iou, l_stop, l_cls]), 2e-6, 1e-5)
     for a, b, nm in zip(dev, leaves, ("dprobs", "dstop", "dsiou")):
         assert_close(nm, a.grad, b.grad, 2e-6, 1e-4)
+
+
+@pytest.mark.gpu
+def test_convlstm_kernel_size_1():
+    """`-kernel_size 1` (model.py:83-84: padding 0): the gate conv is a 1x1 conv -> implicit-GEMM kernel with the LSTM epilogue"""
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules.clstm import ConvLSTMCell
+    from helpers import mk_args
+    B, Cin, hid, H, W = 2, 24, 16, 9, 12
+    ocell = O.ConvLSTMCell(mk_args(), Cin, hid, 1, 0)
+    with torch.no_grad():
+        ocell.Gates.weight.copy_(_rng_t(1, tuple(ocell.Gates.weight.shape), 2.0 / np.sqrt(Cin + hid)))
+        ocell.Gates.bias.copy_(_rng_t(2, (4 * hid,), 0.2))
+    cell = ConvLSTMCell(mk_args(), Cin, hid, 1, 0).cuda()
+    cell.load_state_dict(ocell.state_dict())
+    x0, x1 = _rng_t(30, (B, Cin, H, W)).requires_grad_(), _rng_t(31, (B, Cin, H, W)).requires_grad_()
+    gh = _rng_t(50, (B, hid, H, W))
+    h0, c0 = ocell(x0, None)
+    h1, c1 = ocell(x1, (h0, c0))
+    ((h1 * gh).sum() + (c1 * gh).sum()).backward()
+    x0d, x1d = _dev(x0.detach().clone().requires_grad_()), _dev(x1.detach().clone().requires_grad_())
+    h0d, c0d = cell(x0d, None)
+    h1d, c1d = cell(x1d, (h0d, c0d))
+    ((h1d * gh.cuda()).sum() + (c1d * gh.cuda()).sum()).backward()
+    for n, a, b in (("h1", h1d, h1), ("c1", c1d, c1)):
+        assert_close(n, a, b, 2e-5, 1e-5)
+    assert_close("dx0", x0d.grad, x0.grad, 5e-5, 1e-4)
+    assert_close("dx1", x1d.grad, x1.grad, 5e-5, 1e-4)
+    gw = ocell.Gates.weight.grad
+    assert_close("dW", cell.Gates.weight.grad, gw, 1e-4 * max(1.0, float(gw.abs().max())), 1e-4)
+    assert_close("db", cell.Gates.bias.grad, ocell.Gates.bias.grad, 1e-4 * max(1.0, float(ocell.Gates.bias.grad.abs().max())), 1e-4)
