@@ -32,7 +32,7 @@ int rsis_l_adam(float*, const float*, float*, float*, long, float, float, float,
 int rsis_l_assign(const float*, long long*, int, int, int, hipStream_t);
 int rsis_l_gmax_bwd_add(const float*, const int*, float*, long, int, hipStream_t);
 int rsis_l_pack_batch(const rsis_pack_job*, int, int, hipStream_t);
-int rsis_l_pack_chunk();
+int rsis_l_pack_blocks(int mode, int krows, int ldw);
 int rsis_l_mask_resize_threshold(const float*, int, int, int, const unsigned char*, float, unsigned char*, unsigned char*, unsigned int*,
                                  int, int, hipStream_t);
 int rsis_l_rle_encode(const unsigned char*, int, long, unsigned int*, int, int*, hipStream_t);
@@ -101,9 +101,12 @@ static int check_segments(int Ctot, int nseg, const int* Cseg, const int* Coff) 
   return RSIS_OK;
 }
 
+// the pack kernels index the reference weight with 32-bit arithmetic
+static inline bool weight_too_big(int Cout, int Ctot, int ks) { return Cout < 1 || ks < 1 || (long)Cout * Ctot * ks * ks >= (1L << 31); }
+
 int rsis_conv_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
                        const int* Coff, int lstm_hid, void* stream) {
-  if (!W || !Wp || check_segments(Ctot, nseg, Cseg, Coff)) return RSIS_ERR_ARG;
+  if (!W || !Wp || check_segments(Ctot, nseg, Cseg, Coff) || weight_too_big(Cout, Ctot, ks)) return RSIS_ERR_ARG;
   if (lstm_hid > 0 && Cout != 4 * lstm_hid) return RSIS_ERR_ARG;
   const int ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN);
   int csum = 0;
@@ -115,7 +118,7 @@ int rsis_conv_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, in
 
 int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
                          const int* Coff, int lstm_hid, void* stream) {
-  if (!W || !Wd || check_segments(Ctot, nseg, Cseg, Coff)) return RSIS_ERR_ARG;
+  if (!W || !Wd || check_segments(Ctot, nseg, Cseg, Coff) || weight_too_big(Cout, Ctot, ks)) return RSIS_ERR_ARG;
   if (lstm_hid > 0 && Cout != 4 * lstm_hid) return RSIS_ERR_ARG;
   int csum = 0;
   for (int s = 0; s < nseg; ++s) csum += Cseg[s];
@@ -128,7 +131,7 @@ int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, 
 }
 
 int rsis_conv_pack_job_fill(rsis_pack_job* j) {
-  if (!j || check_segments(j->Ctot, j->nseg, j->Cseg, j->Coff)) return -1;
+  if (!j || check_segments(j->Ctot, j->nseg, j->Cseg, j->Coff) || weight_too_big(j->Cout, j->Ctot, j->ks)) return -1;
   if (j->lstm_hid > 0 && j->Cout != 4 * j->lstm_hid) return -1;
   int csum = 0;
   for (int s = 0; s < j->nseg; ++s) csum += j->Cseg[s];
@@ -142,7 +145,7 @@ int rsis_conv_pack_job_fill(rsis_pack_job* j) {
     else if (use_direct_s2(j->ks, j->stride, j->pad)) { j->imode = 4; j->krows = direct_rows(1, &j->Cout); }
     else { j->imode = 1; j->krows = krows_of(j->Cout, j->ks); }
   }
-  return rsis_cdiv((long)j->krows * j->ldw, rsis_l_pack_chunk());
+  return rsis_l_pack_blocks(j->imode, j->krows, j->ldw);
 }
 
 int rsis_conv_pack_batch(const rsis_pack_job* jobs_dev, int njobs, int total_blocks, void* stream) {

@@ -28,19 +28,20 @@ __device__ __forceinline__ int seg_channel(const SegMap& m, int cg) {   // conca
 __device__ __forceinline__ int ref_row(int cop, int hid) { return hid > 0 ? (cop & 3) * hid + (cop >> 2) : cop; }
 
 // ---- one element of each packed layout (shared by the per-conv kernels and the batched repack) ----
-__device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ W, long e, int Cout, int Ctot, int KK, const SegMap& m,
-                                           int ldw, int hid) {
-  const int row = (int)(e / ldw), col = (int)(e - (long)row * ldw);
+template <int KKC = 0>    // KKC: compile-time ks*ks (0 = use the run-time value) -- makes the row / KK divisions cheap
+__device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ W, int row, int col, int Cout, int Ctot, int KKr,
+                                           const SegMap& m, int hid) {
+  const int KK = KKC ? KKC : KKr;
   if (mode == 0) {                 // igemm fwd: Wp[cg*KK + rs][co_p]
     if (col >= Cout) return 0.f;
     const int cg = row / KK, rs = row - cg * KK;
     const int ci = seg_channel(m, cg);
-    return ci >= 0 ? W[((long)ref_row(col, hid) * Ctot + ci) * KK + rs] : 0.f;
+    return ci >= 0 ? W[(ref_row(col, hid) * Ctot + ci) * KK + rs] : 0.f;
   }
   if (mode == 1) {                 // igemm dgrad: Wd[co_p*KK + rs][cg]
     const int cop = row / KK, rs = row - cop * KK;
     const int ci = seg_channel(m, col);
-    return (cop < Cout && ci >= 0) ? W[((long)ref_row(cop, hid) * Ctot + ci) * KK + rs] : 0.f;
+    return (cop < Cout && ci >= 0) ? W[(ref_row(cop, hid) * Ctot + ci) * KK + rs] : 0.f;
   }
   const int qg = row / (RSIS_CK * 9), kin = row - qg * (RSIS_CK * 9);
   const int pair = kin >> 1, h = kin & 1;
@@ -54,7 +55,7 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ W
         const int nq = (m.C[s] + RSIS_CK - 1) / RSIS_CK;
         if (qg >= qs && qg < qs + nq) {
           const int c = (qg - qs) * RSIS_CK + 2 * cc + h;
-          return c < m.C[s] ? W[((long)ref_row(col, hid) * Ctot + m.off[s] + c) * 9 + rs] : 0.f;
+          return c < m.C[s] ? W[(ref_row(col, hid) * Ctot + m.off[s] + c) * 9 + rs] : 0.f;
         }
         qs += nq;
       }
@@ -65,45 +66,104 @@ __device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ W
   // EPI_S2 of conv3x3_direct.hip) keeps the original tap order (each tap is routed to its parity class by the kernel)
   const int c = qg * RSIS_CK + 2 * cc + h;      // channel of dy (packed row order for ConvLSTM)
   const int ci = seg_channel(m, col);
-  return (c < Cout && ci >= 0) ? W[((long)ref_row(c, hid) * Ctot + ci) * 9 + (mode == 3 ? 8 - rs : rs)] : 0.f;
+  return (c < Cout && ci >= 0) ? W[(ref_row(c, hid) * Ctot + ci) * 9 + (mode == 3 ? 8 - rs : rs)] : 0.f;
 }
 
 __global__ void pack_kernel(int mode, const float* __restrict__ W, float* __restrict__ out, int Cout, int Ctot, int KK, SegMap m, int ldw,
                             int krows, int hid) {
   const long total = (long)krows * ldw;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
-    out[e] = pack_elem(mode, W, e, Cout, Ctot, KK, m, ldw, hid);
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(e / ldw), col = (int)(e - (long)row * ldw);
+    out[e] = pack_elem(mode, W, row, col, Cout, Ctot, KK, m, hid);
+  }
 }
 
 // ---- batched repack: every packed copy of every conv weight in ONE launch (after an optimizer step ~240 tiny pack launches
-// per training step otherwise).  jobs[] lives in device memory; job i owns the blocks [block_begin_i, block_begin_{i+1}). ----
-#define PACK_CHUNK 4096   // elements per block
-__global__ __launch_bounds__(256) void pack_batch_kernel(const rsis_pack_job* __restrict__ jobs, int njobs) {
-  int lo = 0, hi = njobs - 1;
-  const int b = blockIdx.x;
-  while (lo < hi) {                       // last job whose block_begin <= b
-    const int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid].block_begin <= b) lo = mid; else hi = mid - 1;
-  }
-  const rsis_pack_job j = jobs[lo];
+// per training step otherwise).  jobs[] lives in device memory; job i owns the blocks [block_begin_i, block_begin_{i+1}), one block
+// per PACK_T x PACK_T tile of the packed matrix.  The forward layouts (columns = output channel) are transposes of the reference
+// weight: their tiles are gathered with the lanes running down the packed ROWS (= along the contiguous input-channel / tap axis
+// of the reference weight), parked in LDS and written out row-major, so both the global reads and the global writes coalesce. ----
+#define PACK_T 64        // tile rows
+#define PACK_TC 64       // tile columns (divides RSIS_LDW_ALIGN).  Measured: 128 columns with float2 stores is 8 % slower
+template <int KKC>
+__device__ __forceinline__ void pack_tile(const rsis_pack_job& j, int tb, float (*tile)[PACK_TC + 1]) {
   SegMap m;
   m.n = j.nseg;
 #pragma unroll
   for (int s = 0; s < 3; ++s) { m.C[s] = j.Cseg[s]; m.off[s] = j.Coff[s]; }
-  const long total = (long)j.krows * j.ldw;
-  const long base = (long)(b - j.block_begin) * PACK_CHUNK;
+  const int nct = j.ldw / PACK_TC;
+  const int l = threadIdx.x & 63, q = threadIdx.x >> 6, KK = j.ks * j.ks;
+  const int c0 = (tb % nct) * PACK_TC;
+  int r0, nrow;
+  if (j.imode >= 3) {
+    // direct dgrad layouts: tile = one 72-row chunk (8 dy channels x 9 taps) x 128 columns (input channels).  For one dy channel the
+    // reference weight is contiguous over (input channel, tap): the lanes walk that run, LDS re-orders it into packed rows.
+    constexpr int R = RSIS_CK * 9;
+    r0 = (tb / nct) * R;
+    nrow = R;
+    for (int c = 0; c < RSIS_CK; ++c) {
+      for (int i = threadIdx.x; i < PACK_TC * 9; i += 256) {
+        const int cl = i / 9, tap = i - cl * 9;                      // tap of the reference weight
+        const int rs = j.imode == 3 ? 8 - tap : tap;                 // its packed position
+        const int kin = ((c >> 1) * 9 + rs) * 2 + (c & 1);
+        tile[kin][cl] = pack_elem<KKC>(j.imode, j.W, r0 + kin, c0 + cl, j.Cout, j.Ctot, KK, m, j.lstm_hid);
+      }
+    }
+  } else {
+    r0 = (tb / nct) * PACK_T;
+    nrow = min(PACK_T, j.krows - r0);
+    if (j.imode == 1) {          // igemm dgrad: columns already run along the reference weight's input channels
+      for (int rr = q; rr < nrow; rr += 4) {
+#pragma unroll
+        for (int cc = l; cc < PACK_TC; cc += 64) tile[rr][cc] = pack_elem<KKC>(1, j.W, r0 + rr, c0 + cc, j.Cout, j.Ctot, KK, m, j.lstm_hid);
+      }
+    } else if (l < nrow) {       // forward layouts: lanes run down the rows
 #pragma unroll 4
-  for (int i = 0; i < PACK_CHUNK / 256; ++i) {
-    const long e = base + i * 256 + threadIdx.x;
-    if (e < total) j.out[e] = pack_elem(j.imode, j.W, e, j.Cout, j.Ctot, j.ks * j.ks, m, j.ldw, j.lstm_hid);
+      for (int k = 0; k < PACK_TC / 4; ++k) {
+        const int cc = k * 4 + q;
+        tile[l][cc] = pack_elem<KKC>(j.imode, j.W, r0 + l, c0 + cc, j.Cout, j.Ctot, KK, m, j.lstm_hid);
+      }
+    }
+  }
+  __syncthreads();
+  for (int rr = q; rr < nrow; rr += 4) {
+#pragma unroll
+    for (int cc = l; cc < PACK_TC; cc += 64) j.out[(long)(r0 + rr) * j.ldw + c0 + cc] = tile[rr][cc];
+  }
+}
+
+#define PACK_TPB 1     // consecutive tiles per block (measured: 4 is slower than 1 -- the job lookup is not the bottleneck)
+__global__ __launch_bounds__(256) void pack_batch_kernel(const rsis_pack_job* __restrict__ jobs, int njobs, int total_tiles) {
+  __shared__ float tile[RSIS_CK * 9][PACK_TC + 1];     // 72 rows: one channel chunk of the direct-dgrad layouts (>= PACK_T)
+  int lo = 0, hi = njobs - 1;
+  int b = blockIdx.x * PACK_TPB;
+  while (lo < hi) {                       // last job whose block_begin <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_begin <= b) lo = mid; else hi = mid - 1;
+  }
+  rsis_pack_job j = jobs[lo];
+  int next_begin = lo + 1 < njobs ? jobs[lo + 1].block_begin : total_tiles;
+  for (int t = 0; t < PACK_TPB && b < total_tiles; ++t, ++b) {
+    if (b >= next_begin) {                // tiles of a job are consecutive: at most a step to the next job
+      ++lo;
+      j = jobs[lo];
+      next_begin = lo + 1 < njobs ? jobs[lo + 1].block_begin : total_tiles;
+    }
+    const int tb = b - j.block_begin;
+    if (j.ks == 1) pack_tile<1>(j, tb, tile);
+    else if (j.ks == 3) pack_tile<9>(j, tb, tile);
+    else pack_tile<0>(j, tb, tile);
+    __syncthreads();                      // the LDS tile is reused
   }
 }
 
 int rsis_l_pack_batch(const rsis_pack_job* jobs, int njobs, int total_blocks, hipStream_t st) {
-  hipLaunchKernelGGL(pack_batch_kernel, dim3(total_blocks), dim3(256), 0, st, jobs, njobs);
+  hipLaunchKernelGGL(pack_batch_kernel, dim3((total_blocks + PACK_TPB - 1) / PACK_TPB), dim3(256), 0, st, jobs, njobs, total_blocks);
   return rsis_check_launch();
 }
-int rsis_l_pack_chunk() { return PACK_CHUNK; }
+int rsis_l_pack_blocks(int mode, int krows, int ldw) {
+  return (mode >= 3 ? krows / (RSIS_CK * 9) : (krows + PACK_T - 1) / PACK_T) * (ldw / PACK_TC);
+}
 
 static inline int pack_grid(long total) {
   long g = (total + 255) / 256;
