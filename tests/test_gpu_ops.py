@@ -36,6 +36,11 @@ CONV_CASES = [
     (2, [16, 16], 12, 20, 32, 3, 1, 1, True),   # concat by pointer
     (2, [8], 20, 24, 1, 3, 1, 1, True),         # conv_out (Cout = 1: bandwidth kernel)
     (3, [16], 9, 13, 1, 3, 1, 1, True),         # conv_out, 16 channels, odd size
+    (2, [8], 40, 136, 1, 3, 1, 1, True),        # conv_out over several LDS tiles, partial tiles in both directions
+    (1, [16], 20, 72, 1, 3, 1, 1, False),       # conv_out, 16 channels (two channel passes per tile)
+    (3, [4], 16, 64, 1, 3, 1, 1, True),         # conv_out, 4 channels, exactly one tile per image
+    (1, [8], 12, 256, 1, 3, 1, 1, True),        # conv_out, full-width 8 x 256 tiles (the config-2 shape), partial tile rows
+    (2, [8], 9, 160, 1, 3, 1, 1, False),        # conv_out, 256-wide tile on a 160-wide image
     (2, [6], 8, 8, 1, 3, 1, 1, False),          # Cout = 1 with an unsupported Cin -> MFMA path
     (1, [130], 7, 7, 129, 3, 1, 1, True),       # ragged channels
     (2, [2048], 4, 4, 128, 3, 1, 1, True),      # sk5-like deep K

@@ -2,7 +2,7 @@
 """Kernel micro-benchmark (GPU box): times individual C-ABI launches on the shapes of BASELINE config 2 with HIP
 events and prints algorithmic TFLOP/s.  Used for kernel tuning and as the command profiled by rocprofv3.
 
-  python tools/bench_kernels.py [--what gates|trunk|wgrad|dgrad|all] [--iters N] [--tile T] [--batch B]
+  python tools/bench_kernels.py [--what gates|trunk|depth|c1|all] [--iters N] [--tile T] [--batch B]
 """
 import argparse
 import os
@@ -82,10 +82,12 @@ def main():
             ms = timeit(wg, o.iters)
             print("gate wgrad %3dx%-3d %38s %8.1f us  %6.1f TF/s" % (H, W, "", ms * 1e3, fl / ms / 1e9))
         print("gates fwd total: %.1f us/timestep, %.1f TF/s" % (tot_ms * 1e3, tot_f / tot_ms / 1e9))
-    if o.what in ("trunk", "all", "depth"):
+    if o.what in ("trunk", "all", "depth", "c1"):
         tf = tm = 0.0
         # "depth": the same 3x3 / 1x1 layer at growing input depth -> the intercept is the kernel's fixed cost
         shapes = TRUNK if o.what != "depth" else [(c, 256, k, 1, 16, 1) for k in (3, 1) for c in (8, 32, 64, 128, 256, 512, 1024)]
+        if o.what == "c1":     # conv_out of the decoder (HBM-bound vector-ALU kernels): %s of HBM = bytes / time
+            shapes = [(8, 1, 3, 1, 256, 1), (8, 1, 3, 1, 128, 1), (16, 1, 3, 1, 256, 1)]   # config 2: 8 channels at 256x256
         for cin, cout, ks, stride, hw, count in shapes:
             pad = ks // 2
             Hi = hw * stride
