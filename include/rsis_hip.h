@@ -160,7 +160,7 @@ int rsis_softiou_bwd(const float* logits, const float* y, const long long* perm,
  * side[i][B][Cside[i]] (the global max-pools of the hidden states); class_probs[B][ncls] = softmax(Wc side + bc) with
  * Wc[ncls][K], K = sum Cside; stop[B] = Ws . side + bs (a logit).  rsis_heads_bwd: dside[i][B][Cside[i]] (any pointer may be
  * null) from dprobs[B][ncls] / dstop[B] (either may be null = zero), and dWc, dbc, dWs, dbs are ACCUMULATED into (null = skip).
- * K <= 2048, ncls <= 64. ---- */
+ * K <= 2048, ncls <= 64; rsis_heads_bwd: B <= 64 (the parameter gradients are reduced over the batch in-kernel, no atomics). ---- */
 int rsis_heads_fwd(const float* const* side, const int* Cside, int nside, int B, const float* Wc, const float* bc, int ncls,
                    const float* Ws, const float* bs, float* class_probs, float* stop, void* stream);
 int rsis_heads_bwd(const float* const* side, const int* Cside, int nside, int B, const float* Wc, int ncls, const float* Ws,

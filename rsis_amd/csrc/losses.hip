@@ -101,7 +101,7 @@ int rsis_l_softiou_bwd(const float* logits, const float* y, const long long* per
 // Class / stop heads of one decoder timestep (reference src/modules/model.py:169-182): side = cat of the five global-max-pool
 // vectors (248 features at hidden 128) -> class_probs = softmax(fc_class(side)), stop = fc_stop(side).  ~20 tiny launches
 // per timestep in eager form (cat, 2 addmm, softmax; backward: softmax_backward, 4 mm, 5 slice copies, 4 parameter adds): one
-// block per image here, the concatenation is by pointer, the backward accumulates the parameter gradients with atomics.
+// block per image here, the concatenation is by pointer, the backward reduces the parameter gradients over the batch in-kernel.
 // ------------------------------------------------------------------------------------------------
 #define HEADS_MAXK 2048
 #define HEADS_MAXC 64
@@ -127,8 +127,15 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadSides s, int K, cons
   const int row = threadIdx.x >> 4, sub = threadIdx.x & 15;
   for (int r = row; r <= ncls; r += 16) {
     const float* w = r < ncls ? Wc + (size_t)r * K : Ws;
-    float acc = 0.f;
-    for (int k = sub; k < K; k += 16) acc = fmaf(w[k], sv[k], acc);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;     // independent chains: the (L2-latency) weight loads overlap
+    for (int k = sub; k < K; k += 64) {
+      const float w0 = w[k], w1 = k + 16 < K ? w[k + 16] : 0.f, w2 = k + 32 < K ? w[k + 32] : 0.f, w3 = k + 48 < K ? w[k + 48] : 0.f;
+      a0 = fmaf(w0, sv[k], a0);
+      a1 = fmaf(w1, k + 16 < K ? sv[k + 16] : 0.f, a1);
+      a2 = fmaf(w2, k + 32 < K ? sv[k + 32] : 0.f, a2);
+      a3 = fmaf(w3, k + 48 < K ? sv[k + 48] : 0.f, a3);
+    }
+    float acc = (a0 + a1) + (a2 + a3);
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) acc += __shfl_down(acc, o, 16);
     if (sub == 0) lg[r] = acc + (r < ncls ? bc[r] : bs[0]);
@@ -144,44 +151,73 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadSides s, int K, cons
   }
 }
 
-__global__ __launch_bounds__(256) void heads_bwd_kernel(HeadSides s, int K, const float* __restrict__ Wc, int ncls,
+// Backward.  Block b writes d side of image b.  The parameter gradients are sums over the batch: instead of B-deep atomics on
+// every one of the (ncls + 1) * K weights every block recomputes the (tiny) d-logits of ALL images and owns a slab of
+// K / gridDim.x feature columns, which it reduces over the batch and adds to the gradient buffers with plain read-modify-writes.
+// Everything a thread loops over is first staged in LDS with independent parallel loads, and the remaining global loads are
+// issued 8 at a time: the first version (one dependent global load per loop iteration) took 37 us for ~0.5 MFLOP.
+#define HEADS_MAXB 64
+#define HEADS_SLAB (HEADS_MAXK + HEADS_MAXB)     // >= B * ceil(K / B)
+__global__ __launch_bounds__(256) void heads_bwd_kernel(HeadSides s, int K, int B, const float* __restrict__ Wc, int ncls,
                                                         const float* __restrict__ Ws, const float* __restrict__ probs,
                                                         const float* __restrict__ dprobs, const float* __restrict__ dstop,
                                                         float* __restrict__ dWc, float* __restrict__ dbc, float* __restrict__ dWs,
                                                         float* __restrict__ dbs) {
-  __shared__ float sv[HEADS_MAXK];
-  __shared__ float dl[HEADS_MAXC + 1];     // d logits of fc_class, then d stop
-  const int b = blockIdx.x;
-  heads_load_side(s, b, sv);
-  if (threadIdx.x == 0) {
-    float dot = 0.f;
-    if (dprobs)
-      for (int c = 0; c < ncls; ++c) dot += dprobs[(size_t)b * ncls + c] * probs[(size_t)b * ncls + c];
-    for (int c = 0; c < ncls; ++c)          // softmax backward: p * (g - sum g p)
-      dl[c] = dprobs ? probs[(size_t)b * ncls + c] * (dprobs[(size_t)b * ncls + c] - dot) : 0.f;
-    dl[ncls] = dstop ? dstop[b] : 0.f;
+  __shared__ float dl[HEADS_MAXB][HEADS_MAXC + 1];     // probs, then d logits of fc_class | d stop, of every image
+  __shared__ float gp[HEADS_MAXB][HEADS_MAXC + 1];     // dprobs
+  __shared__ float svs[HEADS_SLAB];                    // side features of every image, this block's columns
+  const int b = blockIdx.x, R = ncls + 1;
+  const int slab = (K + gridDim.x - 1) / gridDim.x, k0 = min(K, b * slab), k1 = min(K, k0 + slab), nk = k1 - k0;
+  for (int e = threadIdx.x; e < B * ncls; e += blockDim.x) {
+    const int i = e / ncls, c = e - i * ncls;
+    dl[i][c] = probs[e];
+    gp[i][c] = dprobs ? dprobs[e] : 0.f;
+  }
+  for (int e = threadIdx.x; e < B * nk; e += blockDim.x) {
+    const int i = e / nk, k = k0 + e - i * nk;
+    int sb = 0, si = 0;                                  // which side vector holds feature k
+    while (k >= sb + s.C[si]) { sb += s.C[si]; ++si; }
+    svs[e] = s.p[si][(size_t)i * s.C[si] + (k - sb)];
   }
   __syncthreads();
-  // d side[k] = sum_c dl[c] * Wc[c][k] + dstop * Ws[k]   (coalesced along k), and the parameter gradients
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {   // softmax backward: p * (g - sum g p)
+    float dot = 0.f;
+    for (int c = 0; c < ncls; ++c) dot += gp[i][c] * dl[i][c];
+    for (int c = 0; c < ncls; ++c) dl[i][c] = dl[i][c] * (gp[i][c] - dot);
+    dl[i][ncls] = dstop ? dstop[i] : 0.f;
+  }
+  __syncthreads();
+  // d side[k] = sum_c dl[c] * Wc[c][k] + dstop * Ws[k]   (coalesced along k)
   int base = 0;
   for (int i = 0; i < s.n; ++i) {
     for (int k = threadIdx.x; k < s.C[i]; k += blockDim.x) {
       const int kk = base + k;
-      float acc = dl[ncls] * Ws[kk];
-      for (int c = 0; c < ncls; ++c) acc = fmaf(dl[c], Wc[(size_t)c * K + kk], acc);
+      float acc = dl[b][ncls] * Ws[kk];
+      for (int c0 = 0; c0 < ncls; c0 += 8) {
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[j] = c0 + j < ncls ? Wc[(size_t)(c0 + j) * K + kk] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf(c0 + j < ncls ? dl[b][c0 + j] : 0.f, wv[j], acc);
+      }
       if (s.d[i]) s.d[i][(size_t)b * s.C[i] + k] = acc;
     }
     base += s.C[i];
   }
-  for (int e = threadIdx.x; e < (ncls + 1) * K; e += blockDim.x) {
-    const int r = e / K, k = e - r * K;
-    const float g = dl[r] * sv[k];
-    if (r < ncls) { if (dWc) atomicAdd(dWc + (size_t)r * K + k, g); }
-    else if (dWs) atomicAdd(dWs + k, g);
+  // parameter gradients of this block's feature columns [k0, k1)
+  for (int e = threadIdx.x; e < R * nk; e += blockDim.x) {
+    const int r = e / nk, kl = e - r * nk;
+    if (r < ncls ? !dWc : !dWs) continue;
+    float g = 0.f;
+    for (int i = 0; i < B; ++i) g = fmaf(dl[i][r], svs[i * nk + kl], g);
+    if (r < ncls) dWc[(size_t)r * K + k0 + kl] += g;
+    else dWs[k0 + kl] += g;
   }
-  if (threadIdx.x <= ncls) {
-    if (threadIdx.x < ncls) { if (dbc) atomicAdd(dbc + threadIdx.x, dl[threadIdx.x]); }
-    else if (dbs) atomicAdd(dbs, dl[ncls]);
+  if (b == 0 && threadIdx.x < R) {
+    float g = 0.f;
+    for (int i = 0; i < B; ++i) g += dl[i][threadIdx.x];
+    if (threadIdx.x < ncls) { if (dbc) dbc[threadIdx.x] += g; }
+    else if (dbs) dbs[0] += g;
   }
 }
 
@@ -207,8 +243,8 @@ int rsis_l_heads_bwd(const float* const* side, const int* C, int n, int B, const
                      float* dWs, float* dbs, hipStream_t st) {
   HeadSides s;
   const int K = heads_sides(s, side, dside, C, n);
-  if (K < 1 || K > HEADS_MAXK || ncls < 1 || ncls > HEADS_MAXC) return RSIS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(heads_bwd_kernel, dim3(B), dim3(256), 0, st, s, K, Wc, ncls, Ws, probs, dprobs, dstop, dWc, dbc, dWs, dbs);
+  if (K < 1 || K > HEADS_MAXK || ncls < 1 || ncls > HEADS_MAXC || B < 1 || B > HEADS_MAXB) return RSIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(heads_bwd_kernel, dim3(B), dim3(256), 0, st, s, K, B, Wc, ncls, Ws, probs, dprobs, dstop, dWc, dbc, dWs, dbs);
   return rsis_check_launch();
 }
 

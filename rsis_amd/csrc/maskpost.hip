@@ -72,12 +72,10 @@ __global__ __launch_bounds__(RLE_T) void rle_encode_kernel(const unsigned char* 
     const long j0 = base + (long)tid * RLE_E;
     unsigned char v[RLE_E + 1];
     v[0] = (j0 > 0 && j0 - 1 < len) ? m[j0 - 1] : 0;
-    int nvalid = 0;
 #pragma unroll
     for (int i = 0; i < RLE_E; ++i) {
       const bool ok = j0 + i < len;
       v[i + 1] = ok ? m[j0 + i] : v[i];
-      nvalid += ok ? 1 : 0;
     }
     unsigned int c = 0;
 #pragma unroll

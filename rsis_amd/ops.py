@@ -632,7 +632,7 @@ class _HeadsFn(torch.autograd.Function):
 
 
 def heads_supported(sides, fc_class, fc_stop):
-    return (sides[0].is_cuda and sides[0].shape[0] >= 2 and len(sides) <= 5 and fc_class.weight.shape[1] <= 2048 and
+    return (sides[0].is_cuda and 2 <= sides[0].shape[0] <= 64 and len(sides) <= 5 and fc_class.weight.shape[1] <= 2048 and
             fc_class.weight.shape[0] <= 64 and fc_stop.weight.shape[0] == 1 and fc_class.bias is not None and fc_stop.bias is not None)
 
 
