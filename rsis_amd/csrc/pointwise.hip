@@ -553,17 +553,20 @@ __global__ void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __re
     const int ho = (int)(t % Ho);
     const long bc = t / Ho;
     const float* xb = x + bc * H * W;
-    float best = -INFINITY; int bi = 0;
+    float v[9];
+    bool ok[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
+      for (int s = 0; s < 3; ++s) {            // branch-free: all 9 loads are issued together (clamped address, masked value)
         const int h = ho * 2 - 1 + r, w = wo * 2 - 1 + s;
-        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
-          const float v = xb[h * W + w];
-          if (v > best || v != v) { best = v; bi = r * 3 + s; }
-        }
+        ok[r * 3 + s] = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        v[r * 3 + s] = xb[min(max(h, 0), H - 1) * W + min(max(w, 0), W - 1)];
       }
+    float best = -INFINITY; int bi = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      if (ok[k] && (v[k] > best || v[k] != v[k])) { best = v[k]; bi = k; }
     y[e] = best; arg[e] = (unsigned char)bi;
   }
 }
@@ -579,19 +582,58 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const unsi
     const int ho_lo = h >> 1, wo_lo = w >> 1;            // windows (2*ho-1 .. 2*ho+1) containing h: ho in {h/2, (h+1)/2}
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      const int ho = ho_lo + a;
-      const int r = h - (ho * 2 - 1);
-      if (ho >= Ho || r < 0 || r > 2) continue;
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int wo = wo_lo + b;
-        const int s = w - (wo * 2 - 1);
-        if (wo >= Wo || s < 0 || s > 2) continue;
-        const long o = (bc * Ho + ho) * Wo + wo;
-        if (arg[o] == r * 3 + s) g += dy[o];
+      for (int b = 0; b < 2; ++b) {                      // branch-free: the 4 (arg, dy) pairs are loaded together
+        const int ho = ho_lo + a, wo = wo_lo + b;
+        const int r = h - (ho * 2 - 1), s = w - (wo * 2 - 1);
+        const bool ok = ho < Ho && r >= 0 && r <= 2 && wo < Wo && s >= 0 && s <= 2;
+        const long o = (bc * Ho + min(ho, Ho - 1)) * Wo + min(wo, Wo - 1);
+        const int ar = arg[o];
+        const float d = dy[o];
+        g += (ok && ar == r * 3 + s) ? d : 0.f;
       }
     }
     dx[e] = g;
+  }
+}
+
+// H even, W % 4 == 0: one thread = a 2 x 4 block of dx.  The 6 pooling windows that can point into it (2 rows x 3 columns of
+// the pooled map) are loaded together and scattered in registers: 12 loads + 2 float4 stores per 8 pixels instead of 8 + 1 per
+// pixel (the per-pixel kernel is bound by the number of memory instructions, 134 us on the stem's 128^2 x 64 x 32 map).
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_v8_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                                  float* __restrict__ dx, int H, int W, int Ho, int Wo, long items) {
+  const int Wq = W >> 2, Hp = H >> 1;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < items; e += (long)gridDim.x * blockDim.x) {
+    const int wq = (int)(e % Wq);
+    const long t = e / Wq;
+    const int hp = (int)(t % Hp);
+    const long bc = t / Hp;
+    const int h0 = hp * 2, w0 = wq * 4;
+    float d[6];
+    int th[6], tw[6];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int ho = hp + a, wo = wq * 2 + b;
+        const bool ok = ho < Ho && wo < Wo;
+        const long o = (bc * Ho + min(ho, Ho - 1)) * Wo + min(wo, Wo - 1);
+        const int ar = arg[o];
+        d[a * 3 + b] = dy[o];
+        th[a * 3 + b] = ok ? ho * 2 - 1 + ar / 3 - h0 : -1;       // row / column of the arg-max pixel inside the 2 x 4 block
+        tw[a * 3 + b] = wo * 2 - 1 + ar % 3 - w0;
+      }
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o0[j] += (th[k] == 0 && tw[k] == j) ? d[k] : 0.f;
+        o1[j] += (th[k] == 1 && tw[k] == j) ? d[k] : 0.f;
+      }
+    float* p = dx + (bc * H + h0) * W + w0;
+    *reinterpret_cast<f32x4*>(p) = o0;
+    *reinterpret_cast<f32x4*>(p + W) = o1;
   }
 }
 
@@ -848,6 +890,10 @@ int rsis_l_maxpool_fwd(const float* x, float* y, unsigned char* arg, long BC, in
 int rsis_l_maxpool_bwd(const float* dy, const unsigned char* arg, float* dx, long BC, int H, int W, int Ho, int Wo,
                        hipStream_t st) {
   const long total = BC * H * W;
+  if ((H & 1) == 0 && (W & 3) == 0) {
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_v8_kernel, dim3(ew_grid(total / 8)), dim3(256), 0, st, dy, arg, dx, H, W, Ho, Wo, total / 8);
+    return rsis_check_launch();
+  }
   hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, arg, dx, H, W, Ho, Wo, total);
   return rsis_check_launch();
 }

@@ -163,10 +163,14 @@ def test_global_maxpool(shape):
     assert_close("bwd", xd.grad, x.grad, 0)
 
 
-@pytest.mark.parametrize("shape", [(2, 4, 8, 8), (3, 5, 9, 11), (1, 2, 16, 6), (2, 3, 7, 7)])
-def test_maxpool3x3s2(shape):
+@pytest.mark.parametrize("shape", [(2, 4, 8, 8), (3, 5, 9, 11), (1, 2, 16, 6), (2, 3, 7, 7), (2, 3, 12, 20), (1, 2, 10, 4), (2, 8, 32, 64)])
+@pytest.mark.parametrize("ties", [False, True])
+def test_maxpool3x3s2(shape, ties):
     from rsis_amd import ops
-    x = _rng_t(7, shape).requires_grad_()
+    x = _rng_t(7, shape)
+    if ties:                         # post-ReLU maps: many equal zeros, the FIRST maximum of a window takes the gradient
+        x = torch.clamp(x, min=0.3)
+    x = x.requires_grad_()
     ref = F.max_pool2d(x, 3, 2, 1)
     gy = _rng_t(8, tuple(ref.shape))
     ref.backward(gy)
