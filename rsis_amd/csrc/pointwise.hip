@@ -95,6 +95,56 @@ __global__ __launch_bounds__(256) void upsample_fwd_v4_kernel(const float* __res
   *reinterpret_cast<f32x4*>(y + ((size_t)row * Wq + wq) * 4) = o;
 }
 
+// Large maps (Ho >= 32, Wo >= 64, Wi % 4 == 0, scale <~ 0.56): a block owns a 32 x 64 output tile of one plane, stages the
+// <= 20 x 48 input pixels it interpolates from in LDS with (at most) one aligned float4 load per thread, and every thread
+// writes two float4s.  The v4 kernel issues 16 scalar loads per float4 of output and is bound by the vector-memory pipe
+// (34 us for the 8 x 256^2 x 32 level, a 67 MB write); this one is bound by the write.  Same arithmetic, bit-identical results.
+#define UF_TOH 32
+#define UF_TOW 64
+#define UF_RH 20
+#define UF_RQ 12
+__global__ __launch_bounds__(256) void upsample_fwd_lds_kernel(const float* __restrict__ x, float* __restrict__ y, int Hi, int Wi,
+                                                               int Ho, int Wo, float sh, float sw, int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(16))) float src[UF_RH][UF_RQ * 4];
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y;
+  const long bc = blockIdx.x / (tiles_x * tiles_y);
+  const int oh0 = ty * UF_TOH, ow0 = tx * UF_TOW;
+  int h_lo, w_lo, t0; float tl;
+  ac_coord(oh0, sh, Hi, h_lo, t0, tl);
+  ac_coord(ow0, sw, Wi, w_lo, t0, tl);
+  const int wa = w_lo & ~3;
+  {
+    const int r = threadIdx.x / UF_RQ, q = threadIdx.x - r * UF_RQ;
+    const int h = h_lo + r, col = wa + q * 4;
+    if (r < UF_RH) {
+      const bool ok = h < Hi && col < Wi;          // Wi % 4 == 0: a float4 is all in or all out
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + bc * Hi * Wi + (ok ? (size_t)h * Wi + col : 0));
+      *reinterpret_cast<f32x4*>(&src[r][q * 4]) = v;
+    }
+  }
+  __syncthreads();
+  const int lr = threadIdx.x >> 4, lq = threadIdx.x & 15;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int ho = oh0 + p * 16 + lr, wo = ow0 + lq * 4;
+    if (ho >= Ho || wo >= Wo) continue;
+    int h0, h1; float lh;
+    ac_coord(ho, sh, Hi, h0, h1, lh);
+    const float* r0 = src[h0 - h_lo];
+    const float* r1 = src[h1 - h_lo];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int w0, w1; float lw;
+      ac_coord(wo + k, sw, Wi, w0, w1, lw);
+      w0 -= wa;
+      w1 -= wa;
+      o[k] = (1.f - lh) * ((1.f - lw) * r0[w0] + lw * r0[w1]) + lh * ((1.f - lw) * r1[w0] + lw * r1[w1]);
+    }
+    *reinterpret_cast<f32x4*>(y + (bc * Ho + ho) * (size_t)Wo + wo) = o;
+  }
+}
+
 // backward as a GATHER (no atomics, deterministic): dx[hi][wi] = sum over the few output pixels whose 2x2 stencil touches
 // (hi, wi).  A block owns a UT x UT tile of input pixels of one (b, c) plane.  The 1-D interpolation weights of the (<= UK)
 // consecutive output rows / columns that touch each input row / column are evaluated ONCE per block (with the forward's own
@@ -104,12 +154,12 @@ __global__ __launch_bounds__(256) void upsample_fwd_v4_kernel(const float* __res
 template <int UT, int RM>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Hi, int Wi,
                                                            int Ho, int Wo, float sh, float sw, int tiles_x, int tiles_y, long BC,
-                                                           int planes_per_block) {
-  constexpr int RP = RM + 1;
+                                                           int planes_per_block, int vec) {
+  constexpr int RQ = RM / 4 + 1, RP = RQ * 4;      // staged row: RQ aligned float4s = RM + 4 columns (the region starts 0..3 columns in)
   __shared__ float wgt[2][UT][UK];
   __shared__ int st[2][UT];          // first candidate of each input index (absolute output index)
   __shared__ int org[2], ext[2];     // region origin / extent (rows, cols)
-  __shared__ float reg[RM * RP];
+  __shared__ __attribute__((aligned(16))) float reg[RM * RP];
   __shared__ float tmp[UT * RP];
   const int tid = threadIdx.x;
   const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y;
@@ -154,9 +204,32 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
     const long bc = bc0 + pl;
     if (bc >= BC) break;
     const float* yb = dy + bc * Ho * Wo;
-    for (int e = tid; e < ey * RM; e += 256) {
-      const int r = e / RM, c = e - r * RM;
-      reg[r * RP + c] = c < ex ? yb[(size_t)(oy + r) * Wo + ox + c] : 0.f;
+    int cs = 0;                                   // column of `reg` that holds region column 0
+    if (vec) {
+      // aligned float4 window [ox & ~3, ...): all loads of a thread are independent and issued together (the scalar loop below
+      // waits for memory once per iteration: 50 us instead of 20 on the 256^2 level); columns outside [0, ex) are never read
+      constexpr int NV = RM * RQ, ITER = (NV + 255) / 256;
+      const int oxa = ox & ~3;
+      cs = ox - oxa;
+      f32x4 v[ITER];
+#pragma unroll
+      for (int k = 0; k < ITER; ++k) {
+        const int i = tid + k * 256;
+        const int r = i / RQ, q = i - r * RQ;
+        const int col = oxa + q * 4;
+        const bool ok = i < NV && r < ey && col < Wo;        // Wo % 4 == 0: a float4 is all in or all out
+        v[k] = *reinterpret_cast<const f32x4*>(ok ? yb + (size_t)(oy + r) * Wo + col : yb);
+      }
+#pragma unroll
+      for (int k = 0; k < ITER; ++k) {
+        const int i = tid + k * 256;
+        if (i < NV) *reinterpret_cast<f32x4*>(reg + i * 4) = v[k];
+      }
+    } else {
+      for (int e = tid; e < ey * RM; e += 256) {
+        const int r = e / RM, c = e - r * RM;
+        reg[r * RP + c] = c < ex ? yb[(size_t)(oy + r) * Wo + ox + c] : 0.f;
+      }
     }
     __syncthreads();
     // rows: tmp[ly][c] = sum_k wgt_y[ly][k] * reg[st_y[ly] - oy + k][c]
@@ -165,7 +238,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
       const int r0 = st[0][ly] - oy;
       float acc = 0.f;
 #pragma unroll
-      for (int k = 0; k < UK; ++k) acc = fmaf(wgt[0][ly][k], reg[min(r0 + k, ey - 1) * RP + c], acc);   // weights beyond the region are zero
+      for (int k = 0; k < UK; ++k) acc = fmaf(wgt[0][ly][k], reg[min(r0 + k, ey - 1) * RP + cs + c], acc);   // weights beyond the region are zero
       tmp[ly * RP + c] = acc;
     }
     __syncthreads();
@@ -223,9 +296,33 @@ __global__ __launch_bounds__(256) void global_maxpool_fwd_kernel(const float* __
   const long bc = blockIdx.x;
   const float* xb = x + bc * HW;
   float best = -INFINITY; int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < HW; i += 256) {
-    const float v = xb[i];
-    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  if ((HW & 3) == 0) {
+    // float4 loads, 8 in flight per thread (one plane = one block: a loop with one load per iteration is pure memory latency,
+    // 21 us for a 128 x 128 plane); a thread visits its pixels in increasing order, so `>` keeps the first maximum
+    const f32x4* xv = reinterpret_cast<const f32x4*>(xb);
+    const int n4 = HW >> 2;
+    for (int g0 = threadIdx.x; g0 < n4; g0 += 256 * 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int g = g0 + u * 256;
+        v[u] = xv[g < n4 ? g : g0];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int g = g0 + u * 256;
+        if (g < n4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (v[u][k] > best) { best = v[u][k]; bi = g * 4 + k; }
+        }
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < HW; i += 256) {
+      const float v = xb[i];
+      if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
   }
   __shared__ float sv[256]; __shared__ int si[256];
   sv[threadIdx.x] = best; si[threadIdx.x] = bi;
@@ -784,6 +881,17 @@ int rsis_l_lstm_bwd(const float* dh, const float* dh2, const float* dc_next, con
 static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 int rsis_l_upsample_fwd(const float* x, float* y, long BC, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
   const long total = BC * Ho * Wo;
+  {
+    // the LDS-tiled kernel needs its 32 x 64 output tile to read at most UF_RH x (UF_RQ * 4 - 3) input pixels
+    const float fh = ac_scale(Hi, Ho), fw = ac_scale(Wi, Wo);
+    const int tiles_x = (Wo + UF_TOW - 1) / UF_TOW, tiles_y = (Ho + UF_TOH - 1) / UF_TOH;
+    if (Wo % 4 == 0 && Wi % 4 == 0 && Ho >= UF_TOH && Wo >= UF_TOW && fh * (UF_TOH - 1) + 3.f <= UF_RH &&
+        fw * (UF_TOW - 1) + 6.f <= UF_RQ * 4 && BC * tiles_x * tiles_y < (1L << 31)) {
+      hipLaunchKernelGGL(upsample_fwd_lds_kernel, dim3((unsigned)(BC * tiles_x * tiles_y)), dim3(256), 0, st, x, y, Hi, Wi, Ho, Wo, fh,
+                         fw, tiles_x, tiles_y);
+      return rsis_check_launch();
+    }
+  }
   if (Wo % 4 == 0 && BC * Ho < (1L << 31)) {
     const int Wq = Wo / 4;
     const long rows = BC * Ho;
@@ -813,12 +921,13 @@ int rsis_l_upsample_bwd(const float* dy, float* dx, long BC, int Hi, int Wi, int
     if (ppb < 1) ppb = 1;
     if (ppb > 16) ppb = 16;
     const long blocks = (BC + ppb - 1) / ppb * tiles_x * tiles_y;
+    const int vec = Wo % 4 == 0;
     if (ut == 32)
       hipLaunchKernelGGL((upsample_bwd_kernel<32, 80>), dim3((unsigned)blocks), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, tiles_x,
-                         tiles_y, BC, (int)ppb);
+                         tiles_y, BC, (int)ppb, vec);
     else
       hipLaunchKernelGGL((upsample_bwd_kernel<16, 44>), dim3((unsigned)blocks), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, tiles_x,
-                         tiles_y, BC, (int)ppb);
+                         tiles_y, BC, (int)ppb, vec);
   } else {
     const long total = BC * Hi * Wi;
     hipLaunchKernelGGL(upsample_bwd_generic_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, total);
