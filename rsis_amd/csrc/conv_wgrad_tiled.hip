@@ -240,7 +240,11 @@ static int launch_tiled_cfg(WgradTiledArgs& a, hipStream_t st) {
   const int ntile = a.n_co_tiles * a.n_n_tiles;
   // split-K over the spatial tiles: fill the resident block slots (2 blocks per CU for the 128-wide tiles, 3 otherwise) in one
   // round, keeping >= 2 spatial tiles per split
-  const int slots = 256 * (BM * BN >= 128 * 128 ? 2 : 3);
+  // Every split adds a full dW-sized pass of atomics: with the slots filled that is slots * BM * BN atomics per launch whatever
+  // the layer (8.4 M for 128 x 128 tiles, ~20 us) -- a third of a 1x1 weight gradient's time but < 10 % of a 3x3's.  Measured:
+  // 1x1 layers +15 % with one block per CU (half the splits), 3x3 layers lose up to 20 % (they need the second block to hide
+  // the patch staging).
+  const int slots = KS == 1 ? 256 : 256 * (BM * BN >= 128 * 128 ? 2 : 3);
   int nsplit = ntile >= slots ? 1 : slots / ntile;
   if (nsplit > a.n_sp_tiles / 2) nsplit = a.n_sp_tiles / 2;
   if (nsplit < 1) nsplit = 1;

@@ -38,3 +38,13 @@ for e in prof.key_averages(group_by_input_shape=True):
 rows.sort(reverse=True)
 for r in rows[:70]:
     print("%5d  %-28s %9.1f us  %s" % (r[0], r[1], r[3], r[2]))
+
+# every op / runtime call seen >= 8 times in the step (finds the sources of small copies and fills)
+print("---- calls >= 8 per step (any device time)")
+rows = []
+for e in prof.key_averages():
+    if e.count >= 8:
+        rows.append((e.count, e.key[:70], e.self_device_time_total, e.self_cpu_time_total))
+rows.sort(reverse=True)
+for r in rows[:80]:
+    print("%5d  %-70s dev %9.1f us  cpu %9.1f us" % r)
