@@ -56,8 +56,9 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
 /* ---- nn.Conv2d backward-data (autograd of the above): dx for input channels [c_lo,c_hi) of the conv input, written
  * to ndst tensors dx[i] = [B][Cdx[i]][Hx][Wx] (the inverse of the channel concat). dy = [B][Cout][Hy][Wy].
  * Cin_packed = sum(Cseg) given to rsis_conv_pack_dgrad; sum(Cdx) <= Cin_packed (leading channels are produced).
- * addend (optional, ndst == 1, stride 1 only): dx[0] = dgrad + addend -- the gradient the same tensor receives through another
- * consumer (the identity branch of a residual block), summed in the epilogue instead of by a separate pass. ---- */
+ * addend (optional, ndst == 1): dx[0] = dgrad + addend -- the gradient the same tensor receives through another consumer (the
+ * identity branch of a residual block), summed in the epilogue instead of by a separate pass.  stride 1: any pointer; 1x1 with
+ * stride > 1: addend must BE dx[0] -- the strided gradient is accumulated into the existing tensor in place (no zero fill). ---- */
 int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const float* Wd, int Cin_packed, int ks, int stride,
                       int pad, float* const* dx, const int* Cdx, int ndst, int Hx, int Wx, const float* addend, int tile,
                       void* stream);

@@ -201,7 +201,9 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const fl
                       int pad, float* const* dx, const int* Cdx, int ndst, int Hx, int Wx, const float* addend, int tile,
                       void* stream) {
   if (!dy || !Wd || !dx || !Cdx || ndst < 1 || ndst > RSIS_MAX_SRC) return RSIS_ERR_ARG;
-  if (addend && (ndst != 1 || stride != 1)) return RSIS_ERR_UNSUPPORTED;
+  // addend: stride 1 (any kernel the epilogue supports), or the strided 1x1 scatter accumulating in place (addend == dx[0])
+  const bool inplace = addend && ndst == 1 && stride > 1 && ks == 1 && pad == 0 && addend == dx[0];
+  if (addend && !inplace && (ndst != 1 || stride != 1)) return RSIS_ERR_UNSUPPORTED;
   if (stride != 1 && stride != 2 && stride != 4) return RSIS_ERR_UNSUPPORTED;
   ConvArgs a = {};
   const float* srcs[1] = {dy};
@@ -240,7 +242,7 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const fl
   if (ks == 1 && pad == 0 && stride > 1) {
     // 1x1 / stride-s data gradient: only the (s*ho, s*wo) input pixels receive a gradient -> zero dx, then run the plain
     // 1x1 GEMM over the dy grid and scatter its rows to those pixels (instead of gathering with 1/s^2 useful taps)
-    for (int i = 0; i < ndst; ++i)
+    for (int i = 0; i < ndst && !inplace; ++i)
       if (hipMemsetAsync(dx[i], 0, sizeof(float) * (size_t)B * Cdx[i] * Hx * Wx, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
     a.Ho = Hy; a.Wo = Wy; a.stride = 1; a.sshift = 0; a.ostride = stride;
     return rsis_launch_conv_igemm(a, ks, false, 0, tile, (hipStream_t)stream);

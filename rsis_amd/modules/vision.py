@@ -31,8 +31,9 @@ class HipConv2d(nn.Module):
             self.register_parameter("bias", None)
         self._pack = ops.PackedConv(self.kernel_size, [self.in_channels], stride=self.stride, pad=self.padding)
 
-    def forward(self, x, grad_slot=None):
-        return ops.conv2d([x], self.weight, self.bias, self.stride, self.padding, self._pack, grad_slot=grad_slot)
+    def forward(self, x, grad_slot=None, park_slot=None):
+        return ops.conv2d([x], self.weight, self.bias, self.stride, self.padding, self._pack, grad_slot=grad_slot,
+                          park_slot=park_slot)
 
 
 class HipBatchNorm2d(nn.Module):
@@ -87,16 +88,20 @@ class Bottleneck(nn.Module):
         self.bn3 = HipBatchNorm2d(planes * 4)
         self.downsample = downsample
         self.stride = stride
-        self._slot = ops.GradSlot()
+        self._slot = ops.GradSlot()       # gradient of x handed to conv1's data-gradient kernel
+        self._slot_in = ops.GradSlot()    # (downsample blocks) gradient of x from outside the trunk, see ResNet101.forward
 
     def forward(self, x):
-        # identity blocks in training: x feeds conv1 AND the residual add; the residual gradient is handed to conv1's
-        # data-gradient kernel (ops.GradSlot) instead of being added by autograd
-        slot = self._slot if (self.downsample is None and self.training and torch.is_grad_enabled() and x.requires_grad) else None
+        # In training x has two consumers inside the block (conv1 and the identity branch / downsample conv); instead of
+        # letting autograd add their gradients, the second one is handed to conv1's data-gradient kernel (ops.GradSlot).
+        hand = self.training and torch.is_grad_enabled() and x.requires_grad
+        slot = self._slot if hand else None
         out = self.bn1(self.conv1(x, grad_slot=slot), relu=True)
         out = self.bn2(self.conv2(out), relu=True)
-        residual = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
-        return self.bn3(self.conv3(out), res=residual, relu=True, res_slot=slot)
+        if self.downsample is None:
+            return self.bn3(self.conv3(out), res=x, relu=True, res_slot=slot)
+        residual = self.downsample[1](self.downsample[0](x, grad_slot=self._slot_in if hand else None, park_slot=slot))
+        return self.bn3(self.conv3(out), res=residual, relu=True)
 
 
 class ResNet101(nn.Module):
@@ -131,4 +136,10 @@ class ResNet101(nn.Module):
         x3 = self.layer2(x2)
         x4 = self.layer3(x3)
         x5 = self.layer4(x4)
+        if self.training:
+            # x2..x4 also leave the trunk (skip connections): their outside gradient is parked for the next stage's strided
+            # downsample conv, which accumulates into it in place (no memset, no autograd add)
+            x2 = ops.grad_tap(x2, self.layer2[0]._slot_in)
+            x3 = ops.grad_tap(x3, self.layer3[0]._slot_in)
+            x4 = ops.grad_tap(x4, self.layer4[0]._slot_in)
         return x5, x4, x3, x2, x1

@@ -167,10 +167,11 @@ def _conv_out_size(n, ks, stride, pad):
     return (n + 2 * pad - ks) // stride + 1
 
 
-def _dgrad_all(L, dy, wd, cin_packed, ks, stride, pad, srcs, Hx, Wx, addend=None):
-    """One dgrad launch producing the gradient of every concat source (+ addend: another consumer's gradient of the input)."""
+def _dgrad_all(L, dy, wd, cin_packed, ks, stride, pad, srcs, Hx, Wx, addend=None, inplace=False):
+    """One dgrad launch producing the gradient of every concat source (+ addend: another consumer's gradient of the input;
+    inplace: the strided 1x1 gradient is accumulated INTO the addend tensor, which becomes the result)."""
     B, Cout, Hy, Wy = dy.shape
-    dxs = [torch.empty_like(s) for s in srcs]
+    dxs = [addend] if inplace else [torch.empty_like(s) for s in srcs]
     check(L.rsis_conv2d_dgrad(ptr(dy), B, Cout, Hy, Wy, ptr(wd), cin_packed, ks, stride, pad, ptr_array(dxs),
                               int_array([s.shape[1] for s in srcs]), len(srcs), Hx, Wx, ptr(addend), FORCE_TILE[0], stream()),
           "rsis_conv2d_dgrad")
@@ -178,17 +179,54 @@ def _dgrad_all(L, dy, wd, cin_packed, ks, stride, pad, srcs, Hx, Wx, addend=None
 
 
 class GradSlot(object):
-    """Hand-over of a gradient between two autograd nodes that consume the SAME tensor (the input of a residual block feeds
-    conv1 and, as the identity branch, the block's last BatchNorm): the BatchNorm backward -- which autograd necessarily runs
-    first -- parks its identity-branch gradient here and returns None for it; conv1's data-gradient kernel then adds it in
-    its epilogue.  One full-size `add` pass per residual block less than letting autograd accumulate the two."""
+    """Hand-over of a gradient between two autograd nodes that consume the SAME tensor, so that the consumer's data-gradient
+    kernel adds it in its epilogue instead of autograd running a full-size `add`:
+      * identity residual block: the input feeds conv1 and, as the identity branch, the block's last BatchNorm; the BatchNorm
+        backward parks its identity-branch gradient, conv1's dgrad takes it;
+      * downsample block: the input feeds conv1 and the downsample conv; the downsample conv's dgrad (created later in the
+        forward, hence run earlier by autograd) parks its result, conv1's dgrad takes it;
+      * a trunk feature that also leaves the trunk (skip connection): `grad_tap` parks the outside gradient for the next
+        stage's downsample conv, whose strided 1x1 dgrad accumulates into it in place.
+    `park` refuses (the producer then returns its gradient the normal way) once the consumer has run, so the sum is right
+    whatever order autograd picks."""
 
     def __init__(self):
         self.grad = None
+        self.done = False
+
+    def reset(self):
+        self.grad, self.done = None, False
 
     def take(self):
         g, self.grad = self.grad, None
+        self.done = True
         return g
+
+    def park(self, g):
+        if self.done or self.grad is not None or g is None:
+            return False
+        self.grad = g
+        return True
+
+
+class _GradTapFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is not None and ctx.slot.park(g if g.is_contiguous() else g.contiguous()):
+            return None, None
+        return g, None
+
+
+def grad_tap(x, slot):
+    """Identity whose backward parks the incoming gradient in `slot` (see GradSlot) instead of returning it."""
+    if slot is None or not (torch.is_grad_enabled() and x.requires_grad):
+        return x
+    return _GradTapFn.apply(x, slot)
 
 
 def _wgrad_all(L, dy, srcs, w_shape, ks, stride, pad, lstm_hid, out=None):
@@ -240,15 +278,28 @@ class _Conv2dFn(torch.autograd.Function):
         ks = weight.shape[2]
         nsrc = ctx.nsrc
         grads = [None] * (nsrc + 2)
-        addend = ctx.slot.take() if ctx.slot is not None else None
+        take, park = ctx.slot if isinstance(ctx.slot, tuple) else (ctx.slot, None)
+        addend = take.take() if take is not None else None
         if any(ctx.needs_input_grad[5:5 + nsrc]):
             wd = ctx.pack.dgrad(weight)
-            if addend is not None and (nsrc != 1 or ctx.stride != 1 or addend.shape != srcs[0].shape):
-                raise _lib.RsisHipError("GradSlot: the parked gradient does not belong to this conv's input")
-            dxs = _dgrad_all(L, dy, wd, ctx.pack.cin, ks, ctx.stride, ctx.pad, srcs, srcs[0].shape[2], srcs[0].shape[3], addend)
+            inplace, extra = False, None
+            if addend is not None:
+                if nsrc != 1 or addend.shape != srcs[0].shape:
+                    raise _lib.RsisHipError("GradSlot: the parked gradient does not belong to this conv's input")
+                if ctx.stride != 1:
+                    if ks == 1 and ctx.pad == 0 and addend.is_contiguous():
+                        inplace = True             # strided 1x1: accumulate into the parked tensor (no memset, no add)
+                    else:
+                        extra, addend = addend, None
+            dxs = _dgrad_all(L, dy, wd, ctx.pack.cin, ks, ctx.stride, ctx.pad, srcs, srcs[0].shape[2], srcs[0].shape[3], addend,
+                             inplace)
+            if extra is not None:
+                dxs[0].add_(extra)
             for i in range(nsrc):
                 if ctx.needs_input_grad[5 + i]:
                     grads[i] = dxs[i]
+            if park is not None and nsrc == 1 and grads[0] is not None and park.park(grads[0]):
+                grads[0] = None                    # conv1's data-gradient kernel adds it
         if ctx.needs_input_grad[5 + nsrc]:
             tgt = _direct_target(ctx.wparam)
             dW = _wgrad_all(L, dy, srcs, tuple(weight.shape), ks, ctx.stride, ctx.pad, 0, out=tgt)
@@ -262,14 +313,16 @@ class _Conv2dFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads)
 
 
-def conv2d(srcs, weight, bias, stride, pad, pack, grad_slot=None):
-    """nn.Conv2d over the channel concat of `srcs` (list of NCHW tensors).  grad_slot: see GradSlot."""
+def conv2d(srcs, weight, bias, stride, pad, pack, grad_slot=None, park_slot=None):
+    """nn.Conv2d over the channel concat of `srcs` (list of NCHW tensors).  grad_slot: the slot this conv's data gradient
+    takes an addend from; park_slot: the slot it parks its own data gradient in (see GradSlot)."""
     # (ctx.needs_input_grad is True for parameters even under no_grad, and grad mode is off inside Function.forward, so the
     #  "is this a training call" decision is taken here)
     pack.training_call = torch.is_grad_enabled() and (weight.requires_grad or any(s.requires_grad for s in srcs))
     if grad_slot is not None:
-        grad_slot.grad = None
-    return _Conv2dFn.apply(pack, int(stride), int(pad), len(srcs), grad_slot, *srcs, weight, bias)
+        grad_slot.reset()
+    slot = grad_slot if park_slot is None else (grad_slot, park_slot)
+    return _Conv2dFn.apply(pack, int(stride), int(pad), len(srcs), slot, *srcs, weight, bias)
 
 
 class _ConvLSTMFn(torch.autograd.Function):
@@ -465,8 +518,8 @@ class _BatchNormFn(torch.autograd.Function):
             dres = dy
         if direct:
             dgamma = dbeta = None
-        if ctx.res_slot is not None and dres is not None:
-            ctx.res_slot.grad, dres = dres, None       # picked up by the data-gradient kernel of the block's first conv
+        if ctx.res_slot is not None and ctx.res_slot.park(dres):
+            dres = None                                # picked up by the data-gradient kernel of the block's first conv
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 

@@ -392,3 +392,39 @@ def test_decoder_other_skip_modes_match_oracle(skip_mode):
         assert_close("%s.dfeat%d" % (skip_mode, i), g.grad, f.grad, 2e-4 * max(1.0, float(f.grad.abs().max())), 1e-4)
     for (k, p), (_k2, q) in zip(odec.named_parameters(), dec.named_parameters()):
         assert_close("%s.grad.%s" % (skip_mode, k), q.grad, p.grad, 2e-4 * max(1.0, float(p.grad.abs().max())), 1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stride", [1, 2])
+def test_gradslot_downsample_block_equals_autograd_sum(stride):
+    """A downsample Bottleneck whose input also feeds an outside consumer: the gradient hand-overs (ops.GradSlot: outside
+    gradient -> strided downsample dgrad accumulating in place -> conv1's dgrad epilogue) must give the same input and
+    parameter gradients as letting autograd add the three contributions."""
+    from rsis_amd import ops
+    from rsis_amd.modules.vision import Bottleneck, HipBatchNorm2d, HipConv2d
+    torch.manual_seed(5)
+    ds = torch.nn.Sequential(HipConv2d(64, 128, 1, stride=stride, bias=False), HipBatchNorm2d(128))
+    blk = Bottleneck(64, 32, stride, ds).cuda().train()
+    x = torch.randn(4, 64, 16, 16, device="cuda", requires_grad=True)
+    g1 = torch.randn(4, 128, 16 // stride, 16 // stride, device="cuda")
+    g2 = torch.randn(4, 64, 16, 16, device="cuda")
+
+    def run():
+        x.grad = None
+        blk.zero_grad()
+        xa = x * 1.0                                   # non-leaf, like a trunk feature
+        out = blk(xa)
+        side = ops.grad_tap(xa, blk._slot_in)          # the skip connection leaving the trunk
+        ((out * g1).sum() + (side * g2).sum()).backward()
+        return [x.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+
+    got = run()
+    assert blk._slot.done and blk._slot.grad is None and blk._slot_in.grad is None, "every parked gradient must be consumed"
+    park = ops.GradSlot.park
+    try:
+        ops.GradSlot.park = lambda self, g: False      # no hand-over: autograd adds
+        want = run()
+    finally:
+        ops.GradSlot.park = park
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert_close("grad %d" % i, a, b, 2e-5 * float(b.abs().max()) + 1e-7)
