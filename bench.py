@@ -153,7 +153,8 @@ def gate_kernel_traffic(batch, imsize, timeout=150):
             with open(path) as f:
                 for r in csv.DictReader(f):
                     k = r["Kernel_Name"]
-                    if "conv3x3_direct_kernel" in k and r["Counter_Name"] == counter and re.search(r", 1>", k):
+                    # template arguments <BM, TW, TH, NI, EPI, KSP>: EPI == 1 is the fused LSTM epilogue (the gate kernel)
+                    if r["Counter_Name"] == counter and re.search(r"conv3x3_direct_kernel<\d+, \d+, \d+, \d+, 1, \d+>", k):
                         vals.setdefault((k, r["Grid_Size"]), []).append(float(r["Counter_Value"]))
             if len(vals) != 5:
                 return None, "expected 5 gate-kernel launch shapes in the counter file, found %d" % len(vals)
