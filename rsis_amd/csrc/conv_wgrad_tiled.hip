@@ -36,7 +36,9 @@ struct WgradTiledArgs {
 
 #define RSIS_OOB 0x7FFFFFF0u
 
-template <int BM, int BN, int WGM, int WGN, int KS, int TW>
+// KSP = 2: the block's four waves form a WGM x WGN grid TWICE; the two copies take alternate halves of every stage's reduction
+// depth and both add their partial tile with the (already atomic) epilogue -- lets a 32-row tile be only 64 columns wide.
+template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(const WgradTiledArgs p) {
 #if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; the buffer-resource builtins do not exist there)
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(const WgradTiledA
   constexpr int NA = BM * NG / 256;           // dwordx4 DMA per thread per tile (dy)
   constexpr int NB4 = KS == 1 ? BN * NG / 256 : 0;   // dwordx4 DMA per thread per tile (x, 1x1)
   constexpr int NB1 = KS == 1 ? 0 : XS / 256;        // dword DMA per thread per tile (x patch, 3x3)
-  static_assert(WGM * WGN == 4 && (BM * NG) % 256 == 0 && (KS == 3 || (BN * NG) % 256 == 0), "config");
+  static_assert(WGM * WGN * KSP == 4 && (BM * NG) % 256 == 0 && (KS == 3 || (BN * NG) % 256 == 0) && (NG / 2) % KSP == 0, "config");
 
   __shared__ __attribute__((aligned(16))) float lds[2 * (AS + XS)];
   float* const As0 = lds;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(const WgradTiledA
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
+  const int wk = wave / (WGM * WGN), wm = (wave % (WGM * WGN)) / WGN, wn = wave % WGN;
   const int H = p.H, W = p.W, HW = H * W, Cs = p.Cs, Cout = p.Cout;
   const int co_t = blockIdx.x % p.n_co_tiles, n_t = blockIdx.x / p.n_co_tiles;
   const int co0 = co_t * BM, n0 = n_t * BN;
@@ -109,9 +111,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(const WgradTiledA
   // ---- per-lane LDS read offsets ----
   // A (and 1x1 B): lanes 0-31 take group 2g, lanes 32-63 group 2g+1 of MFMA step block g; the group's slot in this lane's
   // row is (2g+h) ^ (row & 7), and row & 7 == l31 & 7 for every 32-row tile
-  int sg[NG / 2];
+  // (KSP == 2: this wave copy handles the step blocks g = 2 * gg + wk; their offsets live in per-wave registers)
+  int sg[NG / 2 / KSP];
+  int bo[NG / 2 / KSP];                        // 3x3: patch offset of the first pixel of step block g
 #pragma unroll
-  for (int g = 0; g < NG / 2; ++g) sg[g] = ((2 * g + hi) ^ (l31 & 7)) * 4;
+  for (int gg = 0; gg < NG / 2 / KSP; ++gg) {
+    const int g = gg * KSP + (KSP == 1 ? 0 : wk);
+    sg[gg] = ((2 * g + hi) ^ (l31 & 7)) * 4;
+    bo[gg] = KS == 1 ? 0 : (g / (TW / 8)) * PW + (g % (TW / 8)) * 8;
+  }
   const int arow = (wm * TM * 32 + l31) * TP;
   int xb[TN];
 #pragma unroll
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(const WgradTiledA
       const float* As = As0 + cur * AS + arow;
       const float* Xs = Xs0 + cur * XS;
 #pragma unroll
-      for (int g = 0; g < NG / 2; ++g) {
+      for (int g = 0; g < NG / 2 / KSP; ++g) {
         f32x4 a4[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a4[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * TP + sg[g]);
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(const WgradTiledA
           for (int e = 0; e < 4; ++e) {
             float b[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Xs[xb[j] + (g / (TW / 8)) * PW + (g % (TW / 8)) * 8 + e];   // pixel (y, x) of group 2g+h, element e
+            for (int j = 0; j < TN; ++j) b[j] = Xs[xb[j] + (KSP == 1 ? (g / (TW / 8)) * PW + (g % (TW / 8)) * 8 : bo[g]) + e];   // pixel (y, x) of group 2g+h, element e
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(const WgradTiledA
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, int TW>
+template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1>
 static int launch_tiled_cfg(WgradTiledArgs& a, hipStream_t st) {
   constexpr int TH = (KS == 1 ? 32 : 64) / TW;
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
@@ -250,15 +258,19 @@ static int launch_tiled_cfg(WgradTiledArgs& a, hipStream_t st) {
   if (nsplit < 1) nsplit = 1;
   a.tiles_per_split = rsis_cdiv(a.n_sp_tiles, nsplit);
   nsplit = rsis_cdiv(a.n_sp_tiles, a.tiles_per_split);
-  hipLaunchKernelGGL((conv_wgrad_tiled_kernel<BM, BN, WGM, WGN, KS, TW>), dim3(ntile, nsplit), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_wgrad_tiled_kernel<BM, BN, WGM, WGN, KS, TW, KSP>), dim3(ntile, nsplit), dim3(256), 0, st, a);
   return rsis_check_launch();
 }
 
 template <int KS, int TW>
 static int launch_tiled_tw(WgradTiledArgs& a, hipStream_t st) {
-  if (a.Cout <= 32) return launch_tiled_cfg<32, 128, 1, 4, KS, TW>(a, st);
-  if (a.Cout <= 64) return launch_tiled_cfg<64, 128, 2, 2, KS, TW>(a, st);
-  return launch_tiled_cfg<128, 128, 2, 2, KS, TW>(a, st);
+  // N = Cs * KS * KS columns: a 64-wide tile when that pads N less than the 128-wide one (N mod 128 in 1..64), e.g. the decoder's
+  // 16- and 32-channel sources (N = 144 / 288: 56 % / 75 % -> 75 % / 90 % useful MFMA columns)
+  const int nmod = (a.Cs * KS * KS) % 128;
+  const bool narrow = nmod != 0 && nmod <= 64;
+  if (a.Cout <= 32) return narrow ? launch_tiled_cfg<32, 64, 1, 2, KS, TW, 2>(a, st) : launch_tiled_cfg<32, 128, 1, 4, KS, TW>(a, st);
+  if (a.Cout <= 64) return narrow ? launch_tiled_cfg<64, 64, 2, 2, KS, TW>(a, st) : launch_tiled_cfg<64, 128, 2, 2, KS, TW>(a, st);
+  return narrow ? launch_tiled_cfg<128, 64, 2, 2, KS, TW>(a, st) : launch_tiled_cfg<128, 128, 2, 2, KS, TW>(a, st);
 }
 
 // widest tile the map allows: full 128-byte lines of dy / x per tile row on the wide maps, whole rows on the narrow ones

@@ -41,6 +41,11 @@ CONV_CASES = [
     (3, [4], 16, 64, 1, 3, 1, 1, True),         # conv_out, 4 channels, exactly one tile per image
     (1, [8], 12, 256, 1, 3, 1, 1, True),        # conv_out, full-width 8 x 256 tiles (the config-2 shape), partial tile rows
     (2, [8], 9, 160, 1, 3, 1, 1, False),        # conv_out, 256-wide tile on a 160-wide image
+    (3, [16], 16, 16, 32, 3, 1, 1, False),      # tiled wgrad, 64-wide N tile + in-block K split (N = 144, Cout <= 32)
+    (2, [16], 16, 32, 64, 3, 1, 1, True),       # tiled wgrad <64, 64> (N = 144)
+    (2, [32], 16, 16, 128, 3, 1, 1, False),     # tiled wgrad <128, 64> (N = 288)
+    (2, [64], 8, 32, 96, 1, 1, 0, False),       # tiled 1x1 wgrad <128, 64> (N = 64)
+    (2, [16, 8], 16, 16, 32, 3, 1, 1, True),    # two sources: N = 144 (narrow) and N = 72 (wide) in the same conv
     (2, [6], 8, 8, 1, 3, 1, 1, False),          # Cout = 1 with an unsupported Cin -> MFMA path
     (1, [130], 7, 7, 129, 3, 1, 1, True),       # ragged channels
     (2, [2048], 4, 4, 128, 3, 1, 1, True),      # sk5-like deep K
