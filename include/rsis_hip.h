@@ -145,6 +145,13 @@ typedef struct rsis_pack_job {
 int rsis_conv_pack_job_fill(rsis_pack_job* job);
 int rsis_conv_pack_batch(const rsis_pack_job* jobs_dev, int njobs, int total_blocks, void* stream);
 
+/* ---- data-layer augmentation: nearest-neighbour affine warp (dataloader/transforms/utils.py:67-147 th_affine2d(mode='nearest',
+ * center=True); applied by transforms.py:23-142 RandomAffine to the image, the instance map and the class map of a sample).
+ * x, y: [N][C][H][W] float32 (y != x); mat: [N][mat_rows][3] float32 in DEVICE memory, mat_rows = 3 (the reference's 3x3, last
+ * row ignored) or 2.  y[n][c][i][j] = x[n][c][round(clamp(A (i-ci, j-cj) + b + (ci, cj)))], ci = H/2 - 0.5, cj = W/2 - 0.5,
+ * float32 arithmetic in the reference's operation order, round half to even: bit-exact with the reference. ---- */
+int rsis_affine_nearest(const float* x, float* y, const float* mat, int mat_rows, int N, int C, int H, int W, void* stream);
+
 /* ---- soft-IoU matching scores and matched-loss gradient (train.py:98-110,127-131,162-163; hungarian.py:62-89 softIoU) ----
  * rsis_softiou_sums: logits[B][T][N] (mask logits of the T predictions), y[B][G][N] (ground-truth masks, 0/1 floats) ->
  *   S[B][T+1][G+1]:  S[t][g] = sum_n sigmoid(logits[t][n]) * y[g][n],  S[t][G] = sum_n sigmoid(logits[t][n]),

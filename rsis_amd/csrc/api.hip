@@ -33,6 +33,7 @@ int rsis_l_assign(const float*, long long*, int, int, int, hipStream_t);
 int rsis_l_gmax_bwd_add(const float*, const int*, float*, long, int, hipStream_t);
 int rsis_l_pack_batch(const rsis_pack_job*, int, int, hipStream_t);
 int rsis_l_pack_blocks(int mode, int krows, int ldw);
+int rsis_l_affine_nearest(const float*, float*, const float*, int, int, int, int, int, hipStream_t);
 int rsis_l_mask_resize_threshold(const float*, int, int, int, const unsigned char*, float, unsigned char*, unsigned char*, unsigned int*,
                                  int, int, hipStream_t);
 int rsis_l_rle_encode(const unsigned char*, int, long, unsigned int*, int, int*, hipStream_t);
@@ -128,6 +129,12 @@ int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, 
   if (use_direct_s2(ks, stride, pad))
     return rsis_l_pack(4, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, direct_rows(1, &Cout), lstm_hid, (hipStream_t)stream);
   return rsis_l_pack(1, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, krows_of(Cout, ks), lstm_hid, (hipStream_t)stream);
+}
+
+int rsis_affine_nearest(const float* x, float* y, const float* mat, int mat_rows, int N, int C, int H, int W, void* stream) {
+  if (!x || !y || !mat || x == y || N < 1 || C < 1 || H < 1 || W < 1 || (mat_rows != 2 && mat_rows != 3)) return RSIS_ERR_ARG;
+  if ((long)H * W >= (1L << 31) || N > 65535) return RSIS_ERR_UNSUPPORTED;
+  return rsis_l_affine_nearest(x, y, mat, N, C, H, W, mat_rows * 3, (hipStream_t)stream);
 }
 
 int rsis_conv_pack_job_fill(rsis_pack_job* j) {
