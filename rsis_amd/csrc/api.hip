@@ -55,6 +55,13 @@ static inline int log2i(int s) { int l = 0; while ((1 << l) < s) ++l; return l; 
 static inline bool use_direct(int ks, int stride, int pad) { return ks == 3 && stride == 1 && pad == 1; }
 // 3x3 / stride 2 / pad 1 data gradients run on the same kernel (EPI_S2: parity classes of the input pixel)
 static inline bool use_direct_s2(int ks, int stride, int pad) { return ks == 3 && stride == 2 && pad == 1; }
+// ... and so does their forward (EPI_F2): the forward copy of the weights uses the direct layout for both strides
+// (RSIS_CONV_F2=0: A/B switch back to the implicit-GEMM forward for the strided convs)
+static inline bool use_direct_f2(int ks, int stride, int pad) {
+  static const bool on = !(getenv("RSIS_CONV_F2") && getenv("RSIS_CONV_F2")[0] == '0');
+  return on && use_direct_s2(ks, stride, pad);
+}
+static inline bool use_direct_fwd(int ks, int stride, int pad) { return use_direct(ks, stride, pad) || use_direct_f2(ks, stride, pad); }
 static inline int direct_rows(int nseg, const int* Cseg) {
   int q = 0;
   for (int s = 0; s < nseg; ++s) q += (Cseg[s] + RSIS_CK - 1) / RSIS_CK;
@@ -79,7 +86,7 @@ const char* rsis_error_string(int code) {
 long rsis_conv_packed_floats_fwd(int Cout, int ks, int stride, int pad, int nseg, const int* Cseg) {
   if (nseg < 1 || nseg > RSIS_MAX_SRC || !Cseg) return -1;
   const long ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN);
-  if (use_direct(ks, stride, pad)) return (long)direct_rows(nseg, Cseg) * ldw;
+  if (use_direct_fwd(ks, stride, pad)) return (long)direct_rows(nseg, Cseg) * ldw;
   int c = 0;
   for (int s = 0; s < nseg; ++s) c += Cseg[s];
   return (long)krows_of(c, ks) * ldw;
@@ -87,7 +94,11 @@ long rsis_conv_packed_floats_fwd(int Cout, int ks, int stride, int pad, int nseg
 
 long rsis_conv_packed_floats_dgrad(int Cout, int ks, int stride, int pad, int c_count) {
   const long ldw = rsis_roundup(c_count, RSIS_LDW_ALIGN);
-  if (use_direct(ks, stride, pad) || use_direct_s2(ks, stride, pad)) return (long)direct_rows(1, &Cout) * ldw;
+  if (use_direct(ks, stride, pad)) return (long)direct_rows(1, &Cout) * ldw;
+  if (use_direct_s2(ks, stride, pad)) {      // direct layout for one destination, implicit-GEMM layout for several: room for either
+    const long a = (long)direct_rows(1, &Cout) * ldw, b = (long)krows_of(Cout, ks) * ldw;
+    return a > b ? a : b;
+  }
   return (long)krows_of(Cout, ks) * ldw;
 }
 
@@ -112,7 +123,7 @@ int rsis_conv_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, in
   const int ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN);
   int csum = 0;
   for (int s = 0; s < nseg; ++s) csum += Cseg[s];
-  if (use_direct(ks, stride, pad))
+  if (use_direct_fwd(ks, stride, pad))
     return rsis_l_pack(2, W, Wp, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, direct_rows(nseg, Cseg), lstm_hid, (hipStream_t)stream);
   return rsis_l_pack(0, W, Wp, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, krows_of(csum, ks), lstm_hid, (hipStream_t)stream);
 }
@@ -126,7 +137,7 @@ int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, 
   const int ldw = rsis_roundup(csum, RSIS_LDW_ALIGN);
   if (use_direct(ks, stride, pad))
     return rsis_l_pack(3, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, direct_rows(1, &Cout), lstm_hid, (hipStream_t)stream);
-  if (use_direct_s2(ks, stride, pad))
+  if (use_direct_s2(ks, stride, pad) && nseg == 1)      // (the parity-class kernel writes one destination)
     return rsis_l_pack(4, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, direct_rows(1, &Cout), lstm_hid, (hipStream_t)stream);
   return rsis_l_pack(1, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, krows_of(Cout, ks), lstm_hid, (hipStream_t)stream);
 }
@@ -144,12 +155,12 @@ int rsis_conv_pack_job_fill(rsis_pack_job* j) {
   for (int s = 0; s < j->nseg; ++s) csum += j->Cseg[s];
   if (!j->dgrad) {
     j->ldw = rsis_roundup(j->Cout, RSIS_LDW_ALIGN);
-    if (use_direct(j->ks, j->stride, j->pad)) { j->imode = 2; j->krows = direct_rows(j->nseg, j->Cseg); }
+    if (use_direct_fwd(j->ks, j->stride, j->pad)) { j->imode = 2; j->krows = direct_rows(j->nseg, j->Cseg); }
     else { j->imode = 0; j->krows = krows_of(csum, j->ks); }
   } else {
     j->ldw = rsis_roundup(csum, RSIS_LDW_ALIGN);
     if (use_direct(j->ks, j->stride, j->pad)) { j->imode = 3; j->krows = direct_rows(1, &j->Cout); }
-    else if (use_direct_s2(j->ks, j->stride, j->pad)) { j->imode = 4; j->krows = direct_rows(1, &j->Cout); }
+    else if (use_direct_s2(j->ks, j->stride, j->pad) && j->nseg == 1) { j->imode = 4; j->krows = direct_rows(1, &j->Cout); }
     else { j->imode = 1; j->krows = krows_of(j->Cout, j->ks); }
   }
   return rsis_l_pack_blocks(j->imode, j->krows, j->ldw);
@@ -201,6 +212,8 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
     }
     return rsis_launch_conv3x3_direct(a, 0, direct_variant(tile), (hipStream_t)stream);
   }
+  if (use_direct_f2(ks, stride, pad))        // 3x3 / stride 2 forward: the direct kernel on a (2T+1)^2 patch (EPI_F2 = 3)
+    return rsis_launch_conv3x3_direct(a, 3, direct_variant(tile), (hipStream_t)stream);
   return rsis_launch_conv_igemm(a, ks, false, 0, tile, (hipStream_t)stream);
 }
 
@@ -240,7 +253,7 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const fl
     }
     return rsis_launch_conv3x3_direct(a, 0, direct_variant(tile), (hipStream_t)stream);
   }
-  if (use_direct_s2(ks, stride, pad) && ndst == 1 && Hy == (Hx + 1) / 2 && Wy == (Wx + 1) / 2) {
+  if (use_direct_s2(ks, stride, pad) && ndst == 1 && Cdx[0] == Cin_packed && Hy == (Hx + 1) / 2 && Wy == (Wx + 1) / 2) {
     // 3x3 / stride 2: the direct kernel walks the dy grid and scatters the four input-pixel parity classes (every dx pixel is
     // written exactly once: no memset)
     a.Ho = Hy; a.Wo = Wy; a.oH = Hx; a.oW = Wx;

@@ -20,9 +20,13 @@
 // belongs to exactly one class, reads dy at (y + (r == 0), x + (s == 0)) and accumulates into that class's accumulator.  So
 // the block walks the dy grid exactly like a stride-1 conv (9 taps per channel pair, no wasted MFMAs -- the gather
 // formulation multiplies 3/4 zeros) and the epilogue scatters the 4 accumulators to the 2x larger dx tile.
+//
+// EPI_F2: the FORWARD of those 3x3 / stride 2 / pad 1 convs.  Same kernel with a (2 TH + 1) x (2 TW + 1) input patch per
+// TW x TH output tile: lane (y, x) reads patch pixel (2y + r, 2x + s) for tap (r, s) -- still one `ds_read_b32` with an
+// immediate offset per MFMA (2-way LDS bank conflicts from the pixel stride of 2), plain epilogue on the output grid.
 #include "common.h"
 
-enum { EPI_PLAIN = 0, EPI_LSTM = 1, EPI_S2 = 2 };
+enum { EPI_PLAIN = 0, EPI_LSTM = 1, EPI_S2 = 2, EPI_F2 = 3 };
 #ifndef DIRECT_DMA
 #define DIRECT_DMA 1   // 1: stage global -> LDS with buffer_load ... lds (LDS-DMA); 0: through registers + ds_write
 #endif
@@ -43,7 +47,8 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   constexpr int BN = TW * TH * NI;
   constexpr int WGM = BM / 32, WGN = 4 / WGM / KSP;      // BM=64: 2x2 waves, BM=32: 1x4 (KSP = 2: 1x2 tiles x 2 K-halves)
   constexpr int TN = BN / WGN / 32;                 // 32-pixel MFMA column tiles per wave (TM == 1)
-  constexpr int PW = TW + 2, PH = TH + 2;
+  constexpr int S = EPI == EPI_F2 ? 2 : 1;          // pixel stride of the patch reads (forward stride)
+  constexpr int PW = TW * S + 3 - S, PH = TH * S + 3 - S;   // S = 1: tile + 1-pixel halo; S = 2: 2T + 1
   constexpr int IMS = PH * PW;                      // one image of the patch
   constexpr int CHS = NI * IMS;                     // channel stride of the patch
   constexpr int XS = CK * CHS, WS = CK * 9 * BM;    // floats per LDS stage
@@ -52,6 +57,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   constexpr int W_F4 = WS / 4;
   constexpr int NW = (W_F4 + 255) / 256;            // weight float4 loads per thread per chunk
   static_assert(TN >= 1 && BN % (WGN * 32) == 0 && WGM * WGN * KSP == 4 && (CK / 2) % KSP == 0 && (KSP == 1 || EPI != EPI_S2), "tile");
+  static_assert(EPI != EPI_F2 || DIRECT_DMA, "the stride-2 forward exists for the LDS-DMA staging only");
 
   __shared__ __attribute__((aligned(16))) float lds[2 * (XSP + WS)];
   float* const Xs0 = lds;
@@ -66,7 +72,10 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   const int ksplit = gridDim.y, kz = blockIdx.y;
   const int q_begin = (int)((long)nq_all * kz / ksplit), q_end = (int)((long)nq_all * (kz + 1) / ksplit);
   const int nq = q_end - q_begin;
-  const int H = p.H, W = p.W, HW = H * W, B = p.B;
+  // H x W: the grid the block tiles walk and the epilogue writes (the output map; == the gathered map except for EPI_F2);
+  // Hs x Ws: the gathered (source) map the patch is read from
+  const int Hs = p.H, Ws = p.W, HWs = Hs * Ws;
+  const int H = EPI == EPI_F2 ? p.Ho : p.H, W = EPI == EPI_F2 ? p.Wo : p.W, HW = H * W, B = p.B;
   const int ldw = p.ldw;
 
   // ---- block -> (co tile, spatial tile); blocks b, b+8, ... share an XCD: a tile's co tiles stay on one L2 ----
@@ -97,9 +106,9 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
     const int e = tid + i * 256;
     const int cl = e / CHS, rem2 = e - cl * CHS;
     const int py = rem2 / PW, pxx = rem2 - py * PW;
-    const int gy = y0 + py - 1, gx = x0 + pxx - 1;
-    const bool ok = (e < XS) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
-    xvo[i] = ok ? (unsigned)(cl * HW + gy * W + gx) * 4u : 0x7FFFFFF0u;
+    const int gy = y0 * S + py - 1, gx = x0 * S + pxx - 1;
+    const bool ok = (e < XS) && ((unsigned)gy < (unsigned)Hs) && ((unsigned)gx < (unsigned)Ws);
+    xvo[i] = ok ? (unsigned)(cl * HWs + gy * Ws + gx) * 4u : 0x7FFFFFF0u;
   }
   unsigned wvo[NW];
 #pragma unroll
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   for (int j = 0; j < TN; ++j) {
     const int pp = (wn * TN + j) * 32 + l31;
     const int x = pp % TW, y = (pp / TW) % TH, img = pp / (TW * TH);
-    xoff[j] = hi * CHS + img * IMS + y * PW + x;
+    xoff[j] = hi * CHS + img * IMS + y * S * PW + x * S;
   }
   // K-split: wave half wk starts at channel pair wk * (CK/2/KSP) of every chunk (folded into the two read bases)
   constexpr int C2W = CK / 2 / KSP;                 // channel pairs per wave per chunk
@@ -169,8 +178,8 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
     if (cs == 2) { src = src2; Cs = C2; }                                                                 \
     const int c0 = cq * CK;                                                                               \
     const int cn = min(CK, Cs - c0);                                                                      \
-    const float* xb = (const float*)src + ((size_t)b0 * Cs + c0) * HW;                                    \
-    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, cn * HW * 4, 0x00020000); \
+    const float* xb = (const float*)src + ((size_t)b0 * Cs + c0) * HWs;                                   \
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, cn * HWs * 4, 0x00020000); \
     float* Xs = Xs0 + (BUF) * XSP + wave * 64;                                                            \
     _Pragma("unroll") for (int i = 0; i < NX; ++i)                                                        \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_vp_t)(Xs + i * 256), 4, xvo[i], 0, 0, 0);        \
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
           if (co < Cd0) d0[((size_t)ob * Cd0 + co) * ((size_t)oH * oW) + py * oW + px] = accs[c][j][r];
         }
       }
-    } else if (EPI == EPI_PLAIN) {
+    } else if (EPI == EPI_PLAIN || EPI == EPI_F2) {
       const gf_t d0 = (gf_t)p.dst[0], d1 = (gf_t)p.dst[1], d2 = (gf_t)p.dst[2];
       const int Cd0 = p.Cd[0], Cd1 = p.Cd[1], Cd2 = p.Cd[2], Cout = p.Cout;
       const int e1 = Cd0, e2 = Cd0 + Cd1;
@@ -365,7 +374,8 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
 template <int BM, int TW, int TH, int NI, int EPI, int KSP = 1>
 static int launch_direct_cfg(ConvArgs& a, hipStream_t st) {
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
-  a.n_px_tiles = rsis_cdiv(a.W, TW) * rsis_cdiv(a.H, TH) * rsis_cdiv(a.B, NI);
+  const int gw = EPI == EPI_F2 ? a.Wo : a.W, gh = EPI == EPI_F2 ? a.Ho : a.H;      // the grid the tiles walk
+  a.n_px_tiles = rsis_cdiv(gw, TW) * rsis_cdiv(gh, TH) * rsis_cdiv(a.B, NI);
   const int grid = a.n_co_tiles * 8 * rsis_cdiv(a.n_px_tiles, 8);
   int ksplit = 1;
   if (EPI == EPI_PLAIN && a.ksplit == 0) {    // ksplit == 0: the caller zeroed the output and allows split-K
@@ -424,8 +434,17 @@ static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
   }
 }
 
+// stride-2 forward: the (2T + 1)^2 patch limits the tile to 16 x 8 (32 rows) or 8 x 8 (64 rows) inside 64 KB of LDS
+static int launch_direct_f2(ConvArgs& a, hipStream_t st, int force) {
+  int v = force;
+  if (v != 1 && v != 4) v = (a.Wo <= 8 || (long)rsis_cdiv(a.Cout, 32) * rsis_cdiv(a.Wo, 16) * rsis_cdiv(a.Ho, 8) * a.B < 256) ? 1 : 4;
+  if (v == 1) return launch_direct_cfg<64, 8, 8, 1, EPI_F2>(a, st);
+  return launch_direct_cfg<32, 16, 8, 1, EPI_F2>(a, st);
+}
+
 int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st) {
   if (a.nsrc < 0 || a.nsrc > RSIS_MAX_SRC) return RSIS_ERR_ARG;
+  if (epi == EPI_F2) return launch_direct_f2(a, st, force_variant);
   if (epi == EPI_LSTM) return launch_direct_epi<EPI_LSTM>(a, st, force_variant);
   if (epi == EPI_S2) return launch_direct_epi<EPI_S2>(a, st, force_variant);
   return launch_direct_epi<EPI_PLAIN>(a, st, force_variant);

@@ -131,7 +131,7 @@ class PackedConv(object):
             nseg, segs, offs = self._seg_args()
             n = L.rsis_conv_packed_floats_fwd(Cout, self.ks, self.stride, self.pad, nseg, segs)
             if self.wp is None or self.wp.numel() != n:
-                self.wp = torch.empty(n, dtype=torch.float32, device=w.device)
+                self.wp = torch.zeros(n, dtype=torch.float32, device=w.device)     # (a size query may leave slack after the packed rows)
             check(L.rsis_conv_pack_fwd(ptr(w.detach()), ptr(self.wp), Cout, Ctot, self.ks, self.stride, self.pad, nseg, segs, offs,
                                        self.lstm_hid, stream()), "rsis_conv_pack_fwd")
             if bias is not None and self.lstm_hid > 0:
@@ -149,7 +149,7 @@ class PackedConv(object):
             nseg, segs, offs = self._seg_args()
             n = L.rsis_conv_packed_floats_dgrad(Cout, self.ks, self.stride, self.pad, self.cin)
             if self.wd is None or self.wd.numel() != n:
-                self.wd = torch.empty(n, dtype=torch.float32, device=w.device)
+                self.wd = torch.zeros(n, dtype=torch.float32, device=w.device)
             check(L.rsis_conv_pack_dgrad(ptr(w.detach()), ptr(self.wd), Cout, Ctot, self.ks, self.stride, self.pad, nseg, segs, offs,
                                          self.lstm_hid, stream()), "rsis_conv_pack_dgrad")
             self._key_d = key

@@ -44,8 +44,10 @@ def test_packed_size_queries():
     # 3x3/s1/p1 -> direct layout: 8-channel chunks per source (2+2+1) x 72 rows; Cout 32 -> row stride 128
     assert L.rsis_conv_packed_floats_fwd(32, 3, 1, 1, 3, segs) == 5 * 72 * 128
     assert L.rsis_conv_packed_floats_dgrad(32, 3, 1, 1, 40) == 4 * 72 * 128
-    # strided 3x3 -> implicit-GEMM layout: K = 40*9 = 360 -> 384 rows (multiple of 32)
-    assert L.rsis_conv_packed_floats_fwd(32, 3, 2, 1, 3, segs) == 384 * 128
+    # 3x3/s2/p1 forward runs on the direct kernel too (EPI_F2): same direct layout
+    assert L.rsis_conv_packed_floats_fwd(32, 3, 2, 1, 3, segs) == 5 * 72 * 128
+    # other strided / padded 3x3 -> implicit-GEMM layout: K = 40*9 = 360 -> 384 rows (multiple of 32)
+    assert L.rsis_conv_packed_floats_fwd(32, 3, 2, 0, 3, segs) == 384 * 128
     assert L.rsis_conv_packed_floats_dgrad(32, 3, 2, 1, 40) == 288 * 128
 
 

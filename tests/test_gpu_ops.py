@@ -54,6 +54,8 @@ CONV_CASES = [
     (3, [40], 12, 16, 24, 1, 1, 0, False),      # tiled 1x1 wgrad (8x4 tiles), ragged channels
     (2, [24], 32, 48, 40, 3, 2, 1, True),       # strided 3x3, even size, several tiles (parity-class dgrad)
     (1, [16], 9, 64, 72, 3, 2, 1, False),       # strided 3x3, odd height, wide map
+    (2, [128], 16, 16, 96, 3, 2, 1, False),     # strided 3x3 forward on the direct kernel, 8x8 output (64-row variant)
+    (3, [20, 12], 20, 40, 48, 3, 2, 1, True),   # strided 3x3 forward, two sources with channel tails, partial tiles
 ]
 
 
