@@ -122,13 +122,19 @@ class BucketedAllReduce(object):
         self._hooks = []
         self._param_bucket = {}
         for g in groups:
-            start, count, first = None, 0, 0
+            # Parameters are laid out in forward order, so a group's FIRST bucket is the last one whose gradients become final
+            # (the stem / layer1 of the trunk at the very end of backward): nothing is left to hide its all-reduce behind.
+            # Keep it small (1/8 of the bucket size, then 1/2, then full buckets) so that the exposed tail is a short
+            # latency-bound collective instead of a 64 MB one.
+            start, count, first, nb = None, 0, 0, 0
             for i, (p, (off, k)) in enumerate(zip(g.params, g.offsets)):
                 if start is None:
                     start, first = off, i
                 count += k
                 last = i == len(g.params) - 1
-                if count * 4 >= bucket_bytes or last:
+                cap = bucket_bytes // 8 if nb == 0 else (bucket_bytes // 2 if nb == 1 else bucket_bytes)
+                if count * 4 >= cap or last:
+                    nb += 1
                     bi = len(self.buckets)
                     self.buckets.append((g.flat_g[start:start + count], i - first + 1))
                     for q in g.params[first:i + 1]:
