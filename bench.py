@@ -290,7 +290,7 @@ def main():
     loss_val = float(losses[0])
     assert loss_val == loss_val, "loss is NaN"
 
-    cpu = None
+    cpu, out = None, None
     if rank == 0:
         note("timed region %.3f s for %d steps" % (dt, o.steps))
         if world == 1 and not o.skip_cpu:
@@ -312,10 +312,19 @@ def main():
                                       "decoder, fp32, fwd+match+3 losses+bwd+Adam (update_encoder on)" % (o.imsize, o.imsize, o.T, o.batch),
                           "global_batch": world * o.batch, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5)},
                "roofline": roof, "cpu_baseline": cpu}
-        print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a banner (version, library path) through C stdio, which on a pipe is flushed only at exit, i.e. AFTER
+        # anything python printed: flush the C streams first so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
