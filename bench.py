@@ -312,18 +312,23 @@ def main():
                                       "decoder, fp32, fwd+match+3 losses+bwd+Adam (update_encoder on)" % (o.imsize, o.imsize, o.T, o.batch),
                           "global_batch": world * o.batch, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5)},
                "roofline": roof, "cpu_baseline": cpu}
-    if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        # RCCL prints a banner (version, library path) through C stdio, which on a pipe is flushed only at exit, i.e. AFTER
-        # anything python printed: flush the C streams first so that the JSON line is the last line of stdout
+    # RCCL prints a banner (version, library path) through C stdio, which on a pipe is flushed only at exit, i.e. AFTER anything
+    # python printed: every rank flushes its C streams before the final barrier, rank 0 prints after it, so that the JSON line
+    # is the last line of the job's (merged) stdout
+    def flush_c():
         try:
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:  # noqa: BLE001
             pass
         sys.stdout.flush()
+
+    flush_c()
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        flush_c()
         print(json.dumps(out), flush=True)
 
 
