@@ -8,8 +8,9 @@ clstm.py:43-44   gates = W * [x | h_prev] + b   into
     gates_t  = G_i + W[:, up(h_{i-1,t}) | h_{i,t-1}] * [..] -- per timestep, fused kernel  (_StepFn, G_i is the kernel's addend)
 
 (identical to the reference up to fp32 summation order).  The backward mirrors it:
-  * sum_t d(gates_t) is accumulated in-kernel (rsis_convlstm_bwd_gates da_sum) and the skip-channel data/weight/bias
-    gradients are computed ONCE from that sum (linearity), instead of T times;
+  * sum_t d(gates_t) is one reduction over the stacked d(gates) at the end (in-kernel accumulation, rsis_convlstm_bwd_gates
+    da_sum, only for steps beyond the tape capacity) and the skip-channel data/weight/bias gradients are computed ONCE from
+    that sum (linearity), instead of T times;
   * h, c, saved gates, up-sampled inputs and d(gates) of all timesteps live in stacked [T][B][C][H][W] buffers written
     in place by the kernels, so the weight gradient of the recurrent channels is ONE split-K launch over T*B images per
     source instead of T launches (run by the t = 0 backward, which autograd necessarily executes last).
@@ -177,9 +178,7 @@ class _StepFn(torch.autograd.Function):
             c_prev = tl.C[t - 1] if ctx.has_state else None
             if tl.DA is None:
                 tl.DA = torch.empty_like(tl.ACT)
-            if tl.da_sum is None:
-                tl.da_sum = torch.zeros_like(tl.ACT[0])
-            da = tl.DA[t]
+            da = tl.DA[t]                     # (sum_t d(gates_t) is one reduction over the stacked DA at t == 0: no per-step RMW)
             srcs = ([tl.UP[t]] if ctx.has_up else []) + ([tl.H[t - 1]] if ctx.has_state else [])
         else:
             act, c, c_prev = ctx.saved_tensors[1:4]
@@ -191,8 +190,8 @@ class _StepFn(torch.autograd.Function):
         dc_prev = torch.empty_like(c) if ctx.has_state else None
         dh2 = tl.DHP if (ctx.stacked and tl.dhp_t == t) else None
         tl.dhp_t = -1
-        check(L.rsis_convlstm_bwd_gates(ptr(dh), ptr(dh2), ptr(dc), ptr(act), ptr(c_prev), ptr(c), ptr(da), ptr(dc_prev), ptr(tl.da_sum),
-                                        B, hid, H * W, stream()), "rsis_convlstm_bwd_gates(step)")
+        check(L.rsis_convlstm_bwd_gates(ptr(dh), ptr(dh2), ptr(dc), ptr(act), ptr(c_prev), ptr(c), ptr(da), ptr(dc_prev),
+                                        None if ctx.stacked else ptr(tl.da_sum), B, hid, H * W, stream()), "rsis_convlstm_bwd_gates(step)")
         tl.n_bwd += 1
         d_up = dh_prev = None
         if srcs:
@@ -228,7 +227,14 @@ class _StepFn(torch.autograd.Function):
                                           stream()), "rsis_conv2d_wgrad(step)")
         if t == 0:
             # autograd runs the t = 0 backward last (every later step depends on it): flush the time-batched work
-            dG = tl.da_sum
+            if ctx.stacked:
+                if tl.n_bwd < tl.n_fwd:       # (a step without a gradient would leave its DA slot unwritten)
+                    raise RuntimeError("fused RSIS decoder: %d of %d timesteps were back-propagated" % (tl.n_bwd, tl.n_fwd))
+                dG = tl.DA[0] if tl.n_fwd == 1 else tl.DA[:tl.n_fwd].sum(dim=0)
+                if tl.da_sum is not None:     # steps beyond the tape capacity accumulated theirs in the kernel
+                    dG = dG + tl.da_sum
+            else:
+                dG = tl.da_sum
             if ctx.stacked and ctx.needs_input_grad[6]:
                 n = tl.n_fwd
                 if tl.n_bwd < n:   # steps that never received a gradient contribute zero
