@@ -145,6 +145,19 @@ typedef struct rsis_pack_job {
 int rsis_conv_pack_job_fill(rsis_pack_job* job);
 int rsis_conv_pack_batch(const rsis_pack_job* jobs_dev, int njobs, int total_blocks, void* stream);
 
+/* ---- decoder tail: out_mask = conv_out(UpsamplingBilinear2d((Ho, Wo))(hidden)) (model.py:163-167) as ONE kernel each way: the
+ * up-sampled hidden state (Cin channels at the output resolution) is never written -- every block interpolates the patch it
+ * convolves from the hidden pixels in LDS.  h[B][Cin][Hi][Wi]; W = conv_out.weight in the REFERENCE layout [1][Cin][3][3]
+ * (3x3, stride 1, pad 1); bias[1] or NULL; out / dy[B][1][Ho][Wo].  Results equal rsis_upsample_bilinear_ac_*
+ * followed by rsis_conv2d_* on the same tensors to a few ulp (same formulas and summation order).  rsis_upconv_out_bwd: dh (may be NULL) is written,
+ * dW[Cin*9] / db[1] (may be NULL; db needs dW) are ACCUMULATED.  rsis_upconv_out_supported: Cin in {4, 8, 16}, Wi % 4 == 0,
+ * Wo % 4 == 0, up-sampling factor >= ~1.9 per axis; otherwise the entry points return RSIS_ERR_UNSUPPORTED. ---- */
+int rsis_upconv_out_supported(int Cin, int Hi, int Wi, int Ho, int Wo);
+int rsis_upconv_out_fwd(const float* h, const float* W, const float* bias, float* out, int B, int Cin, int Hi, int Wi, int Ho,
+                        int Wo, void* stream);
+int rsis_upconv_out_bwd(const float* dy, const float* h, const float* W, float* dh, float* dW, float* db, int B, int Cin, int Hi,
+                        int Wi, int Ho, int Wo, void* stream);
+
 /* ---- data-layer augmentation: nearest-neighbour affine warp (dataloader/transforms/utils.py:67-147 th_affine2d(mode='nearest',
  * center=True); applied by transforms.py:23-142 RandomAffine to the image, the instance map and the class map of a sample).
  * x, y: [N][C][H][W] float32 (y != x); mat: [N][mat_rows][3] float32 in DEVICE memory, mat_rows = 3 (the reference's 3x3, last

@@ -38,6 +38,9 @@ SIGNATURES = {
     "rsis_conv2d_dgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vpp, _ip, _i, _i, _i, _vp, _i, _vp]),
     "rsis_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsis_affine_nearest": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsis_upconv_out_supported": (_i, [_i, _i, _i, _i, _i]),
+    "rsis_upconv_out_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsis_upconv_out_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsis_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_convlstm_fwd": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_convlstm_bwd_gates": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

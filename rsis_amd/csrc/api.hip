@@ -34,6 +34,10 @@ int rsis_l_gmax_bwd_add(const float*, const int*, float*, long, int, hipStream_t
 int rsis_l_pack_batch(const rsis_pack_job*, int, int, hipStream_t);
 int rsis_l_pack_blocks(int mode, int krows, int ldw);
 int rsis_l_affine_nearest(const float*, float*, const float*, int, int, int, int, int, hipStream_t);
+bool rsis_upconv_c1_supported(int Cin, int Hi, int Wi, int Ho, int Wo);
+int rsis_l_upconv_c1_fwd(const float*, const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
+int rsis_l_upconv_c1_wgrad(const float*, const float*, float*, float*, int, int, int, int, int, int, hipStream_t);
+int rsis_l_upconv_c1_bwd_data(const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
 int rsis_l_mask_resize_threshold(const float*, int, int, int, const unsigned char*, float, unsigned char*, unsigned char*, unsigned int*,
                                  int, int, hipStream_t);
 int rsis_l_rle_encode(const unsigned char*, int, long, unsigned int*, int, int*, hipStream_t);
@@ -140,6 +144,27 @@ int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, 
   if (use_direct_s2(ks, stride, pad) && nseg == 1)      // (the parity-class kernel writes one destination)
     return rsis_l_pack(4, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, direct_rows(1, &Cout), lstm_hid, (hipStream_t)stream);
   return rsis_l_pack(1, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, krows_of(Cout, ks), lstm_hid, (hipStream_t)stream);
+}
+
+int rsis_upconv_out_supported(int Cin, int Hi, int Wi, int Ho, int Wo) { return rsis_upconv_c1_supported(Cin, Hi, Wi, Ho, Wo) ? 1 : 0; }
+
+int rsis_upconv_out_fwd(const float* h, const float* W, const float* bias, float* out, int B, int Cin, int Hi, int Wi, int Ho,
+                        int Wo, void* stream) {
+  if (!h || !W || !out || B < 1) return RSIS_ERR_ARG;
+  if (!rsis_upconv_c1_supported(Cin, Hi, Wi, Ho, Wo)) return RSIS_ERR_UNSUPPORTED;
+  return rsis_l_upconv_c1_fwd(h, W, bias, out, B, Cin, Hi, Wi, Ho, Wo, (hipStream_t)stream);
+}
+
+int rsis_upconv_out_bwd(const float* dy, const float* h, const float* W, float* dh, float* dW, float* db, int B, int Cin, int Hi,
+                        int Wi, int Ho, int Wo, void* stream) {
+  if (!dy || B < 1 || (dh && !W) || (dW && !h) || (db && !dW)) return RSIS_ERR_ARG;
+  if (!rsis_upconv_c1_supported(Cin, Hi, Wi, Ho, Wo)) return RSIS_ERR_UNSUPPORTED;
+  if (dh) {
+    const int rc = rsis_l_upconv_c1_bwd_data(dy, W, dh, B, Cin, Hi, Wi, Ho, Wo, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  if (dW) return rsis_l_upconv_c1_wgrad(dy, h, dW, db, B, Cin, Hi, Wi, Ho, Wo, (hipStream_t)stream);
+  return RSIS_OK;
 }
 
 int rsis_affine_nearest(const float* x, float* y, const float* mat, int mat_rows, int N, int C, int H, int W, void* stream) {

@@ -26,6 +26,17 @@ static inline int rsis_roundup(int a, int b) { return ((a + b - 1) / b) * b; }
 
 __device__ __forceinline__ float rsis_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// align_corners=True bilinear source coordinate (nn.UpsamplingBilinear2d: model.py:149,163): output index o reads inputs i0, i1
+// with weights (1 - l1, l1).  One definition for every kernel that must agree bit for bit on which inputs an output touches.
+__device__ __forceinline__ void ac_coord(int o, float scale, int in, int& i0, int& i1, float& l1) {
+  const float src = scale * o;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - i0;
+}
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
 // Arguments of the implicit-GEMM convolution kernels (NCHW fp32).
 // GEMM view:  D[co][px] = sum_k  Wp[k][co] * Xcol[k][px],   px = (b, ho, wo),  k = (segment, ci, r, s).
 struct ConvArgs {

@@ -39,13 +39,7 @@ __global__ void lstm_bwd_kernel(const float* __restrict__ dh, const float* __res
 // ------------------------------------------------------------------------------------------------
 // bilinear upsample, align_corners=True  (nn.UpsamplingBilinear2d: model.py:149,163; train.py:96; test.py:39)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ac_coord(int o, float scale, int in, int& i0, int& i1, float& l1) {
-  const float src = scale * o;
-  i0 = (int)src;
-  if (i0 > in - 1) i0 = in - 1;
-  i1 = i0 + (i0 < in - 1 ? 1 : 0);
-  l1 = src - i0;
-}
+// (ac_coord / ac_scale: common.h -- shared with upconv_c1.hip)
 
 __global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int Hi, int Wi, int Ho, int Wo,
                                     float sh, float sw, long total) {
@@ -878,7 +872,6 @@ int rsis_l_lstm_bwd(const float* dh, const float* dh2, const float* dc_next, con
                      da_sum, hid, HW, total);
   return rsis_check_launch();
 }
-static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 int rsis_l_upsample_fwd(const float* x, float* y, long BC, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
   const long total = BC * Ho * Wo;
   {

@@ -23,6 +23,15 @@ from . import ops
 from ._lib import check, int_array, lib, ptr, ptr_array, require_cuda_f32, stream
 
 
+import os as _os
+
+# conv_out fused with the final x2 upsample (ops.side_upconv_out, upconv_c1.hip).  OFF by default: it removes 4 of the 5 passes
+# over the up-sampled hidden state, but the three kernels as written (51 / 62 / 66 us per timestep at 256^2 x 32) are slower
+# than the five they replace (21 + 23 / 30 + 10 / 19 + 21 us): building the up-sampled patch costs ~10 LDS reads + ~40 ALU
+# instructions per element and the 70-80 KB of LDS leave one block per CU, so the phases of a tile do not overlap.
+FUSE_TAIL = [_os.environ.get("RSIS_FUSE_TAIL", "0") == "1"]
+
+
 class LevelTape(object):
     """Per-iteration state of one ConvLSTM level."""
 
@@ -349,7 +358,8 @@ class _SideUpFn(torch.autograd.Function):
 
 def decoder_levels(decoder, skip_feats, prev_hidden_list):
     """The 5-level ConvLSTM pyramid of RSIS.forward (model.py:129-165) with hoisting; returns (hidden_list, side_feats,
-    last up-sampled hidden) or None when the fused path does not apply to this call."""
+    last up-sampled hidden, out_mask) -- out_mask is set (and the up-sampled hidden None) when the decoder tail ran fused -- or
+    None when the fused path does not apply to this call."""
     need_grad = torch.is_grad_enabled() and (any(f.requires_grad for f in skip_feats) or
                                             any(p.requires_grad for p in decoder.clstm_list.parameters()))
     tape = decoder._tape
@@ -362,7 +372,7 @@ def decoder_levels(decoder, skip_feats, prev_hidden_list):
         return None
     t = tape.t
     hidden_list, side_feats = [], []
-    up = None
+    up = out_mask = None
     n_levels = len(tape.levels)
     for i, tl in enumerate(tape.levels):
         cell = tl.cell
@@ -375,7 +385,15 @@ def decoder_levels(decoder, skip_feats, prev_hidden_list):
             into = nxt if (nxt.UP is not None and t < nxt.cap) else None
             side, up = _SideUpFn.apply(into, t, h, tuple(skip_feats[i + 1].shape[-2:]))     # model.py:143,149-150
         else:
-            side, up = _SideUpFn.apply(None, t, h, (h.shape[-2] * 2, h.shape[-1] * 2))      # model.py:143,163-164
+            size = (h.shape[-2] * 2, h.shape[-1] * 2)
+            conv = decoder.conv_out
+            if (FUSE_TAIL[0] and conv.bias is not None and conv.stride == 1 and conv.padding == 1 and
+                    ops.upconv_out_supported(h, conv.weight, size)):
+                # max-pool side feature + conv_out(upsample x2 (h)) as one node: the up-sampled state is never written
+                side, out_mask = ops.side_upconv_out(h, conv.weight, conv.bias, size)           # model.py:143,163-167
+                up = None
+            else:
+                side, up = _SideUpFn.apply(None, t, h, size)                                    # model.py:143,163-164
         side_feats.append(side)
     tape.t += 1
-    return hidden_list, side_feats, up
+    return hidden_list, side_feats, up, out_mask

@@ -694,6 +694,77 @@ def heads(sides, fc_class, fc_stop):
     return _HeadsFn.apply(len(sides), *sides, fc_class.weight, fc_class.bias, fc_stop.weight, fc_stop.bias)
 
 
+def upconv_out_supported(h, weight, size):
+    """True when conv_out(upsample(h, size)) can run as the fused kernels (rsis_upconv_out_*)."""
+    return bool(h.is_cuda and h.dtype == torch.float32 and weight.shape[0] == 1 and tuple(weight.shape[2:]) == (3, 3) and
+                lib().rsis_upconv_out_supported(int(weight.shape[1]), int(h.shape[2]), int(h.shape[3]), int(size[0]), int(size[1])))
+
+
+class _SideUpOutFn(torch.autograd.Function):
+    """The three consumers of the LAST level's hidden state besides the recurrence (model.py:143,163-167): the global max-pool
+    side feature and out_mask = conv_out(upsample x2 (h)), as ONE autograd node.  The up-sampled hidden state (Cin channels at
+    the output resolution) is never materialised: forward, data gradient and weight gradient each interpolate what they need
+    in LDS (rsis_upconv_out_*); the pooled gradient is added at the arg-max pixel in place."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, size):
+        h = _contig(h)
+        weight = _contig(weight)
+        B, C, Hi, Wi = h.shape
+        Ho, Wo = int(size[0]), int(size[1])
+        L = lib()
+        side = torch.empty((B, C, 1, 1), dtype=torch.float32, device=h.device)
+        arg = torch.empty((B, C), dtype=torch.int32, device=h.device)
+        check(L.rsis_global_maxpool_fwd(ptr(h), ptr(side), ptr(arg), B * C, Hi * Wi, stream()), "rsis_global_maxpool_fwd")
+        out = torch.empty((B, 1, Ho, Wo), dtype=torch.float32, device=h.device)
+        check(L.rsis_upconv_out_fwd(ptr(h), ptr(weight), ptr(bias), ptr(out), B, C, Hi, Wi, Ho, Wo, stream()), "rsis_upconv_out_fwd")
+        ctx.dims = (B, C, Hi, Wi, Ho, Wo)
+        ctx.wparam, ctx.bparam = weight, bias
+        ctx.save_for_backward(h, weight, arg)
+        return side, out
+
+    @staticmethod
+    def backward(ctx, dside, dout):
+        h, weight, arg = ctx.saved_tensors
+        B, C, Hi, Wi, Ho, Wo = ctx.dims
+        L = lib()
+        dh = dW = db = None
+        if dout is not None:
+            dout = _contig(dout)
+            need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+            need_b = ctx.bparam is not None and ctx.needs_input_grad[2]
+            if need_h:
+                dh = torch.empty_like(h)
+            tw = tb = None
+            if need_w:
+                tw = _direct_target(ctx.wparam)
+                dW = tw if tw is not None else torch.zeros_like(weight)
+            if need_b:
+                tb = _direct_target(ctx.bparam)
+                db = tb if tb is not None else torch.zeros(1, dtype=torch.float32, device=dout.device)
+            if need_b and not need_w:     # (the kernel produces the bias gradient next to the weight gradient)
+                db.add_(dout.sum()) if tb is not None else db.copy_(dout.sum().reshape(1))
+            check(L.rsis_upconv_out_bwd(ptr(dout), ptr(h), ptr(weight), ptr(dh), ptr(dW), ptr(db) if need_w else None, B, C, Hi, Wi,
+                                        Ho, Wo, stream()), "rsis_upconv_out_bwd")
+            if tw is not None:
+                dW = None                 # accumulated straight into weight.grad
+            if tb is not None:
+                db = None
+        if dside is not None and ctx.needs_input_grad[0]:
+            dside = _contig(dside)
+            if dh is None:
+                dh = torch.empty_like(h)
+                check(L.rsis_global_maxpool_bwd(ptr(dside), ptr(arg), ptr(dh), B * C, Hi * Wi, stream()), "rsis_global_maxpool_bwd")
+            else:
+                check(L.rsis_global_maxpool_bwd_add(ptr(dside), ptr(arg), ptr(dh), B * C, Hi * Wi, stream()), "rsis_global_maxpool_bwd_add")
+        return dh, dW, db, None
+
+
+def side_upconv_out(h, weight, bias, size):
+    """(global max-pool of h, conv_out(upsample(h, size))) -- see _SideUpOutFn."""
+    return _SideUpOutFn.apply(h, weight, bias, (int(size[0]), int(size[1])))
+
+
 class _LossTailFn(torch.autograd.Function):
     """(total, [iou, stop, class]) of reference train.py:159-176 from class probabilities (B, T, C), matched class targets
     (B, T), stop logits (B, T), matched soft-IoU costs (B, T) and the two sample-weight matrices; one launch each way."""
