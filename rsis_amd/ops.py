@@ -5,6 +5,7 @@ the hand-written gfx950 kernels.  There is no CPU/eager fallback: the ops raise 
 tensor is not a CUDA fp32 tensor.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -34,6 +35,7 @@ def _direct_target(param):
     return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.is_cuda) else None
 
 
+SUBSAMPLE_1X1 = [os.environ.get("RSIS_SUBSAMPLE_1X1", "1") != "0"]     # A/B switch, see _Conv2dFn.forward
 _PACKS = weakref.WeakSet()       # every PackedConv that holds a packed copy
 _BATCH = {"sig": None, "jobs": None, "n": 0, "blocks": 0}
 
@@ -171,9 +173,11 @@ def _dgrad_all(L, dy, wd, cin_packed, ks, stride, pad, srcs, Hx, Wx, addend=None
     """One dgrad launch producing the gradient of every concat source (+ addend: another consumer's gradient of the input;
     inplace: the strided 1x1 gradient is accumulated INTO the addend tensor, which becomes the result)."""
     B, Cout, Hy, Wy = dy.shape
-    dxs = [addend] if inplace else [torch.empty_like(s) for s in srcs]
+    # srcs: the conv's inputs, or just their shapes (the strided 1x1 path keeps a sub-sampled copy instead of the input)
+    shapes = [tuple(s.shape) if torch.is_tensor(s) else tuple(s) for s in srcs]
+    dxs = [addend] if inplace else [torch.empty(sh, dtype=torch.float32, device=dy.device) for sh in shapes]
     check(L.rsis_conv2d_dgrad(ptr(dy), B, Cout, Hy, Wy, ptr(wd), cin_packed, ks, stride, pad, ptr_array(dxs),
-                              int_array([s.shape[1] for s in srcs]), len(srcs), Hx, Wx, ptr(addend), FORCE_TILE[0], stream()),
+                              int_array([sh[1] for sh in shapes]), len(shapes), Hx, Wx, ptr(addend), FORCE_TILE[0], stream()),
           "rsis_conv2d_dgrad")
     return dxs
 
@@ -257,10 +261,20 @@ class _Conv2dFn(torch.autograd.Function):
             raise _lib.RsisHipError("PackedConv was built for stride %d pad %d, used with %d/%d" % (pack.stride, pack.pad, stride, pad))
         wp = pack.fwd(weight)
         out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=weight.device)
+        # 1x1 / stride s (the downsample convs of ResNet layers 2-4): run the stride-1 GEMM (LDS-DMA path) on a sub-sampled copy
+        # of the input instead of the gather implicit GEMM, and keep THAT copy for the weight gradient (1/s^2 of the input,
+        # tile-aligned for the LDS-DMA weight-gradient kernel).  Same packed weights: a 1x1 pack does not depend on the stride.
+        ctx.in_shape = None
+        if ks == 1 and stride > 1 and pad == 0 and nsrc == 1 and SUBSAMPLE_1X1[0]:
+            ctx.in_shape = tuple(srcs[0].shape)
+            srcs = [srcs[0][:, :, ::stride, ::stride].contiguous()]
+            H, W, stride_k = Ho, Wo, 1
+        else:
+            stride_k = stride
         # split-K (atomic, order-nondeterministic sums) only while training; inference stays bit-reproducible and keeps the
         # forward within the 1e-4 parity bar of the reference (the split sum moves the deepest skip conv by ~1e-5 relative)
         tile = FORCE_TILE[0] + (100 if pack.training_call else 0)
-        check(L.rsis_conv2d_fwd(ptr_array(srcs), int_array([s.shape[1] for s in srcs]), nsrc, B, H, W, ptr(wp), Cout, ks, stride,
+        check(L.rsis_conv2d_fwd(ptr_array(srcs), int_array([s.shape[1] for s in srcs]), nsrc, B, H, W, ptr(wp), Cout, ks, stride_k,
                                 pad, ptr(bias.detach() if bias is not None else None), None, ptr(out), Ho, Wo, tile, stream()),
               "rsis_conv2d_fwd")
         ctx.pack, ctx.stride, ctx.pad, ctx.nsrc = pack, stride, pad, nsrc
@@ -280,18 +294,20 @@ class _Conv2dFn(torch.autograd.Function):
         grads = [None] * (nsrc + 2)
         take, park = ctx.slot if isinstance(ctx.slot, tuple) else (ctx.slot, None)
         addend = take.take() if take is not None else None
+        sub = ctx.in_shape is not None            # srcs[0] is the sub-sampled copy of a strided 1x1 conv's input
+        in_shapes = [ctx.in_shape] if sub else [tuple(t.shape) for t in srcs]
         if any(ctx.needs_input_grad[5:5 + nsrc]):
             wd = ctx.pack.dgrad(weight)
             inplace, extra = False, None
             if addend is not None:
-                if nsrc != 1 or addend.shape != srcs[0].shape:
+                if nsrc != 1 or tuple(addend.shape) != in_shapes[0]:
                     raise _lib.RsisHipError("GradSlot: the parked gradient does not belong to this conv's input")
                 if ctx.stride != 1:
                     if ks == 1 and ctx.pad == 0 and addend.is_contiguous():
                         inplace = True             # strided 1x1: accumulate into the parked tensor (no memset, no add)
                     else:
                         extra, addend = addend, None
-            dxs = _dgrad_all(L, dy, wd, ctx.pack.cin, ks, ctx.stride, ctx.pad, srcs, srcs[0].shape[2], srcs[0].shape[3], addend,
+            dxs = _dgrad_all(L, dy, wd, ctx.pack.cin, ks, ctx.stride, ctx.pad, in_shapes, in_shapes[0][2], in_shapes[0][3], addend,
                              inplace)
             if extra is not None:
                 dxs[0].add_(extra)
@@ -302,7 +318,7 @@ class _Conv2dFn(torch.autograd.Function):
                 grads[0] = None                    # conv1's data-gradient kernel adds it
         if ctx.needs_input_grad[5 + nsrc]:
             tgt = _direct_target(ctx.wparam)
-            dW = _wgrad_all(L, dy, srcs, tuple(weight.shape), ks, ctx.stride, ctx.pad, 0, out=tgt)
+            dW = _wgrad_all(L, dy, srcs, tuple(weight.shape), ks, 1 if sub else ctx.stride, ctx.pad, 0, out=tgt)
             grads[nsrc] = None if tgt is not None else dW
         if ctx.has_bias and ctx.needs_input_grad[6 + nsrc]:
             tgt = _direct_target(ctx.bparam)
