@@ -91,6 +91,10 @@ int rsis_convlstm_bwd_gates(const float* dh, const float* dh2, const float* dc_n
 /* ---- nn.UpsamplingBilinear2d(size) = bilinear, align_corners=True (model.py:149,163; train.py:96; test.py:39) ---- */
 int rsis_upsample_bilinear_ac_fwd(const float* x, float* y, long BC, int Hi, int Wi, int Ho, int Wo, void* stream);
 int rsis_upsample_bilinear_ac_bwd(const float* dy, float* dx, long BC, int Hi, int Wi, int Ho, int Wo, void* stream);
+/* the two consumers of a level's hidden state besides the recurrence (model.py:143,149-150) back-propagated in one launch:
+ * dx = upsample_backward(dy) + dpool[bc] at pixel argmax[bc] of every plane (argmax from rsis_global_maxpool_fwd) */
+int rsis_upsample_maxpool_bwd(const float* dy, const float* dpool, const int* argmax, float* dx, long BC, int Hi, int Wi, int Ho,
+                              int Wo, void* stream);
 
 /* ---- nn.MaxPool2d(full map) side features (model.py:143): y[BC], argmax[BC] (int32 flat index) ---- */
 int rsis_global_maxpool_fwd(const float* x, float* y, int* argmax, long BC, int HW, void* stream);

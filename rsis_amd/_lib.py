@@ -46,6 +46,7 @@ SIGNATURES = {
     "rsis_convlstm_bwd_gates": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "rsis_upsample_bilinear_ac_fwd": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "rsis_upsample_bilinear_ac_bwd": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
+    "rsis_upsample_maxpool_bwd": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "rsis_global_maxpool_fwd": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "rsis_global_maxpool_bwd": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "rsis_global_maxpool_bwd_add": (_i, [_vp, _vp, _vp, _l, _i, _vp]),

@@ -18,7 +18,7 @@ int rsis_l_pack(int, const float*, float*, int, int, int, int, const int*, const
 int rsis_l_lstm_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
                     hipStream_t);
 int rsis_l_upsample_fwd(const float*, float*, long, int, int, int, int, hipStream_t);
-int rsis_l_upsample_bwd(const float*, float*, long, int, int, int, int, hipStream_t);
+int rsis_l_upsample_bwd(const float*, float*, long, int, int, int, int, const float*, const int*, hipStream_t);
 int rsis_l_gmax_fwd(const float*, float*, int*, long, int, hipStream_t);
 int rsis_l_gmax_bwd(const float*, const int*, float*, long, int, hipStream_t);
 int rsis_l_bn_fwd(const float*, const float*, float*, double*, const float*, const float*, float*, float*, float*, float*, int,
@@ -344,7 +344,12 @@ int rsis_upsample_bilinear_ac_fwd(const float* x, float* y, long BC, int Hi, int
 }
 int rsis_upsample_bilinear_ac_bwd(const float* dy, float* dx, long BC, int Hi, int Wi, int Ho, int Wo, void* stream) {
   if (!dy || !dx) return RSIS_ERR_ARG;
-  return rsis_l_upsample_bwd(dy, dx, BC, Hi, Wi, Ho, Wo, (hipStream_t)stream);
+  return rsis_l_upsample_bwd(dy, dx, BC, Hi, Wi, Ho, Wo, nullptr, nullptr, (hipStream_t)stream);
+}
+int rsis_upsample_maxpool_bwd(const float* dy, const float* dpool, const int* argmax, float* dx, long BC, int Hi, int Wi, int Ho,
+                              int Wo, void* stream) {
+  if (!dy || !dx || !dpool || !argmax) return RSIS_ERR_ARG;
+  return rsis_l_upsample_bwd(dy, dx, BC, Hi, Wi, Ho, Wo, dpool, argmax, (hipStream_t)stream);
 }
 int rsis_global_maxpool_fwd(const float* x, float* y, int* argmax, long BC, int HW, void* stream) {
   if (!x || !y || !argmax) return RSIS_ERR_ARG;

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256) void upsample_fwd_lds_kernel(const float* __re
 template <int UT, int RM>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Hi, int Wi,
                                                            int Ho, int Wo, float sh, float sw, int tiles_x, int tiles_y, long BC,
-                                                           int planes_per_block, int vec) {
+                                                           int planes_per_block, int vec, const float* __restrict__ pool_g,
+                                                           const int* __restrict__ pool_arg) {
   constexpr int RQ = RM / 4 + 1, RP = RQ * 4;      // staged row: RQ aligned float4s = RM + 4 columns (the region starts 0..3 columns in)
   __shared__ float wgt[2][UT][UK];
   __shared__ int st[2][UT];          // first candidate of each input index (absolute output index)
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < UK; ++k) acc = fmaf(wgt[1][lx][k], tmp[ly * RP + min(c0 + k, ex - 1)], acc);
+      if (pool_g && hi * Wi + wi == pool_arg[bc]) acc += pool_g[bc];     // + the global max-pool's gradient at its arg-max pixel
       dx[bc * Hi * Wi + (size_t)hi * Wi + wi] = acc;
     }
     // (the next plane's `reg` fill is ordered after this plane's last `reg` read by the barrier above; `tmp` is rewritten only
@@ -253,7 +255,8 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
 
 // general fallback (any scale): per-thread candidate scan
 __global__ void upsample_bwd_generic_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Hi, int Wi, int Ho, int Wo,
-                                            float sh, float sw, long total) {
+                                            float sh, float sw, long total, const float* __restrict__ pool_g,
+                                            const int* __restrict__ pool_arg) {
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int wi = (int)(e % Wi);
     const long t = e / Wi;
@@ -278,6 +281,7 @@ __global__ void upsample_bwd_generic_kernel(const float* __restrict__ dy, float*
       }
       acc += wh * row;
     }
+    if (pool_g && hi * Wi + wi == pool_arg[bc]) acc += pool_g[bc];
     dx[e] = acc;
   }
 }
@@ -899,7 +903,8 @@ int rsis_l_upsample_fwd(const float* x, float* y, long BC, int Hi, int Wi, int H
   }
   return rsis_check_launch();
 }
-int rsis_l_upsample_bwd(const float* dy, float* dx, long BC, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
+int rsis_l_upsample_bwd(const float* dy, float* dx, long BC, int Hi, int Wi, int Ho, int Wo, const float* pool_g, const int* pool_arg,
+                        hipStream_t st) {
   const float sh = ac_scale(Hi, Ho), sw = ac_scale(Wi, Wo);
   // the tiled kernel keeps UK = 6 consecutive candidate outputs per input index (< 2/scale + 1 touch it) and a dy region of
   // at most (UT + 1)/scale + UK outputs per axis in LDS
@@ -917,13 +922,14 @@ int rsis_l_upsample_bwd(const float* dy, float* dx, long BC, int Hi, int Wi, int
     const int vec = Wo % 4 == 0;
     if (ut == 32)
       hipLaunchKernelGGL((upsample_bwd_kernel<32, 80>), dim3((unsigned)blocks), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, tiles_x,
-                         tiles_y, BC, (int)ppb, vec);
+                         tiles_y, BC, (int)ppb, vec, pool_g, pool_arg);
     else
       hipLaunchKernelGGL((upsample_bwd_kernel<16, 44>), dim3((unsigned)blocks), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, tiles_x,
-                         tiles_y, BC, (int)ppb, vec);
+                         tiles_y, BC, (int)ppb, vec, pool_g, pool_arg);
   } else {
     const long total = BC * Hi * Wi;
-    hipLaunchKernelGGL(upsample_bwd_generic_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, total);
+    hipLaunchKernelGGL(upsample_bwd_generic_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, dx, Hi, Wi, Ho, Wo, sh, sw, total, pool_g,
+                       pool_arg);
   }
   return rsis_check_launch();
 }

@@ -342,6 +342,13 @@ class _SideUpFn(torch.autograd.Function):
         B, C, Hi, Wi, Ho, Wo = ctx.dims
         L = lib()
         dx = None
+        if dy is not None and dside is not None:      # the usual case: both gradients in one launch
+            dy = dy if dy.is_contiguous() else dy.contiguous()
+            dside = dside if dside.is_contiguous() else dside.contiguous()
+            dx = torch.empty((B, C, Hi, Wi), dtype=torch.float32, device=dy.device)
+            check(L.rsis_upsample_maxpool_bwd(ptr(dy), ptr(dside), ptr(arg), ptr(dx), B * C, Hi, Wi, Ho, Wo, stream()),
+                  "rsis_upsample_maxpool_bwd")
+            return None, None, dx, None
         if dy is not None:
             dy = dy if dy.is_contiguous() else dy.contiguous()
             dx = torch.empty((B, C, Hi, Wi), dtype=torch.float32, device=dy.device)

@@ -469,3 +469,25 @@ def test_side_upconv_out_equals_unfused(B, C, Hi, Wi):
     assert_close("dh", dh1, dh0, 2e-6 * float(dh0.abs().max()) + 1e-7)
     assert_close("dW", dw1, dw0, 2e-5 * float(dw0.abs().max()) + 1e-6)
     assert_close("db", db1, db0, 2e-5 * float(db0.abs().max()) + 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,size", [((2, 3, 8, 8), (16, 16)), ((2, 5, 13, 25), (25, 50)), ((1, 8, 64, 64), (128, 128)), ((3, 2, 4, 5), (7, 9))])
+def test_upsample_maxpool_bwd_one_launch(shape, size):
+    """rsis_upsample_maxpool_bwd (the side max-pool's gradient folded into the upsample backward) == the two separate kernels"""
+    from rsis_amd._lib import check, lib, ptr, stream
+    B, C, Hi, Wi = shape
+    torch.manual_seed(9)
+    x = torch.randn(shape, device="cuda")
+    dy = torch.randn(B, C, *size, device="cuda")
+    dside = torch.randn(B, C, device="cuda")
+    L = lib()
+    side = torch.empty(B, C, device="cuda")
+    arg = torch.empty(B, C, dtype=torch.int32, device="cuda")
+    check(L.rsis_global_maxpool_fwd(ptr(x), ptr(side), ptr(arg), B * C, Hi * Wi, stream()), "gmax")
+    want = torch.empty_like(x)
+    check(L.rsis_upsample_bilinear_ac_bwd(ptr(dy), ptr(want), B * C, Hi, Wi, size[0], size[1], stream()), "up bwd")
+    check(L.rsis_global_maxpool_bwd_add(ptr(dside), ptr(arg), ptr(want), B * C, Hi * Wi, stream()), "gmax bwd add")
+    got = torch.empty_like(x)
+    check(L.rsis_upsample_maxpool_bwd(ptr(dy), ptr(dside), ptr(arg), ptr(got), B * C, Hi, Wi, size[0], size[1], stream()), "fused")
+    assert torch.equal(got, want)
