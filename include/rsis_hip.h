@@ -149,6 +149,11 @@ typedef struct rsis_pack_job {
 int rsis_conv_pack_job_fill(rsis_pack_job* job);
 int rsis_conv_pack_batch(const rsis_pack_job* jobs_dev, int njobs, int total_blocks, void* stream);
 
+/* ---- conv_out (nn.Conv2d(Cin, 1, 3, padding=1), model.py:109,167): weight AND bias gradient in one launch (the bias gradient is
+ * the sum of dy, which the weight-gradient kernel reads anyway).  dy[B][1][H][W], x[B][Cin][H][W]; dW[Cin*9] (reference layout
+ * [1][Cin][3][3]) and db[1] (may be NULL) are ACCUMULATED.  Cin in {4, 8, 16}, W % 4 == 0, else RSIS_ERR_UNSUPPORTED. ---- */
+int rsis_conv_out_wgrad(const float* dy, const float* x, float* dW, float* db, int B, int Cin, int H, int W, void* stream);
+
 /* ---- decoder tail: out_mask = conv_out(UpsamplingBilinear2d((Ho, Wo))(hidden)) (model.py:163-167) as ONE kernel each way: the
  * up-sampled hidden state (Cin channels at the output resolution) is never written -- every block interpolates the patch it
  * convolves from the hidden pixels in LDS.  h[B][Cin][Hi][Wi]; W = conv_out.weight in the REFERENCE layout [1][Cin][3][3]

@@ -12,7 +12,7 @@ int rsis_launch_conv_wgrad_tiled(const WgradArgs& w, int ks, hipStream_t st);
 bool rsis_c1_supported(int Cin);
 int rsis_l_c1_fwd(const float*, const float*, int, const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_c1_dgrad(const float*, const float*, int, float*, int, int, int, int, hipStream_t);
-int rsis_l_c1_wgrad(const float*, const float*, float*, int, int, int, int, hipStream_t);
+int rsis_l_c1_wgrad(const float*, const float*, float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_pack(int, const float*, float*, int, int, int, int, const int*, const int*, int, int, int, hipStream_t);
 
 int rsis_l_lstm_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
@@ -144,6 +144,12 @@ int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, 
   if (use_direct_s2(ks, stride, pad) && nseg == 1)      // (the parity-class kernel writes one destination)
     return rsis_l_pack(4, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, direct_rows(1, &Cout), lstm_hid, (hipStream_t)stream);
   return rsis_l_pack(1, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, krows_of(Cout, ks), lstm_hid, (hipStream_t)stream);
+}
+
+int rsis_conv_out_wgrad(const float* dy, const float* x, float* dW, float* db, int B, int Cin, int H, int W, void* stream) {
+  if (!dy || !x || !dW || B < 1) return RSIS_ERR_ARG;
+  if (!rsis_c1_supported(Cin) || W % 4 != 0) return RSIS_ERR_UNSUPPORTED;
+  return rsis_l_c1_wgrad(dy, x, dW, db, B, Cin, H, W, (hipStream_t)stream);
 }
 
 int rsis_upconv_out_supported(int Cin, int Hi, int Wi, int Ho, int Wo) { return rsis_upconv_c1_supported(Cin, Hi, Wi, Ho, Wo) ? 1 : 0; }
@@ -302,7 +308,7 @@ int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs,
   a.dy = dy; a.x = x; a.dw = dW; a.B = B; a.Cs = Cs; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.stride = stride; a.pad = pad; a.ldo = Ctot * ks * ks; a.n_off = c_off * ks * ks; a.interleave_hid = lstm_hid;
   if (use_direct(ks, stride, pad) && Cout == 1 && lstm_hid == 0 && rsis_c1_supported(Cs) && H == Ho && W == Wo && W % 4 == 0)
-    return rsis_l_c1_wgrad(dy, x, dW + a.n_off, B, Cs, H, W, (hipStream_t)stream);
+    return rsis_l_c1_wgrad(dy, x, dW + a.n_off, nullptr, B, Cs, H, W, (hipStream_t)stream);
   // stride-1 "same" convs on tile-aligned maps: the LDS-DMA tiled kernel (conv_wgrad_tiled.hip); RSIS_WGRAD_TILED=0 forces the
   // generic split-K implicit GEMM (conv_wgrad.hip), which also covers every other shape
   static const bool tiled_ok = !(getenv("RSIS_WGRAD_TILED") && getenv("RSIS_WGRAD_TILED")[0] == '0');

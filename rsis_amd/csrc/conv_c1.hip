@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_c1_dgrad_kernel(const float* __restr
 // accumulators per thread, 18 atomics per block; the dy tile is re-read once per channel pair).
 template <int CIN, int TW, int TH>
 __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restrict__ dy_, const float* __restrict__ x_,
-                                                            float* __restrict__ dw, int B, int H, int W) {
+                                                            float* __restrict__ dw, float* __restrict__ db, int B, int H, int W) {
   using T = C1Tile<TW, TH>;
   constexpr int CGW = 2, S = CIN / CGW;
   __shared__ __attribute__((aligned(16))) float patch[CGW * T::PH * T::PW];
@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
   float acc[CGW * 9];
 #pragma unroll
   for (int i = 0; i < CGW * 9; ++i) acc[i] = 0.f;
+  float gsum = 0.f;                                          // bias gradient (sum of dy), taken by the blocks of channel pair 0
 #pragma unroll 1
   for (int tile = blockIdx.x / S; tile < ntiles; tile += gridDim.x / S) {
     const int txi = tile % ntx, t2 = tile / ntx;
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
       const int oy = y0 + ty + o * T::RPP, ox = x0 + tx * 4;
       g[o] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (oy < H && ox < W) g[o] = *(const f32x4 __attribute__((address_space(1)))*)(dy + (size_t)b * HW + (size_t)oy * W + ox);
+      gsum += (g[o][0] + g[o][1]) + (g[o][2] + g[o][3]);
     }
     __syncthreads();
     c1_stage_patch<CGW, TW, TH>(patch, x + ((size_t)b * CIN + cb) * HW, H, W, y0, x0);
@@ -196,17 +198,18 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
     }
   }
   // block reduction: wave shuffle, then LDS across the 4 waves, then one atomic per filter tap
-  __shared__ float red[4][CGW * 9];
+  __shared__ float red[4][CGW * 9 + 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < CGW * 9; ++i) {
-    float v = acc[i];
+  for (int i = 0; i <= CGW * 9; ++i) {
+    float v = i < CGW * 9 ? acc[i] : gsum;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if (lane == 0) red[wv][i] = v;
   }
   __syncthreads();
   if (threadIdx.x < CGW * 9) atomicAdd(dw + cb * 9 + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x == CGW * 9 && db && cb == 0) atomicAdd(db, red[0][CGW * 9] + red[1][CGW * 9] + red[2][CGW * 9] + red[3][CGW * 9]);
 }
 
 static inline int c1_grid(long total, int per_cu) {
@@ -254,8 +257,8 @@ int rsis_l_c1_dgrad(const float* dy, const float* wd, int ldw, float* dx, int B,
   C1_DISPATCH(conv_c1_dgrad_kernel, grid, dy, wd, ldw, dx, B, H, W)
   return rsis_check_launch();
 }
-int rsis_l_c1_wgrad(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, hipStream_t st) {
+int rsis_l_c1_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int Cin, int H, int W, hipStream_t st) {
   // one block per (tile, channel pair) up to the cap (a multiple of every Cin / 2), persistent beyond it
-  C1_BY_WIDTH(conv_c1_wgrad_kernel, 512, Cin / 2, dy, x, dw, B, H, W)     // measured: 256 -> 39 us, 512 -> 29 us, 1024 -> 30 us, 2048 -> 43 us
+  C1_BY_WIDTH(conv_c1_wgrad_kernel, 512, Cin / 2, dy, x, dw, db, B, H, W)     // measured: 256 -> 39 us, 512 -> 29 us, 1024 -> 30 us, 2048 -> 43 us
   return rsis_check_launch();
 }

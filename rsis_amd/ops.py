@@ -316,11 +316,25 @@ class _Conv2dFn(torch.autograd.Function):
                     grads[i] = dxs[i]
             if park is not None and nsrc == 1 and grads[0] is not None and park.park(grads[0]):
                 grads[0] = None                    # conv1's data-gradient kernel adds it
-        if ctx.needs_input_grad[5 + nsrc]:
+        want_w = ctx.needs_input_grad[5 + nsrc]
+        want_b = ctx.has_bias and ctx.needs_input_grad[6 + nsrc]
+        if (want_w and want_b and weight.shape[0] == 1 and ks == 3 and ctx.stride == 1 and ctx.pad == 1 and nsrc == 1 and
+                weight.shape[1] in (4, 8, 16) and srcs[0].shape[3] % 4 == 0):
+            # conv_out: weight and bias gradient in one launch (rsis_conv_out_wgrad)
+            tw, tb = _direct_target(ctx.wparam), _direct_target(ctx.bparam)
+            dW = tw if tw is not None else torch.zeros_like(weight)
+            db = tb if tb is not None else torch.zeros(1, dtype=torch.float32, device=dy.device)
+            x0 = srcs[0]
+            check(L.rsis_conv_out_wgrad(ptr(dy), ptr(x0), ptr(dW), ptr(db), x0.shape[0], x0.shape[1], x0.shape[2], x0.shape[3], stream()),
+                  "rsis_conv_out_wgrad")
+            grads[nsrc] = None if tw is not None else dW
+            grads[nsrc + 1] = None if tb is not None else db
+            return (None, None, None, None, None) + tuple(grads)
+        if want_w:
             tgt = _direct_target(ctx.wparam)
             dW = _wgrad_all(L, dy, srcs, tuple(weight.shape), ks, 1 if sub else ctx.stride, ctx.pad, 0, out=tgt)
             grads[nsrc] = None if tgt is not None else dW
-        if ctx.has_bias and ctx.needs_input_grad[6 + nsrc]:
+        if want_b:
             tgt = _direct_target(ctx.bparam)
             db = tgt if tgt is not None else torch.zeros(weight.shape[0], dtype=torch.float32, device=dy.device)
             check(L.rsis_bias_grad(ptr(dy), ptr(db), dy.shape[0], dy.shape[1], dy.shape[2] * dy.shape[3], 0, stream()),
