@@ -949,7 +949,12 @@ int rsis_l_bn_fwd(const float* x, const float* res, float* y, double* stats, con
   const int S = chan_splits(C, N);
   const int train = train_flags & 1;
   if (train && bn_fused_ok(C, HW, N)) {      // channel fits one block: one launch, one read of x
-    if (N / 4 <= 256 * 8)
+    // few channels = few blocks (one per channel): 512 threads x 4 float4 instead of 256 x 8 puts twice the waves on a CU
+    // (measured +0.5 % on the training step; 1024 x 2 is no better)
+    if (N / 4 <= 256 * 8 && C <= 512)
+      hipLaunchKernelGGL((bn_fwd_fused_kernel<512, 4>), dim3(C), dim3(512), 0, st, x, res, y, gamma, beta, run_mean, run_var, save_mean,
+                         save_rstd, C, HW, N, eps, momentum, relu);
+    else if (N / 4 <= 256 * 8)
       hipLaunchKernelGGL((bn_fwd_fused_kernel<256, 8>), dim3(C), dim3(256), 0, st, x, res, y, gamma, beta, run_mean, run_var, save_mean,
                          save_rstd, C, HW, N, eps, momentum, relu);
     else
@@ -972,7 +977,10 @@ int rsis_l_bn_bwd(const float* dy, const float* x, const float* y, const float* 
   const int S = chan_splits(C, N);
   const int relu = relu_flags & 1, accum = (relu_flags >> 2) & 1;
   if (bn_fused_ok(C, HW, N)) {
-    if (N / 4 <= 256 * 8)
+    if (N / 4 <= 256 * 8 && C <= 512)          // (as in the forward)
+      hipLaunchKernelGGL((bn_bwd_fused_kernel<512, 4>), dim3(C), dim3(512), 0, st, dy, x, y, mean, rstd, gamma, dx, dres, dgamma, dbeta,
+                         C, HW, N, relu, accum);
+    else if (N / 4 <= 256 * 8)
       hipLaunchKernelGGL((bn_bwd_fused_kernel<256, 8>), dim3(C), dim3(256), 0, st, dy, x, y, mean, rstd, gamma, dx, dres, dgamma, dbeta,
                          C, HW, N, relu, accum);
     else
