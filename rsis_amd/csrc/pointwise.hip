@@ -93,10 +93,8 @@ __global__ __launch_bounds__(256) void upsample_fwd_v4_kernel(const float* __res
 // <= 20 x 48 input pixels it interpolates from in LDS with (at most) one aligned float4 load per thread, and every thread
 // writes two float4s.  The v4 kernel issues 16 scalar loads per float4 of output and is bound by the vector-memory pipe
 // (34 us for the 8 x 256^2 x 32 level, a 67 MB write); this one is bound by the write.  Same arithmetic, bit-identical results.
-#define UF_TOH 32
-#define UF_TOW 64
-#define UF_RH 20
-#define UF_RQ 12
+// Tile shapes: 16 x 128 outputs (512-byte output rows; <= 12 x 69 inputs) on maps at least 128 wide, 32 x 64 (<= 20 x 45) below.
+template <int UF_TOH, int UF_TOW, int UF_RH, int UF_RQ>
 __global__ __launch_bounds__(256) void upsample_fwd_lds_kernel(const float* __restrict__ x, float* __restrict__ y, int Hi, int Wi,
                                                                int Ho, int Wo, float sh, float sw, int tiles_x, int tiles_y) {
   __shared__ __attribute__((aligned(16))) float src[UF_RH][UF_RQ * 4];
@@ -117,10 +115,11 @@ __global__ __launch_bounds__(256) void upsample_fwd_lds_kernel(const float* __re
     }
   }
   __syncthreads();
-  const int lr = threadIdx.x >> 4, lq = threadIdx.x & 15;
+  constexpr int QW = UF_TOW / 4, RPP = 256 / QW;          // float4 per tile row, tile rows per pass
+  const int lr = threadIdx.x / QW, lq = threadIdx.x % QW;
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int ho = oh0 + p * 16 + lr, wo = ow0 + lq * 4;
+  for (int p = 0; p < UF_TOH / RPP; ++p) {
+    const int ho = oh0 + p * RPP + lr, wo = ow0 + lq * 4;
     if (ho >= Ho || wo >= Wo) continue;
     int h0, h1; float lh;
     ac_coord(ho, sh, Hi, h0, h1, lh);
@@ -879,13 +878,19 @@ int rsis_l_lstm_bwd(const float* dh, const float* dh2, const float* dc_next, con
 int rsis_l_upsample_fwd(const float* x, float* y, long BC, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
   const long total = BC * Ho * Wo;
   {
-    // the LDS-tiled kernel needs its 32 x 64 output tile to read at most UF_RH x (UF_RQ * 4 - 3) input pixels
+    // the LDS-tiled kernel needs its output tile to read at most RH x (RQ * 4 - 3) input pixels
     const float fh = ac_scale(Hi, Ho), fw = ac_scale(Wi, Wo);
-    const int tiles_x = (Wo + UF_TOW - 1) / UF_TOW, tiles_y = (Ho + UF_TOH - 1) / UF_TOH;
-    if (Wo % 4 == 0 && Wi % 4 == 0 && Ho >= UF_TOH && Wo >= UF_TOW && fh * (UF_TOH - 1) + 3.f <= UF_RH &&
-        fw * (UF_TOW - 1) + 6.f <= UF_RQ * 4 && BC * tiles_x * tiles_y < (1L << 31)) {
-      hipLaunchKernelGGL(upsample_fwd_lds_kernel, dim3((unsigned)(BC * tiles_x * tiles_y)), dim3(256), 0, st, x, y, Hi, Wi, Ho, Wo, fh,
-                         fw, tiles_x, tiles_y);
+    const bool al = Wo % 4 == 0 && Wi % 4 == 0;
+    if (al && Ho >= 16 && Wo >= 128 && fh * 15 + 3.f <= 12 && fw * 127 + 6.f <= 72 && BC * ((Wo + 127) / 128) * ((Ho + 15) / 16) < (1L << 31)) {
+      const int tiles_x = (Wo + 127) / 128, tiles_y = (Ho + 15) / 16;
+      hipLaunchKernelGGL((upsample_fwd_lds_kernel<16, 128, 12, 18>), dim3((unsigned)(BC * tiles_x * tiles_y)), dim3(256), 0, st, x, y, Hi,
+                         Wi, Ho, Wo, fh, fw, tiles_x, tiles_y);
+      return rsis_check_launch();
+    }
+    if (al && Ho >= 32 && Wo >= 64 && fh * 31 + 3.f <= 20 && fw * 63 + 6.f <= 48 && BC * ((Wo + 63) / 64) * ((Ho + 31) / 32) < (1L << 31)) {
+      const int tiles_x = (Wo + 63) / 64, tiles_y = (Ho + 31) / 32;
+      hipLaunchKernelGGL((upsample_fwd_lds_kernel<32, 64, 20, 12>), dim3((unsigned)(BC * tiles_x * tiles_y)), dim3(256), 0, st, x, y, Hi,
+                         Wi, Ho, Wo, fh, fw, tiles_x, tiles_y);
       return rsis_check_launch();
     }
   }
