@@ -119,8 +119,9 @@ int rsis_bn_bwd(const float* dy, const float* x, const float* y, const float* sa
 /* ---- nn.MaxPool2d(3, stride 2, padding 1) of the ResNet stem (vision.py:15) ---- */
 int rsis_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* argmax, long BC, int H, int W, int Ho, int Wo,
                           void* stream);
+/* accumulate != 0: dx += (dx already holds the gradient the pooled tensor's input receives from another consumer) */
 int rsis_maxpool3x3s2_bwd(const float* dy, const unsigned char* argmax, float* dx, long BC, int H, int W, int Ho, int Wo,
-                          void* stream);
+                          int accumulate, void* stream);
 
 /* ---- torch.optim.Adam step on a flat parameter range (utils/utils.py:83-84; train.py:185-187); g is scaled by gscale
  * (1/world_size after the RCCL sum all-reduce) before the L2 weight-decay term is added. ---- */

@@ -54,7 +54,7 @@ SIGNATURES = {
     "rsis_bn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp]),
     "rsis_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_maxpool3x3s2_fwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
-    "rsis_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
+    "rsis_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp]),
     "rsis_assign_min_cost": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "rsis_heads_fwd": (_i, [_vpp, _ip, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "rsis_heads_bwd": (_i, [_vpp, _ip, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vpp, _vp, _vp, _vp, _vp, _vp]),

@@ -26,7 +26,7 @@ int rsis_l_bn_fwd(const float*, const float*, float*, double*, const float*, con
 int rsis_l_bn_bwd(const float*, const float*, const float*, const float*, const float*, const float*, double*, float*, float*,
                   float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_maxpool_fwd(const float*, float*, unsigned char*, long, int, int, int, int, hipStream_t);
-int rsis_l_maxpool_bwd(const float*, const unsigned char*, float*, long, int, int, int, int, hipStream_t);
+int rsis_l_maxpool_bwd(const float*, const unsigned char*, float*, long, int, int, int, int, int, hipStream_t);
 int rsis_l_channel_sum(const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_adam(float*, const float*, float*, float*, long, float, float, float, float, float, int, float, hipStream_t);
 int rsis_l_assign(const float*, long long*, int, int, int, hipStream_t);
@@ -391,9 +391,9 @@ int rsis_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* argmax, long 
   return rsis_l_maxpool_fwd(x, y, argmax, BC, H, W, Ho, Wo, (hipStream_t)stream);
 }
 int rsis_maxpool3x3s2_bwd(const float* dy, const unsigned char* argmax, float* dx, long BC, int H, int W, int Ho, int Wo,
-                          void* stream) {
+                          int accumulate, void* stream) {
   if (!dy || !dx || !argmax) return RSIS_ERR_ARG;
-  return rsis_l_maxpool_bwd(dy, argmax, dx, BC, H, W, Ho, Wo, (hipStream_t)stream);
+  return rsis_l_maxpool_bwd(dy, argmax, dx, BC, H, W, Ho, Wo, accumulate ? 1 : 0, (hipStream_t)stream);
 }
 int rsis_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, float gscale, void* stream) {

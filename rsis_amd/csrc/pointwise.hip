@@ -666,7 +666,7 @@ __global__ void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __re
 }
 
 __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
-                                        float* __restrict__ dx, int H, int W, int Ho, int Wo, long total) {
+                                        float* __restrict__ dx, int H, int W, int Ho, int Wo, long total, int accumulate) {
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int w = (int)(e % W);
     const long t = e / W;
@@ -687,6 +687,7 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const unsi
         g += (ok && ar == r * 3 + s) ? d : 0.f;
       }
     }
+    if (accumulate) g += dx[e];
     dx[e] = g;
   }
 }
@@ -695,7 +696,8 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const unsi
 // the pooled map) are loaded together and scattered in registers: 12 loads + 2 float4 stores per 8 pixels instead of 8 + 1 per
 // pixel (the per-pixel kernel is bound by the number of memory instructions, 134 us on the stem's 128^2 x 64 x 32 map).
 __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_v8_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
-                                                                  float* __restrict__ dx, int H, int W, int Ho, int Wo, long items) {
+                                                                  float* __restrict__ dx, int H, int W, int Ho, int Wo, long items,
+                                                                  int accumulate) {
   const int Wq = W >> 2, Hp = H >> 1;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < items; e += (long)gridDim.x * blockDim.x) {
     const int wq = (int)(e % Wq);
@@ -726,6 +728,10 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_v8_kernel(const float* _
         o1[j] += (th[k] == 1 && tw[k] == j) ? d[k] : 0.f;
       }
     float* p = dx + (bc * H + h0) * W + w0;
+    if (accumulate) {                          // dx already holds the gradient of another consumer of the pooled tensor's input
+      o0 += *reinterpret_cast<const f32x4*>(p);
+      o1 += *reinterpret_cast<const f32x4*>(p + W);
+    }
     *reinterpret_cast<f32x4*>(p) = o0;
     *reinterpret_cast<f32x4*>(p + W) = o1;
   }
@@ -1008,14 +1014,15 @@ int rsis_l_maxpool_fwd(const float* x, float* y, unsigned char* arg, long BC, in
   hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, arg, H, W, Ho, Wo, total);
   return rsis_check_launch();
 }
-int rsis_l_maxpool_bwd(const float* dy, const unsigned char* arg, float* dx, long BC, int H, int W, int Ho, int Wo,
+int rsis_l_maxpool_bwd(const float* dy, const unsigned char* arg, float* dx, long BC, int H, int W, int Ho, int Wo, int accumulate,
                        hipStream_t st) {
   const long total = BC * H * W;
   if ((H & 1) == 0 && (W & 3) == 0) {
-    hipLaunchKernelGGL(maxpool3x3s2_bwd_v8_kernel, dim3(ew_grid(total / 8)), dim3(256), 0, st, dy, arg, dx, H, W, Ho, Wo, total / 8);
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_v8_kernel, dim3(ew_grid(total / 8)), dim3(256), 0, st, dy, arg, dx, H, W, Ho, Wo, total / 8,
+                       accumulate);
     return rsis_check_launch();
   }
-  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, arg, dx, H, W, Ho, Wo, total);
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, arg, dx, H, W, Ho, Wo, total, accumulate);
   return rsis_check_launch();
 }
 int rsis_l_channel_sum(const float* dy, float* db, int B, int C, int HW, int hid, hipStream_t st) {

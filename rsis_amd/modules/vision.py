@@ -117,6 +117,7 @@ class ResNet101(nn.Module):
         self.layer3 = self._make_layer(256, 23, stride=2)
         self.layer4 = self._make_layer(512, 3, stride=2)
         self.fc = nn.Linear(2048, 1000)  # present in reference checkpoints, never used in forward (vision.py:11-21)
+        self._slot_x1 = ops.GradSlot()
 
     def _make_layer(self, planes, blocks, stride=1):
         downsample = None
@@ -131,7 +132,8 @@ class ResNet101(nn.Module):
 
     def forward(self, x):
         x1 = self.bn1(self.conv1(x), relu=True)   # vision.py:12-14 (x1 is the post-ReLU stem)
-        x = ops.maxpool3x3s2(x1)                  # :15
+        hand = self.training and torch.is_grad_enabled() and x1.requires_grad
+        x = ops.maxpool3x3s2(x1, grad_slot=self._slot_x1 if hand else None)   # :15
         x2 = self.layer1(x)
         x3 = self.layer2(x2)
         x4 = self.layer3(x3)
@@ -139,6 +141,7 @@ class ResNet101(nn.Module):
         if self.training:
             # x2..x4 also leave the trunk (skip connections): their outside gradient is parked for the next stage's strided
             # downsample conv, which accumulates into it in place (no memset, no autograd add)
+            x1 = ops.grad_tap(x1, self._slot_x1)          # (x1 feeds the stem max-pool and the first skip conv)
             x2 = ops.grad_tap(x2, self.layer2[0]._slot_in)
             x3 = ops.grad_tap(x3, self.layer3[0]._slot_in)
             x4 = ops.grad_tap(x4, self.layer4[0]._slot_in)

@@ -563,7 +563,8 @@ def batchnorm(x, gamma, beta, running_mean, running_var, train, relu=False, res=
 
 class _MaxPool3x3s2Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, slot=None):
+        ctx.slot = slot
         x = _contig(x)
         require_cuda_f32(x)
         B, C, H, W = x.shape
@@ -580,14 +581,21 @@ class _MaxPool3x3s2Fn(torch.autograd.Function):
         (arg,) = ctx.saved_tensors
         B, C, H, W, Ho, Wo = ctx.dims
         dy = _contig(dy)
-        dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dy.device)
-        check(lib().rsis_maxpool3x3s2_bwd(ptr(dy), ptr(arg), ptr(dx), B * C, H, W, Ho, Wo, stream()), "rsis_maxpool3x3s2_bwd")
-        return dx
+        parked = ctx.slot.take() if ctx.slot is not None else None
+        if parked is not None and (tuple(parked.shape) != (B, C, H, W) or not parked.is_contiguous()):
+            raise _lib.RsisHipError("GradSlot: the parked gradient does not belong to this max-pool's input")
+        dx = parked if parked is not None else torch.empty((B, C, H, W), dtype=torch.float32, device=dy.device)
+        check(lib().rsis_maxpool3x3s2_bwd(ptr(dy), ptr(arg), ptr(dx), B * C, H, W, Ho, Wo, 1 if parked is not None else 0, stream()),
+              "rsis_maxpool3x3s2_bwd")
+        return dx, None
 
 
-def maxpool3x3s2(x):
-    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1)."""
-    return _MaxPool3x3s2Fn.apply(x)
+def maxpool3x3s2(x, grad_slot=None):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1).  grad_slot: a GradSlot holding the gradient x receives from another
+    consumer (parked by ops.grad_tap); the backward accumulates into it in place instead of autograd adding the two."""
+    if grad_slot is not None:
+        grad_slot.reset()
+    return _MaxPool3x3s2Fn.apply(x, grad_slot)
 
 
 def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gscale=1.0):

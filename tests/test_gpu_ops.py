@@ -491,3 +491,29 @@ def test_upsample_maxpool_bwd_one_launch(shape, size):
     got = torch.empty_like(x)
     check(L.rsis_upsample_maxpool_bwd(ptr(dy), ptr(dside), ptr(arg), ptr(got), B * C, Hi, Wi, size[0], size[1], stream()), "fused")
     assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 4, 8, 8), (2, 3, 9, 11), (1, 8, 32, 64)])
+def test_maxpool3x3s2_accumulates_into_parked_gradient(shape):
+    """a second consumer's gradient of the pooled tensor's input (ops.grad_tap -> GradSlot) is accumulated into by the max-pool
+    backward in place: same result as autograd adding the two"""
+    from rsis_amd import ops
+    torch.manual_seed(4)
+    x = torch.randn(shape, device="cuda", requires_grad=True)
+    gy = torch.randn(shape[0], shape[1], (shape[2] + 1) // 2, (shape[3] + 1) // 2, device="cuda")
+    gs = torch.randn(shape, device="cuda")
+
+    def run(slot):
+        x.grad = None
+        xa = x * 1.0
+        y = ops.maxpool3x3s2(xa, grad_slot=slot)
+        side = ops.grad_tap(xa, slot) if slot is not None else xa
+        ((y * gy).sum() + (side * gs).sum()).backward()
+        return x.grad.clone()
+
+    slot = ops.GradSlot()
+    got = run(slot)
+    assert slot.done and slot.grad is None
+    want = run(None)
+    assert_close("dx", got, want, 1e-6)
