@@ -68,7 +68,7 @@ def gate_kernel_roofline(B, iters, imsize):
 
         def launch():
             check(L.rsis_convlstm_fwd(pa, ia, len(srcs), B, H, W, ptr(wp), ptr(pack.bias_p), None, ptr(c_prev), ptr(h), ptr(c),
-                                      ptr(act), hid, 3, 1, 0, stream()), "rsis_convlstm_fwd")
+                                      ptr(act), hid, 3, 1, 0, pack.dtype, stream()), "rsis_convlstm_fwd")
         for _ in range(3):
             launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--skip-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel of a step from Python instead of replaying the "
+                    "captured hipGraph of the iteration (rsis_amd.train.GraphedStep)")
     ap.add_argument("--no-settle", action="store_true", help="skip the untimed settle phase after the warm-up steps")
     ap.add_argument("--settle-min", type=float, default=2.0, help="minimum seconds of the untimed settle phase")
     ap.add_argument("--settle-cap", type=float, default=10.0, help="maximum seconds of the untimed settle phase")
@@ -195,7 +197,7 @@ def main():
         print(json.dumps(gate_kernel_roofline(o.batch, o.kernel_iters, o.imsize)))
         return
 
-    from rsis_amd.train import build_optimizers, init_distributed, runIter
+    from rsis_amd.train import GraphedStep, build_optimizers, init_distributed, runIter
     from rsis_amd.modules import FeatureExtractor, RSIS
     from rsis_amd.optim import BucketedAllReduce
     from rsis_amd.synthetic import synthetic_batch
@@ -219,9 +221,15 @@ def main():
     from rsis_amd.train import steps_to_run
     t_run = steps_to_run(a, batch[3])      # early-stop rule evaluated once for the resident batch (it is all T steps here)
 
+    # the whole iteration (fwd, matching, losses, bwd, all-reduce, Adam, repack) is captured once as a hipGraph and replayed:
+    # every step still executes all of its kernels, the host just stops paying ~35 us of Python per launch
+    gstep = None if o.no_graph else GraphedStep(a, encoder, decoder, crits, [enc_opt, dec_opt], reducer, warm=min(2, max(1, o.warmup - 1)))
+
     def step():
+        if gstep is not None:
+            return gstep(batch, t_run)
         return runIter(a, encoder, decoder, *batch, crits, [enc_opt, dec_opt], mode="train", reducer=reducer, sync_losses=False,
-                       t_run=t_run)
+                       t_run=t_run, want_outs=False)
 
     def fence():
         torch.cuda.synchronize()
@@ -251,6 +259,8 @@ def main():
         if i == 0:
             torch.cuda.synchronize()
             note("first step %.2f s" % (time.time() - tw))
+    while gstep is not None and gstep.graph is None and gstep.failed is None:
+        losses = step()[0]              # (still warm-up: the call that captures the graph must not fall into the timed region)
     # Untimed settle phase (still warm-up): keep stepping until the step time has been stable for a while (cold-box clock
     # ramp, allocator growth, first-use code loading), so that the K timed steps measure steady state.
     if not o.no_settle:
@@ -271,6 +281,8 @@ def main():
                 break
         note("settle: %d extra untimed steps, last %s ms" % (len(hist), " ".join("%.1f" % h for h in hist[-4:])))
     fence()
+    if gstep is not None:
+        note("hipGraph: %s" % ("captured, replaying" if gstep.graph is not None else "NOT captured (%s): eager launches" % gstep.failed))
     note("warmup done %.2f s" % (time.time() - tw))
     t0 = time.time()
     marks, evs = [], [torch.cuda.Event(enable_timing=True) for _ in range(o.steps + 1)]
@@ -310,7 +322,9 @@ def main():
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "configs[1]: synthetic %dx%dx3, T=%d, batch=%d/GPU, ResNet-101 encoder + 5-scale ConvLSTM "
                                       "decoder, fp32, fwd+match+3 losses+bwd+Adam (update_encoder on)" % (o.imsize, o.imsize, o.T, o.batch),
-                          "global_batch": world * o.batch, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5)},
+                          "global_batch": world * o.batch, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5),
+                          "launch": "hipGraph replay of the captured iteration" if (gstep is not None and gstep.graph is not None)
+                                    else "eager (one Python launch per kernel)"},
                "roofline": roof, "cpu_baseline": cpu}
     # RCCL prints a banner (version, library path) through C stdio, which on a pipe is flushed only at exit, i.e. AFTER anything
     # python printed: every rank flushes its C streams before the final barrier, rank 0 prints after it, so that the JSON line

@@ -6,14 +6,16 @@
  * it, on caller-owned device buffers, and is what the Python binding in rsis_amd/_lib.py (ctypes) loads.
  *
  * Conventions
- *   - every pointer is a device pointer to a caller-owned, contiguous fp32 NCHW tensor unless stated;
+ *   - every pointer is a device pointer to a caller-owned, contiguous fp32 NCHW tensor unless stated (also under
+ *     RSIS_DTYPE_BF16: only the private packed weight copies are bf16);
  *   - no hidden allocation, no host synchronisation, graph-capture safe; work is enqueued on `stream`
  *     (a hipStream_t passed as void*; NULL = the default stream);
  *   - return value: 0 = OK, nonzero = error code (rsis_error_string); nothing throws across the ABI;
  *   - thread-safe / re-entrant per stream.
  *   - "packed" weights are a private MFMA-friendly copy ([K rows][Cout padded to 128 columns]; K order and padding
- *     depend on the kernel that consumes them: implicit-GEMM (k = ci,r,s padded to 32 rows) or direct 3x3 (8-channel
- *     chunks per concat source, channel pairs interleaved per tap); ConvLSTM rows gate-interleaved 4*j+gate);
+ *     depend on the kernel that consumes them: implicit-GEMM (k = ci,r,s padded to 32 rows), direct 3x3 (8-channel
+ *     chunks per concat source, channel pairs interleaved per tap) or bf16 cells (8 consecutive input channels per 16-byte
+ *     cell, 16- / 64-channel chunks per concat source); ConvLSTM rows gate-interleaved 4*j+gate);
  *     they are rebuilt from the reference-layout weight ([Cout][Cin][k][k], gate order i,f,o,g) and never
  *     serialised.
  */
@@ -24,34 +26,47 @@
 extern "C" {
 #endif
 
-#define RSIS_ABI_VERSION 1
+#define RSIS_ABI_VERSION 2
+
+/* Arithmetic of the MFMA kernels behind the conv / ConvLSTM entry points (the `dtype` arguments below).
+ *   RSIS_DTYPE_F32 : exact-f32 MFMA (v_mfma_f32_32x32x2_f32), bit-for-bit an fp32 fmaf chain.
+ *   RSIS_DTYPE_BF16: operands rounded to bf16 (round-to-nearest-even) when they are staged, fp32 accumulation
+ *                    (v_mfma_f32_32x32x16_bf16).  Tensors stay fp32 NCHW in memory; only the packed weight copy is bf16.
+ *                    Layers without a bf16 kernel (the 7x7 stem, 3x3 / stride 2, the 8 -> 1 channel conv_out, odd-shaped weight
+ *                    gradients) run their f32 kernel under either dtype; rsis_conv_uses_bf16 tells which. */
+#define RSIS_DTYPE_F32 0
+#define RSIS_DTYPE_BF16 1
 
 int rsis_version(void);
 const char* rsis_error_string(int code);
 
 /* ---- weight repacking (private cache of nn.Conv2d.weight; clstm.py:17, model.py:43-47,109, torchvision trunk) ---- */
-/* number of floats of the packed forward copy for a conv whose input is the channel concat of nseg tensors.
- * (ks, stride, pad) select the layout: 3x3/s1/p1 convs use the direct-kernel layout, everything else the implicit-GEMM one */
-long rsis_conv_packed_floats_fwd(int Cout, int ks, int stride, int pad, int nseg, const int* Cseg);
-/* number of floats of the packed dgrad copy producing c_count input channels */
-long rsis_conv_packed_floats_dgrad(int Cout, int ks, int stride, int pad, int c_count);
+/* 1 when a conv of this geometry runs on the bf16 kernels under RSIS_DTYPE_BF16 (3x3 / stride 1 / pad 1, and 1x1 / pad 0 -- the
+ * strided 1x1 convs through their stride-1 form on a sub-sampled input -- with more than one output channel), 0 when it keeps
+ * its f32 kernel and f32 packed layout */
+int rsis_conv_uses_bf16(int ks, int stride, int pad, int Cout);
+/* number of BYTES of the packed forward copy for a conv whose input is the channel concat of nseg tensors.
+ * (dtype, ks, stride, pad) select the layout: bf16 cells, the direct-kernel layout (3x3/s1/p1, 3x3/s2/p1) or the implicit-GEMM one */
+long rsis_conv_packed_bytes_fwd(int dtype, int Cout, int ks, int stride, int pad, int nseg, const int* Cseg);
+/* number of BYTES of the packed dgrad copy producing c_count input channels */
+long rsis_conv_packed_bytes_dgrad(int dtype, int Cout, int ks, int stride, int pad, int c_count);
 /* The packed copy covers nseg (<= 3) input-channel segments of W: Cseg[s] channels starting at Coff[s] (Coff == NULL:
  * consecutive from 0) -- the channel concat the conv will gather from, or any subset of the input channels.
  * lstm_hid > 0: rows of W are [i|f|o|g] x hid (clstm.py:47) and are interleaved to 4*j+gate */
-int rsis_conv_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
-                       const int* Coff, int lstm_hid, void* stream);
+int rsis_conv_pack_fwd(const float* W, void* Wp, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
+                       const int* Coff, int lstm_hid, int dtype, void* stream);
 /* dgrad copy: produces the gradient of the sum(Cseg) input channels of the segments (in segment order) */
-int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
-                         const int* Coff, int lstm_hid, void* stream);
+int rsis_conv_pack_dgrad(const float* W, void* Wd, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
+                         const int* Coff, int lstm_hid, int dtype, void* stream);
 
 /* ---- nn.Conv2d forward (model.py:59-63 skip convs, :167 conv_out, vision.py:12-19 trunk convs) ----
  * out[B][Cout][Ho][Wo] = conv(cat(src[0..nsrc-1], dim=1), W, stride, pad) + bias (+ addend, same shape as out).
  * torch.cat (model.py:153) is folded in: up to 3 sources.  tile = 0 lets the library choose the MFMA tiling; tile + 100
  * additionally allows a split-K schedule (fp32 atomics: faster on deep-K / few-pixel layers such as sk5, but the summation
  * order is not reproducible -- the Python binding allows it only while training). */
-int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const float* Wp, int Cout,
+int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp, int Cout,
                     int ks, int stride, int pad, const float* bias, const float* addend, float* out, int Ho, int Wo,
-                    int tile, void* stream);
+                    int tile, int dtype, void* stream);
 
 /* ---- nn.Conv2d backward-data (autograd of the above): dx for input channels [c_lo,c_hi) of the conv input, written
  * to ndst tensors dx[i] = [B][Cdx[i]][Hx][Wx] (the inverse of the channel concat). dy = [B][Cout][Hy][Wy].
@@ -59,15 +74,15 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
  * addend (optional, ndst == 1): dx[0] = dgrad + addend -- the gradient the same tensor receives through another consumer (the
  * identity branch of a residual block), summed in the epilogue instead of by a separate pass.  stride 1: any pointer; 1x1 with
  * stride > 1: addend must BE dx[0] -- the strided gradient is accumulated into the existing tensor in place (no zero fill). ---- */
-int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const float* Wd, int Cin_packed, int ks, int stride,
+int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const void* Wd, int Cin_packed, int ks, int stride,
                       int pad, float* const* dx, const int* Cdx, int ndst, int Hx, int Wx, const float* addend, int tile,
-                      void* stream);
+                      int dtype, void* stream);
 
 /* ---- nn.Conv2d backward-weight: dW[Cout][Ctot][ks][ks] (reference layout) += corr(x, dy) for the source tensor
  * x = [B][Cs][H][W] that occupies input channels [c_off, c_off+Cs).  ACCUMULATES (fp32 atomics): zero dW first.
  * lstm_hid > 0: dy rows are gate-interleaved (4*j+gate) and are mapped back to reference rows. ---- */
 int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs, int H, int W, int Cout, int Ho, int Wo,
-                      int ks, int stride, int pad, int Ctot, int c_off, int lstm_hid, void* stream);
+                      int ks, int stride, int pad, int Ctot, int c_off, int lstm_hid, int dtype, void* stream);
 
 /* ---- conv bias gradient: db[Cout] += sum_{b,h,w} dy  (ACCUMULATES; lstm_hid as above) ---- */
 int rsis_bias_grad(const float* dy, float* db, int B, int C, int HW, int lstm_hid, void* stream);
@@ -78,9 +93,9 @@ int rsis_bias_grad(const float* dy, float* db, int B, int C, int HW, int lstm_hi
  * by the backward) may be NULL for inference. addend: optional precomputed time-invariant gate contribution (the
  * skip-feature part of the gate conv + bias, computed once per iteration by rsis_conv2d_fwd on interleaved rows); with an
  * addend nsrc may be 0 (level 0 at t = 0). ---- */
-int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const float* Wp,
+int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp,
                       const float* bias_packed, const float* addend, const float* c_prev, float* h_out, float* c_out,
-                      float* act_out, int hid, int ks, int pad, int tile, void* stream);
+                      float* act_out, int hid, int ks, int pad, int tile, int dtype, void* stream);
 
 /* ---- ConvLSTMCell pointwise backward: (dh + dh2, dc_next, saved act, c_prev, c) -> da (gate pre-activation grads,
  * interleaved rows) and dc_prev.  dh / dh2 / dc_next / c_prev / dc_prev / da_sum may be NULL. da_sum += da if given.
@@ -124,9 +139,11 @@ int rsis_maxpool3x3s2_bwd(const float* dy, const unsigned char* argmax, float* d
                           int accumulate, void* stream);
 
 /* ---- torch.optim.Adam step on a flat parameter range (utils/utils.py:83-84; train.py:185-187); g is scaled by gscale
- * (1/world_size after the RCCL sum all-reduce) before the L2 weight-decay term is added. ---- */
+ * (1/world_size after the RCCL sum all-reduce) before the L2 weight-decay term is added.  step: the 1-based update count of
+ * the range (bias correction); step_dev != NULL: the count is read from that device int32 instead (the caller increments it on
+ * the stream), so that a captured hipGraph replays with the live count. ---- */
 int rsis_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                   float weight_decay, int step, float gscale, void* stream);
+                   float weight_decay, int step, float gscale, const int* step_dev, void* stream);
 
 /* ---- Hungarian matching of predictions to ground-truth slots (hungarian.py:91-125, munkres.Munkres().compute per
  * sample): scores[B][G][T] fp32 (rows = GT slots, columns = predictions, T <= G <= 64) -> perm[B][G] int64 with
@@ -141,8 +158,9 @@ int rsis_assign_min_cost(const float* scores, long long* perm, int B, int G, int
  * job's block count (< 0: invalid). ---- */
 typedef struct rsis_pack_job {
   const float* W;      /* reference-layout weight [Cout][Ctot][ks][ks] (device) */
-  float* out;          /* packed copy (device), rsis_conv_packed_floats_fwd / _dgrad floats */
+  void* out;           /* packed copy (device), rsis_conv_packed_bytes_fwd / _dgrad bytes */
   int dgrad;           /* 0: forward copy, 1: data-gradient copy */
+  int dtype;           /* RSIS_DTYPE_* of the kernels that will read the copy */
   int Cout, Ctot, ks, stride, pad, nseg, Cseg[3], Coff[3], lstm_hid;
   int imode, ldw, krows;   /* derived (rsis_conv_pack_job_fill) */
   int block_begin;     /* first block of this job in the batch grid */
@@ -154,19 +172,6 @@ int rsis_conv_pack_batch(const rsis_pack_job* jobs_dev, int njobs, int total_blo
  * the sum of dy, which the weight-gradient kernel reads anyway).  dy[B][1][H][W], x[B][Cin][H][W]; dW[Cin*9] (reference layout
  * [1][Cin][3][3]) and db[1] (may be NULL) are ACCUMULATED.  Cin in {4, 8, 16}, W % 4 == 0, else RSIS_ERR_UNSUPPORTED. ---- */
 int rsis_conv_out_wgrad(const float* dy, const float* x, float* dW, float* db, int B, int Cin, int H, int W, void* stream);
-
-/* ---- decoder tail: out_mask = conv_out(UpsamplingBilinear2d((Ho, Wo))(hidden)) (model.py:163-167) as ONE kernel each way: the
- * up-sampled hidden state (Cin channels at the output resolution) is never written -- every block interpolates the patch it
- * convolves from the hidden pixels in LDS.  h[B][Cin][Hi][Wi]; W = conv_out.weight in the REFERENCE layout [1][Cin][3][3]
- * (3x3, stride 1, pad 1); bias[1] or NULL; out / dy[B][1][Ho][Wo].  Results equal rsis_upsample_bilinear_ac_*
- * followed by rsis_conv2d_* on the same tensors to a few ulp (same formulas and summation order).  rsis_upconv_out_bwd: dh (may be NULL) is written,
- * dW[Cin*9] / db[1] (may be NULL; db needs dW) are ACCUMULATED.  rsis_upconv_out_supported: Cin in {4, 8, 16}, Wi % 4 == 0,
- * Wo % 4 == 0, up-sampling factor >= ~1.9 per axis; otherwise the entry points return RSIS_ERR_UNSUPPORTED. ---- */
-int rsis_upconv_out_supported(int Cin, int Hi, int Wi, int Ho, int Wo);
-int rsis_upconv_out_fwd(const float* h, const float* W, const float* bias, float* out, int B, int Cin, int Hi, int Wi, int Ho,
-                        int Wo, void* stream);
-int rsis_upconv_out_bwd(const float* dy, const float* h, const float* W, float* dh, float* dW, float* db, int B, int Cin, int Hi,
-                        int Wi, int Ho, int Wo, void* stream);
 
 /* ---- data-layer augmentation: nearest-neighbour affine warp (dataloader/transforms/utils.py:67-147 th_affine2d(mode='nearest',
  * center=True); applied by transforms.py:23-142 RandomAffine to the image, the instance map and the class map of a sample).

@@ -18,7 +18,7 @@ _vpp = ctypes.POINTER(ctypes.c_void_p)
 
 class PackJob(ctypes.Structure):
     """struct rsis_pack_job of include/rsis_hip.h"""
-    _fields_ = [("W", ctypes.c_void_p), ("out", ctypes.c_void_p), ("dgrad", ctypes.c_int), ("Cout", ctypes.c_int),
+    _fields_ = [("W", ctypes.c_void_p), ("out", ctypes.c_void_p), ("dgrad", ctypes.c_int), ("dtype", ctypes.c_int), ("Cout", ctypes.c_int),
                 ("Ctot", ctypes.c_int), ("ks", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int),
                 ("nseg", ctypes.c_int), ("Cseg", ctypes.c_int * 3), ("Coff", ctypes.c_int * 3), ("lstm_hid", ctypes.c_int),
                 ("imode", ctypes.c_int), ("ldw", ctypes.c_int), ("krows", ctypes.c_int), ("block_begin", ctypes.c_int)]
@@ -28,22 +28,20 @@ class PackJob(ctypes.Structure):
 SIGNATURES = {
     "rsis_version": (_i, []),
     "rsis_error_string": (ctypes.c_char_p, [_i]),
-    "rsis_conv_packed_floats_fwd": (_l, [_i, _i, _i, _i, _i, _ip]),
-    "rsis_conv_packed_floats_dgrad": (_l, [_i, _i, _i, _i, _i]),
-    "rsis_conv_pack_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ip, _ip, _i, _vp]),
-    "rsis_conv_pack_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ip, _ip, _i, _vp]),
+    "rsis_conv_uses_bf16": (_i, [_i, _i, _i, _i]),
+    "rsis_conv_packed_bytes_fwd": (_l, [_i, _i, _i, _i, _i, _i, _ip]),
+    "rsis_conv_packed_bytes_dgrad": (_l, [_i, _i, _i, _i, _i, _i]),
+    "rsis_conv_pack_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ip, _ip, _i, _i, _vp]),
+    "rsis_conv_pack_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ip, _ip, _i, _i, _vp]),
     "rsis_conv_pack_job_fill": (_i, [ctypes.POINTER(PackJob)]),
     "rsis_conv_pack_batch": (_i, [_vp, _i, _i, _vp]),
-    "rsis_conv2d_fwd": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "rsis_conv2d_dgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vpp, _ip, _i, _i, _i, _vp, _i, _vp]),
-    "rsis_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsis_conv2d_fwd": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsis_conv2d_dgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vpp, _ip, _i, _i, _i, _vp, _i, _i, _vp]),
+    "rsis_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsis_affine_nearest": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "rsis_upconv_out_supported": (_i, [_i, _i, _i, _i, _i]),
-    "rsis_upconv_out_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "rsis_upconv_out_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsis_conv_out_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "rsis_convlstm_fwd": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsis_convlstm_fwd": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsis_convlstm_bwd_gates": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "rsis_upsample_bilinear_ac_fwd": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "rsis_upsample_bilinear_ac_bwd": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
@@ -65,7 +63,7 @@ SIGNATURES = {
     "rsis_rle_encode": (_i, [_vp, _i, _l, _vp, _i, _vp, _vp]),
     "rsis_largest_component": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "rsis_rle_to_string": (_i, [_vp, _i, ctypes.c_char_p, _i]),
-    "rsis_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    "rsis_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
 }
 
 _LIB = None

@@ -100,13 +100,19 @@ _FLAGS = [
     ("-synthetic_batches", dict(dest="synthetic_batches", default=20, type=int)),
     ("-synthetic_instances", dict(dest="synthetic_instances", default=12, type=int)),
     ("-models_root", dict(dest="models_root", default="../models")),
+    # arithmetic of the conv / ConvLSTM-gate MFMA kernels: fp32 (exact-f32 MFMA) or bf16 operands with fp32 accumulation
+    ("-dtype", dict(dest="dtype", default="fp32", choices=["fp32", "bf16"])),
+    # capture one training iteration per (shapes, T, loss switches) as a hipGraph and replay it (no host work per kernel)
+    ("--graph", dict(dest="graph", action="store_true")),
+    # reproduce the reference's accidental 1x/3x/4x trunk learning rate (utils/utils.py:34-52: duplicated tensors handed to Adam)
+    ("--enc_lr_quirk", dict(dest="enc_lr_quirk", action="store_true")),
 ]
 
 _DEFAULTS = dict(resume=False, crop=False, smooth_curves=False, update_encoder=False, transfer=False,
                  curriculum_learning=False, use_class_loss=False, use_stop_loss=False, log_term=False, visdom=False,
                  augment=False, use_gpu=True, resize=False, display=False, display_route=False, use_cats=True,
                  all_classes=False, no_display_text=False, use_gt_cats=False, use_gt_masks=False, use_gt_stop=False,
-                 synthetic=False)
+                 synthetic=False, graph=False, enc_lr_quirk=False)
 
 
 def get_parser():

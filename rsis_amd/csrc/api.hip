@@ -7,13 +7,16 @@
 int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_tile, hipStream_t st);
 int rsis_launch_conv_wgrad(WgradArgs& a, int ks, hipStream_t st);
 int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st);
+int rsis_launch_conv_bf16(ConvArgs& a, int ks, int epi, int force_variant, hipStream_t st);
+bool rsis_wgrad_bf16_supported(const WgradArgs& w, int ks);
+int rsis_launch_conv_wgrad_bf16(const WgradArgs& w, int ks, hipStream_t st);
 bool rsis_wgrad_tiled_supported(const WgradArgs& w, int ks);
 int rsis_launch_conv_wgrad_tiled(const WgradArgs& w, int ks, hipStream_t st);
 bool rsis_c1_supported(int Cin);
 int rsis_l_c1_fwd(const float*, const float*, int, const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_c1_dgrad(const float*, const float*, int, float*, int, int, int, int, hipStream_t);
 int rsis_l_c1_wgrad(const float*, const float*, float*, float*, int, int, int, int, hipStream_t);
-int rsis_l_pack(int, const float*, float*, int, int, int, int, const int*, const int*, int, int, int, hipStream_t);
+int rsis_l_pack(int, const float*, void*, int, int, int, int, const int*, const int*, int, int, int, hipStream_t);
 
 int rsis_l_lstm_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
                     hipStream_t);
@@ -28,16 +31,12 @@ int rsis_l_bn_bwd(const float*, const float*, const float*, const float*, const 
 int rsis_l_maxpool_fwd(const float*, float*, unsigned char*, long, int, int, int, int, hipStream_t);
 int rsis_l_maxpool_bwd(const float*, const unsigned char*, float*, long, int, int, int, int, int, hipStream_t);
 int rsis_l_channel_sum(const float*, float*, int, int, int, int, hipStream_t);
-int rsis_l_adam(float*, const float*, float*, float*, long, float, float, float, float, float, int, float, hipStream_t);
+int rsis_l_adam(float*, const float*, float*, float*, long, float, float, float, float, float, int, float, const int*, hipStream_t);
 int rsis_l_assign(const float*, long long*, int, int, int, hipStream_t);
 int rsis_l_gmax_bwd_add(const float*, const int*, float*, long, int, hipStream_t);
 int rsis_l_pack_batch(const rsis_pack_job*, int, int, hipStream_t);
-int rsis_l_pack_blocks(int mode, int krows, int ldw);
+int rsis_l_pack_blocks(int mode, int krows, int ldw, int ks);
 int rsis_l_affine_nearest(const float*, float*, const float*, int, int, int, int, int, hipStream_t);
-bool rsis_upconv_c1_supported(int Cin, int Hi, int Wi, int Ho, int Wo);
-int rsis_l_upconv_c1_fwd(const float*, const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
-int rsis_l_upconv_c1_wgrad(const float*, const float*, float*, float*, int, int, int, int, int, int, hipStream_t);
-int rsis_l_upconv_c1_bwd_data(const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
 int rsis_l_mask_resize_threshold(const float*, int, int, int, const unsigned char*, float, unsigned char*, unsigned char*, unsigned int*,
                                  int, int, hipStream_t);
 int rsis_l_rle_encode(const unsigned char*, int, long, unsigned int*, int, int*, hipStream_t);
@@ -71,6 +70,22 @@ static inline int direct_rows(int nseg, const int* Cseg) {
   for (int s = 0; s < nseg; ++s) q += (Cseg[s] + RSIS_CK - 1) / RSIS_CK;
   return q * RSIS_CK * 9;
 }
+// bf16 kernels (conv_bf16.hip): 3x3 / s1 / p1 and 1x1 / p0 (a strided 1x1 runs as its stride-1 form on a sub-sampled input)
+// -- convs with ONE output channel (conv_out) keep their HBM-bound vector kernels (conv_c1.hip)
+static inline bool bf16_geom(int ks, int stride, int pad, int Cout) {
+  return Cout > 1 && ((ks == 3 && stride == 1 && pad == 1) || (ks == 1 && pad == 0));
+}
+static inline bool use_bf16(int dtype, int ks, int stride, int pad, int Cout) {
+  return dtype == RSIS_DTYPE_BF16 && bf16_geom(ks, stride, pad, Cout);
+}
+static inline int bf16_ckb(int ks) { return ks == 1 ? RSIS_CKB1 : RSIS_CKB3; }
+// cell rows of a bf16 packed copy whose reduction axis is the concat of nseg channel segments
+static inline int bf16_rows(int ks, int nseg, const int* Cseg) {
+  const int ckb = bf16_ckb(ks);
+  int q = 0;
+  for (int s = 0; s < nseg; ++s) q += (Cseg[s] + ckb - 1) / ckb;
+  return q * ks * ks * (ckb / 8);
+}
 static inline int direct_variant(int tile) { const int v = tile % 10; return (tile > 0 && v >= 1 && v <= 6) ? v : 0; }
 
 extern "C" {
@@ -87,23 +102,27 @@ const char* rsis_error_string(int code) {
   }
 }
 
-long rsis_conv_packed_floats_fwd(int Cout, int ks, int stride, int pad, int nseg, const int* Cseg) {
+int rsis_conv_uses_bf16(int ks, int stride, int pad, int Cout) { return bf16_geom(ks, stride, pad, Cout) ? 1 : 0; }
+
+long rsis_conv_packed_bytes_fwd(int dtype, int Cout, int ks, int stride, int pad, int nseg, const int* Cseg) {
   if (nseg < 1 || nseg > RSIS_MAX_SRC || !Cseg) return -1;
   const long ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN);
-  if (use_direct_fwd(ks, stride, pad)) return (long)direct_rows(nseg, Cseg) * ldw;
+  if (use_bf16(dtype, ks, stride, pad, Cout)) return (long)bf16_rows(ks, nseg, Cseg) * ldw * 16;
+  if (use_direct_fwd(ks, stride, pad)) return (long)direct_rows(nseg, Cseg) * ldw * 4;
   int c = 0;
   for (int s = 0; s < nseg; ++s) c += Cseg[s];
-  return (long)krows_of(c, ks) * ldw;
+  return (long)krows_of(c, ks) * ldw * 4;
 }
 
-long rsis_conv_packed_floats_dgrad(int Cout, int ks, int stride, int pad, int c_count) {
+long rsis_conv_packed_bytes_dgrad(int dtype, int Cout, int ks, int stride, int pad, int c_count) {
   const long ldw = rsis_roundup(c_count, RSIS_LDW_ALIGN);
-  if (use_direct(ks, stride, pad)) return (long)direct_rows(1, &Cout) * ldw;
+  if (use_bf16(dtype, ks, stride, pad, Cout)) return (long)bf16_rows(ks, 1, &Cout) * ldw * 16;
+  if (use_direct(ks, stride, pad)) return (long)direct_rows(1, &Cout) * ldw * 4;
   if (use_direct_s2(ks, stride, pad)) {      // direct layout for one destination, implicit-GEMM layout for several: room for either
     const long a = (long)direct_rows(1, &Cout) * ldw, b = (long)krows_of(Cout, ks) * ldw;
-    return a > b ? a : b;
+    return (a > b ? a : b) * 4;
   }
-  return (long)krows_of(Cout, ks) * ldw;
+  return (long)krows_of(Cout, ks) * ldw * 4;
 }
 
 static int check_segments(int Ctot, int nseg, const int* Cseg, const int* Coff) {
@@ -120,25 +139,29 @@ static int check_segments(int Ctot, int nseg, const int* Cseg, const int* Coff) 
 // the pack kernels index the reference weight with 32-bit arithmetic
 static inline bool weight_too_big(int Cout, int Ctot, int ks) { return Cout < 1 || ks < 1 || (long)Cout * Ctot * ks * ks >= (1L << 31); }
 
-int rsis_conv_pack_fwd(const float* W, float* Wp, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
-                       const int* Coff, int lstm_hid, void* stream) {
+int rsis_conv_pack_fwd(const float* W, void* Wp, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
+                       const int* Coff, int lstm_hid, int dtype, void* stream) {
   if (!W || !Wp || check_segments(Ctot, nseg, Cseg, Coff) || weight_too_big(Cout, Ctot, ks)) return RSIS_ERR_ARG;
   if (lstm_hid > 0 && Cout != 4 * lstm_hid) return RSIS_ERR_ARG;
   const int ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN);
   int csum = 0;
   for (int s = 0; s < nseg; ++s) csum += Cseg[s];
+  if (use_bf16(dtype, ks, stride, pad, Cout))
+    return rsis_l_pack(5, W, Wp, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, bf16_rows(ks, nseg, Cseg), lstm_hid, (hipStream_t)stream);
   if (use_direct_fwd(ks, stride, pad))
     return rsis_l_pack(2, W, Wp, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, direct_rows(nseg, Cseg), lstm_hid, (hipStream_t)stream);
   return rsis_l_pack(0, W, Wp, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, krows_of(csum, ks), lstm_hid, (hipStream_t)stream);
 }
 
-int rsis_conv_pack_dgrad(const float* W, float* Wd, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
-                         const int* Coff, int lstm_hid, void* stream) {
+int rsis_conv_pack_dgrad(const float* W, void* Wd, int Cout, int Ctot, int ks, int stride, int pad, int nseg, const int* Cseg,
+                         const int* Coff, int lstm_hid, int dtype, void* stream) {
   if (!W || !Wd || check_segments(Ctot, nseg, Cseg, Coff) || weight_too_big(Cout, Ctot, ks)) return RSIS_ERR_ARG;
   if (lstm_hid > 0 && Cout != 4 * lstm_hid) return RSIS_ERR_ARG;
   int csum = 0;
   for (int s = 0; s < nseg; ++s) csum += Cseg[s];
   const int ldw = rsis_roundup(csum, RSIS_LDW_ALIGN);
+  if (use_bf16(dtype, ks, stride, pad, Cout))
+    return rsis_l_pack(6, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, bf16_rows(ks, 1, &Cout), lstm_hid, (hipStream_t)stream);
   if (use_direct(ks, stride, pad))
     return rsis_l_pack(3, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, direct_rows(1, &Cout), lstm_hid, (hipStream_t)stream);
   if (use_direct_s2(ks, stride, pad) && nseg == 1)      // (the parity-class kernel writes one destination)
@@ -150,27 +173,6 @@ int rsis_conv_out_wgrad(const float* dy, const float* x, float* dW, float* db, i
   if (!dy || !x || !dW || B < 1) return RSIS_ERR_ARG;
   if (!rsis_c1_supported(Cin) || W % 4 != 0) return RSIS_ERR_UNSUPPORTED;
   return rsis_l_c1_wgrad(dy, x, dW, db, B, Cin, H, W, (hipStream_t)stream);
-}
-
-int rsis_upconv_out_supported(int Cin, int Hi, int Wi, int Ho, int Wo) { return rsis_upconv_c1_supported(Cin, Hi, Wi, Ho, Wo) ? 1 : 0; }
-
-int rsis_upconv_out_fwd(const float* h, const float* W, const float* bias, float* out, int B, int Cin, int Hi, int Wi, int Ho,
-                        int Wo, void* stream) {
-  if (!h || !W || !out || B < 1) return RSIS_ERR_ARG;
-  if (!rsis_upconv_c1_supported(Cin, Hi, Wi, Ho, Wo)) return RSIS_ERR_UNSUPPORTED;
-  return rsis_l_upconv_c1_fwd(h, W, bias, out, B, Cin, Hi, Wi, Ho, Wo, (hipStream_t)stream);
-}
-
-int rsis_upconv_out_bwd(const float* dy, const float* h, const float* W, float* dh, float* dW, float* db, int B, int Cin, int Hi,
-                        int Wi, int Ho, int Wo, void* stream) {
-  if (!dy || B < 1 || (dh && !W) || (dW && !h) || (db && !dW)) return RSIS_ERR_ARG;
-  if (!rsis_upconv_c1_supported(Cin, Hi, Wi, Ho, Wo)) return RSIS_ERR_UNSUPPORTED;
-  if (dh) {
-    const int rc = rsis_l_upconv_c1_bwd_data(dy, W, dh, B, Cin, Hi, Wi, Ho, Wo, (hipStream_t)stream);
-    if (rc) return rc;
-  }
-  if (dW) return rsis_l_upconv_c1_wgrad(dy, h, dW, db, B, Cin, Hi, Wi, Ho, Wo, (hipStream_t)stream);
-  return RSIS_OK;
 }
 
 int rsis_affine_nearest(const float* x, float* y, const float* mat, int mat_rows, int N, int C, int H, int W, void* stream) {
@@ -186,15 +188,17 @@ int rsis_conv_pack_job_fill(rsis_pack_job* j) {
   for (int s = 0; s < j->nseg; ++s) csum += j->Cseg[s];
   if (!j->dgrad) {
     j->ldw = rsis_roundup(j->Cout, RSIS_LDW_ALIGN);
-    if (use_direct_fwd(j->ks, j->stride, j->pad)) { j->imode = 2; j->krows = direct_rows(j->nseg, j->Cseg); }
+    if (use_bf16(j->dtype, j->ks, j->stride, j->pad, j->Cout)) { j->imode = 5; j->krows = bf16_rows(j->ks, j->nseg, j->Cseg); }
+    else if (use_direct_fwd(j->ks, j->stride, j->pad)) { j->imode = 2; j->krows = direct_rows(j->nseg, j->Cseg); }
     else { j->imode = 0; j->krows = krows_of(csum, j->ks); }
   } else {
     j->ldw = rsis_roundup(csum, RSIS_LDW_ALIGN);
-    if (use_direct(j->ks, j->stride, j->pad)) { j->imode = 3; j->krows = direct_rows(1, &j->Cout); }
+    if (use_bf16(j->dtype, j->ks, j->stride, j->pad, j->Cout)) { j->imode = 6; j->krows = bf16_rows(j->ks, 1, &j->Cout); }
+    else if (use_direct(j->ks, j->stride, j->pad)) { j->imode = 3; j->krows = direct_rows(1, &j->Cout); }
     else if (use_direct_s2(j->ks, j->stride, j->pad) && j->nseg == 1) { j->imode = 4; j->krows = direct_rows(1, &j->Cout); }
     else { j->imode = 1; j->krows = krows_of(j->Cout, j->ks); }
   }
-  return rsis_l_pack_blocks(j->imode, j->krows, j->ldw);
+  return rsis_l_pack_blocks(j->imode, j->krows, j->ldw, j->ks);
 }
 
 int rsis_conv_pack_batch(const rsis_pack_job* jobs_dev, int njobs, int total_blocks, void* stream) {
@@ -214,9 +218,9 @@ static int fill_sources(ConvArgs& a, const float* const* src, const int* Csrc, i
   return RSIS_OK;
 }
 
-int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const float* Wp, int Cout,
+int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp, int Cout,
                     int ks, int stride, int pad, const float* bias, const float* addend, float* out, int Ho, int Wo,
-                    int tile, void* stream) {
+                    int tile, int dtype, void* stream) {
   const bool allow_splitk = tile >= 100;     // tile + 100: the caller accepts a split-K (atomic, order-nondeterministic) sum
   tile %= 100;
   ConvArgs a = {};
@@ -225,11 +229,26 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
   if (!Wp || !out || B < 1 || stride < 1) return RSIS_ERR_ARG;
   if (Ho != (H + 2 * pad - ks) / stride + 1 || Wo != (W + 2 * pad - ks) / stride + 1) return RSIS_ERR_ARG;
   a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = pad; a.sshift = 0;
-  a.wp = Wp; a.ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN); a.Cout = Cout; a.bias = bias; a.addend = addend;
+  a.wp = (const float*)Wp; a.ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN); a.Cout = Cout; a.bias = bias; a.addend = addend;
   a.dst[0] = out; a.Cd[0] = Cout; a.ndst = 1;
   a.ostride = 1; a.oH = Ho; a.oW = Wo; a.ksplit = 1;
+  if (use_bf16(dtype, ks, stride, pad, Cout)) {
+    if (stride != 1) return RSIS_ERR_UNSUPPORTED;      // strided 1x1: run the stride-1 form on a sub-sampled input
+    if (ks == 1 && nsrc != 1) return RSIS_ERR_UNSUPPORTED;
+    if (ks == 3) {     // deep-K convs on tiny maps (sk5): split over the channel chunks into a zeroed output
+      static const bool splitk_ok = !(getenv("RSIS_CONV_SPLITK") && getenv("RSIS_CONV_SPLITK")[0] == '0');
+      int nq = 0;
+      for (int s = 0; s < nsrc; ++s) nq += (Csrc[s] + RSIS_CKB3 - 1) / RSIS_CKB3;
+      const long px_tiles = (long)B * rsis_cdiv(H, 8) * rsis_cdiv(W, W <= 8 ? 8 : 16);
+      if (allow_splitk && splitk_ok && !addend && nq >= 16 && px_tiles * rsis_cdiv(Cout, 64) < 160) {
+        if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * Cout * Ho * Wo, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
+        a.ksplit = 0;
+      }
+    }
+    return rsis_launch_conv_bf16(a, ks, 0, direct_variant(tile), (hipStream_t)stream);
+  }
   if (use_direct(ks, stride, pad) && Cout == 1 && nsrc == 1 && !addend && rsis_c1_supported(Csrc[0]) && W % 4 == 0)   // conv_out: HBM-bound VALU kernel
-    return rsis_l_c1_fwd(src[0], Wp, a.ldw, bias, out, B, Csrc[0], H, W, (hipStream_t)stream);
+    return rsis_l_c1_fwd(src[0], (const float*)Wp, a.ldw, bias, out, B, Csrc[0], H, W, (hipStream_t)stream);
   if (use_direct(ks, stride, pad)) {
     // deep-K convs on tiny maps (sk5: 2048x9 deep, 64 blocks) are split over the channel chunks: zero the output here and let
     // the launcher decide (a.ksplit = 0 means "split allowed, output is zeroed")
@@ -248,9 +267,9 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
   return rsis_launch_conv_igemm(a, ks, false, 0, tile, (hipStream_t)stream);
 }
 
-int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const float* Wd, int Cin_packed, int ks, int stride,
+int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const void* Wd, int Cin_packed, int ks, int stride,
                       int pad, float* const* dx, const int* Cdx, int ndst, int Hx, int Wx, const float* addend, int tile,
-                      void* stream) {
+                      int dtype, void* stream) {
   if (!dy || !Wd || !dx || !Cdx || ndst < 1 || ndst > RSIS_MAX_SRC) return RSIS_ERR_ARG;
   // addend: stride 1 (any kernel the epilogue supports), or the strided 1x1 scatter accumulating in place (addend == dx[0])
   const bool inplace = addend && ndst == 1 && stride > 1 && ks == 1 && pad == 0 && addend == dx[0];
@@ -267,11 +286,34 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const fl
   a.B = B; a.H = Hy; a.W = Wy; a.Ho = Hx; a.Wo = Wx; a.stride = stride; a.pad = pad; a.sshift = log2i(stride);
   if (ctot > Cin_packed) return RSIS_ERR_ARG;
   a.ostride = 1; a.oH = Hx; a.oW = Wx; a.ksplit = 1;
-  a.wp = Wd; a.ldw = rsis_roundup(Cin_packed, RSIS_LDW_ALIGN); a.Cout = ctot; a.bias = nullptr; a.addend = addend;
+  a.wp = (const float*)Wd; a.ldw = rsis_roundup(Cin_packed, RSIS_LDW_ALIGN); a.Cout = ctot; a.bias = nullptr; a.addend = addend;
+  if (use_bf16(dtype, ks, stride, pad, Cout)) {
+    if (ks == 3) {
+      if (Hx != Hy || Wx != Wy) return RSIS_ERR_ARG;
+      static const bool splitk_ok = !(getenv("RSIS_CONV_SPLITK") && getenv("RSIS_CONV_SPLITK")[0] == '0');
+      const int nq = (Cout + RSIS_CKB3 - 1) / RSIS_CKB3;
+      const long px_tiles = (long)B * rsis_cdiv(Hx, 8) * rsis_cdiv(Wx, Wx <= 8 ? 8 : 16);
+      if (splitk_ok && !addend && nq >= 16 && px_tiles * rsis_cdiv(ctot, 64) < 160) {
+        for (int i = 0; i < ndst; ++i)
+          if (hipMemsetAsync(dx[i], 0, sizeof(float) * (size_t)B * Cdx[i] * Hx * Wx, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
+        a.ksplit = 0;
+      }
+      return rsis_launch_conv_bf16(a, 3, 0, direct_variant(tile), (hipStream_t)stream);
+    }
+    // 1x1: a GEMM over the dy grid; stride > 1 scatters its rows to every stride-th pixel of a zeroed (or, in place, the parked) dx
+    if (stride > 1) {
+      if (Hy != (Hx - 1) / stride + 1 || Wy != (Wx - 1) / stride + 1) return RSIS_ERR_ARG;
+      for (int i = 0; i < ndst && !inplace; ++i)
+        if (hipMemsetAsync(dx[i], 0, sizeof(float) * (size_t)B * Cdx[i] * Hx * Wx, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
+      a.ostride = stride;
+    } else if (Hx != Hy || Wx != Wy) return RSIS_ERR_ARG;
+    a.Ho = Hy; a.Wo = Wy; a.stride = 1; a.sshift = 0;
+    return rsis_launch_conv_bf16(a, 1, 0, direct_variant(tile), (hipStream_t)stream);
+  }
   if (use_direct(ks, stride, pad)) {
     if (Hx != Hy || Wx != Wy) return RSIS_ERR_ARG;
     if (Cout == 1 && ndst == 1 && Cin_packed == Cdx[0] && rsis_c1_supported(Cdx[0]) && !addend)
-      return rsis_l_c1_dgrad(dy, Wd, a.ldw, dx[0], B, Cdx[0], Hx, Wx, (hipStream_t)stream);
+      return rsis_l_c1_dgrad(dy, (const float*)Wd, a.ldw, dx[0], B, Cdx[0], Hx, Wx, (hipStream_t)stream);
     {  // deep-K data gradients on tiny maps (ConvLSTM level 0: 512 gate rows x 9 taps on 8x8): split over the channel chunks
       static const bool splitk_ok = !(getenv("RSIS_CONV_SPLITK") && getenv("RSIS_CONV_SPLITK")[0] == '0');
       const int nq = (Cout + RSIS_CK - 1) / RSIS_CK;
@@ -302,7 +344,7 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const fl
 }
 
 int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs, int H, int W, int Cout, int Ho, int Wo,
-                      int ks, int stride, int pad, int Ctot, int c_off, int lstm_hid, void* stream) {
+                      int ks, int stride, int pad, int Ctot, int c_off, int lstm_hid, int dtype, void* stream) {
   if (!dy || !x || !dW || c_off < 0 || c_off + Cs > Ctot) return RSIS_ERR_ARG;
   WgradArgs a = {};
   a.dy = dy; a.x = x; a.dw = dW; a.B = B; a.Cs = Cs; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
@@ -311,6 +353,7 @@ int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs,
     return rsis_l_c1_wgrad(dy, x, dW + a.n_off, nullptr, B, Cs, H, W, (hipStream_t)stream);
   // stride-1 "same" convs on tile-aligned maps: the LDS-DMA tiled kernel (conv_wgrad_tiled.hip); RSIS_WGRAD_TILED=0 forces the
   // generic split-K implicit GEMM (conv_wgrad.hip), which also covers every other shape
+  if (dtype == RSIS_DTYPE_BF16 && rsis_wgrad_bf16_supported(a, ks)) return rsis_launch_conv_wgrad_bf16(a, ks, (hipStream_t)stream);
   static const bool tiled_ok = !(getenv("RSIS_WGRAD_TILED") && getenv("RSIS_WGRAD_TILED")[0] == '0');
   if (tiled_ok && rsis_wgrad_tiled_supported(a, ks)) return rsis_launch_conv_wgrad_tiled(a, ks, (hipStream_t)stream);
   return rsis_launch_conv_wgrad(a, ks, (hipStream_t)stream);
@@ -321,19 +364,20 @@ int rsis_bias_grad(const float* dy, float* db, int B, int C, int HW, int lstm_hi
   return rsis_l_channel_sum(dy, db, B, C, HW, lstm_hid, (hipStream_t)stream);
 }
 
-int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const float* Wp,
+int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp,
                       const float* bias_packed, const float* addend, const float* c_prev, float* h_out, float* c_out,
-                      float* act_out, int hid, int ks, int pad, int tile, void* stream) {
+                      float* act_out, int hid, int ks, int pad, int tile, int dtype, void* stream) {
   ConvArgs a = {};
   int rc = fill_sources(a, src, Csrc, nsrc, ks, /*allow_empty=*/addend != nullptr);   // nsrc == 0: gates = addend only
   if (rc) return rc;
   if (!Wp || !h_out || !c_out || hid < 1) return RSIS_ERR_ARG;
   if (2 * pad != ks - 1) return RSIS_ERR_UNSUPPORTED;   // "same" conv only (the state keeps its size)
   a.B = B; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.stride = 1; a.pad = pad; a.sshift = 0;
-  a.wp = Wp; a.ldw = rsis_roundup(4 * hid, RSIS_LDW_ALIGN); a.Cout = 4 * hid; a.bias = bias_packed; a.addend = addend;
+  a.wp = (const float*)Wp; a.ldw = rsis_roundup(4 * hid, RSIS_LDW_ALIGN); a.Cout = 4 * hid; a.bias = bias_packed; a.addend = addend;
   a.ndst = 1; a.dst[0] = nullptr; a.Cd[0] = 4 * hid;
   a.hid = hid; a.c_prev = c_prev; a.h_out = h_out; a.c_out = c_out; a.act_out = act_out;
   a.ostride = 1; a.oH = H; a.oW = W; a.ksplit = 1;
+  if (use_bf16(dtype, ks, 1, pad, 4 * hid) && ks == 3) return rsis_launch_conv_bf16(a, 3, 1, direct_variant(tile), (hipStream_t)stream);
   if (use_direct(ks, 1, pad)) return rsis_launch_conv3x3_direct(a, 1, direct_variant(tile), (hipStream_t)stream);
   return rsis_launch_conv_igemm(a, ks, false, 1, tile, (hipStream_t)stream);
 }
@@ -396,10 +440,10 @@ int rsis_maxpool3x3s2_bwd(const float* dy, const unsigned char* argmax, float* d
   return rsis_l_maxpool_bwd(dy, argmax, dx, BC, H, W, Ho, Wo, accumulate ? 1 : 0, (hipStream_t)stream);
 }
 int rsis_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                   float weight_decay, int step, float gscale, void* stream) {
-  if (!p || !g || !m || !v || n < 0 || step < 1) return RSIS_ERR_ARG;
+                   float weight_decay, int step, float gscale, const int* step_dev, void* stream) {
+  if (!p || !g || !m || !v || n < 0 || (!step_dev && step < 1)) return RSIS_ERR_ARG;
   if (n == 0) return RSIS_OK;
-  return rsis_l_adam(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, gscale, (hipStream_t)stream);
+  return rsis_l_adam(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev ? 1 : step, gscale, step_dev, (hipStream_t)stream);
 }
 
 int rsis_assign_min_cost(const float* scores, long long* perm, int B, int G, int T, void* stream) {

@@ -10,6 +10,8 @@
 
 #define RSIS_KPAD 32        // packed-weight K axis is zero-padded to a multiple of this (BK of every kernel divides it)
 #define RSIS_CK 8            // input channels per LDS chunk of the direct 3x3 kernel (packed per concat source)
+#define RSIS_CKB3 16         // bf16 path: input channels per LDS chunk (and per packed chunk) of the 3x3 kernel
+#define RSIS_CKB1 64         // ... of the 1x1 GEMM kernel
 #define RSIS_LDW_ALIGN 128  // packed-weight row stride is a multiple of this many floats
 #define RSIS_MAX_SRC 3      // channel-concatenated sources / split destinations per conv
 

@@ -1,0 +1,425 @@
+// Weight gradient of the stride-1 "same" convolutions (3x3/p1 and 1x1/p0) with bf16 operands / fp32 accumulation on
+// v_mfma_f32_32x32x16_bf16 (the `-dtype bf16` path):
+//     dW[co][ci][r][s] += sum_{b,y,x} dy[b][co][y][x] * x[b][ci][y+r-pad][x+s-pad]
+// (autograd of nn.Conv2d in reference src/modules/clstm.py:17,44 -- the ConvLSTM gates, time-batched over T*B images --
+//  model.py:43-47 and the 1x1 / 3x3 convs of the torchvision bottlenecks).  dy, x and dW are fp32 (NCHW / reference layout);
+//  the operands are rounded to bf16 while they are staged into LDS.
+//
+// The PIXELS are the reduction axis, and NCHW has them contiguous: a lane's 8 K values are 8 consecutive pixels of one row,
+// i.e. one 16-byte LDS cell, for dy (A operand, rows = co) and for x (B operand) alike.
+//   * 1x1: a plain GEMM D[co][ci] over BM x BN tiles, both operand tiles staged as [row][64 px] (+16 B row padding: the 32 rows
+//     a wave reads land on distinct banks).
+//   * 3x3: the lanes of the B operand are 32 INPUT CHANNELS and the 9 taps are 9 accumulator tiles of the wave, so the tap
+//     (and with it the 1-pixel shift of the window) is a compile-time constant: per patch row the wave reads the aligned 16-byte
+//     window plus one dword on either side and builds the s = 0 / s = 2 windows with 4 v_alignbit_b32 each -- 3 LDS reads and
+//     8 VALU per 3 MFMAs.  The input patch (with halo) is staged once per tile, not 9 times.  The 32 x 288 accumulator slab of
+//     a wave is transposed through LDS before the fp32 atomics so that consecutive lanes hit consecutive dW addresses.
+// Ragged maps (the 7/14/28/56/112-pixel pyramid of 224 x 224 inputs) need no special case: out-of-map pixels are zero-filled
+// when the tile is staged.  Split-K over spatial tiles / images with fp32 atomics into dW, as conv_wgrad_tiled.hip.
+#include "common.h"
+
+typedef __attribute__((address_space(3))) void* lds_vp_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define RSIS_OOB 0x7FFFFFF0u
+
+struct WgradBf16Args {
+  const float* dy;   // [B][CoutDy][H][W]
+  const float* x;    // [B][Cs][H][W]
+  float* dw;         // [Cout][ldo]
+  int B, Cs, H, W, Cout;
+  int ldo, n_off, interleave_hid;
+  int n_co_tiles, n_n_tiles, n_sp_tiles, tiles_per_split;
+};
+
+__device__ __forceinline__ unsigned wg_pack2(float lo, float hi) {
+  const f32x2 f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+
+// One staging task = 8 consecutive pixels of one row of one channel -> one 16-byte bf16 cell.
+// V4: two dwordx4 loads (W % 4 == 0: each is entirely inside or outside the row); otherwise 8 dword loads + a validity mask.
+template <bool V4>
+struct Task8 {
+  float v[8];
+  __device__ __forceinline__ void load(const __amdgpu_buffer_rsrc_t r, int off_elems, bool ok_row, int gx, int W) {
+    if constexpr (V4) {
+      const unsigned o0 = (ok_row && gx >= 0 && gx + 3 < W) ? (unsigned)off_elems * 4u : RSIS_OOB;
+      const unsigned o1 = (ok_row && gx + 4 >= 0 && gx + 7 < W) ? (unsigned)(off_elems + 4) * 4u : RSIS_OOB;
+      const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, o0, 0, 0));
+      const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, o1, 0, 0));
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool ok = ok_row && (unsigned)(gx + i) < (unsigned)W;
+        v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, ok ? (unsigned)(off_elems + i) * 4u : RSIS_OOB, 0, 0));
+      }
+    }
+  }
+  __device__ __forceinline__ u32x4 cell() const {
+    u32x4 c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = wg_pack2(v[2 * k], v[2 * k + 1]);
+    return c;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// 3x3: block = BM dy rows x 32 input channels x 9 taps; wave = 32 rows x 32 channels x 9 taps, the 4 / (BM / 32) wave copies of a
+// row group take alternate 16-pixel reduction steps.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int TW, bool V4>
+__global__ __launch_bounds__(256) void wgrad3_bf16_kernel(const WgradBf16Args p) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int TP = 64, TH = TP / TW, GPR = TW / 8, NG = TP / 8, KSTEPS = NG / 2;
+  constexpr int WGM = BM / 32, KSPW = 4 / WGM, NGG = KSTEPS / KSPW;
+  constexpr int PH = TH + 2, XG = GPR + 2, PWP = XG * 8;          // patch: PH rows of XG 8-pixel groups (tile columns start at 8)
+  constexpr int ARS = (TP + 8) * 2;                               // bytes per dy row (16 B padding)
+  constexpr int CHSB = (PH * PWP * 2 + 31) / 32 * 32 + 16;        // bytes per patch channel: an odd number of 16-byte slots
+  constexpr int A_BYTES = BM * ARS, X_BYTES = 32 * CHSB, ST_BYTES = A_BYTES + X_BYTES;
+  constexpr int NTA = BM * NG / 256;                              // dy tasks per thread
+  constexpr int XT = 32 * PH * XG, NTX = (XT + 255) / 256;        // patch tasks (per thread)
+  constexpr int RED_BYTES = 4 * 8 * 288 * 4;                      // epilogue transposition buffer: 8 rows x 288 n per wave
+  static_assert(WGM * KSPW == 4 && KSTEPS % KSPW == 0 && (BM * NG) % 256 == 0, "config");
+  constexpr int LDS_BYTES = 2 * ST_BYTES > RED_BYTES ? 2 * ST_BYTES : RED_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WGM, wk = wave / WGM;
+  const int H = p.H, W = p.W, HW = H * W, Cs = p.Cs, Cout = p.Cout;
+  const int co_t = blockIdx.x % p.n_co_tiles, n_t = blockIdx.x / p.n_co_tiles;
+  const int co0 = co_t * BM, ci0 = n_t * 32;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int t_begin = blockIdx.y * p.tiles_per_split;
+  const int t_end = min(t_begin + p.tiles_per_split, p.n_sp_tiles);
+  if (t_begin >= t_end) return;
+
+  // ---- loop-invariant parts of the staging tasks ----
+  int a_off[NTA], a_y[NTA], a_x[NTA], a_lds[NTA];
+#pragma unroll
+  for (int i = 0; i < NTA; ++i) {
+    const int e = tid + i * 256;
+    const int row = e / NG, G = e % NG;
+    a_y[i] = G / GPR; a_x[i] = (G % GPR) * 8;
+    a_off[i] = co0 + row < Cout ? row * HW + a_y[i] * W + a_x[i] : -1;
+    a_lds[i] = row * ARS + G * 16;
+  }
+  int x_off[NTX], x_y[NTX], x_x[NTX], x_lds[NTX];
+#pragma unroll
+  for (int i = 0; i < NTX; ++i) {
+    const int e = tid + i * 256;
+    const int cl = e / (PH * XG), rem = e - cl * (PH * XG);
+    const int py = rem / XG, xg = rem - py * XG;
+    x_y[i] = py - 1; x_x[i] = (xg - 1) * 8;
+    x_off[i] = (e < XT && ci0 + cl < Cs) ? cl * HW + x_y[i] * W + x_x[i] : (int)0x40000000;   // (flag: never valid)
+    x_lds[i] = cl * CHSB + (py * PWP + xg * 8) * 2;
+  }
+
+  // ---- per-lane LDS read bases (bytes) ----
+  const int a_base = (wm * 32 + l31) * ARS + hi * 16;
+  // step g covers groups 2g (lanes 0-31) and 2g+1 (lanes 32-63): pixel (y, x8*8) of the tile, patch column 8 + x8*8
+  int bo[NGG];
+#pragma unroll
+  for (int gg = 0; gg < NGG; ++gg) {
+    const int G = 2 * (gg * KSPW + wk) + hi;
+    bo[gg] = l31 * CHSB + ((G / GPR) * PWP + (G % GPR) * 8 + 8) * 2;
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // scalar tile cursor
+  int tb = t_begin / (tiles_x * tiles_y);
+  int trem = t_begin - tb * (tiles_x * tiles_y);
+  int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+
+  Task8<V4> ra[NTA], rxp[NTX];
+#define W3_LOAD()                                                                                                  \
+  {                                                                                                                \
+    const int y0 = ty * TH, x0 = tx * TW;                                                                          \
+    const float* ab = p.dy + ((size_t)tb * Cout + co0) * HW;                                                       \
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (Cout - co0) * HW * 4, 0x00020000); \
+    const int tsc = y0 * W + x0;                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < NTA; ++i)                                                                \
+      ra[i].load(ra_, a_off[i] + tsc, a_off[i] >= 0 && y0 + a_y[i] < H, x0 + a_x[i], W);                           \
+    const float* xb = p.x + ((size_t)tb * Cs + ci0) * HW;                                                          \
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (Cs - ci0) * HW * 4, 0x00020000); \
+    _Pragma("unroll") for (int i = 0; i < NTX; ++i)                                                                \
+      rxp[i].load(rx_, x_off[i] + tsc, x_off[i] < 0x20000000 && (unsigned)(y0 + x_y[i]) < (unsigned)H, x0 + x_x[i], W); \
+    if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++tb; } }                                        \
+  }
+#define W3_STORE(BUF)                                                                                              \
+  {                                                                                                                \
+    char* st = lds + (BUF) * ST_BYTES;                                                                             \
+    _Pragma("unroll") for (int i = 0; i < NTA; ++i) *(u32x4*)(st + a_lds[i]) = ra[i].cell();                       \
+    _Pragma("unroll") for (int i = 0; i < NTX; ++i)                                                                \
+      if (XT % 256 == 0 || tid + i * 256 < XT) *(u32x4*)(st + A_BYTES + x_lds[i]) = rxp[i].cell();                 \
+  }
+
+  W3_LOAD()
+  W3_STORE(0)
+  __syncthreads();
+  const int ntl = t_end - t_begin;
+  for (int t = 0; t < ntl; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntl) W3_LOAD()
+    {
+      const char* As = lds + cur * ST_BYTES + a_base;
+      const char* Xs = lds + cur * ST_BYTES + A_BYTES;
+#pragma unroll
+      for (int gg = 0; gg < NGG; ++gg) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, *(const u32x4*)(As + (gg * KSPW + wk) * 32));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const char* row = Xs + bo[gg] + r * PWP * 2;
+          const unsigned d0 = *(const unsigned*)(row - 4);
+          const u32x4 m = *(const u32x4*)row;
+          const unsigned d5 = *(const unsigned*)(row + 16);
+          const u32x4 w0 = {__builtin_amdgcn_alignbit(m[0], d0, 16), __builtin_amdgcn_alignbit(m[1], m[0], 16),
+                            __builtin_amdgcn_alignbit(m[2], m[1], 16), __builtin_amdgcn_alignbit(m[3], m[2], 16)};
+          const u32x4 w2 = {__builtin_amdgcn_alignbit(m[1], m[0], 16), __builtin_amdgcn_alignbit(m[2], m[1], 16),
+                            __builtin_amdgcn_alignbit(m[3], m[2], 16), __builtin_amdgcn_alignbit(d5, m[3], 16)};
+          acc[r * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, w0), acc[r * 3 + 0], 0, 0, 0);
+          acc[r * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, m), acc[r * 3 + 1], 0, 0, 0);
+          acc[r * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, w2), acc[r * 3 + 2], 0, 0, 0);
+        }
+      }
+    }
+    if (t + 1 < ntl) W3_STORE(cur ^ 1)
+    __syncthreads();
+  }
+#undef W3_LOAD
+#undef W3_STORE
+
+  // ---- epilogue: transpose 8 rows x 288 columns per wave through LDS, then fp32 atomics with the lanes running along n ----
+  float* red = (float*)lds + wave * (8 * 288);
+  const int nvalid = min(32, Cs - ci0) * 9;                        // valid columns of this block's 288
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(r + 4 * hi) * 288 + l31 * 9 + t] = acc[t][4 * q + r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's own writes (each wave owns its slab: no barrier needed)
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int co = co0 + wm * 32 + 8 * q + rr;
+      if (co >= Cout) continue;
+      const int orow = p.interleave_hid > 0 ? (co & 3) * p.interleave_hid + (co >> 2) : co;
+      float* dst = p.dw + (size_t)orow * p.ldo + p.n_off + ci0 * 9;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const int n = c * 64 + lane;
+        if (n < nvalid) atomicAdd(dst + n, red[rr * 288 + n]);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1x1: D[co][ci] = sum_px dy[co][px] x[ci][px]; block tile BM x BN, waves WGM x WGN, TM x TN MFMA tiles per wave.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, int TW, bool V4>
+__global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const WgradBf16Args p) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int TP = 64, TH = TP / TW, GPR = TW / 8, NG = TP / 8, KSTEPS = NG / 2;
+  constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+  constexpr int ARS = (TP + 8) * 2;
+  constexpr int A_BYTES = BM * ARS, B_BYTES = BN * ARS, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int NTA = BM * NG / 256, NTB = BN * NG / 256;
+  static_assert(WGM * WGN == 4 && (BM * NG) % 256 == 0 && (BN * NG) % 256 == 0, "config");
+  __shared__ __attribute__((aligned(16))) char lds[2 * ST_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int H = p.H, W = p.W, HW = H * W, Cs = p.Cs, Cout = p.Cout;
+  const int co_t = blockIdx.x % p.n_co_tiles, n_t = blockIdx.x / p.n_co_tiles;
+  const int co0 = co_t * BM, n0 = n_t * BN;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int t_begin = blockIdx.y * p.tiles_per_split;
+  const int t_end = min(t_begin + p.tiles_per_split, p.n_sp_tiles);
+  if (t_begin >= t_end) return;
+
+  int a_off[NTA], a_y[NTA], a_x[NTA], a_lds[NTA];
+#pragma unroll
+  for (int i = 0; i < NTA; ++i) {
+    const int e = tid + i * 256;
+    const int row = e / NG, G = e % NG;
+    a_y[i] = G / GPR; a_x[i] = (G % GPR) * 8;
+    a_off[i] = co0 + row < Cout ? row * HW + a_y[i] * W + a_x[i] : -1;
+    a_lds[i] = row * ARS + G * 16;
+  }
+  int b_off[NTB], b_y[NTB], b_x[NTB], b_lds[NTB];
+#pragma unroll
+  for (int i = 0; i < NTB; ++i) {
+    const int e = tid + i * 256;
+    const int row = e / NG, G = e % NG;
+    b_y[i] = G / GPR; b_x[i] = (G % GPR) * 8;
+    b_off[i] = n0 + row < Cs ? row * HW + b_y[i] * W + b_x[i] : -1;
+    b_lds[i] = row * ARS + G * 16;
+  }
+  const int a_base = (wm * TM * 32 + l31) * ARS + hi * 16;
+  const int b_base = (wn * TN * 32 + l31) * ARS + hi * 16;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int tb = t_begin / (tiles_x * tiles_y);
+  int trem = t_begin - tb * (tiles_x * tiles_y);
+  int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+
+  Task8<V4> ra[NTA], rb[NTB];
+#define W1_LOAD()                                                                                                  \
+  {                                                                                                                \
+    const int y0 = ty * TH, x0 = tx * TW;                                                                          \
+    const int tsc = y0 * W + x0;                                                                                   \
+    const float* ab = p.dy + ((size_t)tb * Cout + co0) * HW;                                                       \
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (Cout - co0) * HW * 4, 0x00020000); \
+    _Pragma("unroll") for (int i = 0; i < NTA; ++i)                                                                \
+      ra[i].load(ra_, a_off[i] + tsc, a_off[i] >= 0 && y0 + a_y[i] < H, x0 + a_x[i], W);                           \
+    const float* xb = p.x + ((size_t)tb * Cs + n0) * HW;                                                           \
+    const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (Cs - n0) * HW * 4, 0x00020000); \
+    _Pragma("unroll") for (int i = 0; i < NTB; ++i)                                                                \
+      rb[i].load(rb_, b_off[i] + tsc, b_off[i] >= 0 && y0 + b_y[i] < H, x0 + b_x[i], W);                           \
+    if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++tb; } }                                        \
+  }
+#define W1_STORE(BUF)                                                                                              \
+  {                                                                                                                \
+    char* st = lds + (BUF) * ST_BYTES;                                                                             \
+    _Pragma("unroll") for (int i = 0; i < NTA; ++i) *(u32x4*)(st + a_lds[i]) = ra[i].cell();                       \
+    _Pragma("unroll") for (int i = 0; i < NTB; ++i) *(u32x4*)(st + A_BYTES + b_lds[i]) = rb[i].cell();             \
+  }
+
+  W1_LOAD()
+  W1_STORE(0)
+  __syncthreads();
+  const int ntl = t_end - t_begin;
+  for (int t = 0; t < ntl; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntl) W1_LOAD()
+    {
+      const char* As = lds + cur * ST_BYTES + a_base;
+      const char* Bs = lds + cur * ST_BYTES + A_BYTES + b_base;
+#pragma unroll
+      for (int g = 0; g < KSTEPS; ++g) {
+        bf16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = __builtin_bit_cast(bf16x8, *(const u32x4*)(As + i * 32 * ARS + g * 32));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = __builtin_bit_cast(bf16x8, *(const u32x4*)(Bs + j * 32 * ARS + g * 32));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntl) W1_STORE(cur ^ 1)
+    __syncthreads();
+  }
+#undef W1_LOAD
+#undef W1_STORE
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * TN * 32 + j * 32 + l31;
+    if (n >= Cs) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (co >= Cout) continue;
+        const int row = p.interleave_hid > 0 ? (co & 3) * p.interleave_hid + (co >> 2) : co;
+        atomicAdd(p.dw + (size_t)row * p.ldo + p.n_off + n, acc[i][j][r]);
+      }
+    }
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+static void split_plan(WgradBf16Args& a, int TW, int ntile, int slots) {
+  const int TH = 64 / TW;
+  a.n_sp_tiles = a.B * rsis_cdiv(a.H, TH) * rsis_cdiv(a.W, TW);
+  int nsplit = ntile >= slots ? 1 : slots / ntile;
+  if (nsplit > a.n_sp_tiles / 2) nsplit = a.n_sp_tiles / 2;
+  if (nsplit < 1) nsplit = 1;
+  a.tiles_per_split = rsis_cdiv(a.n_sp_tiles, nsplit);
+}
+
+template <int BM, int TW>
+static int launch_w3(WgradBf16Args& a, hipStream_t st) {
+  a.n_co_tiles = rsis_cdiv(a.Cout, BM);
+  a.n_n_tiles = rsis_cdiv(a.Cs, 32);
+  const int ntile = a.n_co_tiles * a.n_n_tiles;
+  split_plan(a, TW, ntile, 512);
+  const dim3 grid(ntile, rsis_cdiv(a.n_sp_tiles, a.tiles_per_split));
+  if (a.W % 4 == 0) hipLaunchKernelGGL((wgrad3_bf16_kernel<BM, TW, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad3_bf16_kernel<BM, TW, false>), grid, dim3(256), 0, st, a);
+  return rsis_check_launch();
+}
+
+template <int TW>
+static int launch_w3_tw(WgradBf16Args& a, hipStream_t st) {
+  if (a.Cout <= 32) return launch_w3<32, TW>(a, st);
+  if (a.Cout <= 64) return launch_w3<64, TW>(a, st);
+  return launch_w3<128, TW>(a, st);
+}
+
+template <int BM, int BN, int WGM, int WGN, int TW>
+static int launch_w1(WgradBf16Args& a, hipStream_t st) {
+  a.n_co_tiles = rsis_cdiv(a.Cout, BM);
+  a.n_n_tiles = rsis_cdiv(a.Cs, BN);
+  const int ntile = a.n_co_tiles * a.n_n_tiles;
+  split_plan(a, TW, ntile, 512);
+  const dim3 grid(ntile, rsis_cdiv(a.n_sp_tiles, a.tiles_per_split));
+  if (a.W % 4 == 0) hipLaunchKernelGGL((wgrad1_bf16_kernel<BM, BN, WGM, WGN, TW, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad1_bf16_kernel<BM, BN, WGM, WGN, TW, false>), grid, dim3(256), 0, st, a);
+  return rsis_check_launch();
+}
+
+template <int TW>
+static int launch_w1_tw(WgradBf16Args& a, hipStream_t st) {
+  if (a.Cout <= 64 && a.Cs <= 64) return launch_w1<64, 64, 2, 2, TW>(a, st);
+  if (a.Cout <= 64) return launch_w1<64, 128, 2, 2, TW>(a, st);
+  if (a.Cs <= 64) return launch_w1<128, 64, 2, 2, TW>(a, st);
+  return launch_w1<128, 128, 2, 2, TW>(a, st);
+}
+
+// stride 1, "same" padding, 32-bit offsets inside one image slab
+bool rsis_wgrad_bf16_supported(const WgradArgs& w, int ks) {
+  if (!(ks == 1 || ks == 3) || w.stride != 1 || w.pad != ks / 2 || w.H != w.Ho || w.W != w.Wo) return false;
+  if (w.Cout == 1) return false;          // conv_out: HBM-bound VALU kernel (conv_c1.hip)
+  const long img = (long)w.H * w.W * 4;
+  return (long)w.Cout * img < (1L << 30) && (long)w.Cs * img < (1L << 30);
+}
+
+int rsis_launch_conv_wgrad_bf16(const WgradArgs& w, int ks, hipStream_t st) {
+  WgradBf16Args a = {};
+  a.dy = w.dy; a.x = w.x; a.dw = w.dw; a.B = w.B; a.Cs = w.Cs; a.H = w.H; a.W = w.W; a.Cout = w.Cout;
+  a.ldo = w.ldo; a.n_off = w.n_off; a.interleave_hid = w.interleave_hid;
+  const int tw = w.W > 16 ? 32 : (w.W > 8 ? 16 : 8);     // widest 64-pixel tile the map fills
+  if (ks == 3) {
+    if (tw == 32) return launch_w3_tw<32>(a, st);
+    if (tw == 16) return launch_w3_tw<16>(a, st);
+    return launch_w3_tw<8>(a, st);
+  }
+  if (tw == 32) return launch_w1_tw<32>(a, st);
+  if (tw == 16) return launch_w1_tw<16>(a, st);
+  return launch_w1_tw<8>(a, st);
+}

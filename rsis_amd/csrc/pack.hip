@@ -78,6 +78,105 @@ __global__ void pack_kernel(int mode, const float* __restrict__ W, float* __rest
   }
 }
 
+// ---- bf16 layouts (conv_bf16.hip): 16-byte cells of 8 consecutive reduction channels, out[(kb * ldw + col) * 8 + e] ----
+//   kb = (q * KK + rs) * NCB + cb: chunk q of CKB channels (CKB = RSIS_CKB3 for 3x3, RSIS_CKB1 for 1x1; chunks never straddle
+//   a concat segment, the tail of a segment is zero), tap rs, 8-channel block cb of the chunk; NCB = CKB / 8.
+//   mode 5 (forward): reduction channel = input channel of the concat, col = co_p.
+//   mode 6 (data gradient): reduction channel = dy channel co_p, col = cg (index in the concat), 3x3 taps flipped.
+typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned pk_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned short to_bf16(float v) {
+  const pk_f32x2 f = {v, 0.f};
+  return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(f, pk_bf16x2)) & 0xFFFFu);
+}
+__host__ __device__ __forceinline__ int bf16_ckb(int KK) { return KK == 1 ? RSIS_CKB1 : RSIS_CKB3; }
+
+__device__ __forceinline__ float pack_bf16_src(int mode, const float* __restrict__ W, int kb, int col, int e, int Cout, int Ctot, int KK,
+                                               const SegMap& m, int hid) {
+  const int CKB = bf16_ckb(KK), NCB = CKB / 8;
+  const int q = kb / (KK * NCB), rem = kb - q * (KK * NCB);
+  const int rs = rem / NCB, cb = rem - rs * NCB;
+  const int cl = cb * 8 + e;                         // channel inside the chunk
+  if (mode == 5) {
+    if (col >= Cout) return 0.f;
+    int qs = 0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      if (s < m.n) {
+        const int nq = (m.C[s] + CKB - 1) / CKB;
+        if (q >= qs && q < qs + nq) {
+          const int c = (q - qs) * CKB + cl;
+          return c < m.C[s] ? W[(ref_row(col, hid) * Ctot + m.off[s] + c) * KK + rs] : 0.f;
+        }
+        qs += nq;
+      }
+    }
+    return 0.f;
+  }
+  const int c = q * CKB + cl;                        // dy channel (packed row order for ConvLSTM)
+  const int ci = seg_channel(m, col);
+  return (c < Cout && ci >= 0) ? W[(ref_row(c, hid) * Ctot + ci) * KK + (KK == 9 ? 8 - rs : rs)] : 0.f;
+}
+
+__global__ void pack_bf16_kernel(int mode, const float* __restrict__ W, unsigned short* __restrict__ out, int Cout, int Ctot, int KK,
+                                 SegMap m, int ldw, int nkb, int hid) {
+  const long total = (long)nkb * ldw * 8;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7);
+    const long cell = i >> 3;
+    const int kb = (int)(cell / ldw), col = (int)(cell - (long)kb * ldw);
+    out[i] = to_bf16(pack_bf16_src(mode, W, kb, col, e, Cout, Ctot, KK, m, hid));
+  }
+}
+
+// batched repack of the bf16 layouts.  Forward (mode 5): one block = one channel chunk (KK * NCB cell rows) x 64 columns; for a
+// column the chunk's KK * CKB source weights are one contiguous run of the reference weight, read with the lanes running along
+// it, converted, parked in LDS in cell order and written out as full 1 KB rows.  Data gradient (mode 6): 16 cell rows x 64
+// columns per block; the lanes run along the columns (= the reference weight's input channels), reads and writes coalesce.
+__device__ __forceinline__ void pack_tile_bf16(const rsis_pack_job& j, int tb, unsigned short* lds16) {
+  SegMap m;
+  m.n = j.nseg;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) { m.C[s] = j.Cseg[s]; m.off[s] = j.Coff[s]; }
+  const int KK = j.ks * j.ks, CKB = bf16_ckb(KK), NCB = CKB / 8;
+  const int nct = j.ldw / 64;
+  const int c0 = (tb % nct) * 64;
+  unsigned short* out = (unsigned short*)j.out;
+  if (j.imode == 5) {
+    const int R = KK * NCB;                          // cell rows of one chunk (18 or 8)
+    const int q = tb / nct;
+    const int run = KK * CKB;                        // source floats per column
+    for (int i = threadIdx.x; i < 64 * run; i += 256) {
+      const int cl = i / run, idx = i - cl * run;    // column, position in the run = (channel in chunk, tap)
+      const int ch = idx / KK, rs = idx - ch * KK;
+      const int kb = q * R + rs * NCB + (ch >> 3);
+      lds16[((rs * NCB + (ch >> 3)) * 64 + cl) * 8 + (ch & 7)] = to_bf16(pack_bf16_src(5, j.W, kb, c0 + cl, ch & 7, j.Cout, j.Ctot, KK, m, j.lstm_hid));
+    }
+    __syncthreads();
+    const pk_u32x4* src = (const pk_u32x4*)lds16;
+    for (int i = threadIdx.x; i < R * 64; i += 256) {
+      const int rr = i >> 6, cl = i & 63;
+      *(pk_u32x4*)(out + ((long)(q * R + rr) * j.ldw + c0 + cl) * 8) = src[i];
+    }
+  } else {
+    const int r0 = (tb / nct) * 16;
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+      const int rr = i >> 6, cl = i & 63;
+      if (r0 + rr >= j.krows) continue;
+      unsigned v[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const unsigned lo = to_bf16(pack_bf16_src(6, j.W, r0 + rr, c0 + cl, 2 * e2, j.Cout, j.Ctot, KK, m, j.lstm_hid));
+        const unsigned hi = to_bf16(pack_bf16_src(6, j.W, r0 + rr, c0 + cl, 2 * e2 + 1, j.Cout, j.Ctot, KK, m, j.lstm_hid));
+        v[e2] = lo | (hi << 16);
+      }
+      const pk_u32x4 cell = {v[0], v[1], v[2], v[3]};
+      *(pk_u32x4*)(out + ((long)(r0 + rr) * j.ldw + c0 + cl) * 8) = cell;
+    }
+  }
+}
+
 // ---- batched repack: every packed copy of every conv weight in ONE launch (after an optimizer step ~240 tiny pack launches
 // per training step otherwise).  jobs[] lives in device memory; job i owns the blocks [block_begin_i, block_begin_{i+1}), one block
 // per PACK_T x PACK_T tile of the packed matrix.  The forward layouts (columns = output channel) are transposes of the reference
@@ -128,13 +227,13 @@ __device__ __forceinline__ void pack_tile(const rsis_pack_job& j, int tb, float 
   __syncthreads();
   for (int rr = q; rr < nrow; rr += 4) {
 #pragma unroll
-    for (int cc = l; cc < PACK_TC; cc += 64) j.out[(long)(r0 + rr) * j.ldw + c0 + cc] = tile[rr][cc];
+    for (int cc = l; cc < PACK_TC; cc += 64) ((float*)j.out)[(long)(r0 + rr) * j.ldw + c0 + cc] = tile[rr][cc];
   }
 }
 
 #define PACK_TPB 1     // consecutive tiles per block (measured: 4 is slower than 1 -- the job lookup is not the bottleneck)
 __global__ __launch_bounds__(256) void pack_batch_kernel(const rsis_pack_job* __restrict__ jobs, int njobs, int total_tiles) {
-  __shared__ float tile[RSIS_CK * 9][PACK_TC + 1];     // 72 rows: one channel chunk of the direct-dgrad layouts (>= PACK_T)
+  __shared__ __attribute__((aligned(16))) float tile[RSIS_CK * 9][PACK_TC + 1];     // 72 rows: one channel chunk of the direct-dgrad layouts (>= PACK_T)
   int lo = 0, hi = njobs - 1;
   int b = blockIdx.x * PACK_TPB;
   while (lo < hi) {                       // last job whose block_begin <= b
@@ -150,7 +249,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const rsis_pack_job* __
       next_begin = lo + 1 < njobs ? jobs[lo + 1].block_begin : total_tiles;
     }
     const int tb = b - j.block_begin;
-    if (j.ks == 1) pack_tile<1>(j, tb, tile);
+    if (j.imode >= 5) pack_tile_bf16(j, tb, (unsigned short*)&tile[0][0]);
+    else if (j.ks == 1) pack_tile<1>(j, tb, tile);
     else if (j.ks == 3) pack_tile<9>(j, tb, tile);
     else pack_tile<0>(j, tb, tile);
     __syncthreads();                      // the LDS tile is reused
@@ -161,7 +261,9 @@ int rsis_l_pack_batch(const rsis_pack_job* jobs, int njobs, int total_blocks, hi
   hipLaunchKernelGGL(pack_batch_kernel, dim3((total_blocks + PACK_TPB - 1) / PACK_TPB), dim3(256), 0, st, jobs, njobs, total_blocks);
   return rsis_check_launch();
 }
-int rsis_l_pack_blocks(int mode, int krows, int ldw) {
+int rsis_l_pack_blocks(int mode, int krows, int ldw, int ks) {
+  if (mode == 5) return krows / (ks * ks * (bf16_ckb(ks * ks) / 8)) * (ldw / 64);     // one chunk x 64 columns per block
+  if (mode == 6) return (krows + 15) / 16 * (ldw / 64);
   return (mode >= 3 ? krows / (RSIS_CK * 9) : (krows + PACK_T - 1) / PACK_T) * (ldw / PACK_TC);
 }
 
@@ -171,8 +273,9 @@ static inline int pack_grid(long total) {
   return (int)(g < 1 ? 1 : g);
 }
 
-// mode: 0 igemm fwd, 1 igemm dgrad, 2 direct fwd, 3 direct dgrad (stride 1), 4 direct dgrad (stride 2: taps not flipped)
-int rsis_l_pack(int mode, const float* W, float* out, int Cout, int Ctot, int ks, int nseg, const int* Cseg, const int* Coff,
+// mode: 0 igemm fwd, 1 igemm dgrad, 2 direct fwd, 3 direct dgrad (stride 1), 4 direct dgrad (stride 2: taps not flipped),
+// 5 bf16 fwd, 6 bf16 dgrad (cell layouts of conv_bf16.hip)
+int rsis_l_pack(int mode, const float* W, void* out, int Cout, int Ctot, int ks, int nseg, const int* Cseg, const int* Coff,
                 int ldw, int krows, int hid, hipStream_t st) {
   SegMap m = {};
   m.n = nseg;
@@ -180,7 +283,12 @@ int rsis_l_pack(int mode, const float* W, float* out, int Cout, int Ctot, int ks
   for (int s = 0; s < nseg; ++s) { m.C[s] = Cseg[s]; m.off[s] = Coff ? Coff[s] : base; base += Cseg[s]; }
   const long total = (long)krows * ldw;
   const dim3 g(pack_grid(total)), b(256);
-  if (mode < 0 || mode > 4) return RSIS_ERR_ARG;
-  hipLaunchKernelGGL(pack_kernel, g, b, 0, st, mode, W, out, Cout, Ctot, ks * ks, m, ldw, krows, hid);
+  if (mode < 0 || mode > 6) return RSIS_ERR_ARG;
+  if (mode >= 5) {     // bf16 cell layouts: krows = cell rows, out = bf16
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(pack_grid(total * 8)), b, 0, st, mode, W, (unsigned short*)out, Cout, Ctot, ks * ks, m, ldw,
+                       krows, hid);
+    return rsis_check_launch();
+  }
+  hipLaunchKernelGGL(pack_kernel, g, b, 0, st, mode, W, (float*)out, Cout, Ctot, ks * ks, m, ldw, krows, hid);
   return rsis_check_launch();
 }

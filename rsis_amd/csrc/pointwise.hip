@@ -39,7 +39,7 @@ __global__ void lstm_bwd_kernel(const float* __restrict__ dh, const float* __res
 // ------------------------------------------------------------------------------------------------
 // bilinear upsample, align_corners=True  (nn.UpsamplingBilinear2d: model.py:149,163; train.py:96; test.py:39)
 // ------------------------------------------------------------------------------------------------
-// (ac_coord / ac_scale: common.h -- shared with upconv_c1.hip)
+// (ac_coord / ac_scale: common.h)
 
 __global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int Hi, int Wi, int Ho, int Wo,
                                     float sh, float sw, long total) {
@@ -772,7 +772,13 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 // flat fused Adam (torch.optim.Adam semantics incl. L2 weight decay: reference utils/utils.py:83-84)
 // ------------------------------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+                            long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
+                            const int* __restrict__ step_dev) {
+  if (step_dev) {   // step count kept on the device (a captured hipGraph replays with the live count, not the captured one)
+    const float st = (float)*step_dev;
+    bc1 = 1.f - powf(b1, st);
+    bc2_sqrt = sqrtf(1.f - powf(b2, st));
+  }
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     float gv = g[e] * gscale + wd * p[e];
     const float mv = b1 * m[e] + (1.f - b1) * gv;
@@ -1033,10 +1039,10 @@ int rsis_l_channel_sum(const float* dy, float* db, int B, int C, int HW, int hid
   return rsis_check_launch();
 }
 int rsis_l_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
-                int step, float gscale, hipStream_t st) {
+                int step, float gscale, const int* step_dev, hipStream_t st) {
   const float bc1 = 1.f - powf(b1, (float)step);
   const float bc2s = sqrtf(1.f - powf(b2, (float)step));
-  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, gscale);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, gscale, step_dev);
   return rsis_check_launch();
 }
 

@@ -23,15 +23,6 @@ from . import ops
 from ._lib import check, int_array, lib, ptr, ptr_array, require_cuda_f32, stream
 
 
-import os as _os
-
-# conv_out fused with the final x2 upsample (ops.side_upconv_out, upconv_c1.hip).  OFF by default: it removes 4 of the 5 passes
-# over the up-sampled hidden state, but the three kernels as written (51 / 62 / 66 us per timestep at 256^2 x 32) are slower
-# than the five they replace (21 + 23 / 30 + 10 / 19 + 21 us): building the up-sampled patch costs ~10 LDS reads + ~40 ALU
-# instructions per element and the 70-80 KB of LDS leave one block per CU, so the phases of a tile do not overlap.
-FUSE_TAIL = [_os.environ.get("RSIS_FUSE_TAIL", "0") == "1"]
-
-
 class LevelTape(object):
     """Per-iteration state of one ConvLSTM level."""
 
@@ -68,14 +59,15 @@ class LevelTape(object):
 
 def _packs(cell, c_up, c_skip):
     """PackedConv triples of one cell: hoisted (skip channels), dynamic (up + h_prev channels)."""
-    key = ("fused", c_up, c_skip)
+    key = ("fused", c_up, c_skip, getattr(cell, "dtype", ops.DTYPE_F32))
     if key not in cell._packs:
         hid, ks, pad = cell.hidden_size, cell.kernel_size, cell.padding
         skip_off = c_up
         h_off = c_up + c_skip
-        hoist = ops.PackedConv(ks, [c_skip], lstm_hid=hid, stride=1, pad=pad, offs=[skip_off])
+        dt = getattr(cell, "dtype", ops.DTYPE_F32)
+        hoist = ops.PackedConv(ks, [c_skip], lstm_hid=hid, stride=1, pad=pad, offs=[skip_off], dtype=dt)
         segs, offs = ([c_up], [0]) if c_up > 0 else ([], [])
-        dyn = ops.PackedConv(ks, segs + [hid], lstm_hid=hid, stride=1, pad=pad, offs=offs + [h_off])
+        dyn = ops.PackedConv(ks, segs + [hid], lstm_hid=hid, stride=1, pad=pad, offs=offs + [h_off], dtype=dt)
         cell._packs[key] = (hoist, dyn)
     return cell._packs[key]
 
@@ -93,7 +85,7 @@ class _HoistFn(torch.autograd.Function):
         wp = hoist.fwd(weight, bias)
         G = torch.empty((B, 4 * tl.hid, H, W), dtype=torch.float32, device=skip.device)
         check(L.rsis_conv2d_fwd(ptr_array([skip]), int_array([Cs]), 1, B, H, W, ptr(wp), 4 * tl.hid, tl.ks, 1, tl.pad,
-                                ptr(hoist.bias_p), None, ptr(G), H, W, ops.FORCE_TILE[0], stream()), "rsis_conv2d_fwd(hoist)")
+                                ptr(hoist.bias_p), None, ptr(G), H, W, ops.FORCE_TILE[0], hoist.dtype, stream()), "rsis_conv2d_fwd(hoist)")
         ctx.tl = tl
         ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(skip, weight)
@@ -112,12 +104,12 @@ class _HoistFn(torch.autograd.Function):
             wd = hoist.dgrad(weight)
             dskip = torch.empty_like(skip)
             check(L.rsis_conv2d_dgrad(ptr(dG), B, 4 * tl.hid, H, W, ptr(wd), hoist.cin, tl.ks, 1, tl.pad, ptr_array([dskip]),
-                                      int_array([Cs]), 1, H, W, None, ops.FORCE_TILE[0], stream()), "rsis_conv2d_dgrad(hoist)")
+                                      int_array([Cs]), 1, H, W, None, ops.FORCE_TILE[0], hoist.dtype, stream()), "rsis_conv2d_dgrad(hoist)")
         if ctx.needs_input_grad[2]:
             tgt = ops._direct_target(ctx.wparam)
             dW = tgt if tgt is not None else torch.zeros_like(weight)
             check(L.rsis_conv2d_wgrad(ptr(dG), ptr(skip), ptr(dW), B, Cs, H, W, 4 * tl.hid, H, W, tl.ks, 1, tl.pad, weight.shape[1],
-                                      tl.c_up, tl.hid, stream()), "rsis_conv2d_wgrad(hoist)")
+                                      tl.c_up, tl.hid, hoist.dtype, stream()), "rsis_conv2d_wgrad(hoist)")
             if tgt is not None:
                 dW = None
         if ctx.needs_input_grad[3]:
@@ -158,7 +150,7 @@ class _StepFn(torch.autograd.Function):
         pa = ptr_array(srcs) if srcs else None
         ia = int_array([s.shape[1] for s in srcs]) if srcs else None
         check(L.rsis_convlstm_fwd(pa, ia, len(srcs), B, H, W, ptr(wp), None, ptr(G), ptr(c_prev) if h_prev is not None else None,
-                                  ptr(h), ptr(c), ptr(act), hid, tl.ks, tl.pad, ops.FORCE_TILE[0], stream()), "rsis_convlstm_fwd(step)")
+                                  ptr(h), ptr(c), ptr(act), hid, tl.ks, tl.pad, ops.FORCE_TILE[0], dyn.dtype, stream()), "rsis_convlstm_fwd(step)")
         ctx.tl, ctx.t, ctx.stacked = tl, t, stacked
         ctx.wparam = weight
         ctx.has_up, ctx.has_state = up is not None, h_prev is not None
@@ -211,7 +203,7 @@ class _StepFn(torch.autograd.Function):
                     tl.DHP = torch.empty_like(srcs[-1])
                 dxs[-1] = tl.DHP
             check(L.rsis_conv2d_dgrad(ptr(da), B, 4 * hid, H, W, ptr(wd), dyn.cin, ks, 1, pad, ptr_array(dxs),
-                                      int_array([s.shape[1] for s in srcs]), len(srcs), H, W, None, ops.FORCE_TILE[0], stream()),
+                                      int_array([s.shape[1] for s in srcs]), len(srcs), H, W, None, ops.FORCE_TILE[0], dyn.dtype, stream()),
                   "rsis_conv2d_dgrad(step)")
             k = 0
             if ctx.has_up:
@@ -233,7 +225,7 @@ class _StepFn(torch.autograd.Function):
             off += [h_off] if ctx.has_state else []
             for s, o in zip(srcs, off):
                 check(L.rsis_conv2d_wgrad(ptr(da), ptr(s), ptr(dW), B, s.shape[1], H, W, 4 * hid, H, W, ks, 1, pad, Ctot, o, hid,
-                                          stream()), "rsis_conv2d_wgrad(step)")
+                                          dyn.dtype, stream()), "rsis_conv2d_wgrad(step)")
         if t == 0:
             # autograd runs the t = 0 backward last (every later step depends on it): flush the time-batched work
             if ctx.stacked:
@@ -252,10 +244,10 @@ class _StepFn(torch.autograd.Function):
                     dW = tgt if tgt is not None else torch.zeros_like(weight)
                 if tl.c_up > 0:
                     check(L.rsis_conv2d_wgrad(ptr(tl.DA), ptr(tl.UP), ptr(dW), n * B, tl.c_up, H, W, 4 * hid, H, W, ks, 1, pad, Ctot, 0,
-                                              hid, stream()), "rsis_conv2d_wgrad(batched up)")
+                                              hid, dyn.dtype, stream()), "rsis_conv2d_wgrad(batched up)")
                 if n > 1:
                     check(L.rsis_conv2d_wgrad(ptr(tl.DA[1]), ptr(tl.H), ptr(dW), (n - 1) * B, hid, H, W, 4 * hid, H, W, ks, 1, pad, Ctot,
-                                              h_off, hid, stream()), "rsis_conv2d_wgrad(batched h)")
+                                              h_off, hid, dyn.dtype, stream()), "rsis_conv2d_wgrad(batched h)")
         if tgt is not None:
             dW = None   # accumulated straight into weight.grad
         if t == 0:
@@ -365,7 +357,7 @@ class _SideUpFn(torch.autograd.Function):
 
 def decoder_levels(decoder, skip_feats, prev_hidden_list):
     """The 5-level ConvLSTM pyramid of RSIS.forward (model.py:129-165) with hoisting; returns (hidden_list, side_feats,
-    last up-sampled hidden, out_mask) -- out_mask is set (and the up-sampled hidden None) when the decoder tail ran fused -- or
+    last up-sampled hidden) -- or
     None when the fused path does not apply to this call."""
     need_grad = torch.is_grad_enabled() and (any(f.requires_grad for f in skip_feats) or
                                             any(p.requires_grad for p in decoder.clstm_list.parameters()))
@@ -379,7 +371,7 @@ def decoder_levels(decoder, skip_feats, prev_hidden_list):
         return None
     t = tape.t
     hidden_list, side_feats = [], []
-    up = out_mask = None
+    up = None
     n_levels = len(tape.levels)
     for i, tl in enumerate(tape.levels):
         cell = tl.cell
@@ -393,14 +385,7 @@ def decoder_levels(decoder, skip_feats, prev_hidden_list):
             side, up = _SideUpFn.apply(into, t, h, tuple(skip_feats[i + 1].shape[-2:]))     # model.py:143,149-150
         else:
             size = (h.shape[-2] * 2, h.shape[-1] * 2)
-            conv = decoder.conv_out
-            if (FUSE_TAIL[0] and conv.bias is not None and conv.stride == 1 and conv.padding == 1 and
-                    ops.upconv_out_supported(h, conv.weight, size)):
-                # max-pool side feature + conv_out(upsample x2 (h)) as one node: the up-sampled state is never written
-                side, out_mask = ops.side_upconv_out(h, conv.weight, conv.bias, size)           # model.py:143,163-167
-                up = None
-            else:
-                side, up = _SideUpFn.apply(None, t, h, size)                                    # model.py:143,163-164
+            side, up = _SideUpFn.apply(None, t, h, size)                                    # model.py:143,163-164
         side_feats.append(side)
     tape.t += 1
-    return hidden_list, side_feats, up, out_mask
+    return hidden_list, side_feats, up

@@ -37,6 +37,12 @@ class ConvLSTMCell(nn.Module):
         self.padding = int(padding)
         self.Gates = _GatesParams(self.input_size + self.hidden_size, 4 * self.hidden_size, self.kernel_size)
         self._packs = {}
+        self.dtype = ops.DTYPES[getattr(args, "dtype", "fp32")]
+
+    def _set_rsis_dtype(self, d):
+        if self.dtype != d:
+            self.dtype = d
+            self._packs = {}
 
     def _pack(self, x_channels):
         key = tuple(x_channels)
@@ -44,7 +50,7 @@ class ConvLSTMCell(nn.Module):
             if sum(key) != self.input_size:
                 raise Exception("ConvLSTMCell: input has %d channels, expected %d" % (sum(key), self.input_size))
             self._packs[key] = ops.PackedConv(self.kernel_size, list(key) + [self.hidden_size], lstm_hid=self.hidden_size, stride=1,
-                                              pad=self.padding)
+                                              pad=self.padding, dtype=self.dtype)
         return self._packs[key]
 
     def forward_multi(self, inputs, prev_state):

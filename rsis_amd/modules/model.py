@@ -42,6 +42,7 @@ class FeatureExtractor(nn.Module):
         self.bn2 = HipBatchNorm2d(hs // 4)
         self.bn1 = HipBatchNorm2d(hs // 8)
         self._bns = None
+        ops.set_dtype(self, getattr(args, "dtype", "fp32"))      # `-dtype bf16`: bf16-operand MFMA kernels where they exist
 
     def _arm_bn_arena(self, device):
         """one zeroed float64 arena per iteration for the batch statistics of all 109 BN layers (forward + backward
@@ -104,11 +105,11 @@ class RSIS(nn.Module):
         # private per-iteration cache of the fused path (time-invariant hoisting + time-batched weight gradients)
         self._tcap = int(getattr(args, "maxseqlen", 10))
         self._tape = None
+        ops.set_dtype(self, getattr(args, "dtype", "fp32"))
         self.fused = os.environ.get("RSIS_DECODER_FUSED", "1") != "0"
 
-    def _heads(self, clstm_in, side_feats, hidden_list, out_mask=None):
-        if out_mask is None:
-            out_mask = self.conv_out(clstm_in)                           # model.py:167
+    def _heads(self, clstm_in, side_feats, hidden_list):
+        out_mask = self.conv_out(clstm_in)                               # model.py:167
         if self.dropout_cls == 0 and self.dropout_stop == 0 and ops.heads_supported(side_feats, self.fc_class, self.fc_stop):
             class_probs, stop_probs = ops.heads(side_feats, self.fc_class, self.fc_stop)   # model.py:169-182 in one launch
             return out_mask, class_probs, stop_probs, hidden_list
@@ -131,8 +132,8 @@ class RSIS(nn.Module):
         if self.fused and self.skip_mode == "concat" and self.dropout == 0 and len(skip_feats) == len(self.clstm_list):
             res = decoder_fused.decoder_levels(self, skip_feats, prev_hidden_list)
             if res is not None:
-                hidden_list, side_feats, up, out_mask = res
-                return self._heads(up, side_feats, hidden_list, out_mask)
+                hidden_list, side_feats, up = res
+                return self._heads(up, side_feats, hidden_list)
         clstm_in = [skip_feats[0]]                                       # model.py:124
         skip_feats = skip_feats[1:]
         side_feats = []

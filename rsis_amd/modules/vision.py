@@ -31,6 +31,11 @@ class HipConv2d(nn.Module):
             self.register_parameter("bias", None)
         self._pack = ops.PackedConv(self.kernel_size, [self.in_channels], stride=self.stride, pad=self.padding)
 
+    def _set_rsis_dtype(self, d):
+        """f32 or bf16 MFMA kernels for this conv (ops.set_dtype); the parameters stay fp32"""
+        if self._pack.dtype != d:
+            self._pack = ops.PackedConv(self.kernel_size, [self.in_channels], stride=self.stride, pad=self.padding, dtype=d)
+
     def forward(self, x, grad_slot=None, park_slot=None):
         return ops.conv2d([x], self.weight, self.bias, self.stride, self.padding, self._pack, grad_slot=grad_slot,
                           park_slot=park_slot)

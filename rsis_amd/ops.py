@@ -35,6 +35,20 @@ def _direct_target(param):
     return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.is_cuda) else None
 
 
+# arithmetic of the MFMA conv kernels (include/rsis_hip.h RSIS_DTYPE_*); a property of each PackedConv, set from `-dtype`
+DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPES = {"fp32": DTYPE_F32, "f32": DTYPE_F32, "float32": DTYPE_F32, "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16}
+
+
+def set_dtype(module, dtype):
+    """Switch every conv / ConvLSTM of a module tree to the f32 or bf16 MFMA kernels (parameters stay fp32)."""
+    d = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+    for m in module.modules():
+        if hasattr(m, "_set_rsis_dtype"):
+            m._set_rsis_dtype(d)
+    return module
+
+
 SUBSAMPLE_1X1 = [os.environ.get("RSIS_SUBSAMPLE_1X1", "1") != "0"]     # A/B switch, see _Conv2dFn.forward
 _PACKS = weakref.WeakSet()       # every PackedConv that holds a packed copy
 _BATCH = {"sig": None, "jobs": None, "n": 0, "blocks": 0}
@@ -91,7 +105,8 @@ class PackedConv(object):
     lstm_hid > 0: ConvLSTM `Gates` conv -- rows [i|f|o|g] are interleaved to 4*j+gate (clstm.py:47).
     """
 
-    def __init__(self, ks, segs, lstm_hid=0, stride=1, pad=None, offs=None):
+    def __init__(self, ks, segs, lstm_hid=0, stride=1, pad=None, offs=None, dtype=DTYPE_F32):
+        self.dtype = int(dtype)
         self.ks = int(ks)
         self.stride = int(stride)
         self.pad = int(ks // 2 if pad is None else pad)
@@ -108,11 +123,11 @@ class PackedConv(object):
         self._refs = None
 
     def _key(self, w):
-        return (_WEIGHT_EPOCH[0], w._version, w.data_ptr())
+        return (_WEIGHT_EPOCH[0], w._version, w.data_ptr(), self.dtype)
 
     def _job(self, w, out, dgrad):
         j = _lib.PackJob()
-        j.W, j.out, j.dgrad = w.data_ptr(), out.data_ptr(), int(dgrad)
+        j.W, j.out, j.dgrad, j.dtype = w.data_ptr(), out.data_ptr(), int(dgrad), self.dtype
         j.Cout, j.Ctot, j.ks, j.stride, j.pad = w.shape[0], w.shape[1], self.ks, self.stride, self.pad
         j.nseg, j.lstm_hid = len(self.segs), self.lstm_hid
         off = 0
@@ -131,11 +146,11 @@ class PackedConv(object):
             L = lib()
             Cout, Ctot = w.shape[0], w.shape[1]
             nseg, segs, offs = self._seg_args()
-            n = L.rsis_conv_packed_floats_fwd(Cout, self.ks, self.stride, self.pad, nseg, segs)
+            n = L.rsis_conv_packed_bytes_fwd(self.dtype, Cout, self.ks, self.stride, self.pad, nseg, segs) // 4
             if self.wp is None or self.wp.numel() != n:
-                self.wp = torch.zeros(n, dtype=torch.float32, device=w.device)     # (a size query may leave slack after the packed rows)
+                self.wp = torch.zeros(n, dtype=torch.float32, device=w.device)     # raw bytes (f32 rows or bf16 cells); may leave slack
             check(L.rsis_conv_pack_fwd(ptr(w.detach()), ptr(self.wp), Cout, Ctot, self.ks, self.stride, self.pad, nseg, segs, offs,
-                                       self.lstm_hid, stream()), "rsis_conv_pack_fwd")
+                                       self.lstm_hid, self.dtype, stream()), "rsis_conv_pack_fwd")
             if bias is not None and self.lstm_hid > 0:
                 self.bias_p = bias.detach().view(4, self.lstm_hid).t().contiguous().view(-1)
             self._key_f = key
@@ -149,11 +164,11 @@ class PackedConv(object):
             L = lib()
             Cout, Ctot = w.shape[0], w.shape[1]
             nseg, segs, offs = self._seg_args()
-            n = L.rsis_conv_packed_floats_dgrad(Cout, self.ks, self.stride, self.pad, self.cin)
+            n = L.rsis_conv_packed_bytes_dgrad(self.dtype, Cout, self.ks, self.stride, self.pad, self.cin) // 4
             if self.wd is None or self.wd.numel() != n:
                 self.wd = torch.zeros(n, dtype=torch.float32, device=w.device)
             check(L.rsis_conv_pack_dgrad(ptr(w.detach()), ptr(self.wd), Cout, Ctot, self.ks, self.stride, self.pad, nseg, segs, offs,
-                                         self.lstm_hid, stream()), "rsis_conv_pack_dgrad")
+                                         self.lstm_hid, self.dtype, stream()), "rsis_conv_pack_dgrad")
             self._key_d = key
             if self._refs is None:
                 self._refs = (weakref.ref(w), None)
@@ -169,7 +184,7 @@ def _conv_out_size(n, ks, stride, pad):
     return (n + 2 * pad - ks) // stride + 1
 
 
-def _dgrad_all(L, dy, wd, cin_packed, ks, stride, pad, srcs, Hx, Wx, addend=None, inplace=False):
+def _dgrad_all(L, dy, wd, cin_packed, ks, stride, pad, srcs, Hx, Wx, addend=None, inplace=False, dtype=DTYPE_F32):
     """One dgrad launch producing the gradient of every concat source (+ addend: another consumer's gradient of the input;
     inplace: the strided 1x1 gradient is accumulated INTO the addend tensor, which becomes the result)."""
     B, Cout, Hy, Wy = dy.shape
@@ -177,7 +192,7 @@ def _dgrad_all(L, dy, wd, cin_packed, ks, stride, pad, srcs, Hx, Wx, addend=None
     shapes = [tuple(s.shape) if torch.is_tensor(s) else tuple(s) for s in srcs]
     dxs = [addend] if inplace else [torch.empty(sh, dtype=torch.float32, device=dy.device) for sh in shapes]
     check(L.rsis_conv2d_dgrad(ptr(dy), B, Cout, Hy, Wy, ptr(wd), cin_packed, ks, stride, pad, ptr_array(dxs),
-                              int_array([sh[1] for sh in shapes]), len(shapes), Hx, Wx, ptr(addend), FORCE_TILE[0], stream()),
+                              int_array([sh[1] for sh in shapes]), len(shapes), Hx, Wx, ptr(addend), FORCE_TILE[0], dtype, stream()),
           "rsis_conv2d_dgrad")
     return dxs
 
@@ -233,14 +248,14 @@ def grad_tap(x, slot):
     return _GradTapFn.apply(x, slot)
 
 
-def _wgrad_all(L, dy, srcs, w_shape, ks, stride, pad, lstm_hid, out=None):
+def _wgrad_all(L, dy, srcs, w_shape, ks, stride, pad, lstm_hid, out=None, dtype=DTYPE_F32):
     B, Cout, Ho, Wo = dy.shape
     Ctot = w_shape[1]
     dW = out if out is not None else torch.zeros(w_shape, dtype=torch.float32, device=dy.device)
     c_off = 0
     for s in srcs:
         _, Cs, H, W = s.shape
-        check(L.rsis_conv2d_wgrad(ptr(dy), ptr(s), ptr(dW), B, Cs, H, W, Cout, Ho, Wo, ks, stride, pad, Ctot, c_off, lstm_hid,
+        check(L.rsis_conv2d_wgrad(ptr(dy), ptr(s), ptr(dW), B, Cs, H, W, Cout, Ho, Wo, ks, stride, pad, Ctot, c_off, lstm_hid, dtype,
                                   stream()), "rsis_conv2d_wgrad")
         c_off += Cs
     return dW
@@ -265,7 +280,7 @@ class _Conv2dFn(torch.autograd.Function):
         # of the input instead of the gather implicit GEMM, and keep THAT copy for the weight gradient (1/s^2 of the input,
         # tile-aligned for the LDS-DMA weight-gradient kernel).  Same packed weights: a 1x1 pack does not depend on the stride.
         ctx.in_shape = None
-        if ks == 1 and stride > 1 and pad == 0 and nsrc == 1 and SUBSAMPLE_1X1[0]:
+        if ks == 1 and stride > 1 and pad == 0 and nsrc == 1 and (SUBSAMPLE_1X1[0] or pack.dtype == DTYPE_BF16):
             ctx.in_shape = tuple(srcs[0].shape)
             srcs = [srcs[0][:, :, ::stride, ::stride].contiguous()]
             H, W, stride_k = Ho, Wo, 1
@@ -275,7 +290,7 @@ class _Conv2dFn(torch.autograd.Function):
         # forward within the 1e-4 parity bar of the reference (the split sum moves the deepest skip conv by ~1e-5 relative)
         tile = FORCE_TILE[0] + (100 if pack.training_call else 0)
         check(L.rsis_conv2d_fwd(ptr_array(srcs), int_array([s.shape[1] for s in srcs]), nsrc, B, H, W, ptr(wp), Cout, ks, stride_k,
-                                pad, ptr(bias.detach() if bias is not None else None), None, ptr(out), Ho, Wo, tile, stream()),
+                                pad, ptr(bias.detach() if bias is not None else None), None, ptr(out), Ho, Wo, tile, pack.dtype, stream()),
               "rsis_conv2d_fwd")
         ctx.pack, ctx.stride, ctx.pad, ctx.nsrc = pack, stride, pad, nsrc
         ctx.has_bias = bias is not None
@@ -308,7 +323,7 @@ class _Conv2dFn(torch.autograd.Function):
                     else:
                         extra, addend = addend, None
             dxs = _dgrad_all(L, dy, wd, ctx.pack.cin, ks, ctx.stride, ctx.pad, in_shapes, in_shapes[0][2], in_shapes[0][3], addend,
-                             inplace)
+                             inplace, dtype=ctx.pack.dtype)
             if extra is not None:
                 dxs[0].add_(extra)
             for i in range(nsrc):
@@ -332,7 +347,7 @@ class _Conv2dFn(torch.autograd.Function):
             return (None, None, None, None, None) + tuple(grads)
         if want_w:
             tgt = _direct_target(ctx.wparam)
-            dW = _wgrad_all(L, dy, srcs, tuple(weight.shape), ks, 1 if sub else ctx.stride, ctx.pad, 0, out=tgt)
+            dW = _wgrad_all(L, dy, srcs, tuple(weight.shape), ks, 1 if sub else ctx.stride, ctx.pad, 0, out=tgt, dtype=ctx.pack.dtype)
             grads[nsrc] = None if tgt is not None else dW
         if want_b:
             tgt = _direct_target(ctx.bparam)
@@ -379,8 +394,8 @@ class _ConvLSTMFn(torch.autograd.Function):
         # simply by passing the x sources only (the kernel walks the K-tiles of the sources it is given).
         segs = [s.shape[1] for s in srcs]
         check(L.rsis_convlstm_fwd(ptr_array(srcs), int_array(segs), len(srcs), B, H, W, ptr(wp), ptr(pack.bias_p), None,
-                                  ptr(c_prev) if has_state else None, ptr(h), ptr(c), ptr(act), hid, ks, pad, FORCE_TILE[0], stream()),
-              "rsis_convlstm_fwd")
+                                  ptr(c_prev) if has_state else None, ptr(h), ptr(c), ptr(act), hid, ks, pad, FORCE_TILE[0], pack.dtype,
+                                  stream()), "rsis_convlstm_fwd")
         ctx.pack, ctx.pad, ctx.nx, ctx.has_state = pack, pad, nx, has_state
         if need_grad:
             ctx.save_for_backward(weight, act, c, c_prev if has_state else None, *srcs)
@@ -404,7 +419,7 @@ class _ConvLSTMFn(torch.autograd.Function):
         need_src = list(ctx.needs_input_grad[4:4 + nx]) + ([ctx.needs_input_grad[4 + nx]] if has_state else [])
         if any(need_src):
             wd = ctx.pack.dgrad(weight)
-            dxs = _dgrad_all(L, da, wd, ctx.pack.cin, ks, 1, ctx.pad, srcs, H, W)
+            dxs = _dgrad_all(L, da, wd, ctx.pack.cin, ks, 1, ctx.pad, srcs, H, W, dtype=ctx.pack.dtype)
             for i in range(nx):
                 if need_src[i]:
                     grads[i] = dxs[i]
@@ -414,7 +429,7 @@ class _ConvLSTMFn(torch.autograd.Function):
             grads[nx + 1] = dc_prev
         if ctx.needs_input_grad[4 + nx + 2]:
             # zero state: the h_prev channels of dW get no contribution (h_prev == 0)
-            grads[nx + 2] = _wgrad_all(L, da, srcs, tuple(weight.shape), ks, 1, ctx.pad, hid)
+            grads[nx + 2] = _wgrad_all(L, da, srcs, tuple(weight.shape), ks, 1, ctx.pad, hid, dtype=ctx.pack.dtype)
         if ctx.needs_input_grad[4 + nx + 3]:
             db = torch.zeros(4 * hid, dtype=torch.float32, device=da.device)
             check(L.rsis_bias_grad(ptr(da), ptr(db), B, 4 * hid, H * W, hid, stream()), "rsis_bias_grad")
@@ -598,12 +613,14 @@ def maxpool3x3s2(x, grad_slot=None):
     return _MaxPool3x3s2Fn.apply(x, grad_slot)
 
 
-def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gscale=1.0):
-    """torch.optim.Adam step on flat fp32 buffers (in place; bumps the packed-weight epoch)."""
+def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gscale=1.0, step_dev=None, bump=True):
+    """torch.optim.Adam step on flat fp32 buffers (in place; bumps the packed-weight epoch).  step_dev: optional int32 device
+    tensor (one element) holding the update count -- read by the kernel instead of `step` (hipGraph replay)."""
     require_cuda_f32(p, g, m, v)
     check(lib().rsis_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
-                               float(weight_decay), int(step), float(gscale), stream()), "rsis_adam_step")
-    bump_weight_epoch()
+                               float(weight_decay), int(step), float(gscale), ptr(step_dev), stream()), "rsis_adam_step")
+    if bump:
+        bump_weight_epoch()
 
 
 def assign_min_cost(scores):
@@ -730,77 +747,6 @@ def heads_supported(sides, fc_class, fc_stop):
 def heads(sides, fc_class, fc_stop):
     """(class_probs (B, ncls), stop logits (B, 1)) of reference RSIS.forward's tail from the list of pooled side features"""
     return _HeadsFn.apply(len(sides), *sides, fc_class.weight, fc_class.bias, fc_stop.weight, fc_stop.bias)
-
-
-def upconv_out_supported(h, weight, size):
-    """True when conv_out(upsample(h, size)) can run as the fused kernels (rsis_upconv_out_*)."""
-    return bool(h.is_cuda and h.dtype == torch.float32 and weight.shape[0] == 1 and tuple(weight.shape[2:]) == (3, 3) and
-                lib().rsis_upconv_out_supported(int(weight.shape[1]), int(h.shape[2]), int(h.shape[3]), int(size[0]), int(size[1])))
-
-
-class _SideUpOutFn(torch.autograd.Function):
-    """The three consumers of the LAST level's hidden state besides the recurrence (model.py:143,163-167): the global max-pool
-    side feature and out_mask = conv_out(upsample x2 (h)), as ONE autograd node.  The up-sampled hidden state (Cin channels at
-    the output resolution) is never materialised: forward, data gradient and weight gradient each interpolate what they need
-    in LDS (rsis_upconv_out_*); the pooled gradient is added at the arg-max pixel in place."""
-
-    @staticmethod
-    def forward(ctx, h, weight, bias, size):
-        h = _contig(h)
-        weight = _contig(weight)
-        B, C, Hi, Wi = h.shape
-        Ho, Wo = int(size[0]), int(size[1])
-        L = lib()
-        side = torch.empty((B, C, 1, 1), dtype=torch.float32, device=h.device)
-        arg = torch.empty((B, C), dtype=torch.int32, device=h.device)
-        check(L.rsis_global_maxpool_fwd(ptr(h), ptr(side), ptr(arg), B * C, Hi * Wi, stream()), "rsis_global_maxpool_fwd")
-        out = torch.empty((B, 1, Ho, Wo), dtype=torch.float32, device=h.device)
-        check(L.rsis_upconv_out_fwd(ptr(h), ptr(weight), ptr(bias), ptr(out), B, C, Hi, Wi, Ho, Wo, stream()), "rsis_upconv_out_fwd")
-        ctx.dims = (B, C, Hi, Wi, Ho, Wo)
-        ctx.wparam, ctx.bparam = weight, bias
-        ctx.save_for_backward(h, weight, arg)
-        return side, out
-
-    @staticmethod
-    def backward(ctx, dside, dout):
-        h, weight, arg = ctx.saved_tensors
-        B, C, Hi, Wi, Ho, Wo = ctx.dims
-        L = lib()
-        dh = dW = db = None
-        if dout is not None:
-            dout = _contig(dout)
-            need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-            need_b = ctx.bparam is not None and ctx.needs_input_grad[2]
-            if need_h:
-                dh = torch.empty_like(h)
-            tw = tb = None
-            if need_w:
-                tw = _direct_target(ctx.wparam)
-                dW = tw if tw is not None else torch.zeros_like(weight)
-            if need_b:
-                tb = _direct_target(ctx.bparam)
-                db = tb if tb is not None else torch.zeros(1, dtype=torch.float32, device=dout.device)
-            if need_b and not need_w:     # (the kernel produces the bias gradient next to the weight gradient)
-                db.add_(dout.sum()) if tb is not None else db.copy_(dout.sum().reshape(1))
-            check(L.rsis_upconv_out_bwd(ptr(dout), ptr(h), ptr(weight), ptr(dh), ptr(dW), ptr(db) if need_w else None, B, C, Hi, Wi,
-                                        Ho, Wo, stream()), "rsis_upconv_out_bwd")
-            if tw is not None:
-                dW = None                 # accumulated straight into weight.grad
-            if tb is not None:
-                db = None
-        if dside is not None and ctx.needs_input_grad[0]:
-            dside = _contig(dside)
-            if dh is None:
-                dh = torch.empty_like(h)
-                check(L.rsis_global_maxpool_bwd(ptr(dside), ptr(arg), ptr(dh), B * C, Hi * Wi, stream()), "rsis_global_maxpool_bwd")
-            else:
-                check(L.rsis_global_maxpool_bwd_add(ptr(dside), ptr(arg), ptr(dh), B * C, Hi * Wi, stream()), "rsis_global_maxpool_bwd_add")
-        return dh, dW, db, None
-
-
-def side_upconv_out(h, weight, bias, size):
-    """(global max-pool of h, conv_out(upsample(h, size))) -- see _SideUpOutFn."""
-    return _SideUpOutFn.apply(h, weight, bias, (int(size[0]), int(size[1])))
 
 
 class _LossTailFn(torch.autograd.Function):

@@ -14,12 +14,23 @@ from . import ops
 
 
 class FlatGroup(object):
-    """A parameter group living in one flat buffer. `params` keep their identity (module attributes still work)."""
+    """A parameter group living in one flat buffer. `params` keep their identity (module attributes still work).
 
-    def __init__(self, params, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, name="group"):
+    torch.optim.Adam semantics per PARAMETER (the reference's optimizer, utils/utils.py:83-84): a parameter that has never
+    received a gradient (`p.grad is None` there) is skipped entirely -- no weight decay, no moment update, no step count --
+    and its bias correction starts at step 1 when its first gradient arrives.  Here every `.grad` is a view of the flat
+    gradient buffer, so "has a gradient" is tracked explicitly: parameters listed in `lazy` start inactive and are switched on
+    by `mark_has_grad` (train.runIter does it for fc_class / fc_stop when their loss is enabled, train.py:173-176); once active
+    a parameter stays active, as a zero-filled `.grad` does in the reference.  Consecutive parameters with the same state are
+    stepped by one kernel launch.
+
+    lr_mult: optional {param: multiplier} -- the reference hands duplicated trunk tensors to Adam (utils/utils.py:34-52,
+    SURVEY.md Appendix C), i.e. it applies 1/3/4 identical updates per step; pass utils.base_param_multiplicity(...) to reproduce
+    that as a per-range learning-rate multiplier (first-order identical; off by default)."""
+
+    def __init__(self, params, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, name="group", lazy=(), lr_mult=None):
         self.params = [p for p in params if p.requires_grad]
         self.lr, self.weight_decay, self.betas, self.eps, self.name = lr, weight_decay, betas, eps, name
-        self.step_count = 0
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
@@ -36,7 +47,50 @@ class FlatGroup(object):
                 p.grad = self.flat_g[off:off + k].view_as(p)
                 self.offsets.append((off, k))
                 off += k
+        lazy_ids = set(id(p) for p in lazy)
+        self.active = [id(p) not in lazy_ids for p in self.params]
+        self.steps = [0] * len(self.params)                 # torch.optim.Adam's per-parameter state['step']
+        self.mult = [float(lr_mult.get(p, 1.0)) if lr_mult else 1.0 for p in self.params]
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._ranges = None
+        self._dev = None          # (ranges, int32 device counters) while a captured graph owns the step counts
         ops.bump_weight_epoch()
+
+    # ---- torch.optim.Adam's "skip parameters without a gradient" ----
+    def mark_has_grad(self, params):
+        for p in params:
+            i = self._index.get(id(p))
+            if i is not None and not self.active[i]:
+                self.active[i] = True
+                self._ranges = None
+
+    @property
+    def step_count(self):
+        return max(self.steps) if self.steps else 0
+
+    @step_count.setter
+    def step_count(self, v):
+        self.steps = [int(v)] * len(self.steps)
+        self._ranges = None
+
+    def state_key(self):
+        """changes whenever the launch ranges change (a captured graph is valid for one key only)"""
+        return tuple(self.active)
+
+    def ranges(self):
+        """[(offset, numel, step, lr multiplier, [param indices])] of the ACTIVE parameters, consecutive equal states merged"""
+        if self._ranges is None:
+            out = []
+            for i, (off, k) in enumerate(self.offsets):
+                if not self.active[i]:
+                    continue
+                if out and out[-1][0] + out[-1][1] == off and out[-1][2] == self.steps[i] and out[-1][3] == self.mult[i]:
+                    last = out[-1]
+                    out[-1] = (last[0], last[1] + k, last[2], last[3], last[4] + [i])
+                else:
+                    out.append((off, k, self.steps[i], self.mult[i], [i]))
+            self._ranges = out
+        return self._ranges
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -45,50 +99,95 @@ class FlatGroup(object):
                 p.grad = self.flat_g[off:off + k].view_as(p)
 
     def step(self, gscale=1.0):
-        self.step_count += 1
-        if self.flat_p.is_cuda:
-            ops.adam_step_flat(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
-                               self.eps, self.weight_decay, self.step_count, gscale)
-        else:
+        if not self.flat_p.is_cuda:
             raise RuntimeError("FlatGroup.step: the fused Adam step runs on the GPU only")
+        if self._dev is not None:
+            # graph mode: the update counts live on the device and are advanced on the stream (captured + replayed)
+            ranges, counters = self._dev
+            counters.add_(1)
+            for k, (off, n, _st, mult, _idx) in enumerate(ranges):
+                ops.adam_step_flat(self.flat_p[off:off + n], self.flat_g[off:off + n], self.exp_avg[off:off + n],
+                                   self.exp_avg_sq[off:off + n], self.lr * mult, self.betas[0], self.betas[1], self.eps,
+                                   self.weight_decay, 1, gscale, step_dev=counters[k:k + 1], bump=False)
+            ops.bump_weight_epoch()
+            return
+        ranges = self.ranges()
+        for off, n, st, mult, idx in ranges:
+            ops.adam_step_flat(self.flat_p[off:off + n], self.flat_g[off:off + n], self.exp_avg[off:off + n],
+                               self.exp_avg_sq[off:off + n], self.lr * mult, self.betas[0], self.betas[1], self.eps,
+                               self.weight_decay, st + 1, gscale, bump=False)
+            for i in idx:
+                self.steps[i] = st + 1
+        self._ranges = None if len(ranges) > 1 else [(r[0], r[1], r[2] + 1, r[3], r[4]) for r in ranges]
+        ops.bump_weight_epoch()
+
+    # ---- hipGraph support (train.GraphedStep) ----
+    def begin_graph(self):
+        """freeze the launch ranges and move their update counts to the device; call before capturing step()"""
+        ranges = [tuple(r) for r in self.ranges()]
+        self._dev = (ranges, torch.tensor([r[2] for r in ranges], dtype=torch.int32, device=self.flat_p.device))
+
+    def note_replay(self):
+        """a captured step() was replayed: mirror its count increments on the host"""
+        for _off, _n, _st, _m, idx in self._dev[0]:
+            for i in idx:
+                self.steps[i] += 1
+        self._ranges = None
+
+    def end_graph(self):
+        self._dev = None
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr,
-                "weight_decay": self.weight_decay, "betas": self.betas, "eps": self.eps}
+        return {"step": self.step_count, "steps": list(self.steps), "active": list(self.active), "exp_avg": self.exp_avg,
+                "exp_avg_sq": self.exp_avg_sq, "lr": self.lr, "weight_decay": self.weight_decay, "betas": self.betas, "eps": self.eps}
 
     def load_state_dict(self, sd):
         if "param_groups" in sd:
             return self._load_torch_adam(sd)
-        self.step_count = int(sd["step"])
+        if self._dev is not None:
+            raise RuntimeError("FlatGroup.load_state_dict: leave graph mode first (end_graph)")
+        if "steps" in sd and len(sd["steps"]) == len(self.steps):
+            self.steps = [int(v) for v in sd["steps"]]
+            self.active = [bool(v) for v in sd["active"]]
+        else:                                   # round-1 checkpoints: one count for the whole group
+            self.steps = [int(sd["step"])] * len(self.steps)
+            self.active = [True] * len(self.steps)
+        self._ranges = None
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        return True
 
     def _load_torch_adam(self, sd):
         """torch.optim.Adam.state_dict() as the reference saved it (utils/utils.py:93-94): per-parameter moments in
-        param_groups order.  They are adopted when they line up with this group's parameters one to one; otherwise
-        (e.g. the reference's trunk group lists tensors several times) the moments restart at zero."""
+        param_groups order.  They are adopted when they line up with this group's parameters one to one (a parameter without
+        an entry had no gradient yet: it stays inactive); otherwise (e.g. the reference's trunk group lists tensors several
+        times) the moments restart at zero."""
         ids = [i for g in sd.get("param_groups", []) for i in g["params"]]
         st = sd.get("state", {})
-        ok = len(ids) == len(self.params) and all(i in st and tuple(st[i]["exp_avg"].shape) == tuple(p.shape)
+        ok = len(ids) == len(self.params) and all(i not in st or tuple(st[i]["exp_avg"].shape) == tuple(p.shape)
                                                   for i, p in zip(ids, self.params))
-        if not ok:
+        if not ok or not st:
             if st:
                 print("FlatGroup(%s): optimizer state does not match the parameter list; moments restart at zero" % self.name)
             return False
-        steps = []
-        for i, (off, k) in zip(ids, self.offsets):
-            self.exp_avg[off:off + k].copy_(st[i]["exp_avg"].reshape(-1))
-            self.exp_avg_sq[off:off + k].copy_(st[i]["exp_avg_sq"].reshape(-1))
-            steps.append(int(st[i]["step"]))
-        self.step_count = max(steps) if steps else 0
+        for k, (i, (off, n)) in enumerate(zip(ids, self.offsets)):
+            if i in st:
+                self.exp_avg[off:off + n].copy_(st[i]["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st[i]["exp_avg_sq"].reshape(-1))
+                self.steps[k] = int(st[i]["step"])
+                self.active[k] = True
+            else:
+                self.steps[k], self.active[k] = 0, False
+        self._ranges = None
         return True
 
 
 class FlatAdam(object):
-    """torch.optim.Adam semantics (incl. L2 weight decay) over FlatGroups; `.step()` / `.zero_grad()` / state_dict."""
+    """torch.optim.Adam semantics (incl. L2 weight decay, parameters without a gradient skipped) over a FlatGroup;
+    `.step()` / `.zero_grad()` / state_dict."""
 
-    def __init__(self, params, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, name="adam"):
-        self.group = FlatGroup(list(params), lr, weight_decay, betas, eps, name)
+    def __init__(self, params, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, name="adam", lazy=(), lr_mult=None):
+        self.group = FlatGroup(list(params), lr, weight_decay, betas, eps, name, lazy=lazy, lr_mult=lr_mult)
         self.gscale = 1.0
 
     def zero_grad(self):
@@ -97,11 +196,14 @@ class FlatAdam(object):
     def step(self):
         self.group.step(self.gscale)
 
+    def mark_has_grad(self, params):
+        self.group.mark_has_grad(params)
+
     def state_dict(self):
         return self.group.state_dict()
 
     def load_state_dict(self, sd):
-        self.group.load_state_dict(sd)
+        return self.group.load_state_dict(sd)
 
 
 class BucketedAllReduce(object):

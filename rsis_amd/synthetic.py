@@ -40,9 +40,9 @@ def synthetic_batch(seed, B, H, W, gt_maxseqlen=20, n_inst=12, num_classes=21, d
 class SyntheticLoader(object):
     """Iterates `n_batches` resident synthetic batches (a few distinct ones, cycled)."""
 
-    def __init__(self, args, n_batches, seed, device="cuda", distinct=2, rank=0):
+    def __init__(self, args, n_batches, seed, device="cuda", distinct=2, rank=0, batch_size=None):
         H = W = args.imsize
-        self.batches = [synthetic_batch(seed + 1000 * rank + i, args.batch_size, H, W, args.gt_maxseqlen,
+        self.batches = [synthetic_batch(seed + 1000 * rank + i, batch_size or args.batch_size, H, W, args.gt_maxseqlen,
                                         getattr(args, "synthetic_instances", 12), args.num_classes, device)
                         for i in range(distinct)]
         self.n = n_batches

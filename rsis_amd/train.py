@@ -29,7 +29,8 @@ from .optim import BucketedAllReduce, FlatAdam
 from .synthetic import SyntheticLoader
 from .utils.hungarian import match_indices, softIoU_matrix
 from .utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
-from .utils.utils import (check_parallel, get_base_params, get_skip_params, load_checkpoint, make_dir, save_checkpoint)
+from .utils.utils import (base_param_multiplicity, check_parallel, get_base_params, get_skip_params, load_checkpoint, make_dir,
+                          save_checkpoint)
 
 
 def _masked_mean(costs, sw):
@@ -49,9 +50,11 @@ def steps_to_run(args, sw_mask):
 
 
 def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits, optims, mode="train", reducer=None,
-            sync_losses=True, t_run=None):
+            sync_losses=True, t_run=None, want_outs=True):
     """Runs forward, computes loss and (if train mode) updates parameters for the provided batch (train.py:54-197).
-    Returns (losses [total, iou, stop, class], outs [sigmoid(masks), class probs], perms [y_mask_perm, y_class_perm])."""
+    Returns (losses [total, iou, stop, class], outs [sigmoid(masks), class probs], perms [y_mask_perm, y_class_perm]).
+    want_outs=False (training loops that only log the losses, as the reference's trainIters does: train.py:344-356): the
+    sigmoid of all T full-resolution masks (train.py:191) is not computed and outs[0] holds the raw logits."""
     from .utils.hungarian import MaskedNLL, StableBalancedMaskedBCE, softIoU
     mask_siou, class_crit, stop_xentropy = crits
     enc_opt, dec_opt = optims
@@ -134,6 +137,13 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
             reducer.reset()
         # FlatAdam keeps every .grad as a zeroed view of one flat buffer: let the wgrad kernels accumulate into it directly
         direct = isinstance(enc_opt, FlatAdam) and isinstance(dec_opt, FlatAdam)
+        if isinstance(dec_opt, FlatAdam):
+            # torch.optim.Adam skips parameters whose grad is None: the heads get their first gradient when their loss is
+            # switched on (train.py:173-176); until then they are not touched (no weight decay, no moments, no step count)
+            if args.use_class_loss:
+                dec_opt.mark_has_grad(decoder.fc_class.parameters())
+            if args.use_stop_loss:
+                dec_opt.mark_has_grad(decoder.fc_stop.parameters())
         prev, ops.DIRECT_GRAD[0] = ops.DIRECT_GRAD[0], direct
         try:
             loss.backward()                                           # :184
@@ -151,7 +161,7 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
     losses = [loss.detach(), loss_mask_iou.detach(), loss_stop.detach(), loss_class.detach()]
     if sync_losses:
         losses = [float(v) for v in torch.stack(losses).cpu()]        # :189 (one D2H for all four)
-    outs = [torch.sigmoid(out_masks.detach()), out_classes.detach()]  # :191-192
+    outs = [torch.sigmoid(out_masks.detach()) if want_outs else out_masks.detach(), out_classes.detach()]  # :191-192
     perms = [y_mask_perm, y_class_perm]
     return losses, outs, perms
 
@@ -178,21 +188,109 @@ def init_distributed():
 def build_optimizers(args, encoder, decoder):
     """train.py:236-240: dec_opt = decoder + skip convs/BNs (lr), enc_opt = trunk (lr_cnn).  Fused flat Adam.
     The reference's get_base_params yields trunk tensors 1-4 times, i.e. an effective 1x/3x/4x
-    lr_cnn; that quirk is NOT reproduced here (each tensor is stepped once)."""
+    lr_cnn; `--enc_lr_quirk` reproduces it as a per-tensor learning-rate multiplier, the default steps each tensor once."""
     if args.optim != "adam" or args.optim_cnn != "adam":
         raise Exception("only -optim adam / -optim_cnn adam run on the fused HIP optimizer")
     decoder_params = list(decoder.parameters()) + list(get_skip_params(encoder))
-    dec_opt = FlatAdam(decoder_params, lr=args.lr, weight_decay=args.weight_decay, name="dec")
-    enc_opt = FlatAdam(list(get_base_params(args, encoder)), lr=args.lr_cnn, weight_decay=args.weight_decay_cnn, name="enc")
+    # fc_class / fc_stop receive no gradient until their loss is enabled: torch.optim.Adam leaves such parameters alone
+    lazy = [] if args.use_class_loss else list(decoder.fc_class.parameters())
+    lazy += [] if args.use_stop_loss else list(decoder.fc_stop.parameters())
+    dec_opt = FlatAdam(decoder_params, lr=args.lr, weight_decay=args.weight_decay, name="dec", lazy=lazy)
+    mult = base_param_multiplicity(encoder) if getattr(args, "enc_lr_quirk", False) else None
+    enc_opt = FlatAdam(list(get_base_params(args, encoder)), lr=args.lr_cnn, weight_decay=args.weight_decay_cnn, name="enc",
+                       lr_mult=mult)
     return enc_opt, dec_opt
 
 
-def init_dataloaders(args, rank=0):
+class GraphedStep(object):
+    """One training iteration (runIter: encoder, T decoder steps, matching, losses, backward, gradient all-reduce, both Adam
+    steps, weight repack) captured ONCE as a hipGraph and replayed: the ~1000 kernel launches of a step cost the host one
+    hipGraphLaunch instead of ~35 us of Python each (the reference's train.py:85-115 loop is host-bound in the same way).
+    The first `warm` calls run eagerly on a side stream (they are real training steps), the next one captures.  A capture is
+    valid for one (input shapes, t_run, loss switches, update_encoder, active parameter set) key; `step_for` keeps one per key.
+    Inputs are copied into static buffers; the returned losses / outs / perms are static device tensors overwritten by the
+    next replay."""
+
+    def __init__(self, args, encoder, decoder, crits, optims, reducer=None, warm=2, pool=None):
+        self.args, self.encoder, self.decoder, self.crits, self.optims, self.reducer = args, encoder, decoder, crits, optims, reducer
+        self.warm, self.pool = warm, pool
+        self.graph, self.static, self.result, self.t_run = None, None, None, None
+        self.stream = torch.cuda.Stream()
+        self.n_eager = 0
+        self._bns = None
+        self.failed = None
+
+    def _run(self, batch, t_run):
+        return runIter(self.args, self.encoder, self.decoder, *batch, self.crits, self.optims, mode="train", reducer=self.reducer,
+                       sync_losses=False, t_run=t_run, want_outs=False)
+
+    def _groups(self):
+        return [o.group for o in self.optims if isinstance(o, FlatAdam)]
+
+    def __call__(self, batch, t_run):
+        if self.graph is None and self.failed is None and self.n_eager >= self.warm:
+            self._capture(batch, t_run)
+        if self.graph is None:                     # warm-up steps (or capture not possible): plain eager iterations
+            self.n_eager += 1
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                res = self._run(batch, t_run)
+            torch.cuda.current_stream().wait_stream(self.stream)
+            return res
+        if t_run != self.t_run:
+            raise RuntimeError("GraphedStep: captured for t_run=%d, called with %d" % (self.t_run, t_run))
+        for dst, src in zip(self.static, batch):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        for g in self._groups():
+            if self.args.update_encoder or g is not self.optims[0].group:
+                g.note_replay()
+        for m in self._bns:                        # HipBatchNorm2d counts its training calls on the host
+            m._nbt_pending += 1
+        return self.result
+
+    def _capture(self, batch, t_run):
+        from .modules.vision import HipBatchNorm2d
+        self.static = [t.clone() for t in batch]
+        self.t_run = t_run
+        self._bns = [m for mod in (self.encoder, self.decoder) for m in mod.modules() if isinstance(m, HipBatchNorm2d)]
+        pend = [m._nbt_pending for m in self._bns]
+        groups = self._groups()
+        for g in groups:
+            g.begin_graph()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
+                self.result = self._run(self.static, t_run)
+            self.graph = graph
+        except Exception as e:  # noqa: BLE001  (capture refused, e.g. by a collective backend: stay eager)
+            self.failed = repr(e)
+            for g in groups:
+                g.end_graph()
+            self.static = None
+        for m, v in zip(self._bns, pend):          # the capture pass itself executed nothing
+            m._nbt_pending = v
+
+    def release(self):
+        for g in self._groups():
+            g.end_graph()
+        self.graph = self.result = self.static = None
+
+
+def init_dataloaders(args, rank=0, world=1):
+    """`-batch_size` is the GLOBAL batch, as in the reference (`-batch_size B -ngpus N` under nn.DataParallel splits B over the
+    GPUs, train.py:269-274): every rank of a torchrun job takes B / world samples, so reference hyper-parameters carry over.
+    (The loss is the mean of the per-rank masked means -- equal to the global masked mean for equal shard sizes.)"""
     if not getattr(args, "synthetic", False):
         raise Exception("only --synthetic data is wired in this build (the dataset readers of the reference's "
                         "src/dataloader are host-side I/O outside the hot path: SURVEY.md section 8(f) row N3)")
-    loaders = {"train": SyntheticLoader(args, args.synthetic_batches, args.seed, rank=rank),
-               "val": SyntheticLoader(args, max(1, args.synthetic_batches // 4), args.seed + 7, rank=rank)}
+    if args.batch_size % world != 0:
+        raise Exception("-batch_size %d (the global batch) is not divisible by the %d ranks" % (args.batch_size, world))
+    per_rank = args.batch_size // world
+    loaders = {"train": SyntheticLoader(args, args.synthetic_batches, args.seed, rank=rank, batch_size=per_rank),
+               "val": SyntheticLoader(args, max(1, args.synthetic_batches // 4), args.seed + 7, rank=rank, batch_size=per_rank)}
     return loaders, ["<eos>"] + ["class%d" % i for i in range(1, args.num_classes)]
 
 
@@ -201,6 +299,7 @@ def trainIters(args):
     epoch_resume = 0
     model_dir = os.path.join(args.models_root, args.model_name)
     enc_opt_dict = dec_opt_dict = None
+    resuming = bool(args.resume)          # (args is replaced by the checkpoint's namespace below, whose `resume` is False)
     if args.resume:                                                       # train.py:204-215
         encoder_dict, decoder_dict, enc_opt_dict, dec_opt_dict, load_args = load_checkpoint(args.model_name, args.use_gpu,
                                                                                             root=args.models_root)
@@ -209,8 +308,9 @@ def trainIters(args):
         encoder_dict, decoder_dict = check_parallel(encoder_dict, decoder_dict)
         encoder.load_state_dict(encoder_dict)
         decoder.load_state_dict(decoder_dict)
-        for k in ("synthetic", "synthetic_batches", "synthetic_instances", "models_root", "max_epoch", "log_term"):
-            setattr(load_args, k, getattr(args, k))
+        for k in ("synthetic", "synthetic_batches", "synthetic_instances", "models_root", "max_epoch", "log_term", "graph", "dtype",
+                  "enc_lr_quirk"):
+            setattr(load_args, k, getattr(args, k, None))
         args = load_args
     elif args.transfer:                                                   # train.py:217-224
         encoder_dict, decoder_dict, enc_opt_dict, dec_opt_dict, load_args = load_checkpoint(args.transfer_from, args.use_gpu,
@@ -236,10 +336,15 @@ def trainIters(args):
         make_dir(model_dir)
         pickle.dump(args, open(os.path.join(model_dir, "args.pkl"), "wb"))   # train.py:234
     enc_opt, dec_opt = build_optimizers(args, encoder, decoder)
-    if (args.resume or args.transfer) and enc_opt_dict is not None and "exp_avg" in enc_opt_dict:
-        enc_opt.load_state_dict(enc_opt_dict)
-        if not (args.transfer and dec_opt_dict["exp_avg"].numel() != dec_opt.group.exp_avg.numel()):
-            dec_opt.load_state_dict(dec_opt_dict)
+    if (resuming or args.transfer) and enc_opt_dict is not None:
+        # own format or the reference's torch.optim.Adam state_dict ('state' / 'param_groups'); load_state_dict dispatches
+        ok_e = enc_opt.load_state_dict(enc_opt_dict)
+        new_head = args.transfer and "exp_avg" in dec_opt_dict and dec_opt_dict["exp_avg"].numel() != dec_opt.group.exp_avg.numel()
+        ok_d = False if new_head else dec_opt.load_state_dict(dec_opt_dict)
+        if rank == 0 and not (ok_e and ok_d):
+            print("optimizer state: %s restored, %s restart from zero moments"
+                  % (", ".join(n for n, ok in (("encoder", ok_e), ("decoder", ok_d)) if ok) or "nothing",
+                     ", ".join(n for n, ok in (("encoder", ok_e), ("decoder", ok_d)) if not ok)))
     reducer = BucketedAllReduce([dec_opt.group, enc_opt.group]) if world > 1 else None
     if not args.log_term and rank == 0:                                   # train.py:253-256
         print("Training logs will be saved to:", os.path.join(model_dir, "train.log"))
@@ -256,12 +361,16 @@ def trainIters(args):
     mt_val = -1
     if args.curriculum_learning and epoch_resume == 0:
         args.limit_seqlen_to = 2                                          # train.py:299-300
-    loaders, _class_names = init_dataloaders(args, rank)
+    loaders, _class_names = init_dataloaders(args, rank, world)
+    graphs = {}
 
     def reload_best():                                                    # train.py:456-460 etc.
         e_d, d_d, eo, do, _ = load_checkpoint(args.model_name, args.use_gpu, root=args.models_root)
         encoder.load_state_dict(e_d)
         decoder.load_state_dict(d_d)
+        if graphs.get("step") is not None:      # the optimizer state is about to change behind the captured graph
+            graphs["step"].release()
+            graphs.clear()
         enc_opt.load_state_dict(eo)
         dec_opt.load_state_dict(do)
         ops.bump_weight_epoch()
@@ -288,8 +397,18 @@ def trainIters(args):
             n_img, t_split = 0, time.time()
             for batch_idx, (x, y_mask, y_class, sw_mask, sw_class) in enumerate(loaders[split]):
                 t_run = loaders[split].steps_to_run(args, sw_mask) if hasattr(loaders[split], "steps_to_run") else None
-                losses, _outs, _perm = runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits, optims,
-                                               mode=split, reducer=reducer, sync_losses=False, t_run=t_run)
+                if split == "train" and getattr(args, "graph", False) and t_run is not None:
+                    # one captured hipGraph per (shapes, T, loss switches, encoder update, active parameter set)
+                    key = (tuple(x.shape), tuple(y_mask.shape), t_run, args.use_class_loss, args.use_stop_loss, args.update_encoder)
+                    if graphs.get("key") != key:
+                        if graphs.get("step") is not None:
+                            graphs["step"].release()
+                        graphs["key"], graphs["step"] = key, GraphedStep(args, encoder, decoder, crits, optims, reducer)
+                    losses, _outs, _perm = graphs["step"]((x, y_mask, y_class, sw_mask, sw_class), t_run)
+                    losses = [v.clone() for v in losses]      # (static tensors of the graph: keep this step's values)
+                else:
+                    losses, _outs, _perm = runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits, optims,
+                                                   mode=split, reducer=reducer, sync_losses=False, t_run=t_run, want_outs=False)
                 for k, v in zip(("total", "iou", "stop", "class"), losses):
                     epoch_losses[split][k].append(v)
                 n_img += x.size(0) * world

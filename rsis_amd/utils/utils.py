@@ -95,18 +95,33 @@ def save_checkpoint(args, encoder, decoder, enc_opt, dec_opt, root="../models"):
     pickle.dump(args, open(os.path.join(d, "args.pkl"), "wb"))
 
 
+class _ArgsUnpickler(pickle.Unpickler):
+    """args.pkl holds an argparse.Namespace of plain values (train.py:234): refuse to resolve anything else, so that loading a
+    third-party checkpoint cannot execute code."""
+    _ALLOWED = {("argparse", "Namespace"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"),
+                ("__builtin__", "dict"), ("__builtin__", "list"), ("__builtin__", "tuple"), ("__builtin__", "set"),
+                ("copy_reg", "_reconstructor"), ("copyreg", "_reconstructor"), ("__builtin__", "object"), ("builtins", "object")}
+
+    def find_class(self, module, name):
+        if (module, name) not in self._ALLOWED:
+            raise pickle.UnpicklingError("args.pkl: refusing to load %s.%s" % (module, name))
+        return super().find_class(module, name)
+
+
 def load_checkpoint(model_name, use_gpu=True, root="../models"):
-    """reference utils/utils.py:97-111 (python-2 pickles of the reference load with encoding='latin1')."""
+    """reference utils/utils.py:97-111 (python-2 pickles of the reference load with encoding='latin1').  The four .pt files are
+    plain tensor dictionaries in both the reference's and this build's format: they are read with weights_only=True; args.pkl
+    goes through an allow-listed unpickler."""
     d = os.path.join(root, model_name)
     ml = None if use_gpu else (lambda storage, location: storage)
-    dicts = [torch.load(os.path.join(d, f), map_location=ml, weights_only=False)
+    dicts = [torch.load(os.path.join(d, f), map_location=ml, weights_only=True)
              for f in ("encoder.pt", "decoder.pt", "enc_opt.pt", "dec_opt.pt")]
     with open(os.path.join(d, "args.pkl"), "rb") as f:
         try:
-            args = pickle.load(f)
+            args = _ArgsUnpickler(f).load()
         except UnicodeDecodeError:
             f.seek(0)
-            args = pickle.load(f, encoding="latin1")
+            args = _ArgsUnpickler(f, encoding="latin1").load()
     return dicts[0], dicts[1], dicts[2], dicts[3], args
 
 

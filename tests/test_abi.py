@@ -33,7 +33,7 @@ def test_binding_covers_header():
 
 def test_version_and_error_strings():
     L = _lib.lib()
-    assert L.rsis_version() == 1
+    assert L.rsis_version() == 2
     assert L.rsis_error_string(0) == b"ok"
     assert b"argument" in L.rsis_error_string(1)
 
@@ -41,14 +41,25 @@ def test_version_and_error_strings():
 def test_packed_size_queries():
     L = _lib.lib()
     segs = _lib.int_array([16, 16, 8])
-    # 3x3/s1/p1 -> direct layout: 8-channel chunks per source (2+2+1) x 72 rows; Cout 32 -> row stride 128
-    assert L.rsis_conv_packed_floats_fwd(32, 3, 1, 1, 3, segs) == 5 * 72 * 128
-    assert L.rsis_conv_packed_floats_dgrad(32, 3, 1, 1, 40) == 4 * 72 * 128
+    F32, BF16 = 0, 1
+    # 3x3/s1/p1 -> direct layout: 8-channel chunks per source (2+2+1) x 72 rows; Cout 32 -> row stride 128; 4 bytes per element
+    assert L.rsis_conv_packed_bytes_fwd(F32, 32, 3, 1, 1, 3, segs) == 5 * 72 * 128 * 4
+    assert L.rsis_conv_packed_bytes_dgrad(F32, 32, 3, 1, 1, 40) == 4 * 72 * 128 * 4
     # 3x3/s2/p1 forward runs on the direct kernel too (EPI_F2): same direct layout
-    assert L.rsis_conv_packed_floats_fwd(32, 3, 2, 1, 3, segs) == 5 * 72 * 128
+    assert L.rsis_conv_packed_bytes_fwd(F32, 32, 3, 2, 1, 3, segs) == 5 * 72 * 128 * 4
     # other strided / padded 3x3 -> implicit-GEMM layout: K = 40*9 = 360 -> 384 rows (multiple of 32)
-    assert L.rsis_conv_packed_floats_fwd(32, 3, 2, 0, 3, segs) == 384 * 128
-    assert L.rsis_conv_packed_floats_dgrad(32, 3, 2, 1, 40) == 288 * 128
+    assert L.rsis_conv_packed_bytes_fwd(F32, 32, 3, 2, 0, 3, segs) == 384 * 128 * 4
+    assert L.rsis_conv_packed_bytes_dgrad(F32, 32, 3, 2, 1, 40) == 288 * 128 * 4
+    # bf16 cells: 16-channel chunks per source (1+1+1) x 9 taps x 2 cells of 8 channels, 16 bytes per cell and column
+    assert L.rsis_conv_packed_bytes_fwd(BF16, 32, 3, 1, 1, 3, segs) == 3 * 9 * 2 * 128 * 16
+    assert L.rsis_conv_packed_bytes_dgrad(BF16, 32, 3, 1, 1, 40) == 2 * 9 * 2 * 128 * 16
+    # 1x1: 64-channel chunks of 8 cells
+    one = _lib.int_array([256])
+    assert L.rsis_conv_packed_bytes_fwd(BF16, 64, 1, 1, 0, 1, one) == 4 * 8 * 128 * 16
+    # layers without a bf16 kernel keep the f32 layout under either dtype
+    assert L.rsis_conv_uses_bf16(3, 1, 1, 64) == 1 and L.rsis_conv_uses_bf16(1, 2, 0, 64) == 1
+    assert L.rsis_conv_uses_bf16(3, 2, 1, 64) == 0 and L.rsis_conv_uses_bf16(7, 2, 3, 64) == 0 and L.rsis_conv_uses_bf16(3, 1, 1, 1) == 0
+    assert L.rsis_conv_packed_bytes_fwd(BF16, 32, 3, 2, 1, 3, segs) == 5 * 72 * 128 * 4
 
 
 def test_product_has_no_cpu_path():

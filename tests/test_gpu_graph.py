@@ -1,0 +1,111 @@
+"""hipGraph replay of a whole training iteration (rsis_amd.train.GraphedStep) and the per-parameter Adam semantics of
+rsis_amd.optim.FlatGroup against torch.optim.Adam (the reference's optimizer: utils/utils.py:83-84)."""
+import copy
+
+import pytest
+import torch
+
+from helpers import mk_args
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(a, seed=0):
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    torch.manual_seed(seed)
+    return FeatureExtractor(a).cuda(), RSIS(a).cuda()
+
+
+def test_flat_adam_matches_torch_adam_with_gradless_parameters():
+    """A parameter that receives no gradient is skipped by torch.optim.Adam (no weight decay, no moments, no step count) and
+    starts its own bias correction when its first gradient arrives; FlatGroup must do the same (lazy + mark_has_grad)."""
+    from rsis_amd.optim import FlatAdam
+    torch.manual_seed(1)
+    shapes = [(7, 5), (11,), (3, 4, 2), (6,)]
+    ref = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    topt = torch.optim.Adam(ref, lr=1e-2, weight_decay=1e-2)
+    fopt = FlatAdam(mine, lr=1e-2, weight_decay=1e-2, lazy=[mine[1], mine[3]])
+    for it in range(12):
+        have = [True, it >= 4, True, it >= 9]          # parameters 1 and 3 get their first gradient at steps 4 and 9
+        g = [torch.randn(s, device="cuda") for s in shapes]
+        topt.zero_grad(set_to_none=False)
+        fopt.zero_grad()
+        for p, q, gi, h in zip(ref, mine, g, have):
+            if h:
+                p.grad = gi.clone()
+                q.grad.copy_(gi)
+            elif p.grad is not None:
+                p.grad.zero_()
+        fopt.mark_has_grad([q for q, h in zip(mine, have) if h])
+        topt.step()
+        fopt.step()
+        for k, (p, q) in enumerate(zip(ref, mine)):
+            assert float((p.detach() - q.detach()).abs().max()) < 2e-6, "param %d diverged at step %d" % (k, it)
+    assert fopt.group.steps == [12, 8, 12, 3]
+    # untouched while inactive: parameter 3 was bit-identical to its initial value through step 8 (checked via torch's copy above)
+
+
+def test_flat_adam_device_step_counter():
+    """graph mode: the bias-correction step count is read from device memory and advanced on the stream"""
+    from rsis_amd.optim import FlatAdam
+    torch.manual_seed(2)
+    a = [torch.nn.Parameter(torch.randn(33, device="cuda")), torch.nn.Parameter(torch.randn(5, 3, device="cuda"))]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa, ob = FlatAdam(a, lr=1e-2, weight_decay=1e-3), FlatAdam(b, lr=1e-2, weight_decay=1e-3)
+    ob.group.begin_graph()
+    for _ in range(5):
+        g = torch.randn(48, device="cuda")
+        oa.group.flat_g.copy_(g)
+        ob.group.flat_g.copy_(g)
+        oa.step()
+        ob.step()
+        ob.group.note_replay()
+    ob.group.end_graph()
+    # (host powf vs device powf for the bias corrections: a few ulp)
+    assert float((oa.group.flat_p - ob.group.flat_p).abs().max()) < 1e-6
+    assert oa.group.steps == ob.group.steps == [5, 5]
+
+
+@pytest.mark.parametrize("use_stop", [True, False])
+def test_graphed_step_equals_eager(use_stop):
+    """2 eager + 3 replayed iterations against 5 eager iterations from the same state.  Two EAGER runs already differ (fp32 atomics
+    of the split-K weight gradients sum in a run-dependent order, and Adam turns noise on near-zero gradients into lr-sized
+    steps; train-mode BatchNorm over 4 images amplifies it: ~3e-4 on the loss after a few steps), so the bar is calibrated in
+    the test: graph-vs-eager must be within 3x the eager-vs-eager spread (+ 2e-4 relative)."""
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import GraphedStep, build_optimizers, runIter, steps_to_run
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    a = mk_args(hidden_size=32, maxseqlen=3, lr=1e-3, lr_cnn=1e-5, weight_decay=1e-6, weight_decay_cnn=1e-6, optim="adam",
+                optim_cnn="adam", imsize=64, batch_size=4, seed=3, use_stop_loss=use_stop)
+    batch = synthetic_batch(5, 4, 64, 64, a.gt_maxseqlen, 3, a.num_classes, "cuda")
+    t_run = steps_to_run(a, batch[3])
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
+    enc0, dec0 = _models(a)
+    results = []
+    for graphed in (False, False, True):
+        enc, dec = copy.deepcopy(enc0), copy.deepcopy(dec0)
+        opts = list(build_optimizers(a, enc, dec))
+        g = GraphedStep(a, enc, dec, crits, opts, None, warm=2) if graphed else None
+        losses = []
+        for _ in range(5):
+            if graphed:
+                out = g(batch, t_run)
+            else:
+                out = runIter(a, enc, dec, *batch, crits, opts, mode="train", sync_losses=False, t_run=t_run, want_outs=False)
+            losses.append([float(v) for v in out[0]])
+        if graphed:
+            assert g.graph is not None, "capture failed: %s" % g.failed
+            assert opts[1].group.steps[0] == 5 and opts[0].group.steps[0] == 5
+            g.release()
+        nbt = int(enc.state_dict()["base.bn1.num_batches_tracked"])
+        results.append((torch.tensor(losses, dtype=torch.float64), torch.cat([o.group.flat_p for o in opts]).double().clone(), nbt,
+                        dec.fc_stop.weight.detach().clone()))
+    (la, pa, na, sa), (lb, pb, nb, sb), (lg, pg, ng, sg) = results
+    assert na == nb == ng == 5
+    spread_l = float((la - lb).abs().max())
+    spread_p = float((pa - pb).norm() / pa.norm())
+    assert float((lg - la).abs().max()) <= 3 * spread_l + 2e-4 * float(la.abs().max()), (la, lb, lg)
+    assert float((pg - pa).norm() / pa.norm()) <= 3 * spread_p + 1e-5, (spread_p, float((pg - pa).norm() / pa.norm()))
+    if not use_stop:     # the stop head never received a gradient: torch.optim.Adam semantics leave it untouched
+        assert torch.equal(sa, dec0.fc_stop.weight.detach()) and torch.equal(sg, sa)

@@ -436,40 +436,3 @@ def test_gradslot_downsample_block_equals_autograd_sum(stride):
         assert_close("grad %d" % i, a, b, 2e-5 * float(b.abs().max()) + 1e-7)
 
 
-@pytest.mark.gpu
-def test_fused_decoder_tail_equals_unfused():
-    """RSIS_FUSE_TAIL: conv_out fused with the final upsample (off by default) gives the unfused decoder's outputs and gradients"""
-    from oracle import filler
-    from oracle import rsis_oracle as O
-    from rsis_amd import decoder_fused
-    from rsis_amd.modules import RSIS
-    a = mk_args(maxseqlen=3)
-    odec = filler.fill_module(O.RSIS(a), seed=5)
-    feats = [filler.tensor(5, "tail.f%d" % i, (2, c, s, s)).cuda().requires_grad_() for i, (c, s) in
-             enumerate(zip([128, 128, 64, 32, 16], [4, 8, 16, 32, 64]))]
-
-    def run(on):
-        dec = RSIS(a).cuda().train()
-        dec.load_state_dict(odec.state_dict())
-        old, decoder_fused.FUSE_TAIL[0] = decoder_fused.FUSE_TAIL[0], on
-        try:
-            hid, loss, masks = None, 0.0, []
-            for t in range(3):
-                m, cls, stop, hid = dec(feats, hid)
-                masks.append(m.detach().clone())
-                loss = loss + (m * m).mean() + cls.square().sum() * 1e-2 + stop.sum() * 1e-2
-            for f in feats:
-                f.grad = None
-            loss.backward()
-        finally:
-            decoder_fused.FUSE_TAIL[0] = old
-        return masks, [f.grad.clone() for f in feats], {k: p.grad.clone() for k, p in dec.named_parameters()}
-
-    m1, g1, p1 = run(True)
-    m0, g0, p0 = run(False)
-    for t, (x, y) in enumerate(zip(m1, m0)):
-        assert_close("mask t=%d" % t, x, y, 2e-6 * float(y.abs().max()) + 1e-7)
-    for i, (x, y) in enumerate(zip(g1, g0)):
-        assert_close("d feat %d" % i, x, y, 2e-5 * float(y.abs().max()) + 1e-8)
-    for k in p0:
-        assert_close("grad " + k, p1[k], p0[k], 5e-5 * float(p0[k].abs().max()) + 1e-8)

@@ -433,45 +433,6 @@ def test_convlstm_kernel_size_1():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,C,Hi,Wi", [(2, 8, 16, 16), (3, 8, 20, 36), (2, 4, 64, 128), (1, 16, 12, 8), (2, 8, 128, 128), (1, 8, 40, 160)])
-def test_side_upconv_out_equals_unfused(B, C, Hi, Wi):
-    """fused decoder tail (max-pool side feature + conv_out(upsample x2 (h)), rsis_upconv_out_*) against the separate kernels it
-    replaces (rsis_upsample_bilinear_ac_* + rsis_conv2d_* + rsis_global_maxpool_*): forward and data gradient to a few ulp, the
-    weight / bias gradients (sums over all pixels in a different order) to fp32 summation order"""
-    from rsis_amd import ops
-    from rsis_amd.decoder_fused import _SideUpFn
-    from rsis_amd.modules.vision import HipConv2d
-    torch.manual_seed(3)
-    conv = HipConv2d(C, 1, 3, padding=1).cuda()
-    h = torch.randn(B, C, Hi, Wi, device="cuda", requires_grad=True)
-    size = (2 * Hi, 2 * Wi)
-    assert ops.upconv_out_supported(h, conv.weight, size)
-    g_side = torch.randn(B, C, 1, 1, device="cuda")
-    g_out = torch.randn(B, 1, *size, device="cuda")
-
-    def run(fused):
-        h.grad = None
-        conv.zero_grad()
-        if fused:
-            side, out = ops.side_upconv_out(h, conv.weight, conv.bias, size)
-        else:
-            side, up = _SideUpFn.apply(None, 0, h, size)
-            out = conv(up)
-        ((side * g_side).sum() + (out * g_out).sum()).backward()
-        return side.detach().clone(), out.detach().clone(), h.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()
-
-    s1, o1, dh1, dw1, db1 = run(True)
-    s0, o0, dh0, dw0, db0 = run(False)
-    assert torch.equal(s1, s0)
-    # same formulas and summation order as the two-kernel sequence; only the compiler's FMA contraction of the interpolation
-    # differs between the kernels: a few ulp
-    assert_close("out", o1, o0, 2e-6 * float(o0.abs().max()) + 1e-7)
-    assert_close("dh", dh1, dh0, 2e-6 * float(dh0.abs().max()) + 1e-7)
-    assert_close("dW", dw1, dw0, 2e-5 * float(dw0.abs().max()) + 1e-6)
-    assert_close("db", db1, db0, 2e-5 * float(db0.abs().max()) + 1e-6)
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("shape,size", [((2, 3, 8, 8), (16, 16)), ((2, 5, 13, 25), (25, 50)), ((1, 8, 64, 64), (128, 128)), ((3, 2, 4, 5), (7, 9))])
 def test_upsample_maxpool_bwd_one_launch(shape, size):
     """rsis_upsample_maxpool_bwd (the side max-pool's gradient folded into the upsample backward) == the two separate kernels"""

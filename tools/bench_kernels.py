@@ -34,13 +34,19 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+DT = 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="gates")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     o = ap.parse_args()
+    global DT
+    DT = ops.DTYPES[o.dtype]
     L = lib()
     B = o.batch
     tot_f = tot_ms = 0.0
@@ -50,7 +56,7 @@ def main():
             cin = sum(segs) + hid
             w = torch.randn(4 * hid, cin, 3, 3, device="cuda") / (3.0 * cin ** 0.5)
             bias = torch.randn(4 * hid, device="cuda") * 0.1
-            pack = ops.PackedConv(3, segs + [hid], lstm_hid=hid)
+            pack = ops.PackedConv(3, segs + [hid], lstm_hid=hid, dtype=DT)
             wp = pack.fwd(w, bias)
             srcs = [torch.randn(B, c, H, W, device="cuda") for c in segs] + [torch.tanh(torch.randn(B, hid, H, W, device="cuda"))]
             c_prev = torch.randn(B, hid, H, W, device="cuda")
@@ -58,7 +64,7 @@ def main():
             act = torch.empty(B, 4 * hid, H, W, device="cuda")
             pa, ia = ptr_array(srcs), int_array(segs + [hid])
             ms = timeit(lambda: check(L.rsis_convlstm_fwd(pa, ia, len(srcs), B, H, W, ptr(wp), ptr(pack.bias_p), None, ptr(c_prev),
-                                                          ptr(h), ptr(c), ptr(act), hid, 3, 1, o.tile, stream()), "lstm"), o.iters)
+                                                          ptr(h), ptr(c), ptr(act), hid, 3, 1, o.tile, DT, stream()), "lstm"), o.iters)
             fl = 2.0 * B * H * W * cin * 9 * 4 * hid
             print("gate fwd  %3dx%-3d M=%7d K=%5d N=%4d  %8.1f us  %6.1f TF/s" % (H, W, B * H * W, cin * 9, 4 * hid, ms * 1e3, fl / ms / 1e9))
             tot_f += fl
@@ -69,7 +75,7 @@ def main():
             dxs = [torch.empty_like(s) for s in srcs]
             pd, idd = ptr_array(dxs), int_array(segs + [hid])
             ms = timeit(lambda: check(L.rsis_conv2d_dgrad(ptr(da), B, 4 * hid, H, W, ptr(wd), cin, 3, 1, 1, pd, idd, len(dxs), H, W,
-                                                          None, o.tile, stream()), "dgrad"), o.iters)
+                                                          None, o.tile, DT, stream()), "dgrad"), o.iters)
             print("gate dgrad %3dx%-3d %38s %8.1f us  %6.1f TF/s" % (H, W, "", ms * 1e3, fl / ms / 1e9))
             dW = torch.zeros_like(w)
 
@@ -77,7 +83,7 @@ def main():
                 off = 0
                 for s_ in srcs:
                     check(L.rsis_conv2d_wgrad(ptr(da), ptr(s_), ptr(dW), B, s_.shape[1], H, W, 4 * hid, H, W, 3, 1, 1, cin, off, hid,
-                                              stream()), "wgrad")
+                                              DT, stream()), "wgrad")
                     off += s_.shape[1]
             ms = timeit(wg, o.iters)
             print("gate wgrad %3dx%-3d %38s %8.1f us  %6.1f TF/s" % (H, W, "", ms * 1e3, fl / ms / 1e9))
@@ -93,20 +99,20 @@ def main():
             Hi = hw * stride
             x = torch.randn(B, cin, Hi, Hi, device="cuda")
             w = torch.randn(cout, cin, ks, ks, device="cuda") / (ks * cin ** 0.5)
-            pack = ops.PackedConv(ks, [cin], stride=stride, pad=pad)
+            pack = ops.PackedConv(ks, [cin], stride=stride, pad=pad, dtype=DT)
             wp, wd = pack.fwd(w), pack.dgrad(w)
             y = torch.empty(B, cout, hw, hw, device="cuda")
             pa, ia = ptr_array([x]), int_array([cin])
             fl = 2.0 * B * hw * hw * cin * ks * ks * cout
             ms_f = timeit(lambda: check(L.rsis_conv2d_fwd(pa, ia, 1, B, Hi, Hi, ptr(wp), cout, ks, stride, pad, None, None, ptr(y), hw, hw,
-                                                          o.tile, stream()), "fwd"), o.iters)
+                                                          o.tile, DT, stream()), "fwd"), o.iters)
             dx = torch.empty_like(x)
             pd = ptr_array([dx])
             ms_d = timeit(lambda: check(L.rsis_conv2d_dgrad(ptr(y), B, cout, hw, hw, ptr(wd), cin, ks, stride, pad, pd, ia, 1, Hi, Hi,
-                                                            None, o.tile, stream()), "dgrad"), o.iters)
+                                                            None, o.tile, DT, stream()), "dgrad"), o.iters)
             dW = torch.zeros_like(w)
             ms_w = timeit(lambda: check(L.rsis_conv2d_wgrad(ptr(y), ptr(x), ptr(dW), B, cin, Hi, Hi, cout, hw, hw, ks, stride, pad, cin, 0, 0,
-                                                            stream()), "wgrad"), o.iters)
+                                                            DT, stream()), "wgrad"), o.iters)
             print("conv %4d->%4d k%d s%d @%3d^2 x%2d  %6.2f GF | fwd %7.1f us %6.1f TF | dgrad %7.1f us %6.1f TF | wgrad %7.1f us %6.1f TF"
                   % (cin, cout, ks, stride, hw, count, fl / 1e9, ms_f * 1e3, fl / ms_f / 1e9, ms_d * 1e3, fl / ms_d / 1e9, ms_w * 1e3,
                      fl / ms_w / 1e9))
