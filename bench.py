@@ -36,10 +36,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_
 GATE_LAYERS = [([128], 128, 8), ([128, 128], 64, 16), ([64, 64], 32, 32), ([32, 32], 16, 64), ([16, 16], 8, 128)]
 
 
-def bench_args(batch, imsize, T):
+def bench_args(batch, imsize, T, dtype="fp32"):
     from rsis_amd.args import get_parser
     a = get_parser().parse_args([])
     a.batch_size, a.imsize, a.maxseqlen, a.gt_maxseqlen, a.num_classes = batch, imsize, T, 20, 21
+    a.dtype = dtype
     a.use_class_loss = a.use_stop_loss = a.update_encoder = True
     a.synthetic = True
     return a
@@ -175,6 +176,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     ap.add_argument("--imsize", type=int, default=256)
     ap.add_argument("--T", type=int, default=10)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="arithmetic of the conv / gate MFMA kernels")
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
@@ -206,7 +208,7 @@ def main():
     rank, local_rank, world = init_distributed()
     assert world == o.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % o.gpus
     assert torch.cuda.is_available(), "bench.py needs the GPU (there is no CPU path)"
-    a = bench_args(o.batch, o.imsize, o.T)
+    a = bench_args(o.batch, o.imsize, o.T, o.dtype)
     torch.manual_seed(a.seed)
     encoder, decoder = FeatureExtractor(a).cuda(), RSIS(a).cuda()
     if world > 1 or os.environ.get("RSIS_FORCE_DIST", "") == "1":
@@ -319,9 +321,9 @@ def main():
         out = {"metric": "training images/sec at %dx%d, T=%d, batch=%d per GPU" % (o.imsize, o.imsize, o.T, o.batch),
                "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": o.steps, "warmup": o.warmup,
                "ms_per_step": round(1000.0 * dt / o.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": "f32" if o.dtype == "fp32" else "bf16", "data": "synthetic",
                "config": {"workload": "configs[1]: synthetic %dx%dx3, T=%d, batch=%d/GPU, ResNet-101 encoder + 5-scale ConvLSTM "
-                                      "decoder, fp32, fwd+match+3 losses+bwd+Adam (update_encoder on)" % (o.imsize, o.imsize, o.T, o.batch),
+                                      "decoder, %s, fwd+match+3 losses+bwd+Adam (update_encoder on)" % (o.imsize, o.imsize, o.T, o.batch, o.dtype),
                           "global_batch": world * o.batch, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5),
                           "launch": "hipGraph replay of the captured iteration" if (gstep is not None and gstep.graph is not None)
                                     else "eager (one Python launch per kernel)"},
