@@ -76,12 +76,173 @@ def npf(t):
     return t.detach().cpu().numpy()
 
 
+def sub_idx(n, cap=4096):
+    """deterministic sub-sample of a flat gradient / parameter vector: every k-th element, at most ~cap of them"""
+    return slice(0, n, max(1, n // cap))
+
+
+def round2_cases(O, filler, ref_model, ref_test, report):
+    """Fixtures added in round 2: the BASELINE geometries that had none (224x224: 7/14/28/56/112-pixel pyramid, partial MFMA
+    tiles everywhere; 512x1024: the Cityscapes configuration) and a well-conditioned TRAINING step (forward, matching, the three
+    losses, backward, one Adam step of both optimizers) on the reference's modules."""
+    import utils.utils as ref_utils     # reference src/utils/utils.py: get_optimizer / get_skip_params (train.py:236-240)
+    a_ref, a_ora = mk_args(py2=True), mk_args()
+    renc, oenc = ref_model.FeatureExtractor(a_ref), O.FeatureExtractor(a_ora)
+    rdec, odec = ref_model.RSIS(a_ref), O.RSIS(a_ora)
+
+    # ---------------- F7: end-to-end test() at 224x224 (T=10) and 512x1024 (T=3) ----------------
+    for name, shape, T, sub in (("e2e_224", (2, 3, 224, 224), 10, 4), ("e2e_512x1024", (2, 3, 512, 1024), 3, 8)):
+        for m in (renc, oenc):
+            filler.fill_module(m, seed=44)
+            m.eval()
+        for m in (rdec, odec):
+            filler.fill_module(m, seed=45)
+            m.eval()
+        x = filler.tensor(44, name + ".x", shape)
+        a_ref.maxseqlen = a_ora.maxseqlen = T
+        logits = []
+        hook = rdec.register_forward_hook(lambda mod, inp, outp: logits.append(outp[0].detach().clone()))
+        with torch.no_grad():
+            rm, rc, rs = ref_test.test(a_ref, renc, rdec, x)
+        hook.remove()
+        om, oc, os_ = O.test(a_ora, oenc, odec, x)
+        _ol, _, osl = O.test(a_ora, oenc, odec, x, return_logits=True)
+        report.append((name + ".masks", close(om, rm, 1e-5, name + ".masks")))
+        report.append((name + ".classes", close(oc, rc, 1e-5, name + ".classes")))
+        report.append((name + ".stops", close(os_, rs, 1e-5, name + ".stops")))
+        ref_logits = torch.cat(logits, 1)
+        with torch.no_grad():
+            feats = oenc(x)
+            hidden, ora_native = None, []
+            for _ in range(T):
+                m, _c, _s, hidden = odec(feats, hidden)
+                ora_native.append(m)
+        ora_native = torch.cat(ora_native, 1)
+        report.append((name + ".logits_native", close(ora_native, ref_logits, 5e-5, name + ".logits")))
+        # the reference's own fp32 noise floor on this fixture: the same op graph evaluated in float64
+        e64, d64 = O.FeatureExtractor(a_ora).double(), O.RSIS(a_ora).double()
+        e64.load_state_dict(oenc.state_dict())
+        d64.load_state_dict(odec.state_dict())
+        e64.eval()
+        d64.eval()
+        with torch.no_grad():
+            f64 = e64(x.double())
+            hidden, nat64, stop64 = None, [], []
+            for _ in range(T):
+                m, _c, s_, hidden = d64(f64, hidden)
+                nat64.append(m)
+                stop64.append(s_)
+        nat64 = torch.cat(nat64, 1)
+        floor = (ref_logits.double() - nat64).abs().max().item()
+        report.append((name + ".fp32_floor_logits", floor))
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), shape=np.array(shape), T=np.array(T), sub=np.array(sub),
+                            mask_logits_sub=npf(ref_logits[:, :, ::sub, ::sub]), mask_probs_sub=npf(rm[:, :, ::sub, ::sub]),
+                            classes=npf(rc), stops=npf(rs), stop_logits=npf(osl),
+                            mask_logits_sub_f64=npf(nat64[:, :, ::sub, ::sub]), stop_logits_f64=npf(torch.stack(stop64, 1)),
+                            logit_absmax=np.array(ref_logits.abs().max().item()), fp32_floor_logits=np.array(floor))
+
+    # ---------------- F8: one full training iteration, 160x160, B=4, T=4 (train-mode BN over >= 100 samples per channel) ----------
+    name = "trainstep_160"
+    B, H, W, T = 4, 160, 160, 4
+    x = filler.tensor(88, name + ".x", (B, 3, H, W))
+    y_mask, y_class, sw_mask, sw_class = filler.synthetic_targets(88, B, H, W, gt_maxseqlen=20, n_inst=6)
+    LR, LR_CNN, WD = 1e-3, 1e-6, 1e-6                      # src/args.py defaults
+    res = {}
+    cases = (("ref", renc, rdec, a_ref, torch.float32), ("ora", oenc, odec, a_ora, torch.float32),
+             ("f64", O.FeatureExtractor(a_ora), O.RSIS(a_ora), a_ora, torch.float64))
+    for tag, enc, dec, a, dt in cases:
+        filler.fill_module(enc, seed=88)
+        filler.fill_module(dec, seed=89)
+        enc.to(dt)
+        dec.to(dt)
+        a.maxseqlen, a.gt_maxseqlen = T, 20
+        a.update_encoder = True
+        # train.py:236-240 with the reference's own helpers; the trunk group is de-duplicated (get_base_params yields tensors 1-4
+        # times -- SURVEY Appendix C -- which modern torch.optim refuses)
+        dec_params = list(dec.parameters()) + list(ref_utils.get_skip_params(enc))
+        seen, base = set(), []
+        for q in ref_utils.get_base_params(a, enc):
+            if id(q) not in seen:
+                seen.add(id(q))
+                base.append(q)
+        dec_opt = ref_utils.get_optimizer("adam", LR, dec_params, WD)
+        enc_opt = ref_utils.get_optimizer("adam", LR_CNN, base, WD)
+        enc.zero_grad()
+        dec.zero_grad()
+        # arg-max pixel of every hidden-state plane (the global max-pool side features of model.py:143 route their gradient there)
+        # and the relative gap between the two largest values: a plane whose gap is at fp32-noise level may legitimately pick
+        # another pixel in another fp32 implementation, which moves its gradient (a discontinuity of the reference function)
+        picks, gaps = [], []
+
+        def hook(_mod, _inp, outp, _p=picks, _g=gaps):
+            for h, _c in outp[3]:
+                flat = h.detach().flatten(2)
+                top = flat.topk(2, dim=-1).values
+                _p.append(flat.argmax(-1))
+                _g.append((top[..., 0] - top[..., 1]) / top[..., 0].abs().clamp_min(1e-30))
+        hk = dec.register_forward_hook(hook)
+        r = O.run_iter_forward(a, enc, dec, x.to(dt), y_mask.to(dt), y_class, sw_mask, sw_class, mode="train")
+        hk.remove()
+        r["loss"].backward()
+        g = {"loss": r["loss"], "loss_mask_iou": r["loss_mask_iou"], "loss_stop": r["loss_stop"], "loss_class": r["loss_class"],
+             "scores": r["scores"], "out_masks_sub": r["out_masks"].view(B, T, H, W)[:, :, ::4, ::4], "out_classes": r["out_classes"],
+             "out_stops": r["out_stops"], "y_class_perm": r["y_class_perm"]}
+        for j, (pk, gp) in enumerate(zip(picks, gaps)):
+            g["argmax.t%d.l%d" % (j // 5, j % 5)] = pk.to(torch.int32)
+            g["gap.t%d.l%d" % (j // 5, j % 5)] = gp.float()
+        named = [("dec." + k, q) for k, q in dec.named_parameters()] + [("enc." + k, q) for k, q in enc.named_parameters()
+                                                                        if not k.startswith("base.fc")]
+        # decoder + skip-conv tensors (the dec_opt group): ~2048 evenly spaced elements each; trunk tensors: 64 + the norm
+        cap = lambda k: 2048 if (k.startswith("dec.") or not k.startswith("enc.base.")) else 64   # noqa: E731
+        for k, q in named:
+            flat = q.grad.detach().reshape(-1)
+            g["grad." + k] = flat[sub_idx(flat.numel(), cap(k))].clone()
+            g["gnorm." + k] = flat.norm()
+        dec_opt.step()
+        enc_opt.step()
+        for k, q in named:
+            if cap(k) == 2048:
+                flat = q.detach().reshape(-1)
+                g["post." + k] = flat[sub_idx(flat.numel(), 2048)].clone()
+        res[tag] = g
+    out = {"B": np.array(B), "H": np.array(H), "W": np.array(W), "T": np.array(T), "n_inst": np.array(6),
+           "lr": np.array(LR), "lr_cnn": np.array(LR_CNN), "weight_decay": np.array(WD)}
+    worst = 0.0
+    for k in res["ref"]:
+        ref = res["ref"][k]
+        scale = max(1.0, float(torch.as_tensor(ref).double().abs().max()))
+        tol = 1e-5 if not k.startswith(("grad.", "gnorm.", "post.")) else 2e-3 * scale   # (two fp32 evaluations of an ill-conditioned BN stack)
+        e = close(res["ora"][k].double(), ref.double(), tol, name + "." + k)
+        worst = max(worst, e / scale)
+        out[k] = npf(ref) if torch.is_tensor(ref) else np.asarray(ref)
+        if k.startswith(("loss", "grad.", "gnorm.", "argmax.", "gap.")) or k in ("out_masks_sub", "out_classes", "out_stops"):
+            out["f64." + k] = npf(res["f64"][k])          # exact (float64) value of the same quantity: the fp32 noise floor
+    report.append((name + ".worst_rel", worst))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    report.append((name + ".bytes", os.path.getsize(os.path.join(GOLD, name + ".npz"))))
+
+
 def main():
     from oracle import rsis_oracle as O
     from oracle import filler
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", default="all", choices=["all", "r1", "r2"],
+                    help="r1: the round-1 fixtures (REPORT.txt), r2: the fixtures added in round 2 (REPORT_r2.txt)")
+    opt = ap.parse_args()
     ref_model, ref_clstm, ref_test, ref_hung, ref_obj = import_reference()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
+    if opt.cases in ("all", "r2"):
+        report = []
+        round2_cases(O, filler, ref_model, ref_test, report)
+        w = max(len(k) for k, _ in report)
+        with open(os.path.join(GOLD, "REPORT_r2.txt"), "w") as f:
+            f.write("oracle vs imported reference (max abs err) and fp32 noise floors, generated by oracle/make_golden.py --cases r2\n")
+            for k, v in report:
+                f.write("%-*s %.3e\n" % (w, k, v))
+        print("round-2 fixtures written (%d checks)" % len(report))
+        if opt.cases == "r2":
+            return
     report = []
 
     # ---------------- F1: ConvLSTMCell fwd (t=0 None state, t=1 with state) + grads ----------------

@@ -38,3 +38,8 @@ def assert_close(what, got, want, atol, rtol=0.0):
         raise AssertionError("%s: max abs err %.3e (tol %.1e + %.1e*|ref|) at %s: got %.6g want %.6g; %d/%d bad; |ref|max %.3g"
                              % (what, float(err.max()), atol, rtol, idx, float(got.reshape(-1)[i]), float(want.reshape(-1)[i]),
                                 int(bad.sum()), got.numel(), float(want.abs().max())))
+
+
+def sub_idx(n, cap=4096):
+    """the deterministic sub-sample oracle/make_golden.py stores of a flat gradient / parameter vector"""
+    return slice(0, n, max(1, n // cap))

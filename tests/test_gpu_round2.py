@@ -1,0 +1,274 @@
+"""Parity at the BASELINE geometries that had no fixture in round 1 (224x224: 7/14/28/56/112-pixel pyramid, i.e. partial MFMA
+tiles at every level; 512x1024: the Cityscapes configuration) and one full TRAINING iteration (forward, matching, losses,
+backward, one Adam step of both optimizers) on a well-conditioned fixture.  Golden data: tests/golden/{e2e_224,e2e_512x1024,
+trainstep_160}.npz, the outputs of the UNMODIFIED reference modules (oracle/make_golden.py --cases r2), each with the float64
+evaluation of the same op graph next to it (the reference's own fp32 noise floor on that fixture).
+
+fp32 bars (fixed before the first run): logits / probabilities within 1e-4 of the reference; training losses within 1e-4;
+gradients by the fixed-k fp64-truth rule  |hip - f64| <= 3 * |ref32 - f64| + 2e-4 * max|f64|  per tensor (train-mode BatchNorm
+through ~100 layers makes the reference's OWN fp32 gradients up to 20 % noisy in layer 4: a tolerance against the fp32 golden
+alone would be either meaningless or unmeetable by any fp32 implementation).
+bf16 bars: tests/test_gpu_bf16.py BF16_TOL.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, gold, mk_args, sub_idx
+
+pytestmark = pytest.mark.gpu
+
+K_FLOOR = 3.0     # fixed-k of the fp64-truth rule
+
+
+def _models(a, seed_enc, seed_dec):
+    from oracle import filler
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    a32 = mk_args(maxseqlen=a.maxseqlen)
+    oenc = filler.fill_module(O.FeatureExtractor(a32), seed=seed_enc)
+    odec = filler.fill_module(O.RSIS(a32), seed=seed_dec)
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    enc.load_state_dict(oenc.state_dict())
+    dec.load_state_dict(odec.state_dict())
+    return enc, dec, oenc, odec
+
+
+def _rel_l2(got, want):
+    got, want = torch.as_tensor(got).detach().double().cpu(), torch.as_tensor(want).detach().double().cpu()
+    return float((got - want).norm() / want.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("name", ["e2e_224", "e2e_512x1024"])
+def test_e2e_geometry_fp32(name):
+    """test() (reference src/test.py:16-50) at 224x224 (T=10) and 512x1024 (T=3): per-timestep mask logits / probabilities,
+    class probabilities and stop probabilities within 1e-4 of the reference CPU path."""
+    from oracle import filler
+    from rsis_amd.test import test as hip_test
+    g = gold(name)
+    a = mk_args(maxseqlen=int(g["T"]))
+    enc, dec, _, _ = _models(a, 44, 45)
+    x = filler.tensor(44, name + ".x", tuple(int(v) for v in g["shape"])).cuda()
+    sub = int(g["sub"])
+    masks, classes, stops = hip_test(a, enc, dec, x)
+    logits, _, stop_logits = hip_test(a, enc, dec, x, return_logits=True)
+    assert_close(name + ".mask_logits", logits[:, :, ::sub, ::sub], g["mask_logits_sub"], 1e-4)
+    assert_close(name + ".mask_probs", masks[:, :, ::sub, ::sub], g["mask_probs_sub"], 1e-4)
+    assert_close(name + ".classes", classes, g["classes"], 1e-4)
+    assert_close(name + ".stops", stops, g["stops"], 1e-4)
+    # raw stop logit: fixed-k rule against the float64 truth (it is the output with the largest fp32 noise of the reference itself)
+    f64 = torch.from_numpy(g["stop_logits_f64"]).reshape(stop_logits.shape)
+    floor = float((torch.from_numpy(g["stop_logits"]).double().reshape(f64.shape) - f64).abs().max())
+    assert_close(name + ".stop_logits", stop_logits, f64, max(1e-4, K_FLOOR * floor))
+
+
+@pytest.mark.parametrize("name", ["e2e_224", "e2e_512x1024"])
+def test_e2e_geometry_bf16(name):
+    """the same geometries under `-dtype bf16` (BASELINE configs[2..4]) against the reference's fp32 golden outputs"""
+    from oracle import filler
+    from rsis_amd.test import test as hip_test
+    from test_gpu_bf16 import BF16_TOL
+    g = gold(name)
+    a = mk_args(maxseqlen=int(g["T"]), dtype="bf16")
+    enc, dec, _, _ = _models(a, 44, 45)
+    x = filler.tensor(44, name + ".x", tuple(int(v) for v in g["shape"])).cuda()
+    sub = int(g["sub"])
+    masks, classes, stops = hip_test(a, enc, dec, x)
+    logits, _, _sl = hip_test(a, enc, dec, x, return_logits=True)
+    ref = torch.from_numpy(g["mask_logits_sub"])
+    got = logits[:, :, ::sub, ::sub]
+    assert _rel_l2(got, ref) < BF16_TOL["rel_l2"], "mask logits rel L2 %.3e" % _rel_l2(got, ref)
+    assert_close(name + ".mask_logits", got, ref, BF16_TOL["decoder_logit"] * float(ref.abs().max()))
+    assert_close(name + ".mask_probs", masks[:, :, ::sub, ::sub], g["mask_probs_sub"], BF16_TOL["probs"])
+    assert_close(name + ".classes", classes, g["classes"], BF16_TOL["probs"])
+    assert_close(name + ".stops", stops, g["stops"], BF16_TOL["probs"])
+
+
+def _train_step(dtype):
+    from oracle import filler
+    from rsis_amd.train import build_optimizers, runIter
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    g = gold("trainstep_160")
+    B, H, W, T = int(g["B"]), int(g["H"]), int(g["W"]), int(g["T"])
+    a = mk_args(maxseqlen=T, optim="adam", optim_cnn="adam", lr=float(g["lr"]), lr_cnn=float(g["lr_cnn"]),
+                weight_decay=float(g["weight_decay"]), weight_decay_cnn=float(g["weight_decay"]), dtype=dtype)
+    enc, dec, _, _ = _models(a, 88, 89)
+    x = filler.tensor(88, "trainstep_160.x", (B, 3, H, W)).cuda()
+    y_mask, y_class, sw_mask, sw_class = [t.cuda() for t in filler.synthetic_targets(88, B, H, W, gt_maxseqlen=20, n_inst=int(g["n_inst"]))]
+    enc_opt, dec_opt = build_optimizers(a, enc, dec)
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
+    pre = {("dec." + k): p.detach().clone() for k, p in dec.named_parameters()}
+    pre.update({("enc." + k): p.detach().clone() for k, p in enc.named_parameters()})
+    picks, orig = [], dec.forward
+
+    def fwd(feats, hidden):       # record the arg-max pixel of every hidden-state plane (what the max-pool side features pick)
+        out = orig(feats, hidden)
+        picks.append([h.detach().flatten(2).argmax(-1).cpu() for h, _c in out[3]])
+        return out
+    dec.forward = fwd
+    losses, outs, perms = runIter(a, enc, dec, x, y_mask, y_class.clone(), sw_mask.double(), sw_class.double(), crits, [enc_opt, dec_opt],
+                                  mode="train", want_outs=False)
+    named = [("dec." + k, p) for k, p in dec.named_parameters()] + [("enc." + k, p) for k, p in enc.named_parameters()
+                                                                    if not k.startswith("base.fc")]
+    # pyramid levels (0 = deepest) at which some plane picked another pixel than the float64 reference run
+    flipped = sorted({i for t in range(T) for i in range(5)
+                      if not np.array_equal(picks[t][i].numpy(), g["f64.argmax.t%d.l%d" % (t, i)])})
+    return g, losses, outs, perms, named, pre, (B, T, H, W), flipped
+
+
+def _level_of(k):
+    """pyramid level (0 = deepest) a dec_opt-group tensor belongs to, None for level-independent tensors, -1 for the trunk"""
+    if k.startswith("enc.base."):
+        return -1
+    if k.startswith("dec.clstm_list."):
+        return int(k.split(".")[2])
+    if k.startswith(("enc.sk", "enc.bn")):
+        return 5 - int(k.split(".")[1][2])
+    return None
+
+
+def test_trainstep_fp32_losses_outputs_gradients_and_adam_step():
+    """rsis_amd.train.runIter (reference src/train.py:54-197) on (4, 3, 160, 160), T = 4, train-mode encoder and decoder, default
+    learning rates: the four loss scalars and the mask outputs within 1e-4 of the reference, the matching permutation identical,
+    class probabilities and EVERY gradient tensor by the fp64-truth rule, and the parameters after ONE Adam step of both
+    optimizers.
+
+    One discontinuity of the reference function is handled explicitly: the global max-pool side features (model.py:143) send
+    their gradient to the arg-max pixel of each hidden-state plane; the fixture records that pixel and the gap between the two
+    largest values for all 3968 plane-timesteps (smallest relative gap: 1.3e-5; the reference's own fp32 run picks another pixel
+    than its float64 run in 2 of them).  Where this implementation picks another pixel than the float64 run, the gradients of that
+    level, of the deeper levels it feeds and of the trunk are held to 15 % relative L2 instead of the fixed-k rule."""
+    g, losses, outs, perms, named, pre, (B, T, H, W), flipped = _train_step("fp32")
+    for k, v in zip(("loss", "loss_mask_iou", "loss_stop", "loss_class"), losses):
+        assert_close(k, v, g[k], 1e-4)
+    assert (perms[1].cpu().numpy() == g["y_class_perm"]).all()
+    assert_close("out_masks", outs[0].view(B, T, H, W)[:, :, ::4, ::4], g["out_masks_sub"], 1e-4)
+    f64c = torch.from_numpy(g["f64.out_classes"])
+    floor_c = float((torch.from_numpy(g["out_classes"]).double() - f64c).abs().max())
+    assert_close("out_classes", outs[1], f64c, max(1e-4, K_FLOOR * floor_c))
+    assert len(flipped) <= 2, "arg-max picks differ from the float64 run at levels %s" % flipped
+    relaxed_upto = max(flipped) if flipped else -2
+    checked = strict = 0
+    for k, p in named:
+        flat = p.grad.detach().reshape(-1)
+        cap = 2048 if (k.startswith("dec.") or not k.startswith("enc.base.")) else 64
+        got = flat[sub_idx(flat.numel(), cap)].double().cpu()
+        f64 = torch.from_numpy(g["f64.grad." + k])
+        ref = torch.from_numpy(g["grad." + k]).double()
+        floor = float((ref - f64).abs().max())
+        scale = float(f64.abs().max())
+        err = float((got - f64).abs().max())
+        lvl = _level_of(k)
+        checked += 1
+        if flipped and (lvl == -1 or (lvl is not None and lvl <= relaxed_upto)):
+            if scale > 1e-12:
+                assert _rel_l2(got, f64) < 0.15, "grad %s (downstream of an arg-max flip): rel L2 %.3e" % (k, _rel_l2(got, f64))
+            continue
+        strict += 1
+        tol = K_FLOOR * floor + 2e-4 * scale + 1e-7
+        assert err <= tol, "grad %s: |hip - f64| %.3e > %.1f x floor %.3e + 2e-4 x %.3e" % (k, err, K_FLOOR, floor, scale)
+        # the full-vector norm as well (catches an error outside the sub-sample)
+        n64, n32 = float(g["f64.gnorm." + k]), float(g["gnorm." + k])
+        assert abs(float(flat.double().norm()) - n64) <= K_FLOOR * abs(n32 - n64) + 2e-4 * n64 + 1e-7, "gnorm " + k
+    assert checked > 300 and strict >= 20
+    # one Adam step (torch.optim.Adam, lr 1e-3 / 1e-6, weight decay 1e-6): first-step update = -lr * g / (|g| + eps), which is
+    # insensitive to the size of g wherever |g| >> eps -- compare where the gradient is well above its own fp32 noise
+    n_cmp = 0
+    lr = float(g["lr"])
+    for k, p in named:
+        if ("post." + k) not in g.files:
+            continue
+        flat = p.detach().reshape(-1)
+        idx = sub_idx(flat.numel(), 2048)
+        got, ref = flat[idx].double().cpu(), torch.from_numpy(g["post." + k]).double()
+        f64 = torch.from_numpy(g["f64.grad." + k])
+        floor = float((torch.from_numpy(g["grad." + k]).double() - f64).abs().max())
+        lvl = _level_of(k)
+        if not (flipped and lvl is not None and lvl <= relaxed_upto):
+            robust = f64.abs() > max(100 * floor, 1e-5)
+            n_cmp += int(robust.sum())
+            if robust.any():
+                assert float((got - ref)[robust].abs().max()) <= 2e-6, "post-Adam " + k
+        # and every element moved by at most one first-step update
+        assert float((got - pre[k].reshape(-1)[idx].double().cpu()).abs().max()) <= 1.001 * lr + 1e-7
+    assert n_cmp > 5000
+
+
+def test_bf16_training_tracks_fp32():
+    """Under `-dtype bf16` a train-mode gradient parity check against the fp32 reference is meaningless on the filler-weight
+    fixtures: train-mode BatchNorm over ~100 samples already amplifies fp32 rounding to 3-20 % gradient noise in the reference
+    itself (tests/golden/trainstep_160.npz, f64.* vs fp32), i.e. a condition number ~1e6, so a 2^-9 operand rounding de-correlates
+    the deep features completely (tools/exp/trainstep_flip_diag.py: 80 % of the deepest planes move their arg-max).  What is
+    checked instead: (1) the forward losses of that fixture stay within 2 % (relative); (2) optimisation behaves: 40 Adam steps from the
+    same initial weights on the same batch follow the fp32 kernels' loss curve within 3 % at every logged step."""
+    import copy
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import build_optimizers, runIter
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    g, losses, _outs, _perms, _named, _pre, _dims, _flipped = _train_step("bf16")
+    for k, v in zip(("loss", "loss_mask_iou", "loss_stop", "loss_class"), losses):
+        assert_close(k, v, g[k], 0.0, 2e-2)
+    batch = synthetic_batch(5, 8, 64, 64, 20, 3, 21, "cuda")
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(0.5)]
+    torch.manual_seed(0)
+    a0 = mk_args(hidden_size=32, maxseqlen=3, optim="adam", optim_cnn="adam", lr=1e-3, lr_cnn=1e-6, weight_decay=1e-6, weight_decay_cnn=1e-6)
+    enc0, dec0 = FeatureExtractor(a0).cuda(), RSIS(a0).cuda()
+    curves = {}
+    for dt in ("fp32", "bf16"):
+        a = copy.copy(a0)
+        a.dtype = dt
+        enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+        enc.load_state_dict(enc0.state_dict())
+        dec.load_state_dict(dec0.state_dict())
+        opts = list(build_optimizers(a, enc, dec))
+        curves[dt] = [float(runIter(a, enc, dec, *batch, crits, opts, mode="train")[0][0]) for _ in range(40)]
+    f, b = curves["fp32"], curves["bf16"]
+    assert f[-1] < 0.85 * f[0] and b[-1] < 0.85 * b[0], (f[::8], b[::8])
+    for i in range(0, 40, 4):
+        assert abs(b[i] - f[i]) <= 0.03 * f[i], "step %d: bf16 loss %.4f vs fp32 %.4f" % (i, b[i], f[i])
+
+
+def test_bf16_backward_against_an_independent_bf16_evaluation():
+    """Encoder (EVAL-mode BatchNorm: running statistics) + 2 decoder steps, mask-only loss (no arg-max-routed gradients), 96x96:
+    every gradient of the bf16 kernels against the fp32 ORACLE, with the bar set per tensor by an implementation-independent
+    bf16 evaluation of the same op graph -- the CPU oracle under torch's bf16 autocast (bf16 conv / linear operands and bf16
+    activations: strictly coarser than this path, which keeps fp32 activations): rel L2 <= max(3 %, 2 x that bf16 floor)."""
+    from oracle import filler
+    from test_gpu_bf16 import BF16_TOL
+    S, B, T = 96, 2, 2
+    a = mk_args(maxseqlen=T, dtype="bf16")
+    enc, dec, oenc, odec = _models(a, 44, 45)
+    x = filler.tensor(5, "evalbn.x", (B, 3, S, S))
+    gms = None
+
+    def run(e, d, xin, ctx):
+        e.eval()
+        d.train()
+        e.zero_grad()
+        d.zero_grad()
+        with ctx:
+            feats = e(xin)
+            hidden, loss = None, 0.0
+            for t in range(T):
+                m, _c, _s, hidden = d(feats, hidden)
+                loss = loss + (m.float() * filler.tensor(5, "evalbn.gm%d" % t, m.shape).to(m.device)).sum()
+        loss.backward()
+        out = {("dec." + k): p.grad.detach().clone().cpu() for k, p in d.named_parameters() if p.grad is not None}
+        out.update({("enc." + k): p.grad.detach().clone().cpu() for k, p in e.named_parameters() if p.grad is not None})
+        return out
+    import contextlib
+    hip16 = run(enc, dec, x.cuda(), contextlib.nullcontext())
+    ora32 = run(oenc, odec, x, contextlib.nullcontext())
+    ora16 = run(oenc, odec, x, torch.autocast("cpu", dtype=torch.bfloat16))
+    del gms
+    bad, n = [], 0
+    for k, ref in ora32.items():
+        if float(ref.abs().max()) < 1e-12:
+            continue
+        n += 1
+        e_hip, e_floor = _rel_l2(hip16[k], ref), _rel_l2(ora16[k], ref)
+        if e_hip > max(BF16_TOL["rel_l2"], 2.0 * e_floor):
+            bad.append((k, e_hip, e_floor))
+    assert n > 300
+    assert not bad, "bf16 gradients further from fp32 than 2x an independent bf16 evaluation: %s" % bad[:6]
