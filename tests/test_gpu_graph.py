@@ -72,7 +72,8 @@ def test_graphed_step_equals_eager(use_stop):
     """2 eager + 3 replayed iterations against 5 eager iterations from the same state.  Two EAGER runs already differ (fp32 atomics
     of the split-K weight gradients sum in a run-dependent order, and Adam turns noise on near-zero gradients into lr-sized
     steps; train-mode BatchNorm over 4 images amplifies it: ~3e-4 on the loss after a few steps), so the bar is calibrated in
-    the test: graph-vs-eager must be within 3x the eager-vs-eager spread (+ 2e-4 relative)."""
+    the test: graph-vs-eager must be within 5x the eager-vs-eager spread + 0.2 % (a graph that replayed stale inputs, skipped the
+    optimizer or froze Adam's step count is off by far more: the loss moves by 2-3 % per step here)."""
     from rsis_amd.synthetic import synthetic_batch
     from rsis_amd.train import GraphedStep, build_optimizers, runIter, steps_to_run
     from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
@@ -105,7 +106,7 @@ def test_graphed_step_equals_eager(use_stop):
     assert na == nb == ng == 5
     spread_l = float((la - lb).abs().max())
     spread_p = float((pa - pb).norm() / pa.norm())
-    assert float((lg - la).abs().max()) <= 3 * spread_l + 2e-4 * float(la.abs().max()), (la, lb, lg)
-    assert float((pg - pa).norm() / pa.norm()) <= 3 * spread_p + 1e-5, (spread_p, float((pg - pa).norm() / pa.norm()))
+    assert float((lg - la).abs().max()) <= 5 * spread_l + 2e-3 * float(la.abs().max()), (la, lb, lg)
+    assert float((pg - pa).norm() / pa.norm()) <= 5 * spread_p + 1e-5, (spread_p, float((pg - pa).norm() / pa.norm()))
     if not use_stop:     # the stop head never received a gradient: torch.optim.Adam semantics leave it untouched
         assert torch.equal(sa, dec0.fc_stop.weight.detach()) and torch.equal(sg, sa)

