@@ -46,49 +46,164 @@ def bench_args(batch, imsize, T, dtype="fp32"):
     return a
 
 
-def gate_kernel_roofline(B, iters, imsize):
-    """Time the fused ConvLSTM gate kernel (with recurrent state = the reference's full K) for the 5 scales with HIP
-    events on the launch stream."""
+PEAK_HBM_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.3 TB/s achievable)
+
+
+def _time_launch(launch, iters):
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def gate_kernel_roofline(B, iters, imsize, dtype="fp32", T=10, product_only=False):
+    """The fused ConvLSTM gate kernel (rsis_convlstm_fwd) of the 5 pyramid scales of one decoder timestep, timed with HIP events
+    on the launch stream, in the TWO forms SURVEY.md 8(d) asks for:
+      product : the launch rsis_amd.decoder_fused issues every timestep -- the time-invariant skip-channel term G enters as the
+                kernel's addend (computed once per iteration by one plain conv per level), only [up(h) | h_prev] is convolved;
+      full_k  : the reference's un-hoisted conv over [x | skip | h_prev] (clstm.py:43-44), as round 1 reported.
+    `achieved` is the EXECUTED TFLOP/s of the product launches (pure kernel efficiency; the hoisting is not credited),
+    `achieved_algorithmic` divides the reference's full-K FLOPs of a timestep (53.15 G at B=32, 256x256) by the product's time per
+    timestep including 1/T of the hoisted convs."""
     from rsis_amd import ops
     from rsis_amd._lib import check, int_array, lib, ptr, ptr_array, stream
     L = lib()
-    scale = imsize // 256 if imsize % 256 == 0 else 1
-    total_flops, total_ms, per_layer = 0.0, 0.0, []
-    for segs, hid, hw in GATE_LAYERS:
+    dt = ops.DTYPES[dtype]
+    rows, tot = [], {"full_flops": 0.0, "full_ms": 0.0, "dyn_flops": 0.0, "dyn_ms": 0.0, "hoist_ms": 0.0, "bytes": 0.0}
+    for li, (segs, hid, hw) in enumerate(GATE_LAYERS):
         H = W = hw * imsize // 256
+        c_skip = segs[-1]
+        c_up = segs[0] if len(segs) > 1 else 0
         cin = sum(segs) + hid
         w = torch.randn(4 * hid, cin, 3, 3, device="cuda") * (1.0 / (3.0 * cin ** 0.5))
         bias = torch.randn(4 * hid, device="cuda") * 0.1
-        pack = ops.PackedConv(3, segs + [hid], lstm_hid=hid)
-        wp = pack.fwd(w, bias)
-        srcs = [torch.randn(B, c, H, W, device="cuda") for c in segs] + [torch.tanh(torch.randn(B, hid, H, W, device="cuda"))]
+        xs = [torch.randn(B, c, H, W, device="cuda") for c in segs]
+        h_prev = torch.tanh(torch.randn(B, hid, H, W, device="cuda"))
         c_prev = torch.randn(B, hid, H, W, device="cuda")
         h, c = torch.empty_like(c_prev), torch.empty_like(c_prev)
         act = torch.empty(B, 4 * hid, H, W, device="cuda")
+        # ---- full K (reference form) ----
+        pack = ops.PackedConv(3, segs + [hid], lstm_hid=hid, dtype=dt)
+        wp = pack.fwd(w, bias)
+        srcs = xs + [h_prev]
         pa, ia = ptr_array(srcs), int_array(segs + [hid])
+        ms_full = 1e-9 if product_only else _time_launch(
+            lambda: check(L.rsis_convlstm_fwd(pa, ia, len(srcs), B, H, W, ptr(wp), ptr(pack.bias_p), None, ptr(c_prev), ptr(h), ptr(c), ptr(act),
+                                              hid, 3, 1, 0, dt, stream()), "rsis_convlstm_fwd"), iters)
+        # ---- product form: hoisted skip term + dynamic channels ----
+        hoist = ops.PackedConv(3, [c_skip], lstm_hid=hid, offs=[c_up], dtype=dt)
+        dyn = ops.PackedConv(3, ([c_up] if c_up else []) + [hid], lstm_hid=hid, offs=([0] if c_up else []) + [c_up + c_skip], dtype=dt)
+        wh, wd = hoist.fwd(w, bias), dyn.fwd(w)
+        G = torch.empty(B, 4 * hid, H, W, device="cuda")
+        skip = xs[-1]
+        ps, is_ = ptr_array([skip]), int_array([c_skip])
+        ms_hoist = _time_launch(lambda: check(L.rsis_conv2d_fwd(ps, is_, 1, B, H, W, ptr(wh), 4 * hid, 3, 1, 1, ptr(hoist.bias_p), None, ptr(G),
+                                                                 H, W, 0, dt, stream()), "rsis_conv2d_fwd(hoist)"), 1 if product_only else iters)
+        dsrc = ([xs[0]] if c_up else []) + [h_prev]
+        pd, idd = ptr_array(dsrc), int_array(([c_up] if c_up else []) + [hid])
+        ms_dyn = _time_launch(lambda: check(L.rsis_convlstm_fwd(pd, idd, len(dsrc), B, H, W, ptr(wd), None, ptr(G), ptr(c_prev), ptr(h), ptr(c),
+                                                                 ptr(act), hid, 3, 1, 0, dt, stream()), "rsis_convlstm_fwd(step)"), iters)
+        M = B * H * W
+        f_full = 2.0 * M * (cin * 9) * (4 * hid)
+        f_dyn = 2.0 * M * ((c_up + hid) * 9) * (4 * hid)
+        # minimum HBM bytes of the product launch: inputs [up | h_prev], G, c_prev in; h, c, saved gates out (fp32)
+        byts = 4.0 * M * ((c_up + hid) + 4 * hid + hid + hid + hid + 4 * hid)
+        rows.append({"HxW": "%dx%d" % (H, W), "gemm_MKN_full": [M, cin * 9, 4 * hid], "gemm_MKN_product": [M, (c_up + hid) * 9, 4 * hid],
+                     "ms_full": round(ms_full, 4), "tflops_full": round(f_full / ms_full / 1e9, 2),
+                     "ms_product": round(ms_dyn, 4), "tflops_product": round(f_dyn / ms_dyn / 1e9, 2),
+                     "gbs_product": round(byts / ms_dyn / 1e6, 1), "ms_hoist_per_iteration": round(ms_hoist, 4)})
+        tot["full_flops"] += f_full
+        tot["full_ms"] += ms_full
+        tot["dyn_flops"] += f_dyn
+        tot["dyn_ms"] += ms_dyn
+        tot["hoist_ms"] += ms_hoist
+        tot["bytes"] += byts
+    executed = tot["dyn_flops"] / tot["dyn_ms"] / 1e9
+    algorithmic = tot["full_flops"] / (tot["dyn_ms"] + tot["hoist_ms"] / T) / 1e9
+    full = tot["full_flops"] / tot["full_ms"] / 1e9
+    out = {"kernel": ("conv3x3_direct_kernel<..., EPI_LSTM>" if dtype == "fp32" else "conv_bf16_kernel<3, ..., EPI_LSTM>") +
+                     " (rsis_convlstm_fwd), the 5 pyramid levels of one decoder timestep as rsis_amd.decoder_fused launches them "
+                     "(hoisted skip term as addend, dynamic channels only)",
+           "per_scale": rows, "ms_per_timestep": round(tot["dyn_ms"], 4), "executed_gflop_per_timestep": round(tot["dyn_flops"] / 1e9, 3),
+           "algorithmic_gflop_per_timestep": round(tot["full_flops"] / 1e9, 3),
+           "hoisted_convs_ms_per_iteration": round(tot["hoist_ms"], 4),
+           "achieved_executed": round(executed, 2), "achieved_algorithmic": round(algorithmic, 2),
+           "full_k": {"ms_per_timestep": round(tot["full_ms"], 4), "achieved": round(full, 2),
+                      "note": "the reference's un-hoisted launch (what round 1 reported as roofline.achieved)"},
+           "traffic": None}
+    out["algorithmic_mbytes_per_timestep"] = round(tot["bytes"] / 1e6, 1)
+    if dtype == "fp32":
+        out.update({"bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4), "frac_algorithmic": round(algorithmic / PEAK_F32_MFMA_TFLOPS, 4),
+                    "frac_full_k": round(full / PEAK_F32_MFMA_TFLOPS, 4)})
+    else:
+        gbs = tot["bytes"] / tot["dyn_ms"] / 1e6
+        out.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "note": "bf16 operands at 16x the f32 MFMA rate: the launch is bound by its fp32 activation traffic"})
+    return out
 
-        def launch():
-            check(L.rsis_convlstm_fwd(pa, ia, len(srcs), B, H, W, ptr(wp), ptr(pack.bias_p), None, ptr(c_prev), ptr(h), ptr(c),
-                                      ptr(act), hid, 3, 1, 0, pack.dtype, stream()), "rsis_convlstm_fwd")
-        for _ in range(3):
-            launch()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            launch()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / iters
-        flops = 2.0 * (B * H * W) * (cin * 9) * (4 * hid)
-        per_layer.append({"HxW": "%dx%d" % (H, W), "gemm_MKN": [B * H * W, cin * 9, 4 * hid], "ms": round(ms, 4),
-                          "tflops": round(flops / ms / 1e9, 2)})
-        total_flops += flops
-        total_ms += ms
-    achieved = total_flops / total_ms / 1e9
-    return {"bound": "mfma", "kernel": "conv3x3_direct_kernel<..., EPI_LSTM> (rsis_convlstm_fwd), the 5 pyramid levels of one decoder timestep, full K",
-            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": None, "algorithmic_gflop_per_timestep": round(total_flops / 1e9, 3), "ms_per_timestep": round(total_ms, 4),
-            "per_scale": per_layer}
+
+# (Cin, Cout, ks, out HxW at 256^2, layers of that shape in ResNet-101 + skip convs) -- SURVEY.md Appendix A
+TRUNK_SHAPES = [(256, 256, 3, 16, 22), (256, 1024, 1, 16, 23), (1024, 256, 1, 16, 22), (64, 64, 3, 64, 3), (128, 128, 3, 32, 3),
+                (512, 512, 3, 8, 2), (64, 256, 1, 64, 4), (128, 512, 1, 32, 4), (512, 128, 1, 32, 3), (512, 2048, 1, 8, 3),
+                (2048, 512, 1, 8, 2), (2048, 128, 3, 8, 1), (1024, 128, 3, 16, 1), (64, 16, 3, 128, 1)]
+
+
+def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
+    """roofline_kernels: the four kernel families that hold most of the step next to the gate kernel -- the 1x1 GEMM (forward and
+    data gradient), the direct 3x3 conv with the plain epilogue (forward and data gradient), and the tiled weight gradients (3x3,
+    1x1) -- on the stride-1 layer shapes of the ResNet-101 trunk and the skip convs, weighted by how many layers have each shape."""
+    from rsis_amd import ops
+    from rsis_amd._lib import check, int_array, lib, ptr, ptr_array, stream
+    L = lib()
+    dt = ops.DTYPES[dtype]
+    fam = {}
+    for cin, cout, ks, hw, count in TRUNK_SHAPES:
+        hw = hw * imsize // 256
+        pad = ks // 2
+        x = torch.randn(B, cin, hw, hw, device="cuda")
+        w = torch.randn(cout, cin, ks, ks, device="cuda") / (ks * cin ** 0.5)
+        pack = ops.PackedConv(ks, [cin], stride=1, pad=pad, dtype=dt)
+        wp, wd = pack.fwd(w), pack.dgrad(w)
+        y = torch.empty(B, cout, hw, hw, device="cuda")
+        dx, dW = torch.empty_like(x), torch.zeros_like(w)
+        pa, ia, pd = ptr_array([x]), int_array([cin]), ptr_array([dx])
+        fl = 2.0 * B * hw * hw * cin * ks * ks * cout
+        ms_f = _time_launch(lambda: check(L.rsis_conv2d_fwd(pa, ia, 1, B, hw, hw, ptr(wp), cout, ks, 1, pad, None, None, ptr(y), hw, hw, 0, dt,
+                                                            stream()), "fwd"), iters)
+        ms_d = _time_launch(lambda: check(L.rsis_conv2d_dgrad(ptr(y), B, cout, hw, hw, ptr(wd), cin, ks, 1, pad, pd, ia, 1, hw, hw, None, 0, dt,
+                                                              stream()), "dgrad"), iters)
+        ms_w = _time_launch(lambda: check(L.rsis_conv2d_wgrad(ptr(y), ptr(x), ptr(dW), B, cin, hw, hw, cout, hw, hw, ks, 1, pad, cin, 0, 0, dt,
+                                                              stream()), "wgrad"), iters)
+        act_bytes = 4.0 * B * hw * hw * (cin + cout)
+        for name, ms, n in (("conv%dx%d fwd+dgrad" % (ks, ks), ms_f + ms_d, 2), ("conv%dx%d wgrad" % (ks, ks), ms_w, 1)):
+            f = fam.setdefault(name, {"flops": 0.0, "ms": 0.0, "bytes": 0.0, "launches": 0})
+            f["flops"] += n * fl * count
+            f["ms"] += ms * count
+            f["bytes"] += n * act_bytes * count
+            f["launches"] += n * count
+    kern = {"conv1x1 fwd+dgrad": ("conv_igemm_kernel<..., V4>", "conv_bf16_kernel<1, ...>"),
+            "conv3x3 fwd+dgrad": ("conv3x3_direct_kernel<..., EPI_PLAIN>", "conv_bf16_kernel<3, ..., EPI_PLAIN>"),
+            "conv1x1 wgrad": ("conv_wgrad_tiled_kernel<..., 1, ...>", "wgrad1_bf16_kernel"),
+            "conv3x3 wgrad": ("conv_wgrad_tiled_kernel<..., 3, ...>", "wgrad3_bf16_kernel")}
+    out = []
+    for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+        tf = f["flops"] / f["ms"] / 1e9
+        r = {"family": name, "kernel": kern[name][0 if dtype == "fp32" else 1], "launches_per_step": f["launches"],
+             "ms_per_step": round(f["ms"], 3), "avg_us": round(1e3 * f["ms"] / f["launches"] * (2 if "fwd" in name else 1), 1),
+             "tflops": round(tf, 1)}
+        if dtype == "fp32":
+            r.update({"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)})
+        else:
+            gbs = f["bytes"] / f["ms"] / 1e6
+            r.update({"bound": "hbm", "gbs": round(gbs, 1), "peak": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4)})
+        out.append(r)
+    return out
 
 
 def cpu_baseline(imsize, T, budget_s=25.0):
@@ -140,8 +255,8 @@ def gate_kernel_traffic(batch, imsize, timeout=150):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", counter.lower(), "--",
-                   sys.executable, os.path.abspath(__file__), "--roofline-only", "--kernel-iters", "4", "--batch", str(batch), "--imsize",
-                   str(imsize)]
+                   sys.executable, os.path.abspath(__file__), "--roofline-only", "--product-only", "--kernel-iters", "4", "--batch", str(batch),
+                   "--imsize", str(imsize)]
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
             path = None
             for root, _d, files in os.walk(tmp):
@@ -187,6 +302,8 @@ def main():
     ap.add_argument("--settle-min", type=float, default=2.0, help="minimum seconds of the untimed settle phase")
     ap.add_argument("--settle-cap", type=float, default=10.0, help="maximum seconds of the untimed settle phase")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--product-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--skip-secondary", action="store_true", help="do not run the bf16 224x224 leg (BASELINE configs[2]) after the headline run")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the gate-kernel roofline leg and print its object (for `rocprofv3 --kernel-trace --stats`: the "
                          "profile then holds exactly the launches the `roofline` figure is computed from)")
@@ -196,7 +313,7 @@ def main():
         return
     if o.roofline_only:
         assert torch.cuda.is_available(), "bench.py needs the GPU (there is no CPU path)"
-        print(json.dumps(gate_kernel_roofline(o.batch, o.kernel_iters, o.imsize)))
+        print(json.dumps(gate_kernel_roofline(o.batch, o.kernel_iters, o.imsize, o.dtype, o.T, product_only=o.product_only)))
         return
 
     from rsis_amd.train import GraphedStep, build_optimizers, init_distributed, runIter
@@ -243,16 +360,22 @@ def main():
         if rank == 0:
             print("[bench] %s" % msg, file=sys.stderr, flush=True)
 
-    roof = None
+    roof = roof_kernels = None
     if rank == 0 and not o.skip_roofline:
-        roof = gate_kernel_roofline(o.batch, o.kernel_iters, o.imsize)
-        note("gate kernel roofline: %s TFLOP/s" % roof["achieved"])
+        roof = gate_kernel_roofline(o.batch, o.kernel_iters, o.imsize, o.dtype, o.T)
+        note("gate kernel roofline: executed %s, algorithmic %s, full-K %s TFLOP/s" % (roof["achieved_executed"], roof["achieved_algorithmic"],
+                                                                                       roof["full_k"]["achieved"]))
+        roof_kernels = trunk_kernel_rooflines(o.batch, max(3, o.kernel_iters // 4), o.imsize, o.dtype)
+        note("roofline_kernels: %s" % "; ".join("%s %.1f TF/s" % (r["family"], r["tflops"]) for r in roof_kernels))
         if world == 1 and not o.skip_traffic:
             t0 = time.time()
             traffic, detail = gate_kernel_traffic(o.batch, o.imsize)
             roof["traffic"] = traffic
             if traffic is not None:
-                roof["traffic_unit"] = "bytes per timestep (5 launches): 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate passes"
+                roof["traffic_unit"] = ("bytes per timestep (the 5 product launches): 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate "
+                                        "passes; the x2 is the guide's gfx950 correction, re-measured for this kernel's dword LDS-DMA reads in "
+                                        "profiles/r02_fetch_calibration.txt")
+                roof["traffic_vs_algorithmic"] = round(traffic / (roof["algorithmic_mbytes_per_timestep"] * 1e6), 3)
                 roof["traffic_detail"] = detail
             note("gate kernel HBM traffic: %s (%.0f s)" % (traffic if traffic is not None else detail, time.time() - t0))
     tw = time.time()
@@ -304,7 +427,7 @@ def main():
     loss_val = float(losses[0])
     assert loss_val == loss_val, "loss is NaN"
 
-    cpu, out = None, None
+    cpu, out, secondary = None, None, None
     if rank == 0:
         note("timed region %.3f s for %d steps" % (dt, o.steps))
         if world == 1 and not o.skip_cpu:
@@ -317,6 +440,20 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 cpu = {"value": None, "unit": "images/s", "cores": None, "kind": "port", "sample": "failed: %r" % (ex,)}
             note("cpu baseline: %s" % (cpu,))
+        secondary = None
+        if world == 1 and o.dtype == "fp32" and not o.skip_secondary:
+            # BASELINE configs[2] (224x224, T=10, batch 32, bf16) as a secondary record: own process, same harness
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", "bf16", "--imsize", "224", "--batch", str(o.batch), "--T",
+                                    str(o.T), "--steps", str(o.steps), "--warmup", str(o.warmup), "--skip-cpu", "--skip-traffic",
+                                    "--skip-secondary", "--kernel-iters", str(o.kernel_iters)], capture_output=True, text=True, timeout=600)
+                sj = json.loads(r.stdout.strip().splitlines()[-1])
+                sj["config"]["workload"] = sj["config"]["workload"].replace("configs[1]", "configs[2]")
+                secondary = [{k: sj[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "roofline_kernels")}]
+            except Exception as ex:  # noqa: BLE001
+                secondary = [{"error": repr(ex)}]
+            note("secondary (bf16, 224x224): %s" % (secondary[0].get("value"),))
         value = world * o.batch * o.steps / dt
         out = {"metric": "training images/sec at %dx%d, T=%d, batch=%d per GPU" % (o.imsize, o.imsize, o.T, o.batch),
                "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": o.steps, "warmup": o.warmup,
@@ -327,7 +464,7 @@ def main():
                           "global_batch": world * o.batch, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5),
                           "launch": "hipGraph replay of the captured iteration" if (gstep is not None and gstep.graph is not None)
                                     else "eager (one Python launch per kernel)"},
-               "roofline": roof, "cpu_baseline": cpu}
+               "roofline": roof, "roofline_kernels": roof_kernels, "cpu_baseline": cpu, "secondary": secondary}
     # RCCL prints a banner (version, library path) through C stdio, which on a pipe is flushed only at exit, i.e. AFTER anything
     # python printed: every rank flushes its C streams before the final barrier, rank 0 prints after it, so that the JSON line
     # is the last line of the job's (merged) stdout
