@@ -49,12 +49,26 @@ def steps_to_run(args, sw_mask):
     return T if len(idx) == 0 else int(idx[0]) + 1
 
 
+def apply_update(args, optims, gscale=1.0):
+    """the two optimizer steps of train.py:185-187 (dec_opt always, enc_opt when the encoder is being updated) and the rebuild of
+    every packed weight copy; gscale = 1 / world_size after a SUM all-reduce of the gradients"""
+    enc_opt, dec_opt = optims
+    dec_opt.gscale = gscale
+    enc_opt.gscale = gscale
+    dec_opt.step()                                                    # :185
+    if args.update_encoder:
+        enc_opt.step()                                                # :186-187
+    ops.repack_all()                                                  # every packed weight copy in one launch
+
+
 def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits, optims, mode="train", reducer=None,
-            sync_losses=True, t_run=None, want_outs=True):
+            sync_losses=True, t_run=None, want_outs=True, do_update=True):
     """Runs forward, computes loss and (if train mode) updates parameters for the provided batch (train.py:54-197).
     Returns (losses [total, iou, stop, class], outs [sigmoid(masks), class probs], perms [y_mask_perm, y_class_perm]).
     want_outs=False (training loops that only log the losses, as the reference's trainIters does: train.py:344-356): the
-    sigmoid of all T full-resolution masks (train.py:191) is not computed and outs[0] holds the raw logits."""
+    sigmoid of all T full-resolution masks (train.py:191) is not computed and outs[0] holds the raw logits.
+    do_update=False: stop after the backward (gradients left in the flat buffers; the caller all-reduces them and calls
+    apply_update) -- the split GraphedStep uses when a gradient exchange sits between the backward and the optimizer."""
     from .utils.hungarian import MaskedNLL, StableBalancedMaskedBCE, softIoU
     mask_siou, class_crit, stop_xentropy = crits
     enc_opt, dec_opt = optims
@@ -149,14 +163,8 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
             loss.backward()                                           # :184
         finally:
             ops.DIRECT_GRAD[0] = prev
-        gscale = reducer.finish() if reducer is not None else 1.0
-        dec_opt.gscale = gscale
-        enc_opt.gscale = gscale
-        dec_opt.step()                                                # :185
-        if args.update_encoder:
-            enc_opt.step()                                            # :186-187
-        if x.is_cuda:
-            ops.repack_all()                                          # every packed weight copy in one launch
+        if do_update:
+            apply_update(args, optims, reducer.finish() if reducer is not None else 1.0)
 
     losses = [loss.detach(), loss_mask_iou.detach(), loss_stop.detach(), loss_class.detach()]
     if sync_losses:
@@ -176,6 +184,18 @@ def init_distributed():
         if os.environ.get("RSIS_SHARE_GPU", "") == "1":     # test hook: several ranks on one GPU (gloo backend only)
             local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
+    if world > 1 and os.environ.get("RSIS_PIN_THREADS", "1") != "0":
+        # one process per GPU on one host: give every rank its own slice of the cores (the step is launched from one Python
+        # thread per rank; 8 ranks all spinning up cores/1 intra-op threads fight each other)
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            per = max(1, len(cores) // int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+            mine = cores[local_rank * per:(local_rank + 1) * per]
+            if mine:
+                os.sched_setaffinity(0, mine)
+                torch.set_num_threads(max(1, min(per, 8)))
+        except (AttributeError, OSError):
+            pass
     force = os.environ.get("RSIS_FORCE_DIST", "") == "1"      # test hook: run the collective path even at world size 1
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -203,29 +223,40 @@ def build_optimizers(args, encoder, decoder):
 
 
 class GraphedStep(object):
-    """One training iteration (runIter: encoder, T decoder steps, matching, losses, backward, gradient all-reduce, both Adam
-    steps, weight repack) captured ONCE as a hipGraph and replayed: the ~1000 kernel launches of a step cost the host one
+    """One training iteration (runIter: encoder, T decoder steps, matching, losses, backward, gradient exchange, both Adam
+    steps, weight repack) captured ONCE as hipGraphs and replayed: the ~1000 kernel launches of a step cost the host a
     hipGraphLaunch instead of ~35 us of Python each (the reference's train.py:85-115 loop is host-bound in the same way).
     The first `warm` calls run eagerly on a side stream (they are real training steps), the next one captures.  A capture is
-    valid for one (input shapes, t_run, loss switches, update_encoder, active parameter set) key; `step_for` keeps one per key.
+    valid for one (input shapes, t_run, loss switches, update_encoder, active parameter set) key; the caller keeps one per key.
     Inputs are copied into static buffers; the returned losses / outs / perms are static device tensors overwritten by the
-    next replay."""
+    next replay.
+
+    With a gradient exchange (`reducer` active: one process per GPU) the iteration is TWO graphs with the RCCL all-reduce of
+    the flat gradient buffers between them, launched eagerly: RCCL refuses stream capture on this stack (ProcessGroupNCCL raises
+    hipErrorStreamCaptureUnsupported from its watchdog thread, which terminates the process), and this keeps the collective
+    out of the capture entirely.  The all-reduce (194 MB, ~1-2 ms over xGMI) is then not overlapped with the backward."""
 
     def __init__(self, args, encoder, decoder, crits, optims, reducer=None, warm=2, pool=None):
         self.args, self.encoder, self.decoder, self.crits, self.optims, self.reducer = args, encoder, decoder, crits, optims, reducer
+        self.split = reducer is not None and getattr(reducer, "active", False)
         self.warm, self.pool = warm, pool
-        self.graph, self.static, self.result, self.t_run = None, None, None, None
+        self.graph, self.graph_update, self.static, self.result, self.t_run = None, None, None, None, None
         self.stream = torch.cuda.Stream()
         self.n_eager = 0
         self._bns = None
         self.failed = None
 
-    def _run(self, batch, t_run):
-        return runIter(self.args, self.encoder, self.decoder, *batch, self.crits, self.optims, mode="train", reducer=self.reducer,
-                       sync_losses=False, t_run=t_run, want_outs=False)
+    def _run(self, batch, t_run, do_update=True):
+        return runIter(self.args, self.encoder, self.decoder, *batch, self.crits, self.optims, mode="train",
+                       reducer=None if self.split else self.reducer, sync_losses=False, t_run=t_run, want_outs=False, do_update=do_update)
 
     def _groups(self):
         return [o.group for o in self.optims if isinstance(o, FlatAdam)]
+
+    def _exchange(self):
+        """SUM all-reduce of the flat gradient buffers (decoder + skip group first), eagerly, on the replay stream"""
+        for g in reversed(self._groups()):
+            dist.all_reduce(g.flat_g, op=dist.ReduceOp.SUM, group=self.reducer.pg)
 
     def __call__(self, batch, t_run):
         if self.graph is None and self.failed is None and self.n_eager >= self.warm:
@@ -234,7 +265,12 @@ class GraphedStep(object):
             self.n_eager += 1
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                res = self._run(batch, t_run)
+                if self.split:
+                    res = self._run(batch, t_run, do_update=False)
+                    self._exchange()
+                    apply_update(self.args, self.optims, 1.0 / self.reducer.world)
+                else:
+                    res = self._run(batch, t_run)
             torch.cuda.current_stream().wait_stream(self.stream)
             return res
         if t_run != self.t_run:
@@ -243,6 +279,9 @@ class GraphedStep(object):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        if self.split:
+            self._exchange()
+            self.graph_update.replay()
         for g in self._groups():
             if self.args.update_encoder or g is not self.optims[0].group:
                 g.note_replay()
@@ -259,13 +298,17 @@ class GraphedStep(object):
         groups = self._groups()
         for g in groups:
             g.begin_graph()
-        graph = torch.cuda.CUDAGraph()
+        graph, graph_u = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         try:
             torch.cuda.synchronize()
             with torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
-                self.result = self._run(self.static, t_run)
+                self.result = self._run(self.static, t_run, do_update=not self.split)
+            if self.split:
+                with torch.cuda.graph(graph_u, pool=graph.pool(), stream=self.stream):
+                    apply_update(self.args, self.optims, 1.0 / self.reducer.world)
+                self.graph_update = graph_u
             self.graph = graph
-        except Exception as e:  # noqa: BLE001  (capture refused, e.g. by a collective backend: stay eager)
+        except Exception as e:  # noqa: BLE001  (capture refused: stay eager)
             self.failed = repr(e)
             for g in groups:
                 g.end_graph()
@@ -276,7 +319,7 @@ class GraphedStep(object):
     def release(self):
         for g in self._groups():
             g.end_graph()
-        self.graph = self.result = self.static = None
+        self.graph = self.graph_update = self.result = self.static = None
 
 
 def init_dataloaders(args, rank=0, world=1):

@@ -104,3 +104,98 @@ def test_runiter_world2_gradients_and_parameters_agree():
         a, b = res[0][i], res[1][i]
         assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]), what
     assert res[0][4] > 0, "the optimizer step did not change the parameters"
+
+
+def _worker_nccl(rank, world, port, q):
+    """one process per GPU over RCCL: identical replicas, different shards, two real steps (eager, then hipGraph replay)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from helpers import mk_args
+    from rsis_amd.modules import RSIS, FeatureExtractor
+    from rsis_amd.optim import BucketedAllReduce
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import GraphedStep, build_optimizers, init_distributed, runIter, steps_to_run
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    init_distributed()                                      # backend nccl (= RCCL), device = LOCAL_RANK
+    a = mk_args(hidden_size=32, maxseqlen=3, optim="adam", optim_cnn="adam", lr=1e-3, lr_cnn=1e-4, weight_decay=0.0, weight_decay_cnn=0.0)
+    torch.manual_seed(0)
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    for p in list(enc.parameters()) + list(dec.parameters()) + list(enc.buffers()):
+        dist.broadcast(p.data, 0)
+    enc_opt, dec_opt = build_optimizers(a, enc, dec)
+    red = BucketedAllReduce([dec_opt.group, enc_opt.group], bucket_bytes=8 << 20)
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(0.5)]
+    batch = synthetic_batch(10 + rank, 2, 64, 64, 20, 3, 21, "cuda")
+    t_run = steps_to_run(a, batch[3])
+    runIter(a, enc, dec, *batch, crits, [enc_opt, dec_opt], mode="train", reducer=red, sync_losses=False, t_run=t_run)
+    g = GraphedStep(a, enc, dec, crits, [enc_opt, dec_opt], red, warm=1)
+    for _ in range(3):
+        g(batch, t_run)
+    torch.cuda.synchronize()
+    p1 = torch.cat([dec_opt.group.flat_p, enc_opt.group.flat_p]).double().cpu()
+    q.put((rank, float(p1.sum()), float(p1.abs().sum()), p1[::997].numpy().copy(), g.graph is not None, g.failed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL: one GPU per rank)")
+def test_runiter_world2_rccl_parameters_agree():
+    """torch.distributed backend `nccl` (RCCL over xGMI), 2 ranks on 2 GPUs: after one eager and three further steps (captured as
+    two hipGraphs around an eager all-reduce of the flat gradient buffers) the replicas hold identical parameters."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_nccl, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    a, b = res
+    assert a[1] == b[1] and a[2] == b[2] and np.array_equal(a[3], b[3]), "parameters diverged between ranks"
+
+
+def _worker_force_dist_graph(q):
+    """world size 1 with the collective path forced on (RCCL all-reduce at one rank): the iteration replays as two hipGraphs with
+    the eager all-reduce of the flat gradient buffers between them (RCCL refuses stream capture on this stack)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", RSIS_FORCE_DIST="1")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import mk_args
+    from rsis_amd.modules import RSIS, FeatureExtractor
+    from rsis_amd.optim import BucketedAllReduce
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import GraphedStep, build_optimizers, init_distributed, steps_to_run
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    init_distributed()
+    a = mk_args(hidden_size=32, maxseqlen=3, optim="adam", optim_cnn="adam", lr=1e-3, lr_cnn=1e-4, weight_decay=0.0, weight_decay_cnn=0.0)
+    torch.manual_seed(0)
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    opts = list(build_optimizers(a, enc, dec))
+    red = BucketedAllReduce([opts[1].group, opts[0].group], bucket_bytes=8 << 20, force=True)
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(0.5)]
+    batch = synthetic_batch(10, 2, 64, 64, 20, 3, 21, "cuda")
+    t_run = steps_to_run(a, batch[3])
+    g = GraphedStep(a, enc, dec, crits, opts, red, warm=1)
+    ls = [float(g(batch, t_run)[0][0]) for _ in range(6)]
+    torch.cuda.synchronize()
+    q.put((g.graph is not None, g.failed, ls))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_graph_capture_with_rccl_collectives_world1():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_force_dist_graph, args=(q,))
+    p.start()
+    captured, failed, ls = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0
+    assert captured, "capture refused: %s" % failed
+    assert all(v == v for v in ls) and ls[-1] < ls[0], ls
