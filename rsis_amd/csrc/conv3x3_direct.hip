@@ -394,7 +394,7 @@ static int launch_direct_cfg(ConvArgs& a, hipStream_t st) {
 }
 
 // variant codes: 1 = BM64 8x8x1 (64 px), 2 = BM64 16x8 (128 px), 3 = BM64 32x8 (256 px), 4 = BM32 16x8, 5 = BM32 32x8,
-// 6 = BM32 8x8 with the K range split over two wave pairs
+// 6 = BM32 8x8 with the K range split over two wave pairs, 7 = BM32 64x8 (512 px), 8 = BM64 64x8
 template <int EPI>
 static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
   int v = force;
@@ -430,6 +430,8 @@ static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
     case 4: return launch_direct_cfg<32, 16, 8, 1, EPI>(a, st);
     case 5: return launch_direct_cfg<32, 32, 8, 1, EPI>(a, st);
     case 6: if constexpr (EPI != EPI_S2) return launch_direct_cfg<32, 8, 8, 1, EPI, 2>(a, st); else return RSIS_ERR_ARG;
+    case 7: if constexpr (EPI != EPI_S2) return launch_direct_cfg<32, 64, 8, 1, EPI>(a, st); else return RSIS_ERR_ARG;
+    case 8: if constexpr (EPI != EPI_S2) return launch_direct_cfg<64, 64, 8, 1, EPI>(a, st); else return RSIS_ERR_ARG;
     default: return RSIS_ERR_ARG;
   }
 }

@@ -198,18 +198,29 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(const WgradBf16Args p)
 #undef W3_LOAD
 #undef W3_STORE
 
-  // ---- epilogue: transpose 8 rows x 288 columns per wave through LDS, then fp32 atomics with the lanes running along n ----
-  float* red = (float*)lds + wave * (8 * 288);
+  // ---- epilogue: the KSPW wave copies of a row group first sum their partial tiles in LDS (fewer same-address atomics: they are
+  // serialised by the L2), 8 rows x 288 columns at a time; the rows are then split over the copies and added to dW with the lanes
+  // running along n (consecutive addresses) ----
+  float* red = (float*)lds + wm * (8 * 288);
   const int nvalid = min(32, Cs - ci0) * 9;                        // valid columns of this block's 288
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int k = 0; k < KSPW; ++k) {
+      if (wk == k) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[(r + 4 * hi) * 288 + l31 * 9 + t] = acc[t][4 * q + r];
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's own writes (each wave owns its slab: no barrier needed)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
+          for (int r = 0; r < 4; ++r) {
+            float* d = red + (r + 4 * hi) * 288 + l31 * 9 + t;
+            if (k == 0) *d = acc[t][4 * q + r];
+            else *d += acc[t][4 * q + r];
+          }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int rr = wk; rr < 8; rr += KSPW) {
       const int co = co0 + wm * 32 + 8 * q + rr;
       if (co >= Cout) continue;
       const int orow = p.interleave_hid > 0 ? (co & 3) * p.interleave_hid + (co >> 2) : co;
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(const WgradBf16Args p)
         if (n < nvalid) atomicAdd(dst + n, red[rr * 288 + n]);
       }
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __syncthreads();
   }
 #endif
 }
@@ -357,6 +368,7 @@ static void split_plan(WgradBf16Args& a, int TW, int ntile, int slots) {
   const int TH = 64 / TW;
   a.n_sp_tiles = a.B * rsis_cdiv(a.H, TH) * rsis_cdiv(a.W, TW);
   int nsplit = ntile >= slots ? 1 : slots / ntile;
+  if (nsplit > 256) nsplit = 256;          // every split adds one atomic per dW element: keep the same-address chains short
   if (nsplit > a.n_sp_tiles / 2) nsplit = a.n_sp_tiles / 2;
   if (nsplit < 1) nsplit = 1;
   a.tiles_per_split = rsis_cdiv(a.n_sp_tiles, nsplit);

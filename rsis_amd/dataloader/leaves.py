@@ -1,0 +1,199 @@
+"""CVPPP A1 leaves data layer -- the reference's src/dataloader/leaves.py:9-113 + dataset.py:47-84 + dataset_utils.py:28-58, wired to
+the device-side target construction and affine augmentation (BASELINE configs[0]).
+
+Split of the work:
+  host   : file list and train / val split (leaves.py:64-94), PNG decode and the bilinear resize of the image (PIL, as the
+           reference: dataset.py:49-54), nearest resize of the instance map to the image size (scipy zoom order 0:
+           dataset_utils.py:133-140), horizontal flip and random crop (index operations, dataset_utils.py:45-58), the draw of the
+           affine matrix (python `random`, same draw order as the reference) -- into PINNED staging buffers, decoded by a small
+           thread pool one batch ahead;
+  device : uint8 -> float, ImageNet normalisation (train.py:34-37), the affine warp of image + instance map (rsis_affine_nearest,
+           bit-equal to the reference's th_affine2d(mode='nearest')), and the target tensors runIter reads
+           (dataloader.targets_from_maps == sequence_from_masks + batch_to_var).
+Deviation: the file list is sorted (the reference takes glob's order, which is file-system dependent)."""
+import glob
+import os
+import random
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from .augment import RandomAffine, affine_nearest
+from .targets import targets_from_maps
+
+MEAN = (0.485, 0.456, 0.406)
+STD = (0.229, 0.224, 0.225)
+
+
+class LeavesDataset(object):
+    """reference LeavesDataset(MyDataset): same constructor arguments, `classes`, `get_raw_sample`, `__len__`, `get_sample_list`."""
+
+    def __init__(self, args, transform=None, target_transform=None, augment=False, split="train", resize=False, imsize=256):
+        self.split = split
+        self.classes = ["<eos>", "leaf"]                                   # leaves.py:20
+        self.num_classes = len(self.classes)
+        self.max_seq_len = args.gt_maxseqlen
+        self.batch_size = args.batch_size
+        self.crop = self.batch_size != 1                                   # :31-34
+        self.flip = augment
+        self.augment, self.resize, self.imsize, self.zoom = augment, resize, imsize, args.zoom
+        if augment:                                                         # :36-47
+            self.augmentation_transform = RandomAffine(rotation_range=args.rotation, translation_range=args.translation,
+                                                       shear_range=args.shear, zoom_range=(args.zoom, 1) if resize else None,
+                                                       interp="nearest")
+        else:
+            self.augmentation_transform = None
+        total = sorted(glob.glob(os.path.join(args.leaves_dir, "*_rgb.png")))
+        gts = [w.replace("_rgb", "_label") for w in total]
+        if split == "train":                                                # :72-94: the first 96 images train, the rest validate
+            self.image_files, self.gt_files = total[:96], gts[:96]
+        elif split == "val":
+            self.image_files, self.gt_files = total[96:], gts[96:]
+        else:
+            self.image_files = sorted(glob.glob(os.path.join(args.leaves_test_dir, "*_rgb.png")))
+            self.gt_files = []
+
+    def get_classes(self):
+        return self.classes
+
+    def get_sample_list(self):
+        return self.image_files
+
+    def __len__(self):
+        return len(self.image_files)
+
+    def get_raw_sample(self, index):
+        """(PIL RGB image, instance-id map, class map) in raw size -- leaves.py:96-113"""
+        from PIL import Image
+        img = Image.open(self.image_files[index]).convert("RGB")
+        if self.split != "test":
+            gt = np.array(Image.open(self.gt_files[index]))
+            ins = gt.copy()
+            seg = gt.copy()
+            seg[seg > 0] = 1
+            return img, ins, seg
+        fake = np.array(img)[:, :, 0]
+        return img, fake, fake
+
+    def host_item(self, index, rng):
+        """everything of dataset.py:47-62 that is decoding / index arithmetic: -> (uint8 image (3, S, S), int32 instance map (S, S))"""
+        from PIL import Image
+        from scipy.ndimage import zoom
+        img, ins, _seg = self.get_raw_sample(index)
+        S = self.imsize
+        if self.resize:
+            img = img.resize((S, S), Image.BILINEAR)                        # transforms.Scale((S, S))
+        else:                                                               # transforms.Scale(S): shorter side -> S
+            w, h = img.size
+            if w <= h:
+                img = img.resize((S, max(S, int(S * h / w))), Image.BILINEAR)
+            else:
+                img = img.resize((max(S, int(S * w / h)), S), Image.BILINEAR)
+        im = np.asarray(img, dtype=np.uint8).transpose(2, 0, 1)             # (3, h, w)
+        h, w = im.shape[1:]
+        ins = zoom(ins, [float(h) / ins.shape[0], float(w) / ins.shape[1]], mode="nearest", order=0)   # dataset_utils.py:133-140
+        if self.flip and rng.random() < 0.5:                                # dataset_utils.py:51-55
+            im, ins = im[:, :, ::-1], ins[:, ::-1]
+        if self.crop:                                                       # transforms.py:15-21 random_crop (centred range)
+            rw, rh = (w - S) // 2, (h - S) // 2
+            ow = 0 if rw <= 0 else rng.randrange(rw)
+            oh = 0 if rh <= 0 else rng.randrange(rh)
+            im, ins = im[:, oh:oh + S, ow:ow + S], ins[oh:oh + S, ow:ow + S]
+        return np.ascontiguousarray(im), np.ascontiguousarray(ins.astype(np.int32))
+
+
+class DeviceLoader(object):
+    """DataLoader(dataset, batch_size, shuffle=True, drop_last=True) of train.py:46-49 yielding DEVICE batches
+    (x, y_mask, y_class, sw_mask, sw_class) -- what utils.batch_to_var returns.  The next batch is decoded into pinned memory by
+    `num_workers` threads and copied on a side stream while the current one trains."""
+
+    def __init__(self, dataset, batch_size, shuffle=True, num_workers=4, seed=0, device="cuda"):
+        if dataset.crop is False and batch_size != 1:
+            raise ValueError("un-cropped samples have different sizes: batch_size must be 1")
+        self.ds, self.bs, self.shuffle, self.device = dataset, int(batch_size), shuffle, device
+        self.rng = random.Random(seed)
+        self.pool = ThreadPoolExecutor(max_workers=max(1, int(num_workers)))
+        self.copy_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self.mean = torch.tensor(MEAN, device=device).view(1, 3, 1, 1)
+        self.std = torch.tensor(STD, device=device).view(1, 3, 1, 1)
+        self._lock = threading.Lock()
+
+    def __len__(self):
+        return len(self.ds) // self.bs                                      # drop_last=True
+
+    def _stage(self, idxs):
+        """decode one batch into pinned buffers (host side only)"""
+        seeds = [self.rng.getrandbits(32) for _ in idxs]
+        items = list(self.pool.map(lambda a: self.ds.host_item(a[0], random.Random(a[1])), zip(idxs, seeds)))
+        S = items[0][0].shape[1:]
+        img = torch.empty((len(items), 3) + S, dtype=torch.uint8).pin_memory()
+        ins = torch.empty((len(items),) + S, dtype=torch.int32).pin_memory()
+        for i, (a, b) in enumerate(items):
+            img[i].copy_(torch.from_numpy(a))
+            ins[i].copy_(torch.from_numpy(b))
+        mats = None
+        if self.ds.augmentation_transform is not None:                      # one matrix per sample, drawn as the reference draws them
+            with self._lock:
+                mats = torch.stack([self.ds.augmentation_transform.matrix(S[0], S[1]) for _ in items])
+        return img, ins, mats
+
+    def _to_device(self, staged):
+        img, ins, mats = staged
+        st = self.copy_stream
+        with torch.cuda.stream(st):
+            x = img.to(self.device, non_blocking=True)
+            m = ins.to(self.device, non_blocking=True)
+        torch.cuda.current_stream().wait_stream(st)
+        x = (x.float() / 255.0 - self.mean) / self.std                      # ToTensor + Normalize (train.py:34-37)
+        mf = m.float().unsqueeze(1)
+        if mats is not None:                                                # dataset.py:66-67: image and maps share one warp
+            x = affine_nearest(x, mats)
+            mf = affine_nearest(mf, mats)
+        ins_d = mf.squeeze(1).round().long()
+        seg_d = (ins_d > 0).long()                                          # leaves.py:105-106
+        y_mask, y_class, sw_mask, sw_class = targets_from_maps(ins_d, seg_d, self.ds.max_seq_len, device=self.device)
+        return x.contiguous(), y_mask, y_class, sw_mask, sw_class
+
+    def __iter__(self):
+        order = list(range(len(self.ds)))
+        if self.shuffle:
+            self.rng.shuffle(order)
+        batches = [order[i * self.bs:(i + 1) * self.bs] for i in range(len(self))]
+        if not batches:
+            return
+        staged = self._stage(batches[0])
+        for k in range(len(batches)):
+            fut, box = None, []
+            if k + 1 < len(batches):                                        # decode the next batch while this one trains
+                fut = threading.Thread(target=lambda kk=k + 1, out=box: out.append(self._stage(batches[kk])))
+                fut.start()
+            yield self._to_device(staged)
+            if fut is not None:
+                fut.join()
+                staged = box[0]
+
+
+def synthesize_leaves_dir(path, n=100, size=(192, 208), seed=0):
+    """Write n synthetic CVPPP-A1-style pairs plantNNN_rgb.png / plantNNN_label.png (instance ids 1..k, 0 = background): elliptical
+    'leaves' on a textured background.  For tests and smoke runs of the data path only."""
+    from PIL import Image
+    os.makedirs(path, exist_ok=True)
+    r = np.random.default_rng(seed)
+    H, W = size
+    yy, xx = np.mgrid[0:H, 0:W]
+    for i in range(n):
+        rgb = r.integers(0, 80, (H, W, 3)).astype(np.uint8)
+        lab = np.zeros((H, W), np.uint8)
+        for k in range(1, int(r.integers(3, 9)) + 1):
+            cy, cx = r.uniform(0.2, 0.8) * H, r.uniform(0.2, 0.8) * W
+            a, b, th = r.uniform(8, 0.25 * H), r.uniform(6, 0.15 * W), r.uniform(0, np.pi)
+            u = (yy - cy) * np.cos(th) + (xx - cx) * np.sin(th)
+            v = -(yy - cy) * np.sin(th) + (xx - cx) * np.cos(th)
+            m = (u / a) ** 2 + (v / b) ** 2 <= 1.0
+            lab[m] = k
+            rgb[m] = (r.integers(20, 90), r.integers(120, 255), r.integers(20, 90))
+        Image.fromarray(rgb).save(os.path.join(path, "plant%03d_rgb.png" % i))
+        Image.fromarray(lab).save(os.path.join(path, "plant%03d_label.png" % i))
+    return path

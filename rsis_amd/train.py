@@ -327,8 +327,18 @@ def init_dataloaders(args, rank=0, world=1):
     GPUs, train.py:269-274): every rank of a torchrun job takes B / world samples, so reference hyper-parameters carry over.
     (The loss is the mean of the per-rank masked means -- equal to the global masked mean for equal shard sizes.)"""
     if not getattr(args, "synthetic", False):
-        raise Exception("only --synthetic data is wired in this build (the dataset readers of the reference's "
-                        "src/dataloader are host-side I/O outside the hot path: SURVEY.md section 8(f) row N3)")
+        if args.dataset != "leaves":
+            raise Exception("data: --synthetic, or -dataset leaves (CVPPP A1, BASELINE configs[0]); the Pascal VOC / Cityscapes readers "
+                            "of the reference's src/dataloader are host-side I/O outside the hot path (SURVEY.md section 8(f) row N3)")
+        from .dataloader.leaves import DeviceLoader, LeavesDataset
+        if args.batch_size % world != 0:
+            raise Exception("-batch_size %d (the global batch) is not divisible by the %d ranks" % (args.batch_size, world))
+        loaders = {}
+        for split in ("train", "val"):                                       # train.py:31-49
+            ds = LeavesDataset(args, split=split, augment=args.augment and split == "train", resize=args.resize, imsize=args.imsize)
+            loaders[split] = DeviceLoader(ds, args.batch_size // world, shuffle=True, num_workers=args.num_workers,
+                                          seed=args.seed + 17 * rank + (0 if split == "train" else 1))
+        return loaders, ds.get_classes()
     if args.batch_size % world != 0:
         raise Exception("-batch_size %d (the global batch) is not divisible by the %d ranks" % (args.batch_size, world))
     per_rank = args.batch_size // world

@@ -22,7 +22,7 @@ batch = synthetic_batch(1, 32, 256, 256, 20, 12, 21, "cuda")
 
 
 def step():
-    return runIter(a, enc, dec, *batch, crits, opts, mode="train", sync_losses=False, t_run=10)
+    return runIter(a, enc, dec, *batch, crits, opts, mode="train", sync_losses=False, t_run=10, want_outs=False)
 
 
 for _ in range(3):
