@@ -420,6 +420,9 @@ static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
       const long blocks = (long)rsis_cdiv(a.Cout, 64) * rsis_cdiv(a.W, tw) * rsis_cdiv(a.H, 8) * a.B;
       if (blocks < 512) v = v == 2 ? 4 : 5;
     }
+    // 32-pixel-wide maps: the 16 x 8 tile beats the 32 x 8 one on the 32-row variant (gate level 2, product launch: 68.8 -> 66.0 us;
+    // its data gradient 80.6 -> 62.4 us)
+    if (v == 5 && a.W <= 32 && a.Cout > 32) v = 4;
   }
   if (EPI == EPI_S2 && v == 3) v = 5;   // 4 accumulator sets: the 256-pixel x 64-row tile would need 256 accumulator registers
   if (EPI == EPI_S2 && v == 6) v = 1;   // (no K-split variant of the 4-accumulator epilogue)

@@ -20,6 +20,7 @@
 // With 16x the f32 MFMA rate these layers are HBM-bound (the f32 kernels are MFMA-bound): what matters here is bytes in
 // flight per CU and one pass over the input, not MFMA utilisation.
 #include "common.h"
+#include <stdlib.h>
 
 enum { EPI_PLAIN = 0, EPI_LSTM = 1 };
 typedef __attribute__((address_space(3))) void* lds_vp_t;
@@ -302,6 +303,193 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 1x1 / stride 1, single source, H*W % 4 == 0: the same GEMM with a DEEP load pipeline.  The register-staged kernel above keeps
+// ONE chunk of loads in flight per block, and with a bf16 MFMA loop of a few hundred cycles per chunk every chunk exposes a full
+// memory round trip: 0.1-0.17 of the HBM roofline on the trunk's 1x1 layers.  Here the fp32 activations are copied global -> LDS
+// RAW by the LDS-DMA into a ring of NR stages (no registers: NR - 1 chunks, 50-100 KB per CU, stay in flight, counted `vmcnt`
+// waits, raw `s_barrier`), a conversion pass turns the landed stage into bf16 cells (8 ds_read_b32 + 4 v_cvt_pk + 1 ds_write_b128
+// per cell, conflict-free both ways), and the MFMA loop reads cells exactly as before.  The weights ride the same ring.
+// ------------------------------------------------------------------------------------------------
+#define RSIS_VMCNT(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))
+
+template <int BM, int BN, int CKB, int NR>
+__global__ __launch_bounds__(256) void conv1x1_bf16_ring_kernel(const ConvArgs p) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int WGM = BM / 32, WGN = 4 / WGM;
+  constexpr int TN = BN / WGN / 32;
+  constexpr int NCB = CKB / 8;
+  constexpr int RAW_F = CKB * BN;                    // floats per raw stage
+  constexpr int WC = NCB * BM, XC = NCB * BN;        // cells per weight / activation stage
+  constexpr int NXD = RAW_F / 4 / 256;               // dwordx4 DMA per thread per chunk (activations)
+  constexpr int NWD = (WC + 255) / 256;              // ... (weights; stage padded to whole 256-lane rows)
+  constexpr int WCP = NWD * 256;
+  constexpr int NCV = XC / 256;                      // cells converted per thread per chunk
+  static_assert(TN >= 1 && WGM * WGN == 4 && (RAW_F / 4) % 256 == 0 && XC % 256 == 0 && CKB % 16 == 0 && NR >= 3, "tile");
+  constexpr int C_DMA = NXD + NWD;                   // DMA instructions per wave per chunk (vmcnt bookkeeping)
+  static_assert((NR - 2) * C_DMA < 64, "vmcnt is 6 bits");
+
+  // ONE shared array (a second __shared__ object makes hipcc drain the LDS-DMA queue before every ds_read)
+  __shared__ __attribute__((aligned(16))) float lds[NR * RAW_F + (NR * WCP + 2 * XC) * 4];
+  float* const raw0 = lds;
+  u32x4* const ws0 = reinterpret_cast<u32x4*>(lds + NR * RAW_F);
+  u32x4* const xb0 = ws0 + NR * WCP;
+
+  const int HW = p.H * p.W, C = p.C[0];
+  const int nq = (C + CKB - 1) / CKB;
+  const int ldw = p.ldw;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = bid >> 3;
+  const int co_t = q % p.n_co_tiles;
+  const int sp_t = (q / p.n_co_tiles) * 8 + xcd;
+  if (sp_t >= p.n_px_tiles) return;
+  const int tiles_x = (HW + BN - 1) / BN;
+  const int tx = sp_t % tiles_x, b0 = sp_t / tiles_x;
+  const int x0 = tx * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // loop-invariant DMA offsets
+  unsigned xvo[NXD], wvo[NWD];
+#pragma unroll
+  for (int i = 0; i < NXD; ++i) {
+    const int e = tid + i * 256;
+    const int ch = e / (BN / 4), c4 = e - ch * (BN / 4);
+    const int gx = x0 + c4 * 4;
+    xvo[i] = gx < HW ? (unsigned)(ch * HW + gx) * 4u : RSIS_OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < NWD; ++i) {
+    const int idx = tid + i * 256;
+    wvo[i] = idx < WC ? (unsigned)((idx / BM) * ldw + idx % BM) * 16u : RSIS_OOB;
+  }
+  const float* const xbase = p.src[0] + (size_t)b0 * C * HW;
+  const char* const wbase = (const char*)p.wp + (size_t)co_t * BM * 16;
+
+#define RING_ISSUE(QG)                                                                                            \
+  {                                                                                                               \
+    const int slot = (QG) % NR;                                                                                   \
+    const int c0 = (QG) * CKB;                                                                                    \
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(xbase + (size_t)c0 * HW), 0, min(CKB, C - c0) * HW * 4, 0x00020000); \
+    float* dst = raw0 + slot * RAW_F + wave * 256;                                                                \
+    _Pragma("unroll") for (int i = 0; i < NXD; ++i)                                                               \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_vp_t)(dst + i * 1024), 16, xvo[i], 0, 0, 0);              \
+    const char* wrow = wbase + (size_t)(QG) * NCB * ldw * 16;                                                     \
+    const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)wrow, 0, NCB * ldw * 16, 0x00020000); \
+    u32x4* wd = ws0 + slot * WCP + wave * 64;                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NWD; ++i)                                                               \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_, (lds_vp_t)(wd + i * 256), 16, wvo[i], 0, 0, 0);                \
+  }
+
+  int xoff[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) xoff[j] = hi * BN + (wn * TN + j) * 32 + l31;
+  const int woff = hi * BM + wm * 32 + l31;
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // prologue: NR - 1 chunks in flight
+#pragma unroll
+  for (int i = 0; i < NR - 1; ++i)
+    if (i < nq) RING_ISSUE(i)
+
+  for (int t = 0; t < nq; ++t) {
+    // chunk t has landed once at most `ahead` younger chunks of this wave's DMA are still outstanding
+    const int ahead = min(NR - 2, nq - 1 - t);
+    if (ahead >= 2) { RSIS_VMCNT(2 * C_DMA); }
+    else if (ahead == 1) { RSIS_VMCNT(C_DMA); }
+    else { RSIS_VMCNT(0); }
+    __builtin_amdgcn_s_barrier();                     // every wave's share of chunk t is in LDS; slot (t-1) % NR is free
+    if (t + NR - 1 < nq) RING_ISSUE(t + NR - 1)
+    {                                                 // raw fp32 [ch][px] -> bf16 cells [c8][px]
+      const float* raw = raw0 + (t % NR) * RAW_F;
+      u32x4* xb = xb0 + (t & 1) * XC;
+#pragma unroll
+      for (int j = 0; j < NCV; ++j) {
+        const int c = tid + j * 256;
+        const int cb = c / BN, px = c - cb * BN;
+        const float* r8 = raw + cb * 8 * BN + px;
+        u32x4 cell;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cell[k] = pack_bf16x2(r8[(2 * k) * BN], r8[(2 * k + 1) * BN]);
+        xb[c] = cell;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): my cells are written
+    __builtin_amdgcn_s_barrier();
+    {
+      const u32x4* Xs = xb0 + (t & 1) * XC;
+      const u32x4* Ws = ws0 + (t % NR) * WCP + woff;
+#pragma unroll
+      for (int kk = 0; kk < NCB / 2; ++kk) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, Ws[2 * kk * BM]);
+        bf16x8 b[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = __builtin_bit_cast(bf16x8, Xs[xoff[j] + 2 * kk * BN]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[j], 0, 0, 0);
+      }
+    }
+  }
+#undef RING_ISSUE
+
+  // ---- epilogue (as conv_bf16_kernel, EPI_PLAIN, KS = 1) ----
+  const int co_base = co_t * BM + wm * 32;
+  const gcf_t bias = (gcf_t)p.bias, addend = (gcf_t)p.addend;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int ox = x0 + (wn * TN + j) * 32 + l31;
+    if (ox >= HW) continue;
+    int osp = ox, oHW = HW;
+    if (p.ostride > 1) {
+      const int oho = osp / p.W;
+      osp = (oho * p.ostride) * p.oW + (osp - oho * p.W) * p.ostride;
+      oHW = p.oH * p.oW;
+    }
+    const gf_t d0 = (gf_t)p.dst[0], d1 = (gf_t)p.dst[1], d2 = (gf_t)p.dst[2];
+    const int Cd0 = p.Cd[0], Cd1 = p.Cd[1], Cd2 = p.Cd[2], Cout = p.Cout;
+    const int e1 = Cd0, e2 = Cd0 + Cd1;
+    float av[16];
+    if (addend) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        av[r] = co < Cout ? addend[((size_t)b0 * Cd0 + co) * oHW + osp] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (co >= Cout) continue;
+      float v = acc[j][r];
+      if (bias) v += bias[co];
+      if (addend) v += av[r];
+      gf_t d = d0;
+      int cl = co, Cd = Cd0;
+      if (co >= e1) { d = d1; cl = co - e1; Cd = Cd1; }
+      if (co >= e2) { d = d2; cl = co - e2; Cd = Cd2; }
+      d[((size_t)b0 * Cd + cl) * oHW + osp] = v;
+    }
+  }
+#endif
+}
+
+template <int BM, int BN>
+static int launch_ring(ConvArgs& a, hipStream_t st) {
+  a.n_co_tiles = rsis_cdiv(a.Cout, BM);
+  a.n_px_tiles = rsis_cdiv(a.H * a.W, BN) * a.B;
+  const int grid = a.n_co_tiles * 8 * rsis_cdiv(a.n_px_tiles, 8);
+  hipLaunchKernelGGL((conv1x1_bf16_ring_kernel<BM, BN, 32, 4>), dim3(grid), dim3(256), 0, st, a);
+  return rsis_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int KS, int BM, int TW, int TH, int EPI, int CKB>
 static int launch_bf16_cfg(ConvArgs& a, hipStream_t st) {
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
@@ -355,9 +543,32 @@ static int launch_bf16_k3(ConvArgs& a, hipStream_t st, int force) {
   }
 }
 
-// 1x1 variants: 1 = BM128 x 128 px, 2 = BM64 x 128 px, 3 = BM32 x 256 px
+// 1x1 variants: 1 = BM128 x 128 px, 2 = BM64 x 128 px, 3 = BM32 x 256 px (register staged); 4-7 = LDS-DMA ring kernel (BM128x128,
+// BM128x64, BM64x128, BM64x64): the default wherever it applies (H*W % 4 == 0, one source, 32-bit offsets)
 static int launch_bf16_k1(ConvArgs& a, hipStream_t st, int force) {
   int v = force;
+  static const bool ring_ok = !(getenv("RSIS_BF16_RING") && getenv("RSIS_BF16_RING")[0] == '0');
+  const bool ring_geom = (a.H * a.W) % 4 == 0 && a.nsrc == 1 && a.Cout > 32 && (long)a.C[0] * a.H * a.W * 4 < (1L << 31);
+  // measured (B = 32 trunk shapes): the ring wins where K is deep and the output small (1024 -> 256 @16^2: 27 -> 22 us, 512 -> 128
+  // @32^2: 25.5 -> 21.4 us); with many output rows or a short K loop its one-or-two-blocks-per-CU footprint loses to the
+  // register-staged kernel's 2-3 co-resident blocks (256 -> 1024 @16^2: 27 vs 41 us).  Both sit near 25 GB/s of LDS fill per CU:
+  // the weight tile every block re-reads weighs as much as the fp32 activations on these small maps.
+  if (v <= 0 && ring_ok && ring_geom && a.C[0] >= 512 && 2 * a.Cout <= a.C[0]) {
+    // enough blocks to cover the chip twice with the widest tile that allows it
+    const long px = (long)a.H * a.W;
+    const long b128 = (long)rsis_cdiv(a.Cout, 128) * rsis_cdiv(px, 128) * a.B;
+    if (a.Cout <= 64) v = ((long)rsis_cdiv(px, 128) * a.B >= 512) ? 6 : 7;
+    else v = b128 >= 512 ? 4 : 5;
+  }
+  if (v >= 4 && v <= 7) {
+    if (!ring_geom) return RSIS_ERR_UNSUPPORTED;
+    switch (v) {
+      case 4: return launch_ring<128, 128>(a, st);
+      case 5: return launch_ring<128, 64>(a, st);
+      case 6: return launch_ring<64, 128>(a, st);
+      default: return launch_ring<64, 64>(a, st);
+    }
+  }
   if (v <= 0) {
     const long px = (long)a.H * a.W;
     if (a.Cout <= 32) v = 3;
