@@ -360,6 +360,17 @@ def main():
         if rank == 0:
             print("[bench] %s" % msg, file=sys.stderr, flush=True)
 
+    def health(tag, losses):
+        """RSIS_BENCH_DEBUG=1: loss values and non-finite parameters / optimizer moments after each phase"""
+        if os.environ.get("RSIS_BENCH_DEBUG", "") != "1":
+            return
+        torch.cuda.synchronize()
+        bad = [k for k, p in list(encoder.named_parameters()) + list(decoder.named_parameters()) if not torch.isfinite(p).all()]
+        mom = [(o.group.name, int((~torch.isfinite(o.group.exp_avg)).sum()), int((~torch.isfinite(o.group.exp_avg_sq)).sum()),
+                int((~torch.isfinite(o.group.flat_g)).sum())) for o in (enc_opt, dec_opt)]
+        note("health[%s]: losses %s, non-finite params %d %s, (group, m, v, g non-finite) %s"
+             % (tag, [round(float(v), 5) for v in losses], len(bad), bad[:4], mom))
+
     roof = roof_kernels = None
     if rank == 0 and not o.skip_roofline:
         roof = gate_kernel_roofline(o.batch, o.kernel_iters, o.imsize, o.dtype, o.T)
@@ -384,6 +395,7 @@ def main():
         if i == 0:
             torch.cuda.synchronize()
             note("first step %.2f s" % (time.time() - tw))
+        health("warmup %d" % i, losses)
     while gstep is not None and gstep.graph is None and gstep.failed is None:
         losses = step()[0]              # (still warm-up: the call that captures the graph must not fall into the timed region)
     # Untimed settle phase (still warm-up): keep stepping until the step time has been stable for a while (cold-box clock
@@ -405,6 +417,7 @@ def main():
             if done:
                 break
         note("settle: %d extra untimed steps, last %s ms" % (len(hist), " ".join("%.1f" % h for h in hist[-4:])))
+    health("after settle", losses)
     fence()
     if gstep is not None:
         note("hipGraph: %s" % ("captured, replaying" if gstep.graph is not None else "NOT captured (%s): eager launches" % gstep.failed))
@@ -418,6 +431,7 @@ def main():
         marks.append(time.time() - t0)      # host enqueue progress (no sync): shows a host-bound step at a glance
     fence()
     dt = time.time() - t0
+    health("after timed", losses)
     note("host enqueue marks (s): %s | end %.3f" % (" ".join("%.3f" % m for m in marks), dt))
     note("GPU ms per step (events): %s" % " ".join("%.1f" % evs[i].elapsed_time(evs[i + 1]) for i in range(o.steps)))
     if world > 1:

@@ -241,7 +241,7 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
       for (int s = 0; s < nsrc; ++s) nq += (Csrc[s] + RSIS_CKB3 - 1) / RSIS_CKB3;
       const long px_tiles = (long)B * rsis_cdiv(H, 8) * rsis_cdiv(W, W <= 8 ? 8 : 16);
       if (allow_splitk && splitk_ok && !addend && nq >= 16 && px_tiles * rsis_cdiv(Cout, 64) < 160) {
-        if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * Cout * Ho * Wo, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
+        if (rsis_zero_async(out, sizeof(float) * (size_t)B * Cout * Ho * Wo, (hipStream_t)stream) != RSIS_OK) return RSIS_ERR_LAUNCH;
         a.ksplit = 0;
       }
     }
@@ -257,7 +257,7 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
     const long px_tiles = (long)B * rsis_cdiv(H, 8) * rsis_cdiv(W, W <= 8 ? 8 : 16);
     static const bool splitk_ok = !(getenv("RSIS_CONV_SPLITK") && getenv("RSIS_CONV_SPLITK")[0] == '0');   // A/B switch
     if (allow_splitk && splitk_ok && nq >= 32 && px_tiles * rsis_cdiv(Cout, 64) < 160) {
-      if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * Cout * Ho * Wo, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
+      if (rsis_zero_async(out, sizeof(float) * (size_t)B * Cout * Ho * Wo, (hipStream_t)stream) != RSIS_OK) return RSIS_ERR_LAUNCH;
       a.ksplit = 0;
     }
     return rsis_launch_conv3x3_direct(a, 0, direct_variant(tile), (hipStream_t)stream);
@@ -295,7 +295,7 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const vo
       const long px_tiles = (long)B * rsis_cdiv(Hx, 8) * rsis_cdiv(Wx, Wx <= 8 ? 8 : 16);
       if (splitk_ok && !addend && nq >= 16 && px_tiles * rsis_cdiv(ctot, 64) < 160) {
         for (int i = 0; i < ndst; ++i)
-          if (hipMemsetAsync(dx[i], 0, sizeof(float) * (size_t)B * Cdx[i] * Hx * Wx, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
+          if (rsis_zero_async(dx[i], sizeof(float) * (size_t)B * Cdx[i] * Hx * Wx, (hipStream_t)stream) != RSIS_OK) return RSIS_ERR_LAUNCH;
         a.ksplit = 0;
       }
       return rsis_launch_conv_bf16(a, 3, 0, direct_variant(tile), (hipStream_t)stream);
@@ -304,7 +304,7 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const vo
     if (stride > 1) {
       if (Hy != (Hx - 1) / stride + 1 || Wy != (Wx - 1) / stride + 1) return RSIS_ERR_ARG;
       for (int i = 0; i < ndst && !inplace; ++i)
-        if (hipMemsetAsync(dx[i], 0, sizeof(float) * (size_t)B * Cdx[i] * Hx * Wx, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
+        if (rsis_zero_async(dx[i], sizeof(float) * (size_t)B * Cdx[i] * Hx * Wx, (hipStream_t)stream) != RSIS_OK) return RSIS_ERR_LAUNCH;
       a.ostride = stride;
     } else if (Hx != Hy || Wx != Wy) return RSIS_ERR_ARG;
     a.Ho = Hy; a.Wo = Wy; a.stride = 1; a.sshift = 0;
@@ -320,7 +320,7 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const vo
       const long px_tiles = (long)B * rsis_cdiv(Hx, 8) * rsis_cdiv(Wx, Wx <= 8 ? 8 : 16);
       if (splitk_ok && !addend && nq >= 32 && px_tiles * rsis_cdiv(ctot, 64) < 160) {
         for (int i = 0; i < ndst; ++i)
-          if (hipMemsetAsync(dx[i], 0, sizeof(float) * (size_t)B * Cdx[i] * Hx * Wx, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
+          if (rsis_zero_async(dx[i], sizeof(float) * (size_t)B * Cdx[i] * Hx * Wx, (hipStream_t)stream) != RSIS_OK) return RSIS_ERR_LAUNCH;
         a.ksplit = 0;
       }
     }
@@ -336,7 +336,7 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const vo
     // 1x1 / stride-s data gradient: only the (s*ho, s*wo) input pixels receive a gradient -> zero dx, then run the plain
     // 1x1 GEMM over the dy grid and scatter its rows to those pixels (instead of gathering with 1/s^2 useful taps)
     for (int i = 0; i < ndst && !inplace; ++i)
-      if (hipMemsetAsync(dx[i], 0, sizeof(float) * (size_t)B * Cdx[i] * Hx * Wx, (hipStream_t)stream) != hipSuccess) return RSIS_ERR_LAUNCH;
+      if (rsis_zero_async(dx[i], sizeof(float) * (size_t)B * Cdx[i] * Hx * Wx, (hipStream_t)stream) != RSIS_OK) return RSIS_ERR_LAUNCH;
     a.Ho = Hy; a.Wo = Wy; a.stride = 1; a.sshift = 0; a.ostride = stride;
     return rsis_launch_conv_igemm(a, ks, false, 0, tile, (hipStream_t)stream);
   }

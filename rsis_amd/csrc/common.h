@@ -23,6 +23,10 @@ static inline int rsis_check_launch() {
   return e == hipSuccess ? RSIS_OK : RSIS_ERR_LAUNCH;
 }
 
+// Zero-fill on a stream with a KERNEL instead of hipMemsetAsync: inside a captured hipGraph a memset becomes a memset NODE, and
+// replaying graphs that contain them back to back corrupted the iteration on this stack (ROCm 7.0 / gfx950).
+int rsis_zero_async(void* p, size_t bytes, hipStream_t st);
+
 static inline int rsis_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int rsis_roundup(int a, int b) { return ((a + b - 1) / b) * b; }
 

@@ -25,6 +25,7 @@
 // TW x TH output tile: lane (y, x) reads patch pixel (2y + r, 2x + s) for tap (r, s) -- still one `ds_read_b32` with an
 // immediate offset per MFMA (2-way LDS bank conflicts from the pixel stride of 2), plain epilogue on the output grid.
 #include "common.h"
+#include <stdlib.h>
 
 enum { EPI_PLAIN = 0, EPI_LSTM = 1, EPI_S2 = 2, EPI_F2 = 3 };
 #ifndef DIRECT_DMA

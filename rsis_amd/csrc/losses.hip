@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void softiou_bwd_kernel(const float* __restric
 }
 
 int rsis_l_softiou_sums(const float* logits, const float* y, float* S, int B, int T, int G, long N, hipStream_t st) {
-  if (hipMemsetAsync(S, 0, sizeof(float) * (size_t)B * (T + 1) * (G + 1), st) != hipSuccess) return RSIS_ERR_LAUNCH;
+  if (rsis_zero_async(S, sizeof(float) * (size_t)B * (T + 1) * (G + 1), st) != RSIS_OK) return RSIS_ERR_LAUNCH;
   // ~4 blocks per CU over the whole batch; each wave gets a multiple of 8 pixels
   int nsplit = (int)((1024 + B - 1) / B);
   long per_wave = (N + (long)nsplit * 4 - 1) / ((long)nsplit * 4);

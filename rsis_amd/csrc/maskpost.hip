@@ -125,7 +125,7 @@ __global__ __launch_bounds__(RLE_T) void rle_encode_kernel(const unsigned char* 
 
 int rsis_l_mask_resize_threshold(const float* prob, int n, int Hm, int Wm, const unsigned char* ignore, float th, unsigned char* seg,
                                  unsigned char* raw, unsigned int* area, int h, int w, hipStream_t st) {
-  if (hipMemsetAsync(area, 0, sizeof(unsigned int) * (size_t)n, st) != hipSuccess) return RSIS_ERR_LAUNCH;
+  if (rsis_zero_async(area, sizeof(unsigned int) * (size_t)n, st) != RSIS_OK) return RSIS_ERR_LAUNCH;
   const float sh = h > 1 ? (float)(Hm - 1) / (float)(h - 1) : 0.f, sw = w > 1 ? (float)(Wm - 1) / (float)(w - 1) : 0.f;
   const long hw = (long)h * w;
   hipLaunchKernelGGL(mask_resize_threshold_kernel, dim3((unsigned)((hw + 255) / 256), n), dim3(256), 0, st, prob, Hm, Wm, ignore, th,

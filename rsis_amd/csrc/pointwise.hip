@@ -815,14 +815,17 @@ __global__ __launch_bounds__(64) void assign_kernel(const float* __restrict__ sc
     double minv = 1e300;
     bool used = false, in_tree = false;
     int way = 0;
-    while (true) {
+    // (at most m + 1 columns can enter the tree; the cap only matters for non-finite scores -- a NaN cost would otherwise cycle
+    // forever between used columns -- which are mapped to a large finite cost below)
+    for (int it = 0; it <= m; ++it) {
       if (j0 > 0 && lane == j0 - 1) used = true;
       const int i0 = j0 == 0 ? p0 : __shfl(p, j0 - 1, 64);
       if (lane == i0 - 1) in_tree = true;
       const double ui0 = __shfl(u, i0 - 1, 64);
       double cand = 1e300;
       if (col && !used) {
-        const double cur = (double)a[(size_t)lane * T + (i0 - 1)] - ui0 - v;
+        const float sc = a[(size_t)lane * T + (i0 - 1)];
+        const double cur = (sc == sc && fabsf(sc) < 1e30f ? (double)sc : 1e30) - ui0 - v;
         if (cur < minv) { minv = cur; way = j0; }
         cand = minv;
       }
@@ -855,6 +858,20 @@ __global__ __launch_bounds__(64) void assign_kernel(const float* __restrict__ sc
   if (col && p != 0) outp[p - 1] = lane;
   __syncthreads();
   if (lane < G) perm[(size_t)b * G + lane] = outp[lane];
+}
+
+// zero fill (see common.h: rsis_zero_async)
+__global__ void zero_fill_kernel(unsigned* __restrict__ p, size_t n_words) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+int rsis_zero_async(void* p, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return RSIS_OK;
+  if ((bytes & 3) || ((size_t)p & 3)) return hipMemsetAsync(p, 0, bytes, st) == hipSuccess ? RSIS_OK : RSIS_ERR_LAUNCH;
+  const size_t n = bytes >> 2;
+  size_t g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)g), dim3(256), 0, st, (unsigned*)p, n);
+  return rsis_check_launch();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -980,7 +997,7 @@ int rsis_l_bn_fwd(const float* x, const float* res, float* y, double* stats, con
     return rsis_check_launch();
   }
   if (train) {
-    if (!(train_flags & 2) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, st) != hipSuccess) return RSIS_ERR_LAUNCH;
+    if (!(train_flags & 2) && rsis_zero_async(stats, sizeof(double) * 2 * C, st) != RSIS_OK) return RSIS_ERR_LAUNCH;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, S), dim3(256), 0, st, x, stats, C, HW, N);
   }
   hipLaunchKernelGGL(bn_apply_kernel, dim3(C, S), dim3(256), 0, st, x, res, y, stats, gamma, beta, run_mean, run_var, save_mean,
@@ -1005,7 +1022,7 @@ int rsis_l_bn_bwd(const float* dy, const float* x, const float* y, const float* 
                          dbeta, C, HW, N, relu, accum);
     return rsis_check_launch();
   }
-  if (!(relu_flags & 2) && hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, st) != hipSuccess) return RSIS_ERR_LAUNCH;
+  if (!(relu_flags & 2) && rsis_zero_async(stats, sizeof(double) * 2 * C, st) != RSIS_OK) return RSIS_ERR_LAUNCH;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, mean, rstd, stats, C, HW, N, relu);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, mean, rstd, gamma, stats, dx, dres, dgamma,
                      dbeta, C, HW, N, relu, accum);

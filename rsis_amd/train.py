@@ -229,7 +229,9 @@ class GraphedStep(object):
     The first `warm` calls run eagerly on a side stream (they are real training steps), the next one captures.  A capture is
     valid for one (input shapes, t_run, loss switches, update_encoder, active parameter set) key; the caller keeps one per key.
     Inputs are copied into static buffers; the returned losses / outs / perms are static device tensors overwritten by the
-    next replay.
+    next replay.  (Nothing inside the iteration may be a hipMemsetAsync: memset NODES of a captured graph are not reliably ordered
+    against the neighbouring kernel nodes when graphs are replayed back to back on this stack -- 60 replays in a row ended in
+    non-finite Adam moments every time -- so the library zero-fills with a kernel, common.h: rsis_zero_async.)
 
     With a gradient exchange (`reducer` active: one process per GPU) the iteration is TWO graphs with the RCCL all-reduce of
     the flat gradient buffers between them, launched eagerly: RCCL refuses stream capture on this stack (ProcessGroupNCCL raises
@@ -245,6 +247,7 @@ class GraphedStep(object):
         self.n_eager = 0
         self._bns = None
         self.failed = None
+        self._in_sig = None
 
     def _run(self, batch, t_run, do_update=True):
         return runIter(self.args, self.encoder, self.decoder, *batch, self.crits, self.optims, mode="train",
@@ -275,13 +278,18 @@ class GraphedStep(object):
             return res
         if t_run != self.t_run:
             raise RuntimeError("GraphedStep: captured for t_run=%d, called with %d" % (self.t_run, t_run))
-        for dst, src in zip(self.static, batch):
-            if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src, non_blocking=True)
+        # inputs -> static buffers (skipped for a resident batch that is already there: same tensors, unmodified)
+        sig = tuple((t.data_ptr(), t._version) for t in batch)
+        if sig != self._in_sig:
+            for dst, src in zip(self.static, batch):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+            self._in_sig = sig
         self.graph.replay()
         if self.split:
             self._exchange()
             self.graph_update.replay()
+
         for g in self._groups():
             if self.args.update_encoder or g is not self.optims[0].group:
                 g.note_replay()

@@ -110,3 +110,35 @@ def test_graphed_step_equals_eager(use_stop):
     assert float((pg - pa).norm() / pa.norm()) <= 5 * spread_p + 1e-5, (spread_p, float((pg - pa).norm() / pa.norm()))
     if not use_stop:     # the stop head never received a gradient: torch.optim.Adam semantics leave it untouched
         assert torch.equal(sa, dec0.fc_stop.weight.detach()) and torch.equal(sg, sa)
+
+
+def test_graph_replay_back_to_back_stays_finite():
+    """60 replays enqueued back to back (no host sync, nothing between the launches but the runtime): parameters, gradients and both
+    Adam moments must stay finite and the loss must follow the eager run.  Regression test for the memset-node ordering problem of
+    captured hipGraphs on this stack (the library zero-fills with a kernel since: common.h rsis_zero_async)."""
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import GraphedStep, build_optimizers, runIter, steps_to_run
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    a = mk_args(hidden_size=128, maxseqlen=5, lr=1e-3, lr_cnn=1e-6, weight_decay=1e-6, weight_decay_cnn=1e-6, optim="adam",
+                optim_cnn="adam", imsize=128, batch_size=16, seed=3)
+    batch = synthetic_batch(5, 16, 128, 128, a.gt_maxseqlen, 6, a.num_classes, "cuda")
+    t_run = steps_to_run(a, batch[3])
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
+    enc0, dec0 = _models(a)
+    finals = []
+    for graphed in (False, True):
+        enc, dec = copy.deepcopy(enc0), copy.deepcopy(dec0)
+        opts = list(build_optimizers(a, enc, dec))
+        g = GraphedStep(a, enc, dec, crits, opts, None, warm=2) if graphed else None
+        for _ in range(63):
+            out = g(batch, t_run) if graphed else runIter(a, enc, dec, *batch, crits, opts, mode="train", sync_losses=False, t_run=t_run,
+                                                           want_outs=False)
+        torch.cuda.synchronize()
+        for o in opts:
+            for name, t in (("p", o.group.flat_p), ("g", o.group.flat_g), ("m", o.group.exp_avg), ("v", o.group.exp_avg_sq)):
+                assert bool(torch.isfinite(t).all()), "%s %s non-finite after 63 %s steps" % (o.group.name, name, "graph" if graphed else "eager")
+        finals.append(float(out[0][0]))
+        if graphed:
+            assert g.graph is not None
+            g.release()
+    assert abs(finals[0] - finals[1]) < 0.1 * abs(finals[0]), finals
