@@ -272,3 +272,58 @@ def test_bf16_backward_against_an_independent_bf16_evaluation():
             bad.append((k, e_hip, e_floor))
     assert n > 300
     assert not bad, "bf16 gradients further from fp32 than 2x an independent bf16 evaluation: %s" % bad[:6]
+
+
+def test_training_step_at_the_bench_configuration_matches_the_oracle():
+    """BASELINE configs[1] as bench.py runs it -- B = 32, 256x256, T = 10, ResNet-101, hidden 128, train mode, all three losses, both
+    optimizers -- one iteration on the device against the CPU oracle's iteration on the same synthetic batch and the same initial
+    weights: the four losses within 1e-4, the matching permutation identical, gradients of conv_out and the heads within 1e-3 relative L2, of
+    the per-level tensors (ConvLSTM gates, skip convs and their BatchNorms) within 5 %: they collect the arg-max-routed gradients
+    of the side features over 7936 hidden-state planes x 10 steps, where two fp32 evaluations of the SAME graph already differ by
+    1-4 % (the reference's own fp32 vs float64 gradients, tests/golden/trainstep_160.npz); the trunk is covered by the fp64-truth test."""
+    import bench
+    from oracle import filler
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import build_optimizers, runIter, steps_to_run
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    a = bench.bench_args(32, 256, 10)
+    a.use_gpu = True
+    oenc = filler.fill_module(O.FeatureExtractor(a), seed=71)
+    odec = filler.fill_module(O.RSIS(a), seed=72)
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    enc.load_state_dict(oenc.state_dict())
+    dec.load_state_dict(odec.state_dict())
+    batch = synthetic_batch(7, 32, 256, 256, a.gt_maxseqlen, 12, a.num_classes, "cpu")
+    dbatch = [t.cuda() for t in batch]
+    opts = list(build_optimizers(a, enc, dec))
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
+    t_run = steps_to_run(a, dbatch[3])
+    assert t_run == 10
+    pre = dec.clstm_list[0].Gates.weight.detach().clone()
+    losses, _outs, perms = runIter(a, enc, dec, *dbatch, crits, opts, mode="train", sync_losses=True, t_run=t_run, want_outs=False)
+    grads = {("dec." + k): p.grad.detach().cpu().clone() for k, p in dec.named_parameters()}
+    grads.update({("enc." + k): p.grad.detach().cpu().clone() for k, p in enc.named_parameters() if not k.startswith("base.")})
+    assert float((dec.clstm_list[0].Gates.weight.detach() - pre).abs().max()) > 0          # the optimizer step happened
+    oenc.zero_grad()
+    odec.zero_grad()
+    a.use_gpu = False
+    r = O.run_iter_forward(a, oenc, odec, *batch, mode="train")
+    r["loss"].backward()
+    for k, got, want in (("loss", losses[0], r["loss"]), ("loss_mask_iou", losses[1], r["loss_mask_iou"]), ("loss_stop", losses[2], r["loss_stop"]),
+                         ("loss_class", losses[3], r["loss_class"])):
+        assert_close(k, got, float(want), 1e-4)
+    assert (perms[1].cpu().numpy() == r["y_class_perm"].numpy()).all()
+    ref = {("dec." + k): p.grad for k, p in odec.named_parameters()}
+    ref.update({("enc." + k): p.grad for k, p in oenc.named_parameters() if not k.startswith("base.")})
+    errs = []
+    for k, g32 in ref.items():
+        if k.startswith("enc.sk") and k.endswith("bias"):
+            continue                       # (a conv bias in front of a BatchNorm has a mathematically zero gradient: both sides are noise)
+        lvl = _level_of(k)
+        tol = 5e-2 if lvl is not None else 1e-3          # per-level tensors: arg-max-routed gradients; conv_out / heads: tight
+        errs.append((k, _rel_l2(grads[k], g32), tol))
+    bad = [e for e in errs if e[1] >= e[2]]
+    assert not bad, "gradients outside their bar: %s; all: %s" % (bad, [(k, "%.1e" % e) for k, e, _t in errs])
