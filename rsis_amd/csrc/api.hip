@@ -86,7 +86,7 @@ static inline int bf16_rows(int ks, int nseg, const int* Cseg) {
   for (int s = 0; s < nseg; ++s) q += (Cseg[s] + ckb - 1) / ckb;
   return q * ks * ks * (ckb / 8);
 }
-static inline int direct_variant(int tile) { const int v = tile % 10; return (tile > 0 && v >= 1 && v <= 8) ? v : 0; }
+static inline int direct_variant(int tile) { const int v = tile % 10; return (tile > 0 && v >= 1 && v <= 9) ? v : 0; }
 
 extern "C" {
 

@@ -42,22 +42,25 @@ typedef const f32x4 __attribute__((address_space(1)))* gcf4_t;
 // two partial accumulators are summed through LDS before the epilogue.  Used for the 8x8 maps (64 pixels = 2 column tiles):
 // twice the blocks (32 instead of 64 output rows each) and twice the waves per SIMD on a launch that otherwise fills only
 // one wave per SIMD.
-template <int BM, int TW, int TH, int NI, int EPI, int KSP = 1>
-__global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
+// NWV = 8: a 512-thread block -- twice the pixels against ONE weight stage (the weight chunk is ~60 % of what a 64-row block
+// copies into LDS per chunk, and the LDS-DMA fill rate of a CU, ~25 GB/s, is what two or three co-resident 4-wave blocks run into).
+template <int BM, int TW, int TH, int NI, int EPI, int KSP = 1, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs p) {
 #if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; the buffer-resource builtins do not exist there)
   constexpr int BN = TW * TH * NI;
-  constexpr int WGM = BM / 32, WGN = 4 / WGM / KSP;      // BM=64: 2x2 waves, BM=32: 1x4 (KSP = 2: 1x2 tiles x 2 K-halves)
+  constexpr int NT = NWV * 64;                           // threads per block
+  constexpr int WGM = BM / 32, WGN = NWV / WGM / KSP;    // BM=64: 2x2 waves, BM=32: 1x4 (KSP = 2: 1x2 tiles x 2 K-halves)
   constexpr int TN = BN / WGN / 32;                 // 32-pixel MFMA column tiles per wave (TM == 1)
   constexpr int S = EPI == EPI_F2 ? 2 : 1;          // pixel stride of the patch reads (forward stride)
   constexpr int PW = TW * S + 3 - S, PH = TH * S + 3 - S;   // S = 1: tile + 1-pixel halo; S = 2: 2T + 1
   constexpr int IMS = PH * PW;                      // one image of the patch
   constexpr int CHS = NI * IMS;                     // channel stride of the patch
   constexpr int XS = CK * CHS, WS = CK * 9 * BM;    // floats per LDS stage
-  constexpr int XSP = DIRECT_DMA ? (XS + 255) / 256 * 256 : XS;   // the DMA writes whole 64-lane rows: pad the stage
-  constexpr int NX = (XS + 255) / 256;              // patch loads per thread per chunk
+  constexpr int XSP = DIRECT_DMA ? (XS + NT - 1) / NT * NT : XS;  // the DMA writes whole 64-lane rows: pad the stage
+  constexpr int NX = (XS + NT - 1) / NT;            // patch loads per thread per chunk
   constexpr int W_F4 = WS / 4;
-  constexpr int NW = (W_F4 + 255) / 256;            // weight float4 loads per thread per chunk
-  static_assert(TN >= 1 && BN % (WGN * 32) == 0 && WGM * WGN * KSP == 4 && (CK / 2) % KSP == 0 && (KSP == 1 || EPI != EPI_S2), "tile");
+  constexpr int NW = (W_F4 + NT - 1) / NT;          // weight float4 loads per thread per chunk
+  static_assert(TN >= 1 && BN % (WGN * 32) == 0 && WGM * WGN * KSP == NWV && (CK / 2) % KSP == 0 && (KSP == 1 || EPI != EPI_S2), "tile");
   static_assert(EPI != EPI_F2 || DIRECT_DMA, "the stride-2 forward exists for the LDS-DMA staging only");
 
   __shared__ __attribute__((aligned(16))) float lds[2 * (XSP + WS)];
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   unsigned xvo[NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    const int e = tid + i * 256;
+    const int e = tid + i * NT;
     const int cl = e / CHS, rem2 = e - cl * CHS;
     const int py = rem2 / PW, pxx = rem2 - py * PW;
     const int gy = y0 * S + py - 1, gx = x0 * S + pxx - 1;
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   unsigned wvo[NW];
 #pragma unroll
   for (int i = 0; i < NW; ++i) {
-    const int idx = tid + i * 256;
+    const int idx = tid + i * NT;
     const int row = idx / (BM / 4), c4 = idx % (BM / 4);
     wvo[i] = (unsigned)(row * ldw + c4 * 4) * 4u;
   }
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
   bool gok[NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
-    const int e = tid + i * 256;
+    const int e = tid + i * NT;
     const int cl = e / CHS, rem = e - cl * CHS;
     const int img = rem / IMS, rem2 = rem - img * IMS;
     const int py = rem2 / PW, pxx = rem2 - py * PW;
@@ -183,13 +186,13 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
     const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, cn * HWs * 4, 0x00020000); \
     float* Xs = Xs0 + (BUF) * XSP + wave * 64;                                                            \
     _Pragma("unroll") for (int i = 0; i < NX; ++i)                                                        \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_vp_t)(Xs + i * 256), 4, xvo[i], 0, 0, 0);        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_vp_t)(Xs + i * NT), 4, xvo[i], 0, 0, 0);        \
     const float* wrow = (const float*)wbase + (size_t)(QG) * (CK * 9) * ldw;                              \
     const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)wrow, 0, CK * 9 * ldw * 4, 0x00020000); \
     float* Ws = Ws0 + (BUF) * WS + wave * 256;                                                            \
     _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                        \
-      if (W_F4 % 256 == 0 || i * 256 + wave * 64 < W_F4)                                                  \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_, (lds_vp_t)(Ws + i * 1024), 16, wvo[i], 0, 0, 0);    \
+      if (W_F4 % NT == 0 || i * NT + wave * 64 < W_F4)                                                    \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_, (lds_vp_t)(Ws + i * NT * 4), 16, wvo[i], 0, 0, 0);  \
     if (++cq == (cs == 0 ? q0 : (cs == 1 ? q1 : q2))) { cq = 0; ++cs; if (cs == 1 && q1 == 0) ++cs; }     \
   }
 #define DIRECT_LAND() __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): this wave's DMA has landed in LDS */
@@ -214,8 +217,8 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
     }                                                                                                     \
     const gcf_t wrow = wbase + (size_t)(QG) * (CK * 9) * ldw;                                             \
     _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                      \
-      const int idx = tid + i * 256;                                                                      \
-      if (W_F4 % 256 == 0 || idx < W_F4) {                                                                \
+      const int idx = tid + i * NT;                                                                      \
+      if (W_F4 % NT == 0 || idx < W_F4) {                                                                \
         const int row = idx / (BM / 4), c4 = idx % (BM / 4);                                              \
         rw[i] = *(gcf4_t)(wrow + (size_t)row * ldw + c4 * 4);                                             \
       }                                                                                                   \
@@ -227,12 +230,12 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
     float* Xs = Xs0 + (BUF) * XSP;                                                                        \
     float* Ws = Ws0 + (BUF) * WS;                                                                         \
     _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                      \
-      const int e = tid + i * 256;                                                                        \
-      if (XS % 256 == 0 || e < XS) Xs[e] = rx[i];                                                         \
+      const int e = tid + i * NT;                                                                        \
+      if (XS % NT == 0 || e < XS) Xs[e] = rx[i];                                                         \
     }                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                      \
-      const int idx = tid + i * 256;                                                                      \
-      if (W_F4 % 256 == 0 || idx < W_F4) *reinterpret_cast<f32x4*>(Ws + idx * 4) = rw[i];                 \
+      const int idx = tid + i * NT;                                                                      \
+      if (W_F4 % NT == 0 || idx < W_F4) *reinterpret_cast<f32x4*>(Ws + idx * 4) = rw[i];                 \
     }                                                                                                     \
   }
   if (nq > 0) {   // nq == 0: no dynamic source at all (ConvLSTM level 0 at t = 0 with the hoisted skip term): gates = addend
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int BM, int TW, int TH, int NI, int EPI, int KSP = 1>
+template <int BM, int TW, int TH, int NI, int EPI, int KSP = 1, int NWV = 4>
 static int launch_direct_cfg(ConvArgs& a, hipStream_t st) {
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
   const int gw = EPI == EPI_F2 ? a.Wo : a.W, gh = EPI == EPI_F2 ? a.Ho : a.H;      // the grid the tiles walk
@@ -390,12 +393,12 @@ static int launch_direct_cfg(ConvArgs& a, hipStream_t st) {
       if (ksplit < 1) ksplit = 1;
     }
   }
-  hipLaunchKernelGGL((conv3x3_direct_kernel<BM, TW, TH, NI, EPI, KSP>), dim3(grid, ksplit), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv3x3_direct_kernel<BM, TW, TH, NI, EPI, KSP, NWV>), dim3(grid, ksplit), dim3(NWV * 64), 0, st, a);
   return rsis_check_launch();
 }
 
 // variant codes: 1 = BM64 8x8x1 (64 px), 2 = BM64 16x8 (128 px), 3 = BM64 32x8 (256 px), 4 = BM32 16x8, 5 = BM32 32x8,
-// 6 = BM32 8x8 with the K range split over two wave pairs, 7 = BM32 64x8 (512 px), 8 = BM64 64x8
+// 6 = BM32 8x8 with the K range split over two wave pairs; 512-thread blocks: 7 = BM64 32x16 (512 px), 8 = BM32 32x16, 9 = BM64 16x16
 template <int EPI>
 static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
   int v = force;
@@ -424,6 +427,9 @@ static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
     // 32-pixel-wide maps: the 16 x 8 tile beats the 32 x 8 one on the 32-row variant (gate level 2, product launch: 68.8 -> 66.0 us;
     // its data gradient 80.6 -> 62.4 us)
     if (v == 5 && a.W <= 32 && a.Cout > 32) v = 4;
+    // wide maps, few output rows: a 512-thread block (32 rows x 32x16 pixels, 8 waves on one weight stage) -- 64->64 @64^2: 87.7 ->
+    // 81.7 us, 64->16 @128^2: 168 -> 151 us, gate level 3 (product launch): 73.0 -> 69.5 us
+    if (EPI != EPI_S2 && (v == 3 || v == 5) && a.W >= 64 && a.H >= 16 && a.Cout <= 64) v = 8;
   }
   if (EPI == EPI_S2 && v == 3) v = 5;   // 4 accumulator sets: the 256-pixel x 64-row tile would need 256 accumulator registers
   if (EPI == EPI_S2 && v == 6) v = 1;   // (no K-split variant of the 4-accumulator epilogue)
@@ -434,8 +440,9 @@ static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
     case 4: return launch_direct_cfg<32, 16, 8, 1, EPI>(a, st);
     case 5: return launch_direct_cfg<32, 32, 8, 1, EPI>(a, st);
     case 6: if constexpr (EPI != EPI_S2) return launch_direct_cfg<32, 8, 8, 1, EPI, 2>(a, st); else return RSIS_ERR_ARG;
-    case 7: if constexpr (EPI != EPI_S2) return launch_direct_cfg<32, 64, 8, 1, EPI>(a, st); else return RSIS_ERR_ARG;
-    case 8: if constexpr (EPI != EPI_S2) return launch_direct_cfg<64, 64, 8, 1, EPI>(a, st); else return RSIS_ERR_ARG;
+    case 7: if constexpr (EPI != EPI_S2) return launch_direct_cfg<64, 32, 16, 1, EPI, 1, 8>(a, st); else return RSIS_ERR_ARG;
+    case 8: if constexpr (EPI != EPI_S2) return launch_direct_cfg<32, 32, 16, 1, EPI, 1, 8>(a, st); else return RSIS_ERR_ARG;
+    case 9: if constexpr (EPI != EPI_S2) return launch_direct_cfg<64, 16, 16, 1, EPI, 1, 8>(a, st); else return RSIS_ERR_ARG;
     default: return RSIS_ERR_ARG;
   }
 }
