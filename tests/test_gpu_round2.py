@@ -327,3 +327,33 @@ def test_training_step_at_the_bench_configuration_matches_the_oracle():
         errs.append((k, _rel_l2(grads[k], g32), tol))
     bad = [e for e in errs if e[1] >= e[2]]
     assert not bad, "gradients outside their bar: %s; all: %s" % (bad, [(k, "%.1e" % e) for k, e, _t in errs])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_config4_geometry_training_steps(dtype):
+    """BASELINE configs[4]'s per-GPU workload -- 512x1024, T = 20, batch 8, 9 classes (Cityscapes) -- three training iterations (two
+    eager, one as a replayed hipGraph): finite, decreasing loss, peak memory far below the 288 GB of one MI355X (256x512 maps at
+    the finest pyramid level, 20 timesteps of saved state)."""
+    import bench
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import GraphedStep, build_optimizers, steps_to_run
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    B, H, W, T = 8, 512, 1024, 20
+    a = bench.bench_args(B, H, T, dtype)
+    a.num_classes, a.gt_maxseqlen, a.maxseqlen = 9, 20, T
+    torch.manual_seed(0)
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    opts = list(build_optimizers(a, enc, dec))
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(0.5)]
+    batch = synthetic_batch(1, B, H, W, 20, 15, 9, "cuda")
+    t_run = steps_to_run(a, batch[3])
+    assert t_run == 16                                    # 15 instances + the end-of-sequence step (train.py:87-92)
+    torch.cuda.reset_peak_memory_stats()
+    g = GraphedStep(a, enc, dec, crits, opts, None, warm=2)
+    ls = [float(g(batch, t_run)[0][0]) for _ in range(4)]
+    assert g.graph is not None, g.failed
+    assert all(v == v and abs(v) < 1e3 for v in ls) and ls[-1] < ls[0], ls
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    assert peak < 150, "peak memory %.1f GB" % peak
+    g.release()
