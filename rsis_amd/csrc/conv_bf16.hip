@@ -523,10 +523,15 @@ template <int EPI>
 static int launch_bf16_k3(ConvArgs& a, hipStream_t st, int force) {
   int v = force;
   if (v <= 0) {
+    // measured on the trunk / decoder shapes at batch 32, 224^2 and 256^2 (tools/exp/bf16_shape_sweep.py): these launches are
+    // latency-bound, so the rule is "enough blocks for two per CU", then the widest tile
     const bool small_co = a.Cout <= 32;
     if (a.W <= 8 && a.H <= 8) v = (a.Cout >= 256 && (long)rsis_cdiv(a.Cout, 128) * a.B >= 256) ? 6 : 1;
-    else if (a.W <= 16) v = small_co ? 4 : 2;
-    else v = small_co ? 5 : 3;
+    else if (a.W <= 16) {
+      v = small_co ? 4 : 2;
+      const long blocks = (long)rsis_cdiv(a.Cout, 64) * rsis_cdiv(a.W, 16) * rsis_cdiv(a.H, 8) * a.B;
+      if (v == 2 && blocks < 512) v = 1;       // 256 -> 256 @14^2 / 16^2: 29.5 -> 26 us
+    } else v = a.Cout <= 64 ? 5 : 3;           // <= 64 rows: 32-row tiles (64 -> 64 @56^2: 36 -> 26 us; 16 -> 64 @112^2: 72 -> 52 us)
     if (v == 3) {      // keep >= ~2 blocks per CU
       const long blocks = (long)rsis_cdiv(a.Cout, 64) * rsis_cdiv(a.W, 32) * rsis_cdiv(a.H, 8) * a.B;
       if (blocks < 512) v = 2;
@@ -572,7 +577,7 @@ static int launch_bf16_k1(ConvArgs& a, hipStream_t st, int force) {
   if (v <= 0) {
     const long px = (long)a.H * a.W;
     if (a.Cout <= 32) v = 3;
-    else if (a.Cout <= 64 || (long)rsis_cdiv(a.Cout, 128) * rsis_cdiv(px, 128) * a.B < 512) v = 2;
+    else if (a.Cout <= 64 || a.C[0] <= 128 || (long)rsis_cdiv(a.Cout, 128) * rsis_cdiv(px, 128) * a.B < 512) v = 2;   // (K <= 128: 1-2 chunks, 64 -> 256 @56^2: 63 -> 49 us)
     else v = 1;
   }
   switch (v) {
