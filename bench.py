@@ -21,6 +21,7 @@ management; see main()); the timed region is still EXACTLY K steps between barri
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -245,13 +246,17 @@ def cpu_baseline(imsize, T, budget_s=25.0):
                       % (B, imsize, imsize, T, n)}
 
 
+# the fused ConvLSTM gate kernel in a profiler's kernel-name column: template arguments <BM, TW, TH, NI, EPI, KSP, NWV>, EPI == 1 is
+# the fused LSTM epilogue (tests/test_abi.py checks the pattern against the symbols of the built library)
+GATE_KERNEL_RE = re.compile(r"conv3x3_direct_kernel<\d+, \d+, \d+, \d+, 1, \d+, \d+>")
+
+
 def gate_kernel_traffic(batch, imsize, timeout=150):
     """HBM bytes of the five gate-kernel launches of one timestep from the memory-side PMC counters: two rocprofv3 passes
     (FETCH_SIZE, then WRITE_SIZE -- they do not fit one pass) over `bench.py --roofline-only` in a child process.
     FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibrated there for 16 B/lane streaming reads; this
     kernel's input patch is fetched 4 B/lane, for which the doubling is an upper bound).  Returns (bytes, detail) or (None, why)."""
     import csv
-    import re
     import shutil
     import statistics
     import tempfile
@@ -277,8 +282,7 @@ def gate_kernel_traffic(batch, imsize, timeout=150):
             with open(path) as f:
                 for r in csv.DictReader(f):
                     k = r["Kernel_Name"]
-                    # template arguments <BM, TW, TH, NI, EPI, KSP>: EPI == 1 is the fused LSTM epilogue (the gate kernel)
-                    if r["Counter_Name"] == counter and re.search(r"conv3x3_direct_kernel<\d+, \d+, \d+, \d+, 1, \d+>", k):
+                    if r["Counter_Name"] == counter and GATE_KERNEL_RE.search(k):
                         vals.setdefault((k, r["Grid_Size"]), []).append(float(r["Counter_Value"]))
             if len(vals) != 5:
                 return None, "expected 5 gate-kernel launch shapes in the counter file, found %d" % len(vals)

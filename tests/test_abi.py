@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from rsis_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -68,3 +70,20 @@ def test_product_has_no_cpu_path():
     from rsis_amd import ops
     with pytest.raises(_lib.RsisHipError):
         ops.upsample_bilinear_ac(torch.zeros(1, 1, 2, 2), (4, 4))
+
+
+def test_bench_finds_the_gate_kernel_by_name():
+    """bench.py picks the gate kernel's rows out of rocprofv3's counter file by its demangled name: the pattern must match the
+    EPI_LSTM instantiations the library actually contains (a template parameter added to the kernel once silently turned
+    `roofline.traffic` into null)."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("nm") is None:
+        pytest.skip("nm not available")
+    sys.path.insert(0, ROOT)
+    import bench
+    out = subprocess.run(["nm", "-C", _lib.LIB_PATH], stdout=subprocess.PIPE, universal_newlines=True, check=True).stdout
+    names = [l for l in out.splitlines() if "conv3x3_direct_kernel<" in l]
+    gates = [l for l in names if bench.GATE_KERNEL_RE.search(l)]
+    assert len(names) >= 20 and len(gates) >= 5, (len(names), len(gates))

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 run (sqlite `*_results.db` or `*_kernel_stats.csv`) into a compact per-kernel table
-(the files committed under profiles/).  usage: tools/prof_summary.py <db-or-csv> [steps] > profiles/<name>.txt"""
+(the files committed under profiles/).  usage: tools/prof_summary.py <db-or-csv> [steps | laststep] > profiles/<name>.txt
+`laststep` (sqlite only): the table of ONE training step -- the kernels between the last two optimizer updates (two adam_kernel
+launches end a step), whatever warm-up / capture steps the run contained."""
 import csv
 import re
 import sqlite3
@@ -16,9 +18,23 @@ def short(name):
 
 def main():
     path = sys.argv[1]
-    steps = float(sys.argv[2]) if len(sys.argv) > 2 else None
+    last = len(sys.argv) > 2 and sys.argv[2] == "laststep"
+    steps = float(sys.argv[2]) if len(sys.argv) > 2 and not last else None
     rows = []
-    if path.endswith(".db"):
+    if last:
+        cur = sqlite3.connect(path).cursor()
+        ks = list(cur.execute("select name,start,end from kernels order by start"))
+        ad = [i for i, k in enumerate(ks) if "adam_kernel" in k[0]]
+        seg = ks[ad[-4] + 1: ad[-2] + 1]
+        agg = {}
+        for n, s0, e0 in seg:
+            a = agg.setdefault(short(n), [0, 0.0])
+            a[0] += 1
+            a[1] += (e0 - s0) / 1e6
+        tot = sum(a[1] for a in agg.values())
+        rows = [(n, a[0], a[1], 1e3 * a[1] / a[0], 100.0 * a[1] / tot) for n, a in agg.items()]
+        print("# one training step: %d kernel launches, first start to last end %.3f ms" % (len(seg), (seg[-1][2] - seg[0][1]) / 1e6))
+    elif path.endswith(".db"):
         cur = sqlite3.connect(path).cursor()
         for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
             rows.append((short(name), int(calls), float(total) / 1e3, float(avg), float(pct)))  # db durations are in us
