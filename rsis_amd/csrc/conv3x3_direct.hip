@@ -326,6 +326,34 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs
       const gf_t d0 = (gf_t)p.dst[0], d1 = (gf_t)p.dst[1], d2 = (gf_t)p.dst[2];
       const int Cd0 = p.Cd[0], Cd1 = p.Cd[1], Cd2 = p.Cd[2], Cout = p.Cout;
       const int e1 = Cd0, e2 = Cd0 + Cd1;
+      if (p.ndst == 1 && ksplit == 1 && (size_t)B * Cout * HW * 4 < (1ull << 31)) {
+        // single destination, no split-K (every trunk / skip / hoisted conv and most data gradients): a row of the tile is ONE
+        // buffer store at a per-lane base + row * HW floats; rows >= Cout get an out-of-range offset (dropped by the descriptor).
+        // ~3 instructions per stored value instead of ~25 of 64-bit index arithmetic and destination selection: the general
+        // path below costs ~8 us of a launch whatever its size (measured by ablation on the bf16 twin of this epilogue).
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)p.dst[0], 0, (unsigned)((size_t)B * Cout * HW * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? p.addend : p.dst[0]), 0, (unsigned)((size_t)B * Cout * HW * 4), 0x00020000);
+        const unsigned vo = (unsigned)((ob * Cout + co_base + 4 * hi) * HW + osp) * 4u;
+        const unsigned rowb = (unsigned)HW * 4u;
+        const int rows_left = Cout - (co_base + 4 * hi);        // rows k of this lane are valid while k < rows_left
+        float av[16];
+        if (addend) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2);
+            av[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, k < rows_left ? vo + k * rowb : 0x7FFFFFF0u, 0, 0));
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = (r & 3) + 8 * (r >> 2);
+          float v = acc[j][r];
+          if (bias) v += k < rows_left ? bias[co_base + 4 * hi + k] : 0.f;
+          if (addend) v += av[r];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, k < rows_left ? vo + k * rowb : 0x7FFFFFF0u, 0, 0);
+        }
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * hi;

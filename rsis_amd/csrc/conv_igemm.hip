@@ -258,6 +258,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       const int ob = opx / HoWo;
       int osp = opx - ob * HoWo;
       if (ostride > 1) { const int oho = osp / Wo; osp = (oho * ostride) * p.oW + (osp - oho * Wo) * ostride; }
+      if (p.ndst == 1 && (size_t)p.B * Cout * oHW * 4 < (1ull << 31)) {
+        // single destination (every 1x1 conv of the trunk and its data gradient): a row of the tile is ONE buffer store at a
+        // per-lane base + row * oHW floats, rows >= Cout get an out-of-range offset -- ~3 instructions per stored value instead
+        // of ~25 of 64-bit index arithmetic and destination selection (the general path costs ~8 us of a 48 us launch)
+        const unsigned span = (unsigned)((size_t)p.B * Cout * oHW * 4);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)p.dst[0], 0, span, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? p.addend : p.dst[0]), 0, span, 0x00020000);
+        const unsigned rowb = (unsigned)oHW * 4u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row0 = co_base + i * 32 + 4 * hi;
+          const unsigned vo = (unsigned)((ob * Cout + row0) * oHW + osp) * 4u;
+          const int rows_left = Cout - row0;
+          float av[16];
+          if (addend) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int k = (r & 3) + 8 * (r >> 2);
+              av[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, k < rows_left ? vo + k * rowb : 0x7FFFFFF0u, 0, 0));
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2);
+            float v = acc[i][j][r];
+            if (bias) v += k < rows_left ? bias[row0 + k] : 0.f;
+            if (addend) v += av[r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, k < rows_left ? vo + k * rowb : 0x7FFFFFF0u, 0, 0);
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if (addend) {
