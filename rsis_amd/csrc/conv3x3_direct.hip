@@ -373,6 +373,49 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs
       const int hid = p.hid;
       const gcf_t c_prev = (gcf_t)p.c_prev;
       const gf_t c_out = (gf_t)p.c_out, h_out = (gf_t)p.h_out, act_out = (gf_t)p.act_out;
+      if ((size_t)p.B * 4 * hid * HW * 4 < (1ull << 31)) {
+        // the cell update through buffer descriptors: per hidden channel 4 addend loads, c_prev, and the c / h / 4 gate stores are
+        // per-lane bases + scalar multiples of HW (no 64-bit index arithmetic per access); channels >= hid get an out-of-range
+        // offset (loads return 0, stores are dropped)
+        const unsigned gspan = (unsigned)((size_t)p.B * 4 * hid * HW * 4), sspan = gspan / 4;
+        const __amdgpu_buffer_rsrc_t r_add = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? p.addend : p.h_out), 0, addend ? gspan : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)(act_out ? p.act_out : p.h_out), 0, act_out ? gspan : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_cp = __builtin_amdgcn_make_buffer_rsrc((void*)(c_prev ? p.c_prev : p.h_out), 0, c_prev ? sspan : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc((void*)p.c_out, 0, sspan, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_h = __builtin_amdgcn_make_buffer_rsrc((void*)p.h_out, 0, sspan, 0x00020000);
+        const unsigned rowb = (unsigned)HW * 4u;
+        const int jh0 = (co_base >> 2) + hi;
+        const unsigned vg = (unsigned)((ob * 4 * hid + 4 * jh0) * HW + osp) * 4u;
+        const unsigned vs = (unsigned)((ob * hid + jh0) * HW + osp) * 4u;
+        float ga[4][4], cpv[4];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {          // all loads of the tile first
+          const bool ok = jh0 + 2 * r4 < hid;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            ga[r4][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_add, ok ? vg + (8 * r4 + g) * rowb : 0x7FFFFFF0u, 0, 0));
+          cpv[r4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_cp, ok ? vs + 2 * r4 * rowb : 0x7FFFFFF0u, 0, 0));
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const bool ok = jh0 + 2 * r4 < hid;
+          const int cop = 4 * (jh0 + 2 * r4);
+          float ai = acc[j][4 * r4 + 0] + ga[r4][0], af = acc[j][4 * r4 + 1] + ga[r4][1];
+          float ao = acc[j][4 * r4 + 2] + ga[r4][2], ag = acc[j][4 * r4 + 3] + ga[r4][3];
+          if (bias && ok) { ai += bias[cop]; af += bias[cop + 1]; ao += bias[cop + 2]; ag += bias[cop + 3]; }
+          const float gi = rsis_sigmoid(ai), gf = rsis_sigmoid(af), go = rsis_sigmoid(ao), gg = tanhf(ag);
+          const float c = gf * cpv[r4] + gi * gg;  // clstm.py:57
+          const float h = go * tanhf(c);           // clstm.py:58
+          const unsigned os = ok ? vs + 2 * r4 * rowb : 0x7FFFFFF0u, og = ok ? vg + 8 * r4 * rowb : 0x7FFFFFF0u;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), r_c, os, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), r_h, os, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gi), r_act, og, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gf), r_act, og + rowb, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, go), r_act, og + 2 * rowb, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gg), r_act, og + 3 * rowb, 0, 0);
+        }
+        continue;
+      }
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const int jh = (co_base >> 2) + 2 * r4 + hi;   // hidden channel
