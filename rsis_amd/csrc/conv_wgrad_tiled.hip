@@ -221,18 +221,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(const WgradTiledA
 #undef WG_LAND
 
   // ---- epilogue: fp32 atomics into dW (reference layout) ----
+  // (buffer atomics: a row of the tile is a per-lane base + a scalar multiple of ldo; the gate-interleaved rows 4 j + g of the
+  //  ConvLSTM weights go to row g * hid + j; rows >= Cout get an out-of-range offset and are dropped)
+  const __amdgpu_buffer_rsrc_t rdw = __builtin_amdgcn_make_buffer_rsrc((void*)p.dw, 0, (unsigned)((size_t)Cout * p.ldo * 4), 0x00020000);
+  const int ihid = p.interleave_hid;
+  const unsigned ldb = (unsigned)p.ldo * 4u;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * TN * 32 + j * 32 + l31;
     if (n >= Nn) continue;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      const int row0 = co0 + wm * TM * 32 + i * 32 + 4 * hi;       // (a multiple of 4)
+      const int rows_left = Cout - row0;
+      const unsigned vo = (unsigned)((ihid > 0 ? row0 >> 2 : row0) * p.ldo + p.n_off + n) * 4u;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (co >= Cout) continue;
-        const int row = p.interleave_hid > 0 ? (co & 3) * p.interleave_hid + (co >> 2) : co;
-        atomicAdd(p.dw + (size_t)row * p.ldo + p.n_off + n, acc[i][j][r]);
+        const int k = (r & 3) + 8 * (r >> 2);
+        const unsigned ro = (unsigned)(ihid > 0 ? (r & 3) * ihid + 2 * (r >> 2) : k) * ldb;
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][j][r], rdw, k < rows_left ? vo + ro : 0x7FFFFFF0u, 0, 0);
       }
     }
   }
