@@ -259,7 +259,7 @@ static int launch_tiled_cfg(WgradTiledArgs& a, hipStream_t st) {
   // the layer (8.4 M for 128 x 128 tiles, ~20 us) -- a third of a 1x1 weight gradient's time but < 10 % of a 3x3's.  Measured:
   // 1x1 layers +15 % with one block per CU (half the splits), 3x3 layers lose up to 20 % (they need the second block to hide
   // the patch staging).
-  const int slots = KS == 1 ? 256 : 256 * (BM * BN >= 128 * 128 ? 2 : 3);
+  const int slots = KS == 1 ? (BM * BN >= 128 * 128 ? 256 : 512) : 256 * (BM * BN >= 128 * 128 ? 2 : 3);
   int nsplit = ntile >= slots ? 1 : slots / ntile;
   if (nsplit > a.n_sp_tiles / 2) nsplit = a.n_sp_tiles / 2;
   if (nsplit < 1) nsplit = 1;
@@ -275,6 +275,10 @@ static int launch_tiled_tw(WgradTiledArgs& a, hipStream_t st) {
   // 16- and 32-channel sources (N = 144 / 288: 56 % / 75 % -> 75 % / 90 % useful MFMA columns)
   const int nmod = (a.Cs * KS * KS) % 128;
   const bool narrow = nmod != 0 && nmod <= 64;
+  // 1x1: 64 x 64 tiles with two blocks per CU.  The split count -- and with it the dW-sized passes of fp32 atomics, which run at
+  // ~0.3 T atomics/s and were a third of these launches -- goes with slots / tiles: a quarter of the 128 x 128 tile's at twice
+  // its slots.  Measured on every 1x1 shape of the trunk at batch 32 (tools/exp/bf16_shape_sweep.py --dtype fp32): 47-54 -> 38-44 us.
+  if (KS == 1 && a.Cout > 32) return launch_tiled_cfg<64, 64, 2, 2, KS, TW>(a, st);
   if (a.Cout <= 32) return narrow ? launch_tiled_cfg<32, 64, 1, 2, KS, TW, 2>(a, st) : launch_tiled_cfg<32, 128, 1, 4, KS, TW>(a, st);
   if (a.Cout <= 64) return narrow ? launch_tiled_cfg<64, 64, 2, 2, KS, TW>(a, st) : launch_tiled_cfg<64, 128, 2, 2, KS, TW>(a, st);
   return narrow ? launch_tiled_cfg<128, 64, 2, 2, KS, TW>(a, st) : launch_tiled_cfg<128, 128, 2, 2, KS, TW>(a, st);
