@@ -218,6 +218,7 @@ class BucketedAllReduce(object):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = dist.is_initialized() and (self.world > 1 or force)   # force: exercise the collective path at world 1
+        self.hooks_enabled = True
         self.buckets = []      # (flat_g view, n_params)
         self._pending = []
         self._handles = []
@@ -249,6 +250,8 @@ class BucketedAllReduce(object):
 
     def _make_hook(self, bi):
         def hook(_p):
+            if not self.hooks_enabled:         # split-graph replay (train.GraphedStep) exchanges the flat buffers itself
+                return
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
                 self._handles.append(dist.all_reduce(self.buckets[bi][0], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))

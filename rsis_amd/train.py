@@ -241,6 +241,10 @@ class GraphedStep(object):
     def __init__(self, args, encoder, decoder, crits, optims, reducer=None, warm=2, pool=None):
         self.args, self.encoder, self.decoder, self.crits, self.optims, self.reducer = args, encoder, decoder, crits, optims, reducer
         self.split = reducer is not None and getattr(reducer, "active", False)
+        if self.split:
+            # the two-graph schedule all-reduces the flat gradient buffers itself (_exchange): the reducer's per-bucket hooks
+            # must not fire inside these backward passes (they would reduce the first warm-up step's gradients twice)
+            reducer.hooks_enabled = False
         self.warm, self.pool = warm, pool
         self.graph, self.graph_update, self.static, self.result, self.t_run = None, None, None, None, None
         self.stream = torch.cuda.Stream()
@@ -309,10 +313,21 @@ class GraphedStep(object):
         graph, graph_u = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         try:
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
+            if dist.is_initialized():
+                # Let the RCCL watchdog thread retire the (now complete) collectives of the warm-up steps before the capture
+                # starts: it polls its work list every 100 ms with event queries, and an event query that lands while this
+                # stream captures kills the process from inside the watchdog (hipErrorStreamCaptureUnsupported under the global
+                # capture mode, hipErrorCapturedEvent under the thread-local one: 1 run in 4-6 of tests/test_gpu_ddp.py's
+                # world-size-1 worker).  No collective is issued during the capture, so an empty list stays empty.
+                time.sleep(0.6)
+            # thread-local capture mode: under the default (global) mode an event query from ANY thread while this one captures
+            # is an error, and the RCCL watchdog thread polls the events of the eager all-reduces that ran just before -- one
+            # run in six died with hipErrorStreamCaptureUnsupported raised inside the watchdog (the loader's staging threads
+            # are the other candidate)
+            with torch.cuda.graph(graph, pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
                 self.result = self._run(self.static, t_run, do_update=not self.split)
             if self.split:
-                with torch.cuda.graph(graph_u, pool=graph.pool(), stream=self.stream):
+                with torch.cuda.graph(graph_u, pool=graph.pool(), stream=self.stream, capture_error_mode="thread_local"):
                     apply_update(self.args, self.optims, 1.0 / self.reducer.world)
                 self.graph_update = graph_u
             self.graph = graph
