@@ -248,6 +248,7 @@ def cpu_baseline(imsize, T, budget_s=25.0):
 
 # the fused ConvLSTM gate kernel in a profiler's kernel-name column: template arguments <BM, TW, TH, NI, EPI, KSP, NWV>, EPI == 1 is
 # the fused LSTM epilogue (tests/test_abi.py checks the pattern against the symbols of the built library)
+REAL_STDOUT = 1
 GATE_KERNEL_RE = re.compile(r"conv3x3_direct_kernel<\d+, \d+, \d+, \d+, 1, \d+, \d+>")
 
 
@@ -334,6 +335,12 @@ def main():
     from rsis_amd.synthetic import synthetic_batch
     from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
 
+    # ONE line on stdout, whatever the libraries print: RCCL writes its version banner to stdout when the first communicator is
+    # created.  From here on file descriptor 1 is stderr; the JSON line goes to the saved descriptor.
+    global REAL_STDOUT
+    sys.stdout.flush()
+    REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     rank, local_rank, world = init_distributed()
     assert world == o.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % o.gpus
     assert torch.cuda.is_available(), "bench.py needs the GPU (there is no CPU path)"
@@ -508,7 +515,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         flush_c()
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(REAL_STDOUT, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
