@@ -84,6 +84,20 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const vo
 int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs, int H, int W, int Cout, int Ho, int Wo,
                       int ks, int stride, int pad, int Ctot, int c_off, int lstm_hid, int dtype, void* stream);
 
+/* ---- many weight gradients in one call (same semantics as njobs calls of rsis_conv2d_wgrad, every dW ACCUMULATED; the dW regions
+ * of different jobs may coincide -- e.g. the sources of one conv).  A weight gradient is off the critical path of the backward pass
+ * (autograd of train.py:184 only needs it before the optimizer step), so the caller may park them and flush them here: the jobs that
+ * run on the exact-f32 LDS-DMA tiled kernel are launched as ONE grid per tile configuration, sized for the whole set -- a layer on
+ * its own must split its pixel axis 8-32 ways to fill the chip and pays a dW-sized pass of fp32 atomics per split.  The other jobs
+ * are launched one by one.  The job array is host memory and is not referenced after the call returns. ---- */
+typedef struct rsis_wgrad_job {
+  const float* dy;     /* [B][Cout][Ho][Wo] */
+  const float* x;      /* [B][Cs][H][W] */
+  float* dW;           /* [Cout][Ctot][ks][ks], this source's channels start at c_off */
+  int B, Cs, H, W, Cout, Ho, Wo, ks, stride, pad, Ctot, c_off, lstm_hid, dtype;
+} rsis_wgrad_job;
+int rsis_conv2d_wgrad_batch(const rsis_wgrad_job* jobs, int njobs, void* stream);
+
 /* ---- conv bias gradient: db[Cout] += sum_{b,h,w} dy  (ACCUMULATES; lstm_hid as above) ---- */
 int rsis_bias_grad(const float* dy, float* db, int B, int C, int HW, int lstm_hid, void* stream);
 

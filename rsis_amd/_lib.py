@@ -24,6 +24,12 @@ class PackJob(ctypes.Structure):
                 ("imode", ctypes.c_int), ("ldw", ctypes.c_int), ("krows", ctypes.c_int), ("block_begin", ctypes.c_int)]
 
 
+class WgradJob(ctypes.Structure):
+    """struct rsis_wgrad_job of include/rsis_hip.h"""
+    _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dW", ctypes.c_void_p)] + \
+               [(k, ctypes.c_int) for k in ("B", "Cs", "H", "W", "Cout", "Ho", "Wo", "ks", "stride", "pad", "Ctot", "c_off", "lstm_hid", "dtype")]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/rsis_hip.h
 SIGNATURES = {
     "rsis_version": (_i, []),
@@ -38,6 +44,7 @@ SIGNATURES = {
     "rsis_conv2d_fwd": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_conv2d_dgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vpp, _ip, _i, _i, _i, _vp, _i, _i, _vp]),
     "rsis_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsis_conv2d_wgrad_batch": (_i, [ctypes.POINTER(WgradJob), _i, _vp]),
     "rsis_affine_nearest": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsis_conv_out_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

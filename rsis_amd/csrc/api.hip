@@ -12,6 +12,7 @@ bool rsis_wgrad_bf16_supported(const WgradArgs& w, int ks);
 int rsis_launch_conv_wgrad_bf16(const WgradArgs& w, int ks, hipStream_t st);
 bool rsis_wgrad_tiled_supported(const WgradArgs& w, int ks);
 int rsis_launch_conv_wgrad_tiled(const WgradArgs& w, int ks, hipStream_t st);
+int rsis_launch_conv_wgrad_tiled_group(const WgradArgs* w, int n, int ks, hipStream_t st);
 bool rsis_c1_supported(int Cin);
 int rsis_l_c1_fwd(const float*, const float*, int, const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_c1_dgrad(const float*, const float*, int, float*, int, int, int, int, hipStream_t);
@@ -343,20 +344,60 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const vo
   return rsis_launch_conv_igemm(a, ks, true, 0, tile, (hipStream_t)stream);
 }
 
-int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs, int H, int W, int Cout, int Ho, int Wo,
-                      int ks, int stride, int pad, int Ctot, int c_off, int lstm_hid, int dtype, void* stream) {
-  if (!dy || !x || !dW || c_off < 0 || c_off + Cs > Ctot) return RSIS_ERR_ARG;
-  WgradArgs a = {};
-  a.dy = dy; a.x = x; a.dw = dW; a.B = B; a.Cs = Cs; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
-  a.stride = stride; a.pad = pad; a.ldo = Ctot * ks * ks; a.n_off = c_off * ks * ks; a.interleave_hid = lstm_hid;
-  if (use_direct(ks, stride, pad) && Cout == 1 && lstm_hid == 0 && rsis_c1_supported(Cs) && H == Ho && W == Wo && W % 4 == 0)
-    return rsis_l_c1_wgrad(dy, x, dW + a.n_off, nullptr, B, Cs, H, W, (hipStream_t)stream);
+// route of one weight gradient: 0 conv_out vector kernel, 1 bf16 tiled, 2 exact-f32 LDS-DMA tiled, 3 generic split-K implicit GEMM
+static int wgrad_route(const WgradArgs& a, int ks, int lstm_hid, int dtype) {
+  if (use_direct(ks, a.stride, a.pad) && a.Cout == 1 && lstm_hid == 0 && rsis_c1_supported(a.Cs) && a.H == a.Ho && a.W == a.Wo && a.W % 4 == 0)
+    return 0;
   // stride-1 "same" convs on tile-aligned maps: the LDS-DMA tiled kernel (conv_wgrad_tiled.hip); RSIS_WGRAD_TILED=0 forces the
   // generic split-K implicit GEMM (conv_wgrad.hip), which also covers every other shape
-  if (dtype == RSIS_DTYPE_BF16 && rsis_wgrad_bf16_supported(a, ks)) return rsis_launch_conv_wgrad_bf16(a, ks, (hipStream_t)stream);
+  if (dtype == RSIS_DTYPE_BF16 && rsis_wgrad_bf16_supported(a, ks)) return 1;
   static const bool tiled_ok = !(getenv("RSIS_WGRAD_TILED") && getenv("RSIS_WGRAD_TILED")[0] == '0');
-  if (tiled_ok && rsis_wgrad_tiled_supported(a, ks)) return rsis_launch_conv_wgrad_tiled(a, ks, (hipStream_t)stream);
-  return rsis_launch_conv_wgrad(a, ks, (hipStream_t)stream);
+  if (tiled_ok && rsis_wgrad_tiled_supported(a, ks)) return 2;
+  return 3;
+}
+static int wgrad_fill(WgradArgs& a, const float* dy, const float* x, float* dW, int B, int Cs, int H, int W, int Cout, int Ho, int Wo,
+                      int ks, int stride, int pad, int Ctot, int c_off, int lstm_hid) {
+  if (!dy || !x || !dW || c_off < 0 || c_off + Cs > Ctot) return RSIS_ERR_ARG;
+  a = WgradArgs{};
+  a.dy = dy; a.x = x; a.dw = dW; a.B = B; a.Cs = Cs; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+  a.stride = stride; a.pad = pad; a.ldo = Ctot * ks * ks; a.n_off = c_off * ks * ks; a.interleave_hid = lstm_hid;
+  return RSIS_OK;
+}
+static int wgrad_launch_one(WgradArgs& a, int route, int ks, hipStream_t st) {
+  switch (route) {
+    case 0: return rsis_l_c1_wgrad(a.dy, a.x, a.dw + a.n_off, nullptr, a.B, a.Cs, a.H, a.W, st);
+    case 1: return rsis_launch_conv_wgrad_bf16(a, ks, st);
+    case 2: return rsis_launch_conv_wgrad_tiled(a, ks, st);
+    default: return rsis_launch_conv_wgrad(a, ks, st);
+  }
+}
+
+int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs, int H, int W, int Cout, int Ho, int Wo,
+                      int ks, int stride, int pad, int Ctot, int c_off, int lstm_hid, int dtype, void* stream) {
+  WgradArgs a;
+  const int rc = wgrad_fill(a, dy, x, dW, B, Cs, H, W, Cout, Ho, Wo, ks, stride, pad, Ctot, c_off, lstm_hid);
+  if (rc) return rc;
+  return wgrad_launch_one(a, wgrad_route(a, ks, lstm_hid, dtype), ks, (hipStream_t)stream);
+}
+
+int rsis_conv2d_wgrad_batch(const rsis_wgrad_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs < 1) return RSIS_ERR_ARG;
+  WgradArgs* tiled[2] = {(WgradArgs*)malloc(sizeof(WgradArgs) * njobs), (WgradArgs*)malloc(sizeof(WgradArgs) * njobs)};
+  int nt[2] = {0, 0};
+  int rc = (tiled[0] && tiled[1]) ? RSIS_OK : RSIS_ERR_LAUNCH;
+  for (int j = 0; j < njobs && rc == RSIS_OK; ++j) {
+    const rsis_wgrad_job& q = jobs[j];
+    WgradArgs a;
+    rc = wgrad_fill(a, q.dy, q.x, q.dW, q.B, q.Cs, q.H, q.W, q.Cout, q.Ho, q.Wo, q.ks, q.stride, q.pad, q.Ctot, q.c_off, q.lstm_hid);
+    if (rc) break;
+    const int route = wgrad_route(a, q.ks, q.lstm_hid, q.dtype);
+    if (route == 2 && (q.ks == 1 || q.ks == 3)) tiled[q.ks == 3][nt[q.ks == 3]++] = a;     // grouped below
+    else rc = wgrad_launch_one(a, route, q.ks, (hipStream_t)stream);
+  }
+  if (rc == RSIS_OK) rc = rsis_launch_conv_wgrad_tiled_group(tiled[0], nt[0], 1, (hipStream_t)stream);
+  if (rc == RSIS_OK) rc = rsis_launch_conv_wgrad_tiled_group(tiled[1], nt[1], 3, (hipStream_t)stream);
+  free(tiled[0]); free(tiled[1]);
+  return rc;
 }
 
 int rsis_bias_grad(const float* dy, float* db, int B, int C, int HW, int lstm_hid, void* stream) {

@@ -22,6 +22,7 @@
 // 32x1 / 16x2 / 8x4 for 1x1) so that dy / x rows are read as full 128-byte lines; maps that no tile shape divides use
 // conv_wgrad.hip.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((address_space(3))) void* lds_vp_t;
 
@@ -39,7 +40,7 @@ struct WgradTiledArgs {
 // KSP = 2: the block's four waves form a WGM x WGN grid TWICE; the two copies take alternate halves of every stage's reduction
 // depth and both add their partial tile with the (already atomic) epilogue -- lets a 32-row tile be only 64 columns wide.
 template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1>
-__global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(const WgradTiledArgs p) {
+__device__ __forceinline__ void wgrad_tiled_body(const WgradTiledArgs& p, const int bx, const int by) {
 #if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; the buffer-resource builtins do not exist there)
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int KK = KS * KS, HALO = KS / 2;
@@ -64,12 +65,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(const WgradTiledA
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wk = wave / (WGM * WGN), wm = (wave % (WGM * WGN)) / WGN, wn = wave % WGN;
   const int H = p.H, W = p.W, HW = H * W, Cs = p.Cs, Cout = p.Cout;
-  const int co_t = blockIdx.x % p.n_co_tiles, n_t = blockIdx.x / p.n_co_tiles;
+  const int co_t = bx % p.n_co_tiles, n_t = bx / p.n_co_tiles;
   const int co0 = co_t * BM, n0 = n_t * BN;
   const int ci0 = n0 / KK;                     // first input channel of this block's patch / x tile
   const int Nn = Cs * KK;
   const int tiles_x = W / TW, tiles_y = H / TH;
-  const int t_begin = blockIdx.y * p.tiles_per_split;
+  const int t_begin = by * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.n_sp_tiles);
   if (t_begin >= t_end) return;
 
@@ -247,6 +248,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(const WgradTiledA
 }
 
 template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1>
+__global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(const WgradTiledArgs p) {
+  wgrad_tiled_body<BM, BN, WGM, WGN, KS, TW, KSP>(p, blockIdx.x, blockIdx.y);
+}
+
+// ---- grouped launch: the weight gradients of many layers in ONE grid (rsis_conv2d_wgrad_batch).  A weight gradient is off the
+// backward pass's critical path (nothing reads it before the optimizer step), so the training driver parks them and flushes
+// them together: every launch costs ~15 us of ramp, prologue and drain whatever its size, and alone a layer has to split its
+// pixel axis 8-32 ways to fill the chip -- each split a dW-sized pass of fp32 atomics -- while forty layers together fill it with
+// one or two.  The jobs travel by value in the kernel arguments (no device-side table, nothing to keep alive under graph replay);
+// block b belongs to the job whose [begin, end) range holds it and plays block (x, y) = (b' % tiles, b' / tiles) of that job. ----
+#define RSIS_WG_MAXJ 48
+struct WgradTiledGroup {
+  int n;
+  int begin[RSIS_WG_MAXJ + 1];
+  WgradTiledArgs job[RSIS_WG_MAXJ];
+};
+static_assert(sizeof(WgradTiledGroup) <= 4000, "kernel arguments are limited to 4 KB");
+
+template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1>
+__global__ __launch_bounds__(256) void conv_wgrad_tiled_group_kernel(const WgradTiledGroup g) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = g.n - 1;
+  while (lo < hi) {                       // last job whose begin <= b (uniform: scalar code)
+    const int mid = (lo + hi + 1) >> 1;
+    if (g.begin[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const WgradTiledArgs& p = g.job[lo];
+  const int local = b - g.begin[lo];
+  const int ntile = p.n_co_tiles * p.n_n_tiles;
+  wgrad_tiled_body<BM, BN, WGM, WGN, KS, TW, KSP>(p, local % ntile, local / ntile);
+}
+
+template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1>
 static int launch_tiled_cfg(WgradTiledArgs& a, hipStream_t st) {
   constexpr int TH = (KS == 1 ? 32 : 64) / TW;
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
@@ -292,6 +326,97 @@ static int tiled_tw(int H, int W, int ks) {
   for (int tw = ks == 1 ? 32 : 16; tw >= 8; tw >>= 1)
     if (W % tw == 0 && H % (tp / tw) == 0) return tw;
   return 0;
+}
+
+// ---- grouped launch (host side) ----
+// tile configuration of a job, the same rule as launch_tiled_tw: 0 = 32x64 (KSP 2), 1 = 32x128, 2 = 64x64, 3 = 64x128, 4 = 128x64, 5 = 128x128
+static int tiled_cfg_code(const WgradTiledArgs& a, int ks) {
+  const int nmod = (a.Cs * ks * ks) % 128;
+  const bool narrow = nmod != 0 && nmod <= 64;
+  if (ks == 1 && a.Cout > 32) return 2;
+  if (a.Cout <= 32) return narrow ? 0 : 1;
+  if (a.Cout <= 64) return narrow ? 2 : 3;
+  return narrow ? 4 : 5;
+}
+
+template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1>
+static int launch_group_cfg(WgradTiledArgs* jobs, int n, hipStream_t st) {
+  constexpr int TH = (KS == 1 ? 32 : 64) / TW;
+  long total_iters = 0;
+  for (int j = 0; j < n; ++j) {
+    WgradTiledArgs& a = jobs[j];
+    a.n_co_tiles = rsis_cdiv(a.Cout, BM);
+    a.n_n_tiles = rsis_cdiv((long)a.Cs * KS * KS, BN);
+    a.n_sp_tiles = a.B * (a.H / TH) * (a.W / TW);
+    total_iters += (long)a.n_co_tiles * a.n_n_tiles * a.n_sp_tiles;
+  }
+  // equal work per block: every block walks ~L spatial tiles of its job; ~8 blocks per CU over the whole group keeps the tail short,
+  // and a job is split as little as that allows (each split is a dW-sized pass of atomics)
+  static const int env_tb = getenv("RSIS_WG_GROUP_BLOCKS") ? atoi(getenv("RSIS_WG_GROUP_BLOCKS")) : 0;     // tuning knob
+  const long target_blocks = env_tb > 0 ? env_tb : 2048;
+  long L = (total_iters + target_blocks - 1) / target_blocks;
+  if (L < 2) L = 2;
+  for (int j0 = 0; j0 < n; j0 += RSIS_WG_MAXJ) {
+    WgradTiledGroup g;
+    g.n = n - j0 < RSIS_WG_MAXJ ? n - j0 : RSIS_WG_MAXJ;
+    int blocks = 0;
+    for (int j = 0; j < g.n; ++j) {
+      WgradTiledArgs a = jobs[j0 + j];
+      int nsplit = rsis_cdiv(a.n_sp_tiles, L);
+      if (nsplit < 1) nsplit = 1;
+      a.tiles_per_split = rsis_cdiv(a.n_sp_tiles, nsplit);
+      nsplit = rsis_cdiv(a.n_sp_tiles, a.tiles_per_split);
+      g.begin[j] = blocks;
+      g.job[j] = a;
+      blocks += a.n_co_tiles * a.n_n_tiles * nsplit;
+    }
+    g.begin[g.n] = blocks;
+    hipLaunchKernelGGL((conv_wgrad_tiled_group_kernel<BM, BN, WGM, WGN, KS, TW, KSP>), dim3(blocks), dim3(256), 0, st, g);
+    if (rsis_check_launch() != RSIS_OK) return RSIS_ERR_LAUNCH;
+  }
+  return RSIS_OK;
+}
+
+template <int KS, int TW>
+static int launch_group_tw(int code, WgradTiledArgs* jobs, int n, hipStream_t st) {
+  switch (code) {
+    case 0: return launch_group_cfg<32, 64, 1, 2, KS, TW, 2>(jobs, n, st);
+    case 1: return launch_group_cfg<32, 128, 1, 4, KS, TW>(jobs, n, st);
+    case 2: return launch_group_cfg<64, 64, 2, 2, KS, TW>(jobs, n, st);
+    case 3: return launch_group_cfg<64, 128, 2, 2, KS, TW>(jobs, n, st);
+    case 4: return launch_group_cfg<128, 64, 2, 2, KS, TW>(jobs, n, st);
+    default: return launch_group_cfg<128, 128, 2, 2, KS, TW>(jobs, n, st);
+  }
+}
+
+// n weight gradients that rsis_wgrad_tiled_supported accepts, all with the same kernel size: bucketed by (tile width, tile
+// configuration), one grouped launch per bucket (per RSIS_WG_MAXJ jobs of a bucket)
+int rsis_launch_conv_wgrad_tiled_group(const WgradArgs* w, int n, int ks, hipStream_t st) {
+  if (n < 1) return RSIS_OK;
+  WgradTiledArgs* all = (WgradTiledArgs*)malloc(sizeof(WgradTiledArgs) * n * 2);
+  int* key = (int*)malloc(sizeof(int) * n);
+  if (!all || !key) { free(all); free(key); return RSIS_ERR_LAUNCH; }
+  WgradTiledArgs* bucket = all + n;
+  for (int j = 0; j < n; ++j) {
+    WgradTiledArgs a = {};
+    a.dy = w[j].dy; a.x = w[j].x; a.dw = w[j].dw; a.B = w[j].B; a.Cs = w[j].Cs; a.H = w[j].H; a.W = w[j].W; a.Cout = w[j].Cout;
+    a.ldo = w[j].ldo; a.n_off = w[j].n_off; a.interleave_hid = w[j].interleave_hid;
+    all[j] = a;
+    key[j] = tiled_tw(a.H, a.W, ks) * 8 + tiled_cfg_code(a, ks);
+  }
+  int rc = RSIS_OK;
+  for (int j = 0; j < n && rc == RSIS_OK; ++j) {
+    if (key[j] < 0) continue;
+    const int k = key[j];
+    int m = 0;
+    for (int i = j; i < n; ++i)
+      if (key[i] == k) { bucket[m++] = all[i]; key[i] = -1; }
+    const int tw = k / 8, code = k % 8;
+    if (ks == 1) rc = tw == 32 ? launch_group_tw<1, 32>(code, bucket, m, st) : (tw == 16 ? launch_group_tw<1, 16>(code, bucket, m, st) : launch_group_tw<1, 8>(code, bucket, m, st));
+    else rc = tw == 16 ? launch_group_tw<3, 16>(code, bucket, m, st) : launch_group_tw<3, 8>(code, bucket, m, st);
+  }
+  free(all); free(key);
+  return rc;
 }
 
 // true when the LDS-DMA tiled kernel covers this weight gradient (stride 1, "same" padding, tile-aligned map, 32-bit offsets)

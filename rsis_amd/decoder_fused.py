@@ -108,8 +108,8 @@ class _HoistFn(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             tgt = ops._direct_target(ctx.wparam)
             dW = tgt if tgt is not None else torch.zeros_like(weight)
-            check(L.rsis_conv2d_wgrad(ptr(dG), ptr(skip), ptr(dW), B, Cs, H, W, 4 * tl.hid, H, W, tl.ks, 1, tl.pad, weight.shape[1],
-                                      tl.c_up, tl.hid, hoist.dtype, stream()), "rsis_conv2d_wgrad(hoist)")
+            ops.wgrad_launch(L, dG, skip, dW, B, Cs, H, W, 4 * tl.hid, H, W, tl.ks, 1, tl.pad, weight.shape[1], tl.c_up, tl.hid,
+                             hoist.dtype, "rsis_conv2d_wgrad(hoist)", tgt is not None)
             if tgt is not None:
                 dW = None
         if ctx.needs_input_grad[3]:
@@ -224,8 +224,8 @@ class _StepFn(torch.autograd.Function):
             off = [0] if ctx.has_up else []
             off += [h_off] if ctx.has_state else []
             for s, o in zip(srcs, off):
-                check(L.rsis_conv2d_wgrad(ptr(da), ptr(s), ptr(dW), B, s.shape[1], H, W, 4 * hid, H, W, ks, 1, pad, Ctot, o, hid,
-                                          dyn.dtype, stream()), "rsis_conv2d_wgrad(step)")
+                ops.wgrad_launch(L, da, s, dW, B, s.shape[1], H, W, 4 * hid, H, W, ks, 1, pad, Ctot, o, hid, dyn.dtype,
+                                 "rsis_conv2d_wgrad(step)", tgt is not None)
         if t == 0:
             # autograd runs the t = 0 backward last (every later step depends on it): flush the time-batched work
             if ctx.stacked:
@@ -243,11 +243,11 @@ class _StepFn(torch.autograd.Function):
                 if dW is None:
                     dW = tgt if tgt is not None else torch.zeros_like(weight)
                 if tl.c_up > 0:
-                    check(L.rsis_conv2d_wgrad(ptr(tl.DA), ptr(tl.UP), ptr(dW), n * B, tl.c_up, H, W, 4 * hid, H, W, ks, 1, pad, Ctot, 0,
-                                              hid, dyn.dtype, stream()), "rsis_conv2d_wgrad(batched up)")
+                    ops.wgrad_launch(L, tl.DA, tl.UP, dW, n * B, tl.c_up, H, W, 4 * hid, H, W, ks, 1, pad, Ctot, 0, hid, dyn.dtype,
+                                     "rsis_conv2d_wgrad(batched up)", tgt is not None)
                 if n > 1:
-                    check(L.rsis_conv2d_wgrad(ptr(tl.DA[1]), ptr(tl.H), ptr(dW), (n - 1) * B, hid, H, W, 4 * hid, H, W, ks, 1, pad, Ctot,
-                                              h_off, hid, dyn.dtype, stream()), "rsis_conv2d_wgrad(batched h)")
+                    ops.wgrad_launch(L, tl.DA[1], tl.H, dW, (n - 1) * B, hid, H, W, 4 * hid, H, W, ks, 1, pad, Ctot, h_off, hid, dyn.dtype,
+                                     "rsis_conv2d_wgrad(batched h)", tgt is not None)
         if tgt is not None:
             dW = None   # accumulated straight into weight.grad
         if t == 0:

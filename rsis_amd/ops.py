@@ -248,6 +248,38 @@ def grad_tap(x, slot):
     return _GradTapFn.apply(x, slot)
 
 
+# Parked weight gradients.  Nothing reads a weight gradient before the optimizer step (or, one process per GPU, before its bucket is
+# all-reduced), so while the training driver has DIRECT_GRAD on -- the result goes straight into the flat gradient buffer, autograd
+# never sees it -- the launches are queued and flushed together through rsis_conv2d_wgrad_batch: one grid per tile configuration
+# over ~40 layers instead of ~95 launches that each split their pixel axis 8-32 ways to fill the chip alone (include/rsis_hip.h).
+# The queue keeps dy / x / dW alive until the flush.
+WGRAD_DEFER = [False]
+_WGRAD_QUEUE = []
+
+
+def wgrad_launch(L, dy, x, dW, B, Cs, H, W, Cout, Ho, Wo, ks, stride, pad, Ctot, c_off, lstm_hid, dtype, what, direct):
+    """rsis_conv2d_wgrad now, or parked until flush_wgrads() (only when dW is the flat-buffer target: `direct`)"""
+    if direct and WGRAD_DEFER[0]:
+        _WGRAD_QUEUE.append(((dy.data_ptr(), x.data_ptr(), dW.data_ptr(), B, Cs, H, W, Cout, Ho, Wo, ks, stride, pad, Ctot, c_off, lstm_hid,
+                              dtype), (dy, x, dW)))
+        return
+    check(L.rsis_conv2d_wgrad(ptr(dy), ptr(x), ptr(dW), B, Cs, H, W, Cout, Ho, Wo, ks, stride, pad, Ctot, c_off, lstm_hid, dtype, stream()), what)
+
+
+def flush_wgrads():
+    """launch every parked weight gradient (call before anything reads the flat gradient buffers)"""
+    n = len(_WGRAD_QUEUE)
+    if n == 0:
+        return
+    jobs = (_lib.WgradJob * n)()
+    for j, (f, _keep) in zip(jobs, _WGRAD_QUEUE):
+        (j.dy, j.x, j.dW, j.B, j.Cs, j.H, j.W, j.Cout, j.Ho, j.Wo, j.ks, j.stride, j.pad, j.Ctot, j.c_off, j.lstm_hid, j.dtype) = f
+    try:
+        check(lib().rsis_conv2d_wgrad_batch(jobs, n, stream()), "rsis_conv2d_wgrad_batch")
+    finally:
+        del _WGRAD_QUEUE[:]
+
+
 def _wgrad_all(L, dy, srcs, w_shape, ks, stride, pad, lstm_hid, out=None, dtype=DTYPE_F32):
     B, Cout, Ho, Wo = dy.shape
     Ctot = w_shape[1]
@@ -255,8 +287,8 @@ def _wgrad_all(L, dy, srcs, w_shape, ks, stride, pad, lstm_hid, out=None, dtype=
     c_off = 0
     for s in srcs:
         _, Cs, H, W = s.shape
-        check(L.rsis_conv2d_wgrad(ptr(dy), ptr(s), ptr(dW), B, Cs, H, W, Cout, Ho, Wo, ks, stride, pad, Ctot, c_off, lstm_hid, dtype,
-                                  stream()), "rsis_conv2d_wgrad")
+        wgrad_launch(L, dy, s, dW, B, Cs, H, W, Cout, Ho, Wo, ks, stride, pad, Ctot, c_off, lstm_hid, dtype, "rsis_conv2d_wgrad",
+                     out is not None)
         c_off += Cs
     return dW
 

@@ -254,6 +254,7 @@ class BucketedAllReduce(object):
                 return
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
+                ops.flush_wgrads()     # weight gradients parked by ops.wgrad_launch must be in the flat buffer before it travels
                 self._handles.append(dist.all_reduce(self.buckets[bi][0], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         return hook
 

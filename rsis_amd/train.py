@@ -159,10 +159,14 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
             if args.use_stop_loss:
                 dec_opt.mark_has_grad(decoder.fc_stop.parameters())
         prev, ops.DIRECT_GRAD[0] = ops.DIRECT_GRAD[0], direct
+        prev_defer, ops.WGRAD_DEFER[0] = ops.WGRAD_DEFER[0], direct and WGRAD_DEFER_DEFAULT[0]
         try:
             loss.backward()                                           # :184
+            ops.flush_wgrads()         # the weight gradients parked during backward (ops.wgrad_launch), as grouped launches
         finally:
             ops.DIRECT_GRAD[0] = prev
+            ops.WGRAD_DEFER[0] = prev_defer
+            del ops._WGRAD_QUEUE[:]
         if do_update:
             apply_update(args, optims, reducer.finish() if reducer is not None else 1.0)
 
@@ -175,6 +179,11 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
 
 
 # --------------------------------------------------------------------------------------------------
+# park the weight gradients during backward and flush them as grouped launches (rsis_amd.ops.wgrad_launch); RSIS_WGRAD_DEFER=0: launch
+# each one where autograd reaches it
+WGRAD_DEFER_DEFAULT = [os.environ.get("RSIS_WGRAD_DEFER", "1") != "0"]
+
+
 def init_distributed():
     """one process per GPU; torchrun provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -480,3 +480,49 @@ def test_maxpool3x3s2_accumulates_into_parked_gradient(shape):
     assert slot.done and slot.grad is None
     want = run(None)
     assert_close("dx", got, want, 1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv2d_wgrad_batch(dtype):
+    """rsis_conv2d_wgrad_batch: a mixed bag of weight gradients (tiled 3x3 / 1x1 in several tile configurations, two sources of one
+    conv into the same dW, a gate-interleaved ConvLSTM weight, an odd-sized map and a strided conv that fall back to single launches)
+    in ONE call, each against torch's autograd; every dW is accumulated on top of its previous contents."""
+    from rsis_amd import ops
+    from rsis_amd._lib import WgradJob, check, lib, stream
+    dt = ops.DTYPES[dtype]
+    # (B, [Cin segs], H, W, Cout, ks, stride, pad, lstm_hid)
+    cases = [(2, [16], 16, 16, 32, 3, 1, 1, 0), (2, [16], 16, 32, 64, 3, 1, 1, 0), (2, [32], 16, 16, 128, 3, 1, 1, 0),
+             (2, [64], 8, 32, 96, 1, 1, 0, 0), (2, [20, 12], 16, 24, 40, 3, 1, 1, 0), (2, [72], 8, 16, 200, 3, 1, 1, 0),
+             (3, [40], 12, 16, 24, 1, 1, 0, 0), (2, [24, 8], 16, 16, 32, 3, 1, 1, 8), (2, [8], 9, 11, 16, 3, 1, 1, 0),
+             (2, [24], 32, 48, 40, 3, 2, 1, 0), (2, [256], 16, 16, 256, 3, 1, 1, 0), (2, [256], 16, 16, 64, 1, 1, 0, 0),
+             (2, [64], 16, 16, 256, 1, 1, 0, 0), (1, [256], 16, 16, 256, 3, 1, 1, 0)]
+    jobs, keep, want = [], [], []
+    for k, (B, segs, H, W, Cout, ks, stride, pad, hid) in enumerate(cases):
+        Ctot = sum(segs)
+        Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        xs = [_rng_t(100 + 10 * k + i, (B, c, H, W)) for i, c in enumerate(segs)]
+        w = _rng_t(300 + k, (Cout, Ctot, ks, ks)).requires_grad_()
+        gy = _rng_t(400 + k, (B, Cout, Ho, Wo))
+        F.conv2d(torch.cat(xs, 1), w, None, stride=stride, padding=pad).backward(gy)
+        ref = w.grad.clone()
+        if hid > 0:       # the kernel sees gate-interleaved dy rows 4 j + g and writes reference row g * hid + j
+            gy = gy.reshape(B, 4, hid, Ho, Wo).transpose(1, 2).reshape(B, Cout, Ho, Wo).contiguous()
+        prev = _rng_t(500 + k, (Cout, Ctot, ks, ks))
+        dW, dy = _dev(prev.clone()), _dev(gy)
+        c_off = 0
+        for x in xs:
+            xd = _dev(x)
+            j = WgradJob()
+            (j.dy, j.x, j.dW, j.B, j.Cs, j.H, j.W, j.Cout, j.Ho, j.Wo, j.ks, j.stride, j.pad, j.Ctot, j.c_off, j.lstm_hid, j.dtype) = (
+                dy.data_ptr(), xd.data_ptr(), dW.data_ptr(), B, x.shape[1], H, W, Cout, Ho, Wo, ks, stride, pad, Ctot, c_off, hid, dt)
+            jobs.append(j)
+            keep.append(xd)
+            c_off += x.shape[1]
+        keep.append(dy)
+        want.append((dW, prev + ref, Ctot * ks * ks * B * Ho * Wo))
+    arr = (WgradJob * len(jobs))(*jobs)
+    check(lib().rsis_conv2d_wgrad_batch(arr, len(jobs), stream()), "rsis_conv2d_wgrad_batch")
+    torch.cuda.synchronize()
+    for k, (got, ref, _n) in enumerate(want):
+        scale = max(1.0, float((ref).abs().max()))
+        assert_close("dW of job set %d" % k, got, ref, (1e-4 if dtype == "fp32" else 2e-2) * scale, 1e-5)
