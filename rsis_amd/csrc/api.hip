@@ -10,6 +10,7 @@ int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStrea
 int rsis_launch_conv_bf16(ConvArgs& a, int ks, int epi, int force_variant, hipStream_t st);
 bool rsis_wgrad_bf16_supported(const WgradArgs& w, int ks);
 int rsis_launch_conv_wgrad_bf16(const WgradArgs& w, int ks, hipStream_t st);
+int rsis_launch_conv_wgrad_bf16_group(const WgradArgs* w, int n, int ks, hipStream_t st);
 bool rsis_wgrad_tiled_supported(const WgradArgs& w, int ks);
 int rsis_launch_conv_wgrad_tiled(const WgradArgs& w, int ks, hipStream_t st);
 int rsis_launch_conv_wgrad_tiled_group(const WgradArgs* w, int n, int ks, hipStream_t st);
@@ -382,21 +383,27 @@ int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs,
 
 int rsis_conv2d_wgrad_batch(const rsis_wgrad_job* jobs, int njobs, void* stream) {
   if (!jobs || njobs < 1) return RSIS_ERR_ARG;
-  WgradArgs* tiled[2] = {(WgradArgs*)malloc(sizeof(WgradArgs) * njobs), (WgradArgs*)malloc(sizeof(WgradArgs) * njobs)};
-  int nt[2] = {0, 0};
-  int rc = (tiled[0] && tiled[1]) ? RSIS_OK : RSIS_ERR_LAUNCH;
+  // [0], [1]: exact-f32 tiled, 1x1 / 3x3; [2], [3]: bf16, 1x1 / 3x3
+  WgradArgs* tiled[4] = {(WgradArgs*)malloc(sizeof(WgradArgs) * njobs), (WgradArgs*)malloc(sizeof(WgradArgs) * njobs),
+                         (WgradArgs*)malloc(sizeof(WgradArgs) * njobs), (WgradArgs*)malloc(sizeof(WgradArgs) * njobs)};
+  int nt[4] = {0, 0, 0, 0};
+  int rc = (tiled[0] && tiled[1] && tiled[2] && tiled[3]) ? RSIS_OK : RSIS_ERR_LAUNCH;
   for (int j = 0; j < njobs && rc == RSIS_OK; ++j) {
     const rsis_wgrad_job& q = jobs[j];
     WgradArgs a;
     rc = wgrad_fill(a, q.dy, q.x, q.dW, q.B, q.Cs, q.H, q.W, q.Cout, q.Ho, q.Wo, q.ks, q.stride, q.pad, q.Ctot, q.c_off, q.lstm_hid);
     if (rc) break;
     const int route = wgrad_route(a, q.ks, q.lstm_hid, q.dtype);
-    if (route == 2 && (q.ks == 1 || q.ks == 3)) tiled[q.ks == 3][nt[q.ks == 3]++] = a;     // grouped below
-    else rc = wgrad_launch_one(a, route, q.ks, (hipStream_t)stream);
+    if ((route == 1 || route == 2) && (q.ks == 1 || q.ks == 3)) {      // grouped below
+      const int li = (route == 1 ? 2 : 0) + (q.ks == 3);
+      tiled[li][nt[li]++] = a;
+    } else rc = wgrad_launch_one(a, route, q.ks, (hipStream_t)stream);
   }
   if (rc == RSIS_OK) rc = rsis_launch_conv_wgrad_tiled_group(tiled[0], nt[0], 1, (hipStream_t)stream);
   if (rc == RSIS_OK) rc = rsis_launch_conv_wgrad_tiled_group(tiled[1], nt[1], 3, (hipStream_t)stream);
-  free(tiled[0]); free(tiled[1]);
+  if (rc == RSIS_OK) rc = rsis_launch_conv_wgrad_bf16_group(tiled[2], nt[2], 1, (hipStream_t)stream);
+  if (rc == RSIS_OK) rc = rsis_launch_conv_wgrad_bf16_group(tiled[3], nt[3], 3, (hipStream_t)stream);
+  for (int i = 0; i < 4; ++i) free(tiled[i]);
   return rc;
 }
 

@@ -72,7 +72,7 @@ struct Task8 {
 // row group take alternate 16-pixel reduction steps.
 // ------------------------------------------------------------------------------------------------
 template <int BM, int TW, bool V4>
-__global__ __launch_bounds__(256) void wgrad3_bf16_kernel(const WgradBf16Args p) {
+__device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const int bx, const int by) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int TP = 64, TH = TP / TW, GPR = TW / 8, NG = TP / 8, KSTEPS = NG / 2;
   constexpr int WGM = BM / 32, KSPW = 4 / WGM, NGG = KSTEPS / KSPW;
@@ -91,10 +91,10 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(const WgradBf16Args p)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WGM, wk = wave / WGM;
   const int H = p.H, W = p.W, HW = H * W, Cs = p.Cs, Cout = p.Cout;
-  const int co_t = blockIdx.x % p.n_co_tiles, n_t = blockIdx.x / p.n_co_tiles;
+  const int co_t = bx % p.n_co_tiles, n_t = bx / p.n_co_tiles;
   const int co0 = co_t * BM, ci0 = n_t * 32;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-  const int t_begin = blockIdx.y * p.tiles_per_split;
+  const int t_begin = by * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.n_sp_tiles);
   if (t_begin >= t_end) return;
 
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(const WgradBf16Args p)
 // 1x1: D[co][ci] = sum_px dy[co][px] x[ci][px]; block tile BM x BN, waves WGM x WGN, TM x TN MFMA tiles per wave.
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WGM, int WGN, int TW, bool V4>
-__global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const WgradBf16Args p) {
+__device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const int bx, const int by) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int TP = 64, TH = TP / TW, GPR = TW / 8, NG = TP / 8, KSTEPS = NG / 2;
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -254,10 +254,10 @@ __global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const WgradBf16Args p)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
   const int H = p.H, W = p.W, HW = H * W, Cs = p.Cs, Cout = p.Cout;
-  const int co_t = blockIdx.x % p.n_co_tiles, n_t = blockIdx.x / p.n_co_tiles;
+  const int co_t = bx % p.n_co_tiles, n_t = bx / p.n_co_tiles;
   const int co0 = co_t * BM, n0 = n_t * BN;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-  const int t_begin = blockIdx.y * p.tiles_per_split;
+  const int t_begin = by * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.n_sp_tiles);
   if (t_begin >= t_end) return;
 
@@ -370,6 +370,46 @@ __global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const WgradBf16Args p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// single launches, and grouped launches: the weight gradients of many layers in one grid (rsis_conv2d_wgrad_batch; see
+// conv_wgrad_tiled.hip).  The jobs travel by value in the kernel arguments.
+template <int BM, int TW, bool V4>
+__global__ __launch_bounds__(256) void wgrad3_bf16_kernel(const WgradBf16Args p) { wgrad3_bf16_body<BM, TW, V4>(p, blockIdx.x, blockIdx.y); }
+template <int BM, int BN, int WGM, int WGN, int TW, bool V4>
+__global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const WgradBf16Args p) {
+  wgrad1_bf16_body<BM, BN, WGM, WGN, TW, V4>(p, blockIdx.x, blockIdx.y);
+}
+
+#define RSIS_WGB_MAXJ 48
+struct WgradBf16Group {
+  int n;
+  int begin[RSIS_WGB_MAXJ + 1];
+  WgradBf16Args job[RSIS_WGB_MAXJ];
+};
+static_assert(sizeof(WgradBf16Group) <= 4000, "kernel arguments are limited to 4 KB");
+
+__device__ __forceinline__ int wgb_find(const WgradBf16Group& g, int b) {
+  int lo = 0, hi = g.n - 1;
+  while (lo < hi) {                       // last job whose begin <= b (uniform: scalar code)
+    const int mid = (lo + hi + 1) >> 1;
+    if (g.begin[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+template <int BM, int TW, bool V4>
+__global__ __launch_bounds__(256) void wgrad3_bf16_group_kernel(const WgradBf16Group g) {
+  const int j = wgb_find(g, blockIdx.x);
+  const WgradBf16Args& p = g.job[j];
+  const int local = blockIdx.x - g.begin[j], ntile = p.n_co_tiles * p.n_n_tiles;
+  wgrad3_bf16_body<BM, TW, V4>(p, local % ntile, local / ntile);
+}
+template <int BM, int BN, int WGM, int WGN, int TW, bool V4>
+__global__ __launch_bounds__(256) void wgrad1_bf16_group_kernel(const WgradBf16Group g) {
+  const int j = wgb_find(g, blockIdx.x);
+  const WgradBf16Args& p = g.job[j];
+  const int local = blockIdx.x - g.begin[j], ntile = p.n_co_tiles * p.n_n_tiles;
+  wgrad1_bf16_body<BM, BN, WGM, WGN, TW, V4>(p, local % ntile, local / ntile);
+}
+
 static void split_plan(WgradBf16Args& a, int TW, int ntile, int slots) {
   const int TH = 64 / TW;
   a.n_sp_tiles = a.B * rsis_cdiv(a.H, TH) * rsis_cdiv(a.W, TW);
@@ -447,4 +487,111 @@ int rsis_launch_conv_wgrad_bf16(const WgradArgs& w, int ks, hipStream_t st) {
   // VMEM instructions, and the texture-address rate -- not HBM -- bound the loop (256 -> 1024 @14^2: 43 -> 29 us).
   a.W = w.H * w.W; a.H = 1;
   return launch_w1_tw<64>(a, st);
+}
+
+// ---- grouped launch (host side): jobs bucketed by kernel instantiation, every block of a bucket walks ~L spatial tiles ----
+struct WgbKey { int ks, bm, bn, tw, v4; };
+static WgbKey wgb_key(const WgradBf16Args& a, int ks) {      // the rules of launch_w3_tw / launch_w1_tw / rsis_launch_conv_wgrad_bf16
+  WgbKey k = {ks, 0, 0, 0, 0};
+  if (ks == 3) {
+    k.tw = a.W > 16 ? 32 : (a.W > 8 ? 16 : 8);
+    k.bm = a.Cout <= 32 ? 32 : ((a.Cout <= 64 || a.Cs <= 512) ? 64 : 128);
+    k.bn = 32;
+  } else {
+    k.tw = 64;
+    k.bm = a.Cout <= 64 ? 64 : 128;
+    k.bn = a.Cs <= 64 ? 64 : 128;
+  }
+  k.v4 = a.W % 4 == 0;
+  return k;
+}
+static inline bool wgb_same(const WgbKey& a, const WgbKey& b) { return a.ks == b.ks && a.bm == b.bm && a.bn == b.bn && a.tw == b.tw && a.v4 == b.v4; }
+
+template <typename LaunchFn>
+static int wgb_launch_bucket(WgradBf16Args* jobs, int n, const WgbKey& k, LaunchFn launch) {
+  const int TH = 64 / k.tw;
+  long total = 0;
+  for (int j = 0; j < n; ++j) {
+    WgradBf16Args& a = jobs[j];
+    a.n_co_tiles = rsis_cdiv(a.Cout, k.bm);
+    a.n_n_tiles = rsis_cdiv(a.Cs, k.bn);
+    a.n_sp_tiles = a.B * rsis_cdiv(a.H, TH) * rsis_cdiv(a.W, k.tw);
+    total += (long)a.n_co_tiles * a.n_n_tiles * a.n_sp_tiles;
+  }
+  static const int env_tb = getenv("RSIS_WGB_GROUP_BLOCKS") ? atoi(getenv("RSIS_WGB_GROUP_BLOCKS")) : 0;     // tuning knob
+  const long target_blocks = env_tb > 0 ? env_tb : 1024;
+  long L = (total + target_blocks - 1) / target_blocks;
+  if (L < 2) L = 2;
+  for (int j0 = 0; j0 < n; j0 += RSIS_WGB_MAXJ) {
+    WgradBf16Group g;
+    g.n = n - j0 < RSIS_WGB_MAXJ ? n - j0 : RSIS_WGB_MAXJ;
+    int blocks = 0;
+    for (int j = 0; j < g.n; ++j) {
+      WgradBf16Args a = jobs[j0 + j];
+      int nsplit = rsis_cdiv(a.n_sp_tiles, L);
+      if (nsplit < 1) nsplit = 1;
+      a.tiles_per_split = rsis_cdiv(a.n_sp_tiles, nsplit);
+      nsplit = rsis_cdiv(a.n_sp_tiles, a.tiles_per_split);
+      g.begin[j] = blocks;
+      g.job[j] = a;
+      blocks += a.n_co_tiles * a.n_n_tiles * nsplit;
+    }
+    g.begin[g.n] = blocks;
+    launch(g, blocks);
+    if (rsis_check_launch() != RSIS_OK) return RSIS_ERR_LAUNCH;
+  }
+  return RSIS_OK;
+}
+
+#define WGB3(BMv, TWv)                                                                                             \
+  if (k.bm == BMv && k.tw == TWv) {                                                                                \
+    if (k.v4) return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                      \
+      hipLaunchKernelGGL((wgrad3_bf16_group_kernel<BMv, TWv, true>), dim3(blocks), dim3(256), 0, st, g); });       \
+    return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                                \
+      hipLaunchKernelGGL((wgrad3_bf16_group_kernel<BMv, TWv, false>), dim3(blocks), dim3(256), 0, st, g); });      \
+  }
+#define WGB1(BMv, BNv)                                                                                             \
+  if (k.bm == BMv && k.bn == BNv) {                                                                                \
+    if (k.v4) return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                      \
+      hipLaunchKernelGGL((wgrad1_bf16_group_kernel<BMv, BNv, 2, 2, 64, true>), dim3(blocks), dim3(256), 0, st, g); });   \
+    return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                                \
+      hipLaunchKernelGGL((wgrad1_bf16_group_kernel<BMv, BNv, 2, 2, 64, false>), dim3(blocks), dim3(256), 0, st, g); });  \
+  }
+static int wgb_dispatch(WgradBf16Args* jobs, int n, const WgbKey& k, hipStream_t st) {
+  if (k.ks == 3) {
+    WGB3(32, 32) WGB3(64, 32) WGB3(128, 32) WGB3(32, 16) WGB3(64, 16) WGB3(128, 16) WGB3(32, 8) WGB3(64, 8) WGB3(128, 8)
+  } else {
+    WGB1(64, 64) WGB1(64, 128) WGB1(128, 64) WGB1(128, 128)
+  }
+  return RSIS_ERR_ARG;
+}
+#undef WGB3
+#undef WGB1
+
+// n weight gradients that rsis_wgrad_bf16_supported accepts, all with the same kernel size
+int rsis_launch_conv_wgrad_bf16_group(const WgradArgs* w, int n, int ks, hipStream_t st) {
+  if (n < 1) return RSIS_OK;
+  WgradBf16Args* all = (WgradBf16Args*)malloc(sizeof(WgradBf16Args) * n * 2);
+  WgbKey* key = (WgbKey*)malloc(sizeof(WgbKey) * n);
+  if (!all || !key) { free(all); free(key); return RSIS_ERR_LAUNCH; }
+  WgradBf16Args* bucket = all + n;
+  for (int j = 0; j < n; ++j) {
+    WgradBf16Args a = {};
+    a.dy = w[j].dy; a.x = w[j].x; a.dw = w[j].dw; a.B = w[j].B; a.Cs = w[j].Cs; a.H = w[j].H; a.W = w[j].W; a.Cout = w[j].Cout;
+    a.ldo = w[j].ldo; a.n_off = w[j].n_off; a.interleave_hid = w[j].interleave_hid;
+    if (ks == 1) { a.W = w[j].H * w[j].W; a.H = 1; }      // 1x1: the flattened map
+    all[j] = a;
+    key[j] = wgb_key(a, ks);
+  }
+  int rc = RSIS_OK;
+  for (int j = 0; j < n && rc == RSIS_OK; ++j) {
+    if (key[j].ks < 0) continue;
+    const WgbKey k = key[j];
+    int m = 0;
+    for (int i = j; i < n; ++i)
+      if (key[i].ks >= 0 && wgb_same(key[i], k)) { bucket[m++] = all[i]; key[i].ks = -1; }
+    rc = wgb_dispatch(bucket, m, k, st);
+  }
+  free(all); free(key);
+  return rc;
 }
