@@ -188,14 +188,41 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
             f["ms"] += ms * count
             f["bytes"] += n * act_bytes * count
             f["launches"] += n * count
+    # the weight gradients as the training step launches them: parked during backward, flushed in ONE rsis_conv2d_wgrad_batch call
+    # (grouped launches over all layers of a tile configuration); per family = all layers of that kernel size in one call
+    from rsis_amd._lib import WgradJob
+    for ksz in (3, 1):
+        jobs, keep, fl, by = [], [], 0.0, 0.0
+        for cin, cout, ks, hw, count in TRUNK_SHAPES:
+            if ks != ksz:
+                continue
+            hw = hw * imsize // 256
+            x = torch.randn(B, cin, hw, hw, device="cuda")
+            y = torch.randn(B, cout, hw, hw, device="cuda")
+            keep += [x, y]
+            for _ in range(count):
+                dW = torch.zeros(cout, cin, ks, ks, device="cuda")
+                keep.append(dW)
+                j = WgradJob()
+                (j.dy, j.x, j.dW, j.B, j.Cs, j.H, j.W, j.Cout, j.Ho, j.Wo, j.ks, j.stride, j.pad, j.Ctot, j.c_off, j.lstm_hid, j.dtype) = (
+                    y.data_ptr(), x.data_ptr(), dW.data_ptr(), B, cin, hw, hw, cout, hw, hw, ks, 1, ks // 2, cin, 0, 0, dt)
+                jobs.append(j)
+                fl += 2.0 * B * hw * hw * cin * ks * ks * cout
+                by += 4.0 * B * hw * hw * (cin + cout)
+        arr = (WgradJob * len(jobs))(*jobs)
+        ms = _time_launch(lambda: check(L.rsis_conv2d_wgrad_batch(arr, len(jobs), stream()), "wgrad_batch"), max(2, iters // 2))
+        f = fam["conv%dx%d wgrad" % (ksz, ksz)]
+        f.update({"flops": fl, "ms": ms, "bytes": by, "launches": len(jobs), "grouped": True})
+        del keep
     kern = {"conv1x1 fwd+dgrad": ("conv_igemm_kernel<..., V4>", "conv_bf16_kernel<1, ...>"),
             "conv3x3 fwd+dgrad": ("conv3x3_direct_kernel<..., EPI_PLAIN>", "conv_bf16_kernel<3, ..., EPI_PLAIN>"),
-            "conv1x1 wgrad": ("conv_wgrad_tiled_kernel<..., 1, ...>", "wgrad1_bf16_kernel"),
-            "conv3x3 wgrad": ("conv_wgrad_tiled_kernel<..., 3, ...>", "wgrad3_bf16_kernel")}
+            "conv1x1 wgrad": ("conv_wgrad_tiled_group_kernel<..., 1, ...> (rsis_conv2d_wgrad_batch)", "wgrad1_bf16_group_kernel (rsis_conv2d_wgrad_batch)"),
+            "conv3x3 wgrad": ("conv_wgrad_tiled_group_kernel<..., 3, ...> (rsis_conv2d_wgrad_batch)", "wgrad3_bf16_group_kernel (rsis_conv2d_wgrad_batch)")}
     out = []
     for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
         tf = f["flops"] / f["ms"] / 1e9
-        r = {"family": name, "kernel": kern[name][0 if dtype == "fp32" else 1], "launches_per_step": f["launches"],
+        r = {"family": name, "kernel": kern[name][0 if dtype == "fp32" else 1],
+             ("layers_per_step" if f.get("grouped") else "launches_per_step"): f["launches"],
              "ms_per_step": round(f["ms"], 3), "avg_us": round(1e3 * f["ms"] / f["launches"] * (2 if "fwd" in name else 1), 1),
              "tflops": round(tf, 1)}
         if dtype == "fp32":
