@@ -357,3 +357,49 @@ def test_config4_geometry_training_steps(dtype):
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
     assert peak < 150, "peak memory %.1f GB" % peak
     g.release()
+
+
+def test_ragged_targets_match_the_oracle():
+    """Edge cases of the target side (reference train.py:85-176): a batch whose images hold 0, 1, 3 and T+2 instances -- an image
+    without any ground truth, images that run out of instances before the last step, one with more instances than steps -- at
+    128x128, B = 4, T = 4: the losses of rsis_amd.train.runIter against the oracle's restated runIter (1e-4 + 1e-4 relative) and the
+    same matching."""
+    from oracle import filler
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import build_optimizers, runIter, steps_to_run
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    B, S, T, G = 4, 128, 4, 8
+    a = mk_args(maxseqlen=T, gt_maxseqlen=G, optim="adam", optim_cnn="adam", lr=0.0, lr_cnn=0.0, weight_decay=0.0, weight_decay_cnn=0.0)
+    a.use_class_loss = a.use_stop_loss = True
+    oenc = filler.fill_module(O.FeatureExtractor(a), seed=81)
+    odec = filler.fill_module(O.RSIS(a), seed=82)
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    enc.load_state_dict(oenc.state_dict())
+    dec.load_state_dict(odec.state_dict())
+    x, y_mask, y_class, sw_mask, sw_class = synthetic_batch(9, B, S, S, G, 6, a.num_classes, "cpu")
+    counts = [0, 1, 3, T + 2]
+    for b, n in enumerate(counts):                  # keep the first n instances of image b
+        y_mask[b, n:] = 0
+        y_class[b, n:] = 0
+        sw_mask[b, n:] = 0
+        sw_class[b, n:] = 0
+        sw_mask[b, :n] = 1
+        sw_class[b, :n] = 1
+        if n < sw_class.shape[1]:
+            sw_class[b, n] = 1                      # the stop step is supervised by the class / stop losses (dataset convention)
+    batch = [x, y_mask, y_class, sw_mask, sw_class]
+    dbatch = [t.cuda() for t in batch]
+    t_run = steps_to_run(a, dbatch[3])
+    opts = list(build_optimizers(a, enc, dec))
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
+    losses, _outs, perms = runIter(a, enc, dec, *dbatch, crits, opts, mode="train", sync_losses=True, t_run=t_run, want_outs=False)
+    a.use_gpu = False
+    r = O.run_iter_forward(a, oenc, odec, *batch, mode="train")
+    for k, got, want in (("loss", losses[0], r["loss"]), ("loss_mask_iou", losses[1], r["loss_mask_iou"]), ("loss_stop", losses[2], r["loss_stop"]),
+                         ("loss_class", losses[3], r["loss_class"])):
+        want = float(want.detach())
+        assert want == want, k + ": the oracle's value is NaN"
+        assert_close(k, got, want, 1e-4, 1e-4)      # (train-mode BN over 64 samples per channel at the deepest level: 4e-5 relative on the class loss)
+    assert (perms[1].cpu().numpy() == r["y_class_perm"].numpy()).all()
