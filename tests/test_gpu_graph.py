@@ -142,3 +142,22 @@ def test_graph_replay_back_to_back_stays_finite():
             assert g.graph is not None
             g.release()
     assert abs(finals[0] - finals[1]) < 0.1 * abs(finals[0]), finals
+
+
+def test_graphed_inference_equals_eager():
+    """rsis_amd.test.GraphedTest: test() (reference src/test.py:16-50) replayed as a hipGraph returns exactly what the eager call
+    returns (inference launches no split-K kernels: bit-reproducible), for fresh inputs copied into its static buffer and across a
+    change of input shape."""
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.test import GraphedTest, test
+    torch.manual_seed(0)
+    a = mk_args(hidden_size=32, maxseqlen=3)
+    enc, dec = FeatureExtractor(a).cuda().eval(), RSIS(a).cuda().eval()
+    g = GraphedTest(a, enc, dec, warm=1)
+    for k, shape in enumerate([(2, 3, 64, 64), (2, 3, 64, 64), (2, 3, 64, 64), (2, 3, 96, 80), (2, 3, 96, 80)]):
+        x = torch.randn(shape, device="cuda", generator=torch.Generator("cuda").manual_seed(k))
+        want = [t.clone() for t in test(a, enc, dec, x)]
+        got = g(x)
+        for w, o in zip(want, got):
+            assert torch.equal(w, o), "call %d" % k
+    assert g.graph is not None
