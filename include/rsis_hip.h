@@ -40,6 +40,16 @@ extern "C" {
 int rsis_version(void);
 const char* rsis_error_string(int code);
 
+/* Bit-reproducible mode (process-wide; initial value 1 when the environment has RSIS_DETERMINISTIC=1, else 0).  The reference's
+ * CPU path is deterministic; this library's default is not: split-K sums, weight gradients and BatchNorm / bias / soft-IoU
+ * reductions that span several blocks end in fp32 (fp64 for BatchNorm) atomics whose order varies run to run.  With the mode on
+ * every such reduction has ONE contributor per address (no grid split-K, one block per reduced channel / dW tile, one wave per
+ * soft-IoU image): same kernels, same results up to summation order, identical bits on every run -- at the price of launches
+ * that no longer fill the chip.  Meant for debugging and for asserting graph replay == eager execution exactly.
+ * rsis_set_deterministic returns the previous value. */
+int rsis_set_deterministic(int on);
+int rsis_get_deterministic(void);
+
 /* ---- weight repacking (private cache of nn.Conv2d.weight; clstm.py:17, model.py:43-47,109, torchvision trunk) ---- */
 /* 1 when a conv of this geometry runs on the bf16 kernels under RSIS_DTYPE_BF16 (3x3 / stride 1 / pad 1, and 1x1 / pad 0 -- the
  * strided 1x1 convs through their stride-1 form on a sub-sampled input -- with more than one output channel), 0 when it keeps
@@ -106,7 +116,8 @@ int rsis_bias_grad(const float* dy, float* db, int B, int C, int HW, int lstm_hi
  * clstm.py:26-37).  bias_packed / act_out / addend use interleaved rows.  act_out (post-nonlinearity i,f,o,g, needed
  * by the backward) may be NULL for inference. addend: optional precomputed time-invariant gate contribution (the
  * skip-feature part of the gate conv + bias, computed once per iteration by rsis_conv2d_fwd on interleaved rows); with an
- * addend nsrc may be 0 (level 0 at t = 0). ---- */
+ * addend nsrc may be 0 (level 0 at t = 0).  RSIS_DTYPE_BF16 covers ks == 3 only (RSIS_ERR_UNSUPPORTED otherwise, from
+ * this call and from rsis_conv_pack_fwd with lstm_hid > 0): cells with another kernel size run under RSIS_DTYPE_F32. ---- */
 int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp,
                       const float* bias_packed, const float* addend, const float* c_prev, float* h_out, float* c_out,
                       float* act_out, int hid, int ks, int pad, int tile, int dtype, void* stream);

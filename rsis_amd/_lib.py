@@ -34,6 +34,8 @@ class WgradJob(ctypes.Structure):
 SIGNATURES = {
     "rsis_version": (_i, []),
     "rsis_error_string": (ctypes.c_char_p, [_i]),
+    "rsis_set_deterministic": (_i, [_i]),
+    "rsis_get_deterministic": (_i, []),
     "rsis_conv_uses_bf16": (_i, [_i, _i, _i, _i]),
     "rsis_conv_packed_bytes_fwd": (_l, [_i, _i, _i, _i, _i, _i, _ip]),
     "rsis_conv_packed_bytes_dgrad": (_l, [_i, _i, _i, _i, _i, _i]),

@@ -88,11 +88,29 @@ static inline int bf16_rows(int ks, int nseg, const int* Cseg) {
   for (int s = 0; s < nseg; ++s) q += (Cseg[s] + ckb - 1) / ckb;
   return q * ks * ks * (ckb / 8);
 }
+// ---- bit-reproducible mode (rsis_set_deterministic; initial value from RSIS_DETERMINISTIC=1) ----
+static int g_deterministic = -1;
+int rsis_deterministic() {
+  if (g_deterministic < 0) g_deterministic = (getenv("RSIS_DETERMINISTIC") && getenv("RSIS_DETERMINISTIC")[0] == '1') ? 1 : 0;
+  return g_deterministic;
+}
+// grid split-K of the forward / data-gradient convs (atomics into a zeroed output): RSIS_CONV_SPLITK=0 or the deterministic mode turn it off
+static inline bool conv_splitk_ok() {
+  static const bool env_ok = !(getenv("RSIS_CONV_SPLITK") && getenv("RSIS_CONV_SPLITK")[0] == '0');
+  return env_ok && !rsis_deterministic();
+}
 static inline int direct_variant(int tile) { const int v = tile % 10; return (tile > 0 && v >= 1 && v <= 9) ? v : 0; }
 
 extern "C" {
 
 int rsis_version(void) { return RSIS_ABI_VERSION; }
+
+int rsis_set_deterministic(int on) {
+  const int prev = rsis_deterministic();
+  g_deterministic = on ? 1 : 0;
+  return prev;
+}
+int rsis_get_deterministic(void) { return rsis_deterministic(); }
 
 const char* rsis_error_string(int code) {
   switch (code) {
@@ -145,6 +163,7 @@ int rsis_conv_pack_fwd(const float* W, void* Wp, int Cout, int Ctot, int ks, int
                        const int* Coff, int lstm_hid, int dtype, void* stream) {
   if (!W || !Wp || check_segments(Ctot, nseg, Cseg, Coff) || weight_too_big(Cout, Ctot, ks)) return RSIS_ERR_ARG;
   if (lstm_hid > 0 && Cout != 4 * lstm_hid) return RSIS_ERR_ARG;
+  if (lstm_hid > 0 && dtype == RSIS_DTYPE_BF16 && ks != 3) return RSIS_ERR_UNSUPPORTED;     // (see rsis_convlstm_fwd)
   const int ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN);
   int csum = 0;
   for (int s = 0; s < nseg; ++s) csum += Cseg[s];
@@ -186,6 +205,7 @@ int rsis_affine_nearest(const float* x, float* y, const float* mat, int mat_rows
 int rsis_conv_pack_job_fill(rsis_pack_job* j) {
   if (!j || check_segments(j->Ctot, j->nseg, j->Cseg, j->Coff) || weight_too_big(j->Cout, j->Ctot, j->ks)) return -1;
   if (j->lstm_hid > 0 && j->Cout != 4 * j->lstm_hid) return -1;
+  if (j->lstm_hid > 0 && j->dtype == RSIS_DTYPE_BF16 && j->ks != 3) return -1;                  // (see rsis_convlstm_fwd)
   int csum = 0;
   for (int s = 0; s < j->nseg; ++s) csum += j->Cseg[s];
   if (!j->dgrad) {
@@ -238,7 +258,7 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
     if (stride != 1) return RSIS_ERR_UNSUPPORTED;      // strided 1x1: run the stride-1 form on a sub-sampled input
     if (ks == 1 && nsrc != 1) return RSIS_ERR_UNSUPPORTED;
     if (ks == 3) {     // deep-K convs on tiny maps (sk5): split over the channel chunks into a zeroed output
-      static const bool splitk_ok = !(getenv("RSIS_CONV_SPLITK") && getenv("RSIS_CONV_SPLITK")[0] == '0');
+      const bool splitk_ok = conv_splitk_ok();
       int nq = 0;
       for (int s = 0; s < nsrc; ++s) nq += (Csrc[s] + RSIS_CKB3 - 1) / RSIS_CKB3;
       const long px_tiles = (long)B * rsis_cdiv(H, 8) * rsis_cdiv(W, W <= 8 ? 8 : 16);
@@ -257,7 +277,7 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
     int nq = 0;
     for (int s = 0; s < nsrc; ++s) nq += (Csrc[s] + RSIS_CK - 1) / RSIS_CK;
     const long px_tiles = (long)B * rsis_cdiv(H, 8) * rsis_cdiv(W, W <= 8 ? 8 : 16);
-    static const bool splitk_ok = !(getenv("RSIS_CONV_SPLITK") && getenv("RSIS_CONV_SPLITK")[0] == '0');   // A/B switch
+    const bool splitk_ok = conv_splitk_ok();   // A/B switch / deterministic mode
     if (allow_splitk && splitk_ok && nq >= 32 && px_tiles * rsis_cdiv(Cout, 64) < 160) {
       if (rsis_zero_async(out, sizeof(float) * (size_t)B * Cout * Ho * Wo, (hipStream_t)stream) != RSIS_OK) return RSIS_ERR_LAUNCH;
       a.ksplit = 0;
@@ -292,7 +312,7 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const vo
   if (use_bf16(dtype, ks, stride, pad, Cout)) {
     if (ks == 3) {
       if (Hx != Hy || Wx != Wy) return RSIS_ERR_ARG;
-      static const bool splitk_ok = !(getenv("RSIS_CONV_SPLITK") && getenv("RSIS_CONV_SPLITK")[0] == '0');
+      const bool splitk_ok = conv_splitk_ok();
       const int nq = (Cout + RSIS_CKB3 - 1) / RSIS_CKB3;
       const long px_tiles = (long)B * rsis_cdiv(Hx, 8) * rsis_cdiv(Wx, Wx <= 8 ? 8 : 16);
       if (splitk_ok && !addend && nq >= 16 && px_tiles * rsis_cdiv(ctot, 64) < 160) {
@@ -317,7 +337,7 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const vo
     if (Cout == 1 && ndst == 1 && Cin_packed == Cdx[0] && rsis_c1_supported(Cdx[0]) && !addend)
       return rsis_l_c1_dgrad(dy, (const float*)Wd, a.ldw, dx[0], B, Cdx[0], Hx, Wx, (hipStream_t)stream);
     {  // deep-K data gradients on tiny maps (ConvLSTM level 0: 512 gate rows x 9 taps on 8x8): split over the channel chunks
-      static const bool splitk_ok = !(getenv("RSIS_CONV_SPLITK") && getenv("RSIS_CONV_SPLITK")[0] == '0');
+      const bool splitk_ok = conv_splitk_ok();
       const int nq = (Cout + RSIS_CK - 1) / RSIS_CK;
       const long px_tiles = (long)B * rsis_cdiv(Hx, 8) * rsis_cdiv(Wx, Wx <= 8 ? 8 : 16);
       if (splitk_ok && !addend && nq >= 32 && px_tiles * rsis_cdiv(ctot, 64) < 160) {
@@ -420,12 +440,15 @@ int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B,
   if (rc) return rc;
   if (!Wp || !h_out || !c_out || hid < 1) return RSIS_ERR_ARG;
   if (2 * pad != ks - 1) return RSIS_ERR_UNSUPPORTED;   // "same" conv only (the state keeps its size)
+  // bf16 gates: 3x3 only (the fused-cell epilogue of conv_bf16_kernel); rsis_conv_pack_fwd refuses the same combination, so a
+  // bf16-packed buffer can never reach the f32 kernels below
+  if (dtype == RSIS_DTYPE_BF16 && ks != 3) return RSIS_ERR_UNSUPPORTED;
   a.B = B; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.stride = 1; a.pad = pad; a.sshift = 0;
   a.wp = (const float*)Wp; a.ldw = rsis_roundup(4 * hid, RSIS_LDW_ALIGN); a.Cout = 4 * hid; a.bias = bias_packed; a.addend = addend;
   a.ndst = 1; a.dst[0] = nullptr; a.Cd[0] = 4 * hid;
   a.hid = hid; a.c_prev = c_prev; a.h_out = h_out; a.c_out = c_out; a.act_out = act_out;
   a.ostride = 1; a.oH = H; a.oW = W; a.ksplit = 1;
-  if (use_bf16(dtype, ks, 1, pad, 4 * hid) && ks == 3) return rsis_launch_conv_bf16(a, 3, 1, direct_variant(tile), (hipStream_t)stream);
+  if (use_bf16(dtype, ks, 1, pad, 4 * hid)) return rsis_launch_conv_bf16(a, 3, 1, direct_variant(tile), (hipStream_t)stream);
   if (use_direct(ks, 1, pad)) return rsis_launch_conv3x3_direct(a, 1, direct_variant(tile), (hipStream_t)stream);
   return rsis_launch_conv_igemm(a, ks, false, 1, tile, (hipStream_t)stream);
 }

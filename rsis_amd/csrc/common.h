@@ -27,6 +27,10 @@ static inline int rsis_check_launch() {
 // replaying graphs that contain them back to back corrupted the iteration on this stack (ROCm 7.0 / gfx950).
 int rsis_zero_async(void* p, size_t bytes, hipStream_t st);
 
+// rsis_set_deterministic (api.hip): 1 = every reduction of the library runs in a fixed order (no grid split-K, one block per
+// reduced address, no same-address atomics from more than one contributor) -- bit-reproducible run to run, slower.
+int rsis_deterministic();
+
 static inline int rsis_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int rsis_roundup(int a, int b) { return ((a + b - 1) / b) * b; }
 

@@ -259,6 +259,8 @@ int rsis_l_c1_dgrad(const float* dy, const float* wd, int ldw, float* dx, int B,
 }
 int rsis_l_c1_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int Cin, int H, int W, hipStream_t st) {
   // one block per (tile, channel pair) up to the cap (a multiple of every Cin / 2), persistent beyond it
-  C1_BY_WIDTH(conv_c1_wgrad_kernel, 512, Cin / 2, dy, x, dw, db, B, H, W)     // measured: 256 -> 39 us, 512 -> 29 us, 1024 -> 30 us, 2048 -> 43 us
+  // (deterministic mode: ONE persistent block per channel pair, so every dW / db address has a single contributor)
+  const int cap = rsis_deterministic() ? Cin / 2 : 512;
+  C1_BY_WIDTH(conv_c1_wgrad_kernel, cap, Cin / 2, dy, x, dw, db, B, H, W)     // measured: 256 -> 39 us, 512 -> 29 us, 1024 -> 30 us, 2048 -> 43 us
   return rsis_check_launch();
 }

@@ -194,7 +194,7 @@ static int launch_wgrad_cfg(WgradArgs& a, hipStream_t st) {
   int nsplit = ntile >= slots ? 1 : slots / ntile;
   const int max_split = (int)((Npx + 4 * BKW - 1) / (4 * BKW));
   if (nsplit > max_split) nsplit = max_split;
-  if (nsplit < 1) nsplit = 1;
+  if (nsplit < 1 || rsis_deterministic()) nsplit = 1;
   a.chunk = rsis_roundup(rsis_cdiv(Npx, nsplit), BKW);
   nsplit = rsis_cdiv(Npx, a.chunk);   // (rounding the chunk up can only lower the split count)
   if constexpr (KS == 1 && BM % 32 == 0 && BN % 32 == 0) {

@@ -419,7 +419,7 @@ static void split_plan(WgradBf16Args& a, int TW, int ntile, int slots) {
   int nsplit = ntile >= slots ? 1 : slots / ntile;
   if (nsplit > 256) nsplit = 256;
   if (nsplit > a.n_sp_tiles / 2) nsplit = a.n_sp_tiles / 2;
-  if (nsplit < 1) nsplit = 1;
+  if (nsplit < 1 || rsis_deterministic()) nsplit = 1;
   a.tiles_per_split = rsis_cdiv(a.n_sp_tiles, nsplit);
 }
 
@@ -522,6 +522,7 @@ static int wgb_launch_bucket(WgradBf16Args* jobs, int n, const WgbKey& k, Launch
   const long target_blocks = env_tb > 0 ? env_tb : 1024;
   long L = (total + target_blocks - 1) / target_blocks;
   if (L < 2) L = 2;
+  if (rsis_deterministic()) L = 1L << 40;
   for (int j0 = 0; j0 < n; j0 += RSIS_WGB_MAXJ) {
     WgradBf16Group g;
     g.n = n - j0 < RSIS_WGB_MAXJ ? n - j0 : RSIS_WGB_MAXJ;

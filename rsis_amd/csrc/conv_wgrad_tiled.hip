@@ -296,7 +296,7 @@ static int launch_tiled_cfg(WgradTiledArgs& a, hipStream_t st) {
   const int slots = KS == 1 ? (BM * BN >= 128 * 128 ? 256 : 512) : 256 * (BM * BN >= 128 * 128 ? 2 : 3);
   int nsplit = ntile >= slots ? 1 : slots / ntile;
   if (nsplit > a.n_sp_tiles / 2) nsplit = a.n_sp_tiles / 2;
-  if (nsplit < 1) nsplit = 1;
+  if (nsplit < 1 || rsis_deterministic()) nsplit = 1;     // deterministic mode: one block walks every spatial tile of its dW tile
   a.tiles_per_split = rsis_cdiv(a.n_sp_tiles, nsplit);
   nsplit = rsis_cdiv(a.n_sp_tiles, a.tiles_per_split);
   hipLaunchKernelGGL((conv_wgrad_tiled_kernel<BM, BN, WGM, WGN, KS, TW, KSP>), dim3(ntile, nsplit), dim3(256), 0, st, a);
@@ -309,6 +309,8 @@ static int launch_tiled_tw(WgradTiledArgs& a, hipStream_t st) {
   // 16- and 32-channel sources (N = 144 / 288: 56 % / 75 % -> 75 % / 90 % useful MFMA columns)
   const int nmod = (a.Cs * KS * KS) % 128;
   const bool narrow = nmod != 0 && nmod <= 64;
+  // (deterministic mode: not the KSP = 2 tile -- its two wave copies both add into dW, in either order)
+  if (rsis_deterministic() && a.Cout <= 32) return launch_tiled_cfg<32, 128, 1, 4, KS, TW>(a, st);
   // 1x1: 64 x 64 tiles with two blocks per CU.  The split count -- and with it the dW-sized passes of fp32 atomics, which run at
   // ~0.3 T atomics/s and were a third of these launches -- goes with slots / tiles: a quarter of the 128 x 128 tile's at twice
   // its slots.  Measured on every 1x1 shape of the trunk at batch 32 (tools/exp/bf16_shape_sweep.py --dtype fp32): 47-54 -> 38-44 us.
@@ -334,7 +336,7 @@ static int tiled_cfg_code(const WgradTiledArgs& a, int ks) {
   const int nmod = (a.Cs * ks * ks) % 128;
   const bool narrow = nmod != 0 && nmod <= 64;
   if (ks == 1 && a.Cout > 32) return 2;
-  if (a.Cout <= 32) return narrow ? 0 : 1;
+  if (a.Cout <= 32) return narrow && !rsis_deterministic() ? 0 : 1;
   if (a.Cout <= 64) return narrow ? 2 : 3;
   return narrow ? 4 : 5;
 }
@@ -356,6 +358,7 @@ static int launch_group_cfg(WgradTiledArgs* jobs, int n, hipStream_t st) {
   const long target_blocks = env_tb > 0 ? env_tb : 2048;
   long L = (total_iters + target_blocks - 1) / target_blocks;
   if (L < 2) L = 2;
+  if (rsis_deterministic()) L = 1L << 40;            // no split: every dW tile has one contributor
   for (int j0 = 0; j0 < n; j0 += RSIS_WG_MAXJ) {
     WgradTiledGroup g;
     g.n = n - j0 < RSIS_WG_MAXJ ? n - j0 : RSIS_WG_MAXJ;

@@ -82,6 +82,7 @@ int rsis_l_softiou_sums(const float* logits, const float* y, float* S, int B, in
   long per_wave = (N + (long)nsplit * 4 - 1) / ((long)nsplit * 4);
   per_wave = (per_wave + 7) / 8 * 8;
   if (per_wave < 64) per_wave = 64;
+  if (rsis_deterministic()) per_wave = (N + 7) / 8 * 8;      // one wave per image walks every pixel: a single contributor per sum
   nsplit = (int)((N + per_wave * 4 - 1) / (per_wave * 4));
   hipLaunchKernelGGL(softiou_sums_kernel, dim3(nsplit, B), dim3(256), 0, st, logits, y, S, T, G, N, per_wave);
   return rsis_check_launch();

@@ -772,13 +772,13 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 // flat fused Adam (torch.optim.Adam semantics incl. L2 weight decay: reference utils/utils.py:83-84)
 // ------------------------------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
+                            long n, float lr, float b1, float b2, float eps, float wd, int step, float gscale,
                             const int* __restrict__ step_dev) {
-  if (step_dev) {   // step count kept on the device (a captured hipGraph replays with the live count, not the captured one)
-    const float st = (float)*step_dev;
-    bc1 = 1.f - powf(b1, st);
-    bc2_sqrt = sqrtf(1.f - powf(b2, st));
-  }
+  // step count from the argument, or kept on the device (a captured hipGraph replays with the live count, not the captured one);
+  // the bias corrections are computed HERE in both cases, so that an eager step and a replayed one are the same arithmetic
+  const float st = (float)(step_dev ? *step_dev : step);
+  const float bc1 = 1.f - powf(b1, st);
+  const float bc2_sqrt = sqrtf(1.f - powf(b2, st));
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     float gv = g[e] * gscale + wd * p[e];
     const float mv = b1 * m[e] + (1.f - b1) * gv;
@@ -890,6 +890,7 @@ static inline bool bn_fused_ok(int C, int HW, long N) {
   return on && (HW & 3) == 0 && N / 4 <= 1024 * 8 && C >= 64;
 }
 static inline int chan_splits(int C, long N) {
+  if (rsis_deterministic()) return 1;        // all of a channel in one block: no cross-block atomics
   long s = (2048 + C - 1) / C;
   const long maxs = (N + 1023) / 1024;
   if (s > maxs) s = maxs;
@@ -1057,9 +1058,7 @@ int rsis_l_channel_sum(const float* dy, float* db, int B, int C, int HW, int hid
 }
 int rsis_l_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
                 int step, float gscale, const int* step_dev, hipStream_t st) {
-  const float bc1 = 1.f - powf(b1, (float)step);
-  const float bc2s = sqrtf(1.f - powf(b2, (float)step));
-  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, gscale, step_dev);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, step, gscale, step_dev);
   return rsis_check_launch();
 }
 

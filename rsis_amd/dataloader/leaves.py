@@ -104,16 +104,31 @@ class LeavesDataset(object):
         return np.ascontiguousarray(im), np.ascontiguousarray(ins.astype(np.int32))
 
 
+def shard_batches(order, batch_size, rank=0, world=1):
+    """Per-rank index lists of one epoch: the (already shuffled, identical on every rank) sample order is cut into GLOBAL batches of
+    batch_size * world (the tail that does not fill one is dropped: drop_last=True, train.py:46-49) and rank r takes elements
+    r, r + world, ... of each -- the ranks' shards of a step are disjoint and together are the reference's global batch."""
+    gb = int(batch_size) * int(world)
+    return [order[i * gb:(i + 1) * gb][rank::world] for i in range(len(order) // gb)]
+
+
 class DeviceLoader(object):
     """DataLoader(dataset, batch_size, shuffle=True, drop_last=True) of train.py:46-49 yielding DEVICE batches
     (x, y_mask, y_class, sw_mask, sw_class) -- what utils.batch_to_var returns.  The next batch is decoded into pinned memory by
-    `num_workers` threads and copied on a side stream while the current one trains."""
+    `num_workers` threads and copied on a side stream while the current one trains.
 
-    def __init__(self, dataset, batch_size, shuffle=True, num_workers=4, seed=0, device="cuda"):
+    One process per GPU (rank / world): `batch_size` is the PER-RANK batch; every rank shuffles the whole dataset with the SAME
+    seed and takes samples r, r + world, ... of each global batch of batch_size * world, so that an epoch is
+    len(dataset) // (batch_size * world) steps of the reference's global batch (train.py:46-49 under nn.DataParallel) and no
+    sample is seen twice in a step; only the per-sample augmentation draws are rank-specific."""
+
+    def __init__(self, dataset, batch_size, shuffle=True, num_workers=4, seed=0, device="cuda", rank=0, world=1):
         if dataset.crop is False and batch_size != 1:
             raise ValueError("un-cropped samples have different sizes: batch_size must be 1")
         self.ds, self.bs, self.shuffle, self.device = dataset, int(batch_size), shuffle, device
-        self.rng = random.Random(seed)
+        self.rank, self.world = int(rank), int(world)
+        self.order_rng = random.Random(seed)                                # the same on every rank
+        self.rng = random.Random(seed * 1000003 + 17 * self.rank + 1)       # per-sample draws (crop / flip / warp)
         self.pool = ThreadPoolExecutor(max_workers=max(1, int(num_workers)))
         self.copy_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self.mean = torch.tensor(MEAN, device=device).view(1, 3, 1, 1)
@@ -121,7 +136,12 @@ class DeviceLoader(object):
         self._lock = threading.Lock()
 
     def __len__(self):
-        return len(self.ds) // self.bs                                      # drop_last=True
+        return len(self.ds) // (self.bs * self.world)                       # drop_last=True on the GLOBAL batch
+
+    def steps_to_run(self, args, sw_mask):
+        """early-stop rule of train.py:80-92 for this batch (one host sync; the batch is fresh, so nothing can be cached)"""
+        from ..train import steps_to_run
+        return steps_to_run(args, sw_mask)
 
     def _stage(self, idxs):
         """decode one batch into pinned buffers (host side only)"""
@@ -145,7 +165,10 @@ class DeviceLoader(object):
         with torch.cuda.stream(st):
             x = img.to(self.device, non_blocking=True)
             m = ins.to(self.device, non_blocking=True)
-        torch.cuda.current_stream().wait_stream(st)
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(st)
+        x.record_stream(cur)                # allocated on the copy stream, consumed on this one: keep the caching allocator from
+        m.record_stream(cur)                # handing the blocks to the next side-stream copy while these kernels still read them
         x = (x.float() / 255.0 - self.mean) / self.std                      # ToTensor + Normalize (train.py:34-37)
         mf = m.float().unsqueeze(1)
         if mats is not None:                                                # dataset.py:66-67: image and maps share one warp
@@ -159,8 +182,8 @@ class DeviceLoader(object):
     def __iter__(self):
         order = list(range(len(self.ds)))
         if self.shuffle:
-            self.rng.shuffle(order)
-        batches = [order[i * self.bs:(i + 1) * self.bs] for i in range(len(self))]
+            self.order_rng.shuffle(order)
+        batches = shard_batches(order, self.bs, self.rank, self.world)
         if not batches:
             return
         staged = self._stage(batches[0])

@@ -49,6 +49,17 @@ def set_dtype(module, dtype):
     return module
 
 
+def set_deterministic(on=True):
+    """Bit-reproducible mode of the library (include/rsis_hip.h: rsis_set_deterministic): every reduction gets a single
+    contributor per address, so two runs -- or an eager run and a hipGraph replay -- produce identical bits.  Slower (launches
+    stop filling the chip); returns the previous setting.  RSIS_DETERMINISTIC=1 turns it on from the environment."""
+    return bool(lib().rsis_set_deterministic(1 if on else 0))
+
+
+def is_deterministic():
+    return bool(lib().rsis_get_deterministic())
+
+
 SUBSAMPLE_1X1 = [os.environ.get("RSIS_SUBSAMPLE_1X1", "1") != "0"]     # A/B switch, see _Conv2dFn.forward
 _PACKS = weakref.WeakSet()       # every PackedConv that holds a packed copy
 _BATCH = {"sig": None, "jobs": None, "n": 0, "blocks": 0}
@@ -107,6 +118,10 @@ class PackedConv(object):
 
     def __init__(self, ks, segs, lstm_hid=0, stride=1, pad=None, offs=None, dtype=DTYPE_F32):
         self.dtype = int(dtype)
+        if int(lstm_hid) > 0 and int(ks) != 3:
+            # the fused-cell epilogue of the bf16 kernels exists for 3x3 gates only (rsis_convlstm_fwd returns UNSUPPORTED otherwise):
+            # a ConvLSTM with another kernel size keeps the f32 kernels -- packing, forward, data and weight gradient alike
+            self.dtype = DTYPE_F32
         self.ks = int(ks)
         self.stride = int(stride)
         self.pad = int(ks // 2 if pad is None else pad)

@@ -53,7 +53,8 @@ class FlatGroup(object):
         self.mult = [float(lr_mult.get(p, 1.0)) if lr_mult else 1.0 for p in self.params]
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._ranges = None
-        self._dev = None          # (ranges, int32 device counters) while a captured graph owns the step counts
+        self._dev = None          # (ranges, int32 device counters) while captured graphs own the step counts
+        self._dev_users = 0       # live captures sharing those counters (train.GraphedStep instances)
         ops.bump_weight_epoch()
 
     # ---- torch.optim.Adam's "skip parameters without a gradient" ----
@@ -109,6 +110,8 @@ class FlatGroup(object):
                 ops.adam_step_flat(self.flat_p[off:off + n], self.flat_g[off:off + n], self.exp_avg[off:off + n],
                                    self.exp_avg_sq[off:off + n], self.lr * mult, self.betas[0], self.betas[1], self.eps,
                                    self.weight_decay, 1, gscale, step_dev=counters[k:k + 1], bump=False)
+            if not torch.cuda.is_current_stream_capturing():
+                self.note_replay()          # an EAGER step while a capture owns the counts (warm-up of another capture): mirror it
             ops.bump_weight_epoch()
             return
         ranges = self.ranges()
@@ -123,9 +126,16 @@ class FlatGroup(object):
 
     # ---- hipGraph support (train.GraphedStep) ----
     def begin_graph(self):
-        """freeze the launch ranges and move their update counts to the device; call before capturing step()"""
+        """freeze the launch ranges and move their update counts to the device; call before capturing step().  Several captures
+        may be alive at once (one per input shape / step count): they share ONE set of device counters, which every replay and
+        every eager step advances, so each of them always reads the live count."""
         ranges = [tuple(r) for r in self.ranges()]
-        self._dev = (ranges, torch.tensor([r[2] for r in ranges], dtype=torch.int32, device=self.flat_p.device))
+        same = self._dev is not None and [(r[0], r[1], r[3], r[4]) for r in self._dev[0]] == [(r[0], r[1], r[3], r[4]) for r in ranges]
+        if self._dev is not None and not same:
+            raise RuntimeError("FlatGroup.begin_graph: the active parameter set changed while a capture is alive (release it first)")
+        if self._dev is None:
+            self._dev = (ranges, torch.tensor([r[2] for r in ranges], dtype=torch.int32, device=self.flat_p.device))
+        self._dev_users += 1
 
     def note_replay(self):
         """a captured step() was replayed: mirror its count increments on the host"""
@@ -135,7 +145,9 @@ class FlatGroup(object):
         self._ranges = None
 
     def end_graph(self):
-        self._dev = None
+        self._dev_users = max(0, self._dev_users - 1)
+        if self._dev_users == 0:
+            self._dev = None
 
     def state_dict(self):
         return {"step": self.step_count, "steps": list(self.steps), "active": list(self.active), "exp_avg": self.exp_avg,

@@ -260,7 +260,7 @@ class GraphedStep(object):
         self.n_eager = 0
         self._bns = None
         self.failed = None
-        self._in_sig = None
+        self._in_src = None
 
     def _run(self, batch, t_run, do_update=True):
         return runIter(self.args, self.encoder, self.decoder, *batch, self.crits, self.optims, mode="train",
@@ -291,13 +291,16 @@ class GraphedStep(object):
             return res
         if t_run != self.t_run:
             raise RuntimeError("GraphedStep: captured for t_run=%d, called with %d" % (self.t_run, t_run))
-        # inputs -> static buffers (skipped for a resident batch that is already there: same tensors, unmodified)
-        sig = tuple((t.data_ptr(), t._version) for t in batch)
-        if sig != self._in_sig:
+        # inputs -> static buffers.  Skipped only for a resident batch that is already there: the SAME tensor objects (held here by
+        # strong references, so their addresses cannot have been recycled by the caching allocator for another batch), unmodified
+        # since the last copy.  A loader that yields fresh tensors per step always pays the copy.
+        same = (self._in_src is not None and len(self._in_src) == len(batch) and
+                all(a is b and a._version == v for a, (b, v) in zip(batch, self._in_src)))
+        if not same:
             for dst, src in zip(self.static, batch):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
-            self._in_sig = sig
+            self._in_src = [(t, t._version) for t in batch]
         self.graph.replay()
         if self.split:
             self._exchange()
@@ -351,7 +354,7 @@ class GraphedStep(object):
     def release(self):
         for g in self._groups():
             g.end_graph()
-        self.graph = self.graph_update = self.result = self.static = None
+        self.graph = self.graph_update = self.result = self.static = self._in_src = None
 
 
 def init_dataloaders(args, rank=0, world=1):
@@ -369,7 +372,7 @@ def init_dataloaders(args, rank=0, world=1):
         for split in ("train", "val"):                                       # train.py:31-49
             ds = LeavesDataset(args, split=split, augment=args.augment and split == "train", resize=args.resize, imsize=args.imsize)
             loaders[split] = DeviceLoader(ds, args.batch_size // world, shuffle=True, num_workers=args.num_workers,
-                                          seed=args.seed + 17 * rank + (0 if split == "train" else 1))
+                                          seed=args.seed + (0 if split == "train" else 1), rank=rank, world=world)
         return loaders, ds.get_classes()
     if args.batch_size % world != 0:
         raise Exception("-batch_size %d (the global batch) is not divisible by the %d ranks" % (args.batch_size, world))
@@ -389,17 +392,21 @@ def trainIters(args):
         encoder_dict, decoder_dict, enc_opt_dict, dec_opt_dict, load_args = load_checkpoint(args.model_name, args.use_gpu,
                                                                                             root=args.models_root)
         epoch_resume = load_args.epoch_resume
+        # command-line settings of THIS run that override the checkpoint's namespace -- copied BEFORE the modules are built: the
+        # modules read `dtype` (which MFMA kernels they run) from the namespace they are constructed with, and the namespace that
+        # is re-saved next to the checkpoint must say what actually ran
+        for k in ("synthetic", "synthetic_batches", "synthetic_instances", "models_root", "max_epoch", "log_term", "graph", "dtype",
+                  "enc_lr_quirk"):
+            setattr(load_args, k, getattr(args, k, None))
         encoder, decoder = FeatureExtractor(load_args), RSIS(load_args)
         encoder_dict, decoder_dict = check_parallel(encoder_dict, decoder_dict)
         encoder.load_state_dict(encoder_dict)
         decoder.load_state_dict(decoder_dict)
-        for k in ("synthetic", "synthetic_batches", "synthetic_instances", "models_root", "max_epoch", "log_term", "graph", "dtype",
-                  "enc_lr_quirk"):
-            setattr(load_args, k, getattr(args, k, None))
         args = load_args
     elif args.transfer:                                                   # train.py:217-224
         encoder_dict, decoder_dict, enc_opt_dict, dec_opt_dict, load_args = load_checkpoint(args.transfer_from, args.use_gpu,
                                                                                             root=args.models_root)
+        load_args.dtype = getattr(args, "dtype", "fp32")                   # (the architecture comes from the checkpoint, the arithmetic from this run)
         encoder, decoder = FeatureExtractor(load_args), RSIS(load_args)
         encoder_dict, decoder_dict = check_parallel(encoder_dict, decoder_dict)
         encoder.load_state_dict(encoder_dict)
@@ -453,9 +460,9 @@ def trainIters(args):
         e_d, d_d, eo, do, _ = load_checkpoint(args.model_name, args.use_gpu, root=args.models_root)
         encoder.load_state_dict(e_d)
         decoder.load_state_dict(d_d)
-        if graphs.get("step") is not None:      # the optimizer state is about to change behind the captured graph
-            graphs["step"].release()
-            graphs.clear()
+        for gs in graphs.get("cache", {}).values():      # the optimizer state is about to change behind the captured graphs
+            gs.release()
+        graphs.clear()
         enc_opt.load_state_dict(eo)
         dec_opt.load_state_dict(do)
         ops.bump_weight_epoch()
@@ -485,10 +492,20 @@ def trainIters(args):
                 if split == "train" and getattr(args, "graph", False) and t_run is not None:
                     # one captured hipGraph per (shapes, T, loss switches, encoder update, active parameter set)
                     key = (tuple(x.shape), tuple(y_mask.shape), t_run, args.use_class_loss, args.use_stop_loss, args.update_encoder)
+                    if graphs.get("mode", key[3:]) != key[3:]:       # loss switches / encoder update changed: other launch set
+                        for gs in graphs.pop("cache", {}).values():
+                            gs.release()
+                        graphs.pop("key", None)
+                    graphs["mode"] = key[3:]
                     if graphs.get("key") != key:
-                        if graphs.get("step") is not None:
-                            graphs["step"].release()
-                        graphs["key"], graphs["step"] = key, GraphedStep(args, encoder, decoder, crits, optims, reducer)
+                        # (a data set whose batches stop at different steps alternates between a few keys: keep the last few
+                        #  captures instead of re-capturing on every change; a resident synthetic batch only ever has one)
+                        cache = graphs.setdefault("cache", {})
+                        if key not in cache:
+                            while len(cache) >= 4:
+                                cache.pop(next(iter(cache))).release()
+                            cache[key] = GraphedStep(args, encoder, decoder, crits, optims, reducer)
+                        graphs["key"], graphs["step"] = key, cache[key]
                     losses, _outs, _perm = graphs["step"]((x, y_mask, y_class, sw_mask, sw_class), t_run)
                     losses = [v.clone() for v in losses]      # (static tensors of the graph: keep this step's values)
                 else:

@@ -97,15 +97,46 @@ def save_checkpoint(args, encoder, decoder, enc_opt, dec_opt, root="../models"):
 
 class _ArgsUnpickler(pickle.Unpickler):
     """args.pkl holds an argparse.Namespace of plain values (train.py:234): refuse to resolve anything else, so that loading a
-    third-party checkpoint cannot execute code."""
+    third-party checkpoint cannot execute code.  "Plain values" includes numpy SCALARS: the reference stores
+    `args.best_val_loss = np.mean(...)` (train.py:406-443), a numpy.float64, before every save_checkpoint, whose pickle
+    reconstructs through numpy.core.multiarray.scalar(numpy.dtype(...), bytes) -- both allow-listed (they build a scalar from
+    raw bytes; object dtypes are refused), and the loaded scalars are turned into python numbers by `_plain`."""
     _ALLOWED = {("argparse", "Namespace"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"),
                 ("__builtin__", "dict"), ("__builtin__", "list"), ("__builtin__", "tuple"), ("__builtin__", "set"),
                 ("copy_reg", "_reconstructor"), ("copyreg", "_reconstructor"), ("__builtin__", "object"), ("builtins", "object")}
+    _NUMPY = {("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy", "dtype")}
+    _ALLOWED = _ALLOWED | {("_codecs", "encode")}      # how a python-3 protocol-2 pickle spells a bytes payload (str -> bytes)
 
     def find_class(self, module, name):
+        if (module, name) in self._NUMPY:
+            import numpy as np
+            if name == "dtype":
+                return _plain_dtype
+            return np._core.multiarray.scalar if hasattr(np, "_core") else np.core.multiarray.scalar
         if (module, name) not in self._ALLOWED:
             raise pickle.UnpicklingError("args.pkl: refusing to load %s.%s" % (module, name))
         return super().find_class(module, name)
+
+
+def _plain_dtype(*a, **kw):
+    """numpy.dtype for the unpickler: numeric / bool scalars only (an object dtype would make numpy unpickle arbitrary payloads)"""
+    import numpy as np
+    dt = np.dtype(*a, **kw)
+    if dt.kind not in "biuf":
+        raise pickle.UnpicklingError("args.pkl: refusing numpy dtype %r" % (dt,))
+    return dt
+
+
+def _plain(v):
+    """numpy scalars -> python numbers (recursively through the containers an args namespace holds)"""
+    import numpy as np
+    if isinstance(v, np.generic):
+        return v.item()
+    if isinstance(v, (list, tuple)):
+        return type(v)(_plain(x) for x in v)
+    if isinstance(v, dict):
+        return {k: _plain(x) for k, x in v.items()}
+    return v
 
 
 def load_checkpoint(model_name, use_gpu=True, root="../models"):
@@ -122,6 +153,8 @@ def load_checkpoint(model_name, use_gpu=True, root="../models"):
         except UnicodeDecodeError:
             f.seek(0)
             args = _ArgsUnpickler(f, encoding="latin1").load()
+    for k, v in list(vars(args).items()):
+        setattr(args, k, _plain(v))
     return dicts[0], dicts[1], dicts[2], dicts[3], args
 
 

@@ -47,10 +47,13 @@ def test_reference_era_checkpoint_loads(tmp_path):
     torch.save({"state": {}, "param_groups": []}, os.path.join(d, "dec_opt.pt"))
     ns = argparse.Namespace(**{k: v for k, v in vars(a).items()})
     ns.epoch_resume = 3
+    ns.best_val_loss = np.mean([0.5, 0.75])     # what the reference stores before every save (train.py:406-443): a numpy.float64
+    assert isinstance(ns.best_val_loss, np.float64)
     with open(os.path.join(d, "args.pkl"), "wb") as f:
         pickle.dump(ns, f, protocol=2)
     e_sd, d_sd, e_opt, d_opt, largs = load_checkpoint("ref_era", use_gpu=False, root=str(tmp_path))
     assert largs.epoch_resume == 3 and largs.hidden_size == 32
+    assert type(largs.best_val_loss) is float and largs.best_val_loss == 0.625
     e_sd, d_sd = check_parallel(e_sd, d_sd)
     assert not any(k.startswith("module.") for k in list(e_sd) + list(d_sd))
     enc2, dec2 = FeatureExtractor(largs), RSIS(largs)
@@ -113,3 +116,26 @@ def test_torch_adam_state_is_adopted():
     opt3 = FlatAdam(list(lin2.parameters())[:2], lr=1e-3)
     opt3.load_state_dict(sd)
     assert float(opt3.group.exp_avg.abs().sum()) == 0.0
+
+
+def test_args_pickle_numpy_scalars_and_refusals(tmp_path):
+    """args.pkl as python 2 + old numpy wrote it (module path numpy.core.multiarray, str payload -> latin1 under python 3) loads with
+    its numpy.float64 turned into a float; anything that is not a plain value or a numeric numpy scalar is refused"""
+    from rsis_amd.utils.utils import _ArgsUnpickler
+    import io
+    # protocol-2 pickle of Namespace(best_val_loss=np.float64(0.625), epoch_resume=np.int64(4)) with the python-2 era module path
+    ns = argparse.Namespace(best_val_loss=np.float64(0.625), epoch_resume=np.int64(4), lr=1e-3)
+    raw = pickle.dumps(ns, protocol=2).replace(b"numpy._core.multiarray", b"numpy.core.multiarray")
+    raw = raw.replace(b"cnumpy._core.multiarray", b"cnumpy.core.multiarray")
+    got = _ArgsUnpickler(io.BytesIO(raw)).load()
+    assert float(got.best_val_loss) == 0.625 and int(got.epoch_resume) == 4
+
+    class Evil(object):
+        def __reduce__(self):
+            return (os.system, ("true",))
+    for bad in (argparse.Namespace(x=Evil()), argparse.Namespace(x=np.zeros(3)), argparse.Namespace(x=np.array([None], dtype=object)[0:1])):
+        try:
+            _ArgsUnpickler(io.BytesIO(pickle.dumps(bad, protocol=2))).load()
+        except pickle.UnpicklingError:
+            continue
+        raise AssertionError("the args unpickler accepted %r" % (bad,))

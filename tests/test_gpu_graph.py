@@ -59,8 +59,7 @@ def test_flat_adam_device_step_counter():
         oa.group.flat_g.copy_(g)
         ob.group.flat_g.copy_(g)
         oa.step()
-        ob.step()
-        ob.group.note_replay()
+        ob.step()                   # (an eager step in graph mode mirrors its count on the host itself)
     ob.group.end_graph()
     # (host powf vs device powf for the bias corrections: a few ulp)
     assert float((oa.group.flat_p - ob.group.flat_p).abs().max()) < 1e-6
@@ -113,9 +112,17 @@ def test_graphed_step_equals_eager(use_stop):
 
 
 def test_graph_replay_back_to_back_stays_finite():
-    """60 replays enqueued back to back (no host sync, nothing between the launches but the runtime): parameters, gradients and both
-    Adam moments must stay finite and the loss must follow the eager run.  Regression test for the memset-node ordering problem of
-    captured hipGraphs on this stack (the library zero-fills with a kernel since: common.h rsis_zero_async)."""
+    """60 replays enqueued back to back (no host sync, nothing between the launches but the runtime), default (non-deterministic)
+    kernels: parameters, gradients and both Adam moments must stay finite, and the run must stay as close to an eager run as a
+    SECOND EAGER run does.  Regression test for the memset-node ordering problem of captured hipGraphs on this stack (the library
+    zero-fills with a kernel since: common.h rsis_zero_async).
+
+    The comparison is calibrated in the test, at this step count: two eager runs from the same state already diverge (fp32
+    atomics sum in a run-dependent order, Adam turns that noise into lr-sized steps on near-zero gradients, train-mode BatchNorm
+    amplifies it; after 63 steps at lr 1e-3 the final loss of two eager runs has been seen 0.1 % to 10 % apart), so the bars are
+    graph-vs-eager <= 5 x eager-vs-eager + a floor, on the parameter vector (the well-behaved measure) and on the mean loss of the
+    last 10 steps.  The EXACT statement -- replay == eager bit for bit over 60 replays -- is made where it can be made, in the
+    library's deterministic mode: tests/test_gpu_determinism.py."""
     from rsis_amd.synthetic import synthetic_batch
     from rsis_amd.train import GraphedStep, build_optimizers, runIter, steps_to_run
     from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
@@ -125,23 +132,36 @@ def test_graph_replay_back_to_back_stays_finite():
     t_run = steps_to_run(a, batch[3])
     crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
     enc0, dec0 = _models(a)
-    finals = []
-    for graphed in (False, True):
+    runs = []
+    for graphed in (False, False, True):
         enc, dec = copy.deepcopy(enc0), copy.deepcopy(dec0)
         opts = list(build_optimizers(a, enc, dec))
         g = GraphedStep(a, enc, dec, crits, opts, None, warm=2) if graphed else None
+        losses = []
         for _ in range(63):
             out = g(batch, t_run) if graphed else runIter(a, enc, dec, *batch, crits, opts, mode="train", sync_losses=False, t_run=t_run,
                                                            want_outs=False)
+            losses.append(out[0][0].detach().clone())
         torch.cuda.synchronize()
         for o in opts:
             for name, t in (("p", o.group.flat_p), ("g", o.group.flat_g), ("m", o.group.exp_avg), ("v", o.group.exp_avg_sq)):
                 assert bool(torch.isfinite(t).all()), "%s %s non-finite after 63 %s steps" % (o.group.name, name, "graph" if graphed else "eager")
-        finals.append(float(out[0][0]))
+        losses = torch.stack(losses).double().cpu()
+        assert bool(torch.isfinite(losses).all())
+        runs.append((losses, torch.cat([o.group.flat_p for o in opts]).double().clone()))
         if graphed:
             assert g.graph is not None
             g.release()
-    assert abs(finals[0] - finals[1]) < 0.1 * abs(finals[0]), finals
+    (la, pa), (lb, pb), (lg, pg) = runs
+    spread_p = float((pa - pb).norm() / pa.norm())
+    dist_p = float((pg - pa).norm() / pa.norm())
+    tail = lambda l: float(l[-10:].mean())                                             # noqa: E731
+    spread_l, dist_l = abs(tail(la) - tail(lb)), abs(tail(lg) - tail(la))
+    print("63 steps: eager-vs-eager params %.3e tail-loss %.3e | graph-vs-eager params %.3e tail-loss %.3e (tail loss %.4f, first %.4f)"
+          % (spread_p, spread_l, dist_p, dist_l, tail(la), float(la[0])))
+    assert tail(la) < float(la[0]) and tail(lg) < float(lg[0]), "the loss did not go down over 63 steps"
+    assert dist_p <= 5 * spread_p + 1e-4, (spread_p, dist_p)
+    assert dist_l <= 5 * spread_l + 0.05 * abs(tail(la)), (spread_l, dist_l)
 
 
 def test_graphed_inference_equals_eager():

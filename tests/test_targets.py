@@ -49,3 +49,21 @@ def test_synthetic_targets_clamp_instances_to_gt_slots():
     from rsis_amd.synthetic import synthetic_targets
     ym, yc, swm, swc = synthetic_targets(1, 2, 16, 16, gt_maxseqlen=5, n_inst=12, num_classes=7)
     assert ym.shape == (2, 5, 256) and float(swm.sum()) == 10 and float(swc.sum()) == 10
+
+
+def test_leaves_loader_rank_sharding():
+    """rsis_amd.dataloader.leaves.shard_batches: under one process per GPU every rank sees len(ds) // (B_rank * world) steps per epoch
+    (the reference's len(ds) // B with B the global batch, train.py:46-49), the shards of a step are disjoint and their union is
+    the global batch"""
+    import random
+    from rsis_amd.dataloader.leaves import shard_batches
+    order = list(range(103))
+    random.Random(5).shuffle(order)
+    for world, bs in ((1, 4), (2, 4), (8, 2), (4, 32)):
+        per_rank = [shard_batches(order, bs, r, world) for r in range(world)]
+        steps = len(order) // (bs * world)
+        assert all(len(p) == steps for p in per_rank)
+        for k in range(steps):
+            got = [i for p in per_rank for i in p[k]]
+            assert all(len(p[k]) == bs for p in per_rank)
+            assert sorted(got) == sorted(order[k * bs * world:(k + 1) * bs * world]) and len(set(got)) == len(got)
