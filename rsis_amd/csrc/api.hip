@@ -414,7 +414,9 @@ int rsis_conv2d_wgrad_batch(const rsis_wgrad_job* jobs, int njobs, void* stream)
     rc = wgrad_fill(a, q.dy, q.x, q.dW, q.B, q.Cs, q.H, q.W, q.Cout, q.Ho, q.Wo, q.ks, q.stride, q.pad, q.Ctot, q.c_off, q.lstm_hid);
     if (rc) break;
     const int route = wgrad_route(a, q.ks, q.lstm_hid, q.dtype);
-    if ((route == 1 || route == 2) && (q.ks == 1 || q.ks == 3)) {      // grouped below
+    // (deterministic mode: one launch per job, in order -- several jobs may accumulate into the SAME dW (a conv applied at every
+    //  decoder timestep), and inside one grid their atomics would land in a run-dependent order)
+    if ((route == 1 || route == 2) && (q.ks == 1 || q.ks == 3) && !rsis_deterministic()) {      // grouped below
       const int li = (route == 1 ? 2 : 0) + (q.ks == 3);
       tiled[li][nt[li]++] = a;
     } else rc = wgrad_launch_one(a, route, q.ks, (hipStream_t)stream);

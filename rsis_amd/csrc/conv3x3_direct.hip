@@ -28,9 +28,6 @@
 #include <stdlib.h>
 
 enum { EPI_PLAIN = 0, EPI_LSTM = 1, EPI_S2 = 2, EPI_F2 = 3 };
-#ifndef DIRECT_DMA
-#define DIRECT_DMA 1   // 1: stage global -> LDS with buffer_load ... lds (LDS-DMA); 0: through registers + ds_write
-#endif
 typedef __attribute__((address_space(3))) void* lds_vp_t;
 #define CK RSIS_CK
 
@@ -56,12 +53,11 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs
   constexpr int IMS = PH * PW;                      // one image of the patch
   constexpr int CHS = NI * IMS;                     // channel stride of the patch
   constexpr int XS = CK * CHS, WS = CK * 9 * BM;    // floats per LDS stage
-  constexpr int XSP = DIRECT_DMA ? (XS + NT - 1) / NT * NT : XS;  // the DMA writes whole 64-lane rows: pad the stage
+  constexpr int XSP = (XS + NT - 1) / NT * NT;      // the DMA writes whole 64-lane rows: pad the stage
   constexpr int NX = (XS + NT - 1) / NT;            // patch loads per thread per chunk
   constexpr int W_F4 = WS / 4;
   constexpr int NW = (W_F4 + NT - 1) / NT;          // weight float4 loads per thread per chunk
   static_assert(TN >= 1 && BN % (WGN * 32) == 0 && WGM * WGN * KSP == NWV && (CK / 2) % KSP == 0 && (KSP == 1 || EPI != EPI_S2), "tile");
-  static_assert(EPI != EPI_F2 || DIRECT_DMA, "the stride-2 forward exists for the LDS-DMA staging only");
 
   __shared__ __attribute__((aligned(16))) float lds[2 * (XSP + WS)];
   float* const Xs0 = lds;
@@ -100,7 +96,6 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs
   const int wk = wave / (WGM * WGN);                 // K-half of this wave (0 when KSP == 1)
   const int wm = (wave / WGN) % WGM, wn = wave % WGN;
 
-#if DIRECT_DMA
   // ---- loop-invariant byte offset of this thread's patch elements inside the [CK][H][W] slab of one chunk of image b0;
   // halo / out-of-image elements get an offset beyond the buffer range, which the buffer load turns into a zero ----
   static_assert(NI == 1, "LDS-DMA staging addresses one image per block");
@@ -121,26 +116,6 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs
     const int row = idx / (BM / 4), c4 = idx % (BM / 4);
     wvo[i] = (unsigned)(row * ldw + c4 * 4) * 4u;
   }
-#else
-  // ---- loop-invariant decode of this thread's patch elements: element e -> (channel-in-chunk, image, row, col) ----
-  int goff[NX];      // offset inside one channel plane set: img*Cs*HW is added per source (NI > 1 only)
-  int gimg[NX];
-  int gcl[NX];
-  bool gok[NX];
-#pragma unroll
-  for (int i = 0; i < NX; ++i) {
-    const int e = tid + i * NT;
-    const int cl = e / CHS, rem = e - cl * CHS;
-    const int img = rem / IMS, rem2 = rem - img * IMS;
-    const int py = rem2 / PW, pxx = rem2 - py * PW;
-    const int gy = y0 + py - 1, gx = x0 + pxx - 1;
-    gok[i] = (e < XS) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W) && (b0 + img < B);
-    goff[i] = cl * HW + gy * W + gx;
-    gimg[i] = b0 + img;
-    gcl[i] = cl;
-  }
-
-#endif
 
   // ---- per-lane LDS read bases (bytes are immediates in the unrolled loop) ----
   int xoff[TN];
@@ -172,7 +147,6 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs
   if (cs == 0 && cq >= q0 && q0 < nq_all) { cq -= q0; cs = 1; }
   if (cs == 1 && cq >= q1 && q0 + q1 < nq_all) { cq -= q1; cs = 2; }
 
-#if DIRECT_DMA
   // One chunk = NX dword + NW dwordx4 `buffer_load ... lds` per thread: no staging registers, no ds_write pass, no per-lane
   // 64-bit addresses or predicates (the descriptor's range check zero-fills the halo and the channel tail).
 #define DIRECT_ISSUE(QG, BUF)                                                                             \
@@ -198,60 +172,11 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs
 #define DIRECT_LAND() __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): this wave's DMA has landed in LDS */
   if (nq > 0) DIRECT_ISSUE(q_begin, 0)
   DIRECT_LAND()
-#else
-  float rx[NX];
-  f32x4 rw[NW];
-#define DIRECT_LOAD(QG)                                                                                   \
-  {                                                                                                       \
-    gcf_t src = src0; int Cs = C0;                                                                        \
-    if (cs == 1) { src = src1; Cs = C1; }                                                                 \
-    if (cs == 2) { src = src2; Cs = C2; }                                                                 \
-    const int c0 = cq * CK;                                                                               \
-    const gcf_t sb = src + (size_t)c0 * HW;                                                               \
-    const int crem = Cs - c0;                                                                             \
-    const int CsHW = Cs * HW;                                                                             \
-    _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                      \
-      float v = 0.f;                                                                                      \
-      if (gok[i] && gcl[i] < crem) v = sb[(size_t)gimg[i] * CsHW + goff[i]];                              \
-      rx[i] = v;                                                                                          \
-    }                                                                                                     \
-    const gcf_t wrow = wbase + (size_t)(QG) * (CK * 9) * ldw;                                             \
-    _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                      \
-      const int idx = tid + i * NT;                                                                      \
-      if (W_F4 % NT == 0 || idx < W_F4) {                                                                \
-        const int row = idx / (BM / 4), c4 = idx % (BM / 4);                                              \
-        rw[i] = *(gcf4_t)(wrow + (size_t)row * ldw + c4 * 4);                                             \
-      }                                                                                                   \
-    }                                                                                                     \
-    if (++cq == (cs == 0 ? q0 : (cs == 1 ? q1 : q2))) { cq = 0; ++cs; if (cs == 1 && q1 == 0) ++cs; }     \
-  }
-#define DIRECT_STORE(BUF)                                                                                 \
-  {                                                                                                       \
-    float* Xs = Xs0 + (BUF) * XSP;                                                                        \
-    float* Ws = Ws0 + (BUF) * WS;                                                                         \
-    _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                      \
-      const int e = tid + i * NT;                                                                        \
-      if (XS % NT == 0 || e < XS) Xs[e] = rx[i];                                                         \
-    }                                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                      \
-      const int idx = tid + i * NT;                                                                      \
-      if (W_F4 % NT == 0 || idx < W_F4) *reinterpret_cast<f32x4*>(Ws + idx * 4) = rw[i];                 \
-    }                                                                                                     \
-  }
-  if (nq > 0) {   // nq == 0: no dynamic source at all (ConvLSTM level 0 at t = 0 with the hoisted skip term): gates = addend
-    DIRECT_LOAD(q_begin)
-    DIRECT_STORE(0)
-  }
-#endif
   __syncthreads();
   for (int t = 0; t < nq; ++t) {
     const int cur = t & 1;
     const bool more = t + 1 < nq;
-#if DIRECT_DMA
     if (more) DIRECT_ISSUE(q_begin + t + 1, cur ^ 1)   // stage cur^1 was last read before the barrier that ended step t-1
-#else
-    if (more) DIRECT_LOAD(q_begin + t + 1)
-#endif
     {
       const float* Xs = Xs0 + cur * XSP;
       const float* Ws = Ws0 + cur * WS + woff;
@@ -271,17 +196,11 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs
             for (int j = 0; j < TN; ++j) accs[cls][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], accs[cls][j], 0, 0, 0);
           }
     }
-#if DIRECT_DMA
     DIRECT_LAND()
-#else
-    if (more) DIRECT_STORE(cur ^ 1)
-#endif
     __syncthreads();
   }
 #undef DIRECT_ISSUE
 #undef DIRECT_LAND
-#undef DIRECT_LOAD
-#undef DIRECT_STORE
 
   if constexpr (KSP > 1) {
     // sum the K-halves: waves with wk > 0 park their accumulators in LDS (the staging buffers are dead after the last barrier)

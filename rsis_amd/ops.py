@@ -99,7 +99,7 @@ def repack_all():
         if d == 0:
             p._key_f = p._key(w) + ((b._version, b.data_ptr()) if b is not None else ())
             if b is not None and p.lstm_hid > 0:
-                p.bias_p = b.detach().view(4, p.lstm_hid).t().contiguous().view(-1)
+                p._pack_bias(b)
         else:
             p._key_d = p._key(w)
 
@@ -140,6 +140,16 @@ class PackedConv(object):
     def _key(self, w):
         return (_WEIGHT_EPOCH[0], w._version, w.data_ptr(), self.dtype)
 
+    def _pack_bias(self, bias):
+        """gate-interleaved copy of a ConvLSTM bias (row 4*j + gate), refreshed IN PLACE in a buffer allocated once: the kernels of
+        a captured training iteration read this address in its forward part and repack_all() rewrites it at the end of the same
+        capture -- a freshly allocated tensor per repack would leave every replay after the first reading the capture-time values
+        (in freed memory)."""
+        n = 4 * self.lstm_hid
+        if self.bias_p is None or self.bias_p.numel() != n or self.bias_p.device != bias.device:
+            self.bias_p = torch.empty(n, dtype=torch.float32, device=bias.device)
+        self.bias_p.view(self.lstm_hid, 4).copy_(bias.detach().view(4, self.lstm_hid).t())
+
     def _job(self, w, out, dgrad):
         j = _lib.PackJob()
         j.W, j.out, j.dgrad, j.dtype = w.data_ptr(), out.data_ptr(), int(dgrad), self.dtype
@@ -167,7 +177,7 @@ class PackedConv(object):
             check(L.rsis_conv_pack_fwd(ptr(w.detach()), ptr(self.wp), Cout, Ctot, self.ks, self.stride, self.pad, nseg, segs, offs,
                                        self.lstm_hid, self.dtype, stream()), "rsis_conv_pack_fwd")
             if bias is not None and self.lstm_hid > 0:
-                self.bias_p = bias.detach().view(4, self.lstm_hid).t().contiguous().view(-1)
+                self._pack_bias(bias)
             self._key_f = key
             self._refs = (weakref.ref(w), weakref.ref(bias) if bias is not None else None)
             _PACKS.add(self)
