@@ -468,6 +468,12 @@ def main():
     if gstep is not None:
         note("hipGraph: %s" % ("captured, replaying" if gstep.graph is not None else "NOT captured (%s): eager launches" % gstep.failed))
     note("warmup done %.2f s" % (time.time() - tw))
+    if dist.is_initialized():
+        note("gradient exchange: backend %s, communicator size %d (%s)" % (dist.get_backend(), dist.get_world_size(),
+             "graph A | all-reduce(dec) || graph B | all-reduce(trunk) | graph C" if (gstep is not None and gstep.graph is not None and gstep.split)
+             else "bucketed all-reduce from autograd hooks (eager launches)"))
+    if gstep is not None and gstep.graph is not None and gstep.split:
+        gstep.timing = True            # HIP events around graph A / graph B (+ overlapped collective) / exposed collective / graph C
     t0 = time.time()
     marks, evs = [], [torch.cuda.Event(enable_timing=True) for _ in range(o.steps + 1)]
     evs[0].record()
@@ -480,6 +486,12 @@ def main():
     health("after timed", losses)
     note("host enqueue marks (s): %s | end %.3f" % (" ".join("%.3f" % m for m in marks), dt))
     note("GPU ms per step (events): %s" % " ".join("%.1f" % evs[i].elapsed_time(evs[i + 1]) for i in range(o.steps)))
+    seg = gstep.segment_ms() if (gstep is not None and gstep.timing) else None
+    if seg is not None:
+        note("split-graph schedule, ms per step over %d replays: graph A (fwd + BPTT + decoder/skip wgrads) %.2f | graph B (trunk backward, the "
+             "decoder group's all-reduce in flight) %.2f | EXPOSED all-reduce (wait for the decoder group + the trunk group) %.2f | graph C "
+             "(Adam + repack) %.2f" % (seg["replays"], seg["graph_A_fwd_bptt"], seg["graph_B_trunk_bwd_overlapping_allreduce_dec"],
+                                       seg["exposed_allreduce"], seg["graph_C_adam_repack"]))
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -525,6 +537,8 @@ def main():
                           "launch": "hipGraph replay of the captured iteration" if (gstep is not None and gstep.graph is not None)
                                     else "eager (one Python launch per kernel)"},
                "roofline": roof, "roofline_kernels": roof_kernels, "cpu_baseline": cpu, "secondary": secondary}
+        if seg is not None:
+            out["config"]["exchange_ms_per_step"] = {k: round(v, 3) for k, v in seg.items()}
     # RCCL prints a banner (version, library path) through C stdio, which on a pipe is flushed only at exit, i.e. AFTER anything
     # python printed: every rank flushes its C streams before the final barrier, rank 0 prints after it, so that the JSON line
     # is the last line of the job's (merged) stdout

@@ -42,6 +42,11 @@ class FeatureExtractor(nn.Module):
         self.bn2 = HipBatchNorm2d(hs // 4)
         self.bn1 = HipBatchNorm2d(hs // 8)
         self._bns = None
+        # split_backward: cut the autograd graph between the trunk and the skip convs (train.GraphedStep with a gradient exchange):
+        # the skip convs / decoder then back-propagate into leaf copies of x5..x1, and backward_trunk() continues from there --
+        # so that the decoder-group gradients are final (and can travel) before the trunk's backward starts
+        self.split_backward = False
+        self._cut = None
         ops.set_dtype(self, getattr(args, "dtype", "fp32"))      # `-dtype bf16`: bf16-operand MFMA kernels where they exist
 
     def _arm_bn_arena(self, device):
@@ -65,12 +70,31 @@ class FeatureExtractor(nn.Module):
             return x5
         if raw:
             return x5, x4, x3, x2, x1
+        self._cut = None
+        if self.split_backward and self.training and torch.is_grad_enabled() and x5.requires_grad:
+            roots = (x5, x4, x3, x2, x1)
+            leaves = tuple(t.detach().requires_grad_(True) for t in roots)
+            self._cut = (roots, leaves)
+            x5, x4, x3, x2, x1 = leaves
         x5_skip = self.bn5(self.sk5(x5))             # model.py:59-63 (BN, no ReLU)
         x4_skip = self.bn4(self.sk4(x4))
         x3_skip = self.bn3(self.sk3(x3))
         x2_skip = self.bn2(self.sk2(x2))
         x1_skip = self.bn1(self.sk1(x1))
         return x5_skip, x4_skip, x3_skip, x2_skip, x1_skip
+
+    def backward_trunk(self):
+        """second half of a split backward (see split_backward): back-propagate the gradients the skip convs left on the leaf
+        copies of x5..x1 through the trunk.  The taps of x1..x4 (ops.grad_tap, ResNet101.forward) are the youngest nodes of the
+        trunk's graph, so autograd runs them first: they park their gradient for the in-place hand-over exactly as in the
+        unsplit backward."""
+        if self._cut is None:
+            return False
+        roots, leaves = self._cut
+        self._cut = None
+        pairs = [(r, l.grad) for r, l in zip(roots, leaves) if l.grad is not None]
+        torch.autograd.backward([r for r, _g in pairs], [g for _r, g in pairs])
+        return True
 
 
 class RSIS(nn.Module):

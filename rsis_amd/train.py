@@ -62,13 +62,15 @@ def apply_update(args, optims, gscale=1.0):
 
 
 def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits, optims, mode="train", reducer=None,
-            sync_losses=True, t_run=None, want_outs=True, do_update=True):
+            sync_losses=True, t_run=None, want_outs=True, do_update=True, between=None):
     """Runs forward, computes loss and (if train mode) updates parameters for the provided batch (train.py:54-197).
     Returns (losses [total, iou, stop, class], outs [sigmoid(masks), class probs], perms [y_mask_perm, y_class_perm]).
     want_outs=False (training loops that only log the losses, as the reference's trainIters does: train.py:344-356): the
     sigmoid of all T full-resolution masks (train.py:191) is not computed and outs[0] holds the raw logits.
     do_update=False: stop after the backward (gradients left in the flat buffers; the caller all-reduces them and calls
-    apply_update) -- the split GraphedStep uses when a gradient exchange sits between the backward and the optimizer."""
+    apply_update) -- the split GraphedStep uses when a gradient exchange sits between the backward and the optimizer.
+    between: called between the two halves of a split backward (encoder.split_backward: decoder + skip convs first -- their
+    gradients are final when it is called -- then the trunk)."""
     from .utils.hungarian import MaskedNLL, StableBalancedMaskedBCE, softIoU
     mask_siou, class_crit, stop_xentropy = crits
     enc_opt, dec_opt = optims
@@ -163,6 +165,11 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
         try:
             loss.backward()                                           # :184
             ops.flush_wgrads()         # the weight gradients parked during backward (ops.wgrad_launch), as grouped launches
+            if getattr(encoder, "_cut", None) is not None:            # split backward: the trunk's half
+                if between is not None:
+                    between()
+                encoder.backward_trunk()
+                ops.flush_wgrads()
         finally:
             ops.DIRECT_GRAD[0] = prev
             ops.WGRAD_DEFER[0] = prev_defer
@@ -238,41 +245,56 @@ class GraphedStep(object):
     The first `warm` calls run eagerly on a side stream (they are real training steps), the next one captures.  A capture is
     valid for one (input shapes, t_run, loss switches, update_encoder, active parameter set) key; the caller keeps one per key.
     Inputs are copied into static buffers; the returned losses / outs / perms are static device tensors overwritten by the
-    next replay.  (Nothing inside the iteration may be a hipMemsetAsync: memset NODES of a captured graph are not reliably ordered
-    against the neighbouring kernel nodes when graphs are replayed back to back on this stack -- 60 replays in a row ended in
-    non-finite Adam moments every time -- so the library zero-fills with a kernel, common.h: rsis_zero_async.)
+    next replay.  State that flows from one iteration to the next (parameters, packed weights and gate biases, Adam moments and
+    step counts, BatchNorm statistics) must live in buffers allocated BEFORE the capture and be updated in place: a tensor
+    re-allocated inside the capture is read at its OLD address by the part of the graph captured before it (ops.PackedConv._pack_bias;
+    found by tests/test_gpu_determinism.py).  The library zero-fills with a kernel, never hipMemsetAsync (common.h rsis_zero_async).
 
-    With a gradient exchange (`reducer` active: one process per GPU) the iteration is TWO graphs with the RCCL all-reduce of
-    the flat gradient buffers between them, launched eagerly: RCCL refuses stream capture on this stack (ProcessGroupNCCL raises
-    hipErrorStreamCaptureUnsupported from its watchdog thread, which terminates the process), and this keeps the collective
-    out of the capture entirely.  The all-reduce (194 MB, ~1-2 ms over xGMI) is then not overlapped with the backward."""
+    With a gradient exchange (`reducer` active: one process per GPU) the iteration is THREE graphs, because RCCL refuses stream
+    capture on this stack (ProcessGroupNCCL raises hipErrorStreamCaptureUnsupported from its watchdog thread, which terminates the
+    process) and the collectives are therefore launched eagerly BETWEEN graphs, cut where the gradient groups become final:
+        graph A : forward, matching, losses, BPTT through the decoder and the skip convs, their weight-gradient flush
+                  -> the decoder + skip group's flat gradient is final
+        RCCL    : all-reduce of that group, asynchronous (ProcessGroupNCCL's own stream)      ||  graph B
+        graph B : the trunk's backward (FeatureExtractor.backward_trunk) + its weight-gradient flush
+        RCCL    : all-reduce of the trunk group (the exposed part of the exchange)
+        graph C : both Adam steps (gradient scale 1 / world) + the batched weight repack
+    i.e. the bucketed, overlapped schedule of the eager path (optim.BucketedAllReduce) at the granularity the capture allows.
+    `timing = True` brackets the five segments with HIP events (bench.py prints their averages)."""
 
     def __init__(self, args, encoder, decoder, crits, optims, reducer=None, warm=2, pool=None):
         self.args, self.encoder, self.decoder, self.crits, self.optims, self.reducer = args, encoder, decoder, crits, optims, reducer
         self.split = reducer is not None and getattr(reducer, "active", False)
         if self.split:
-            # the two-graph schedule all-reduces the flat gradient buffers itself (_exchange): the reducer's per-bucket hooks
-            # must not fire inside these backward passes (they would reduce the first warm-up step's gradients twice)
+            # this schedule all-reduces the flat gradient buffers itself: the reducer's per-bucket hooks must not fire inside
+            # these backward passes (they would reduce the first warm-up step's gradients twice)
             reducer.hooks_enabled = False
+            encoder.split_backward = True
         self.warm, self.pool = warm, pool
-        self.graph, self.graph_update, self.static, self.result, self.t_run = None, None, None, None, None
+        self.graph, self.graph_b, self.graph_update, self.static, self.result, self.t_run = None, None, None, None, None, None
         self.stream = torch.cuda.Stream()
         self.n_eager = 0
         self._bns = None
         self.failed = None
         self._in_src = None
+        self.timing, self._events = False, []
 
-    def _run(self, batch, t_run, do_update=True):
+    def _run(self, batch, t_run, do_update=True, between=None):
         return runIter(self.args, self.encoder, self.decoder, *batch, self.crits, self.optims, mode="train",
-                       reducer=None if self.split else self.reducer, sync_losses=False, t_run=t_run, want_outs=False, do_update=do_update)
+                       reducer=None if self.split else self.reducer, sync_losses=False, t_run=t_run, want_outs=False, do_update=do_update,
+                       between=between)
 
     def _groups(self):
         return [o.group for o in self.optims if isinstance(o, FlatAdam)]
 
-    def _exchange(self):
-        """SUM all-reduce of the flat gradient buffers (decoder + skip group first), eagerly, on the replay stream"""
-        for g in reversed(self._groups()):
-            dist.all_reduce(g.flat_g, op=dist.ReduceOp.SUM, group=self.reducer.pg)
+    def _reduce(self, group, async_op=False):
+        """SUM all-reduce of one flat gradient buffer, issued from the current stream (RCCL runs it on its own stream after the
+        work already enqueued here; `wait()` -- or the synchronous form -- makes the current stream wait for it)"""
+        return dist.all_reduce(group.flat_g, op=dist.ReduceOp.SUM, group=self.reducer.pg, async_op=async_op)
+
+    def _dec_enc(self):
+        enc_g = self.optims[0].group
+        return [g for g in self._groups() if g is not enc_g], enc_g
 
     def __call__(self, batch, t_run):
         if self.graph is None and self.failed is None and self.n_eager >= self.warm:
@@ -282,8 +304,12 @@ class GraphedStep(object):
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 if self.split:
-                    res = self._run(batch, t_run, do_update=False)
-                    self._exchange()
+                    dec_gs, enc_g = self._dec_enc()
+                    pending = []
+                    res = self._run(batch, t_run, do_update=False, between=lambda: pending.extend(self._reduce(g, True) for g in dec_gs))
+                    for h in pending:
+                        h.wait()
+                    self._reduce(enc_g)
                     apply_update(self.args, self.optims, 1.0 / self.reducer.world)
                 else:
                     res = self._run(batch, t_run)
@@ -301,10 +327,26 @@ class GraphedStep(object):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
             self._in_src = [(t, t._version) for t in batch]
-        self.graph.replay()
-        if self.split:
-            self._exchange()
-            self.graph_update.replay()
+        if not self.split:
+            self.graph.replay()
+        else:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if self.timing else None
+            mark = (lambda k: ev[k].record()) if ev is not None else (lambda k: None)
+            dec_gs, enc_g = self._dec_enc()
+            mark(0)
+            self.graph.replay()                                    # A
+            mark(1)
+            pending = [self._reduce(g, True) for g in dec_gs]      # decoder + skip group: travels while graph B runs
+            self.graph_b.replay()                                  # B
+            mark(2)
+            for h in pending:
+                h.wait()
+            self._reduce(enc_g)                                    # trunk group: the exposed part
+            mark(3)
+            self.graph_update.replay()                             # C
+            mark(4)
+            if ev is not None:
+                self._events.append(ev)
 
         for g in self._groups():
             if self.args.update_encoder or g is not self.optims[0].group:
@@ -312,6 +354,18 @@ class GraphedStep(object):
         for m in self._bns:                        # HipBatchNorm2d counts its training calls on the host
             m._nbt_pending += 1
         return self.result
+
+    def segment_ms(self):
+        """average milliseconds of (graph A, graph B incl. the overlapped collective, exposed collective, graph C) over the timed
+        replays so far (`timing`); synchronises"""
+        if not self._events:
+            return None
+        torch.cuda.synchronize()
+        n = len(self._events)
+        seg = [sum(e[k].elapsed_time(e[k + 1]) for e in self._events) / n for k in range(4)]
+        self._events = []
+        return {"graph_A_fwd_bptt": seg[0], "graph_B_trunk_bwd_overlapping_allreduce_dec": seg[1], "exposed_allreduce": seg[2],
+                "graph_C_adam_repack": seg[3], "replays": n}
 
     def _capture(self, batch, t_run):
         from .modules.vision import HipBatchNorm2d
@@ -322,7 +376,7 @@ class GraphedStep(object):
         groups = self._groups()
         for g in groups:
             g.begin_graph()
-        graph, graph_u = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        graph, graph_b, graph_u = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         try:
             torch.cuda.synchronize()
             if dist.is_initialized():
@@ -336,12 +390,38 @@ class GraphedStep(object):
             # is an error, and the RCCL watchdog thread polls the events of the eager all-reduces that ran just before -- one
             # run in six died with hipErrorStreamCaptureUnsupported raised inside the watchdog (the loader's staging threads
             # are the other candidate)
-            with torch.cuda.graph(graph, pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
-                self.result = self._run(self.static, t_run, do_update=not self.split)
-            if self.split:
-                with torch.cuda.graph(graph_u, pool=graph.pool(), stream=self.stream, capture_error_mode="thread_local"):
-                    apply_update(self.args, self.optims, 1.0 / self.reducer.world)
-                self.graph_update = graph_u
+            if not self.split:
+                with torch.cuda.graph(graph, pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
+                    self.result = self._run(self.static, t_run)
+            else:
+                # one pass of runIter, cut into graph A | graph B where its split backward calls back (same thread: the callback
+                # runs in runIter between the two backward calls), then graph C; all three share one memory pool (they always
+                # replay in this order, so blocks freed by one may be reused by the next exactly as inside a single capture)
+                state = {"cur": graph}
+
+                def cut():
+                    state["cur"].capture_end()
+                    state["cur"] = graph_b
+                    graph_b.capture_begin(pool=graph.pool(), capture_error_mode="thread_local")
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                self.stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.stream):
+                    graph.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+                    try:
+                        self.result = self._run(self.static, t_run, do_update=False, between=cut)
+                        if state["cur"] is graph:      # (no split point was reached: the encoder produced no cut)
+                            cut()
+                    finally:
+                        state["cur"].capture_end()
+                    graph_u.capture_begin(pool=graph.pool(), capture_error_mode="thread_local")
+                    try:
+                        apply_update(self.args, self.optims, 1.0 / self.reducer.world)
+                    finally:
+                        graph_u.capture_end()
+                torch.cuda.current_stream().wait_stream(self.stream)
+                self.graph_b, self.graph_update = graph_b, graph_u
             self.graph = graph
         except Exception as e:  # noqa: BLE001  (capture refused: stay eager)
             self.failed = repr(e)
@@ -354,7 +434,7 @@ class GraphedStep(object):
     def release(self):
         for g in self._groups():
             g.end_graph()
-        self.graph = self.graph_update = self.result = self.static = self._in_src = None
+        self.graph = self.graph_b = self.graph_update = self.result = self.static = self._in_src = None
 
 
 def init_dataloaders(args, rank=0, world=1):

@@ -1,0 +1,55 @@
+"""bench.py as the driver launches it for N > 1 (BASELINE configs[3]'s plumbing): `python -m torch.distributed.run --nproc-per-node 2
+bench.py --gpus 2 ...`, here with both ranks sharing the one GPU of the test box over gloo (RSIS_SHARE_GPU=1, RSIS_DIST_BACKEND=gloo;
+RCCL needs one GPU per rank).  Checks the contract of the output -- exactly one JSON line on stdout, n_gpus 2, weak scaling, a finite
+loss -- and that the replayed launch mode used the three-graph overlapped gradient exchange (train.GraphedStep)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(extra, env_extra):
+    env = dict(os.environ, RSIS_SHARE_GPU="1", RSIS_DIST_BACKEND="gloo", **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--batch", "4",
+           "--imsize", "128", "--T", "3", "--skip-cpu", "--skip-roofline", "--skip-secondary", "--no-settle"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, "bench.py --gpus 2 failed:\n%s\n%s" % (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    return lines, r.stderr
+
+
+def test_bench_two_ranks_one_json_line_graph_replay():
+    lines, err = _run([], {})
+    assert len(lines) == 1, "stdout must hold exactly one line, got %d: %s" % (len(lines), lines[:3])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3 and out["higher_is_better"] is True
+    assert out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
+    assert "hipGraph replay" in out["config"]["launch"], out["config"]["launch"]
+    ex = out["config"]["exchange_ms_per_step"]
+    assert ex["replays"] == 3 and all(ex[k] >= 0 for k in ("graph_A_fwd_bptt", "graph_B_trunk_bwd_overlapping_allreduce_dec", "exposed_allreduce",
+                                                          "graph_C_adam_repack"))
+    assert "communicator size 2" in err and "split-graph schedule" in err
+
+
+def test_bench_two_ranks_eager_bucketed_exchange():
+    lines, err = _run(["--no-graph"], {})
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
+    assert "eager" in out["config"]["launch"]

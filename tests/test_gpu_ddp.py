@@ -106,6 +106,95 @@ def test_runiter_world2_gradients_and_parameters_agree():
     assert res[0][4] > 0, "the optimizer step did not change the parameters"
 
 
+def _worker_split_graph(rank, world, port, q):
+    """the three-graph overlapped schedule of train.GraphedStep (graph A | all-reduce(decoder group) || graph B | all-reduce(trunk) |
+    graph C) against the eager bucketed schedule (optim.BucketedAllReduce hooks), both ranks on the one GPU over gloo, library in
+    its deterministic mode: the two schedules are the same arithmetic, so after three steps from identical replicas on different
+    shards every parameter must be BIT-identical between them -- and between the ranks"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      RSIS_DETERMINISTIC="1")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import copy
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import mk_args
+    from rsis_amd import ops
+    from rsis_amd.modules import RSIS, FeatureExtractor
+    from rsis_amd.optim import BucketedAllReduce
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import GraphedStep, build_optimizers, runIter, steps_to_run
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    torch.cuda.set_device(0)
+    assert ops.is_deterministic()
+    a = mk_args(hidden_size=32, maxseqlen=3, optim="adam", optim_cnn="adam", lr=1e-3, lr_cnn=1e-4, weight_decay=0.0, weight_decay_cnn=0.0)
+    a.gt_maxseqlen, a.num_classes = 5, 7
+    torch.manual_seed(0)                                   # identical replicas
+    enc0, dec0 = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(0.5)]
+    batch = synthetic_batch(10 + rank, 2, 64, 64, 5, 3, 7, "cuda")          # a different shard per rank
+    t_run = steps_to_run(a, batch[3])
+    finals, losses = [], []
+    for graphed in (False, True):
+        enc, dec = copy.deepcopy(enc0), copy.deepcopy(dec0)
+        enc_opt, dec_opt = build_optimizers(a, enc, dec)
+        red = BucketedAllReduce([dec_opt.group, enc_opt.group], bucket_bytes=8 << 20)
+        g = GraphedStep(a, enc, dec, crits, [enc_opt, dec_opt], red, warm=1) if graphed else None
+        for _ in range(3):
+            if graphed:
+                out = g(batch, t_run)
+            else:
+                out = runIter(a, enc, dec, *batch, crits, [enc_opt, dec_opt], mode="train", reducer=red, sync_losses=False, t_run=t_run,
+                              want_outs=False)
+        torch.cuda.synchronize()
+        losses.append(float(out[0][0]))
+        if graphed:
+            assert g.graph is not None and g.graph_b is not None and g.graph_update is not None, "capture failed: %s" % g.failed
+            assert dec_opt.group.steps[0] == 3 and enc_opt.group.steps[0] == 3
+        finals.append((torch.cat([dec_opt.group.flat_p, enc_opt.group.flat_p]).clone(),
+                       torch.cat([dec_opt.group.flat_g, enc_opt.group.flat_g]).clone()))
+        if graphed:
+            g.release()
+        for h in red._hooks:
+            h.remove()
+    (pe, ge), (pg, gg) = finals
+    dp, dg = float((pe - pg).abs().max()), float((ge - gg).abs().max())
+    moved = float((pe[:1000] - torch.cat([p.detach().reshape(-1) for p in dec0.parameters()])[:1000]).abs().max())
+    assert moved > 0, "the optimizer steps did not change the parameters"
+    t = pg.double().cpu()
+    q.put((rank, dp, dg, float(t.sum()), float(t.abs().sum()), t[::997].numpy().copy(), losses, moved))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_split_graph_schedule_equals_eager_bucketed_schedule_world2():
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_split_graph, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    res, t0 = [], time.time()
+    while len(res) < 2:
+        try:
+            res.append(q.get(timeout=5))
+        except queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), "a rank crashed: %s" % [p.exitcode for p in procs]
+            assert time.time() - t0 < 300, "timed out"
+    res.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] == 0.0 and r[2] == 0.0, "rank %d: split-graph vs eager schedule: max |d param| %.3e, max |d grad| %.3e" % (r[0], r[1], r[2])
+        assert r[6][0] == r[6][1] and r[6][0] == r[6][0]
+    a, b = res
+    assert a[3] == b[3] and a[4] == b[4] and np.array_equal(a[5], b[5]), "parameters diverged between ranks"
+
+
 def _worker_nccl(rank, world, port, q):
     """one process per GPU over RCCL: identical replicas, different shards, two real steps (eager, then hipGraph replay)"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
