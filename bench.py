@@ -470,7 +470,8 @@ def main():
     note("warmup done %.2f s" % (time.time() - tw))
     if dist.is_initialized():
         note("gradient exchange: backend %s, communicator size %d (%s)" % (dist.get_backend(), dist.get_world_size(),
-             "graph A | all-reduce(dec) || graph B | all-reduce(trunk) | graph C" if (gstep is not None and gstep.graph is not None and gstep.split)
+             "%d cuts: graph A | all-reduce(dec) || graph B1 | all-reduce(layers 3-4) || graph B2 | all-reduce(rest) | graph C" % gstep.cuts
+             if (gstep is not None and gstep.graph is not None and gstep.split)
              else "bucketed all-reduce from autograd hooks (eager launches)"))
     if gstep is not None and gstep.graph is not None and gstep.split:
         gstep.timing = True            # HIP events around graph A / graph B (+ overlapped collective) / exposed collective / graph C
@@ -488,10 +489,10 @@ def main():
     note("GPU ms per step (events): %s" % " ".join("%.1f" % evs[i].elapsed_time(evs[i + 1]) for i in range(o.steps)))
     seg = gstep.segment_ms() if (gstep is not None and gstep.timing) else None
     if seg is not None:
-        note("split-graph schedule, ms per step over %d replays: graph A (fwd + BPTT + decoder/skip wgrads) %.2f | graph B (trunk backward, the "
-             "decoder group's all-reduce in flight) %.2f | EXPOSED all-reduce (wait for the decoder group + the trunk group) %.2f | graph C "
-             "(Adam + repack) %.2f" % (seg["replays"], seg["graph_A_fwd_bptt"], seg["graph_B_trunk_bwd_overlapping_allreduce_dec"],
-                                       seg["exposed_allreduce"], seg["graph_C_adam_repack"]))
+        note("split-graph schedule (%d cuts), ms per step over %d replays: %s | EXPOSED all-reduce (wait for the ranges in flight + the "
+             "remaining range) %.2f | graph C (Adam + repack) %.2f"
+             % (seg["cuts"], seg["replays"], " | ".join("%s %.2f" % (k, v) for k, v in seg.items() if k.startswith(("graph_A", "graph_B"))),
+                seg["exposed_allreduce"], seg["graph_C_adam_repack"]))
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

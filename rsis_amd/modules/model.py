@@ -45,7 +45,7 @@ class FeatureExtractor(nn.Module):
         # split_backward: cut the autograd graph between the trunk and the skip convs (train.GraphedStep with a gradient exchange):
         # the skip convs / decoder then back-propagate into leaf copies of x5..x1, and backward_trunk() continues from there --
         # so that the decoder-group gradients are final (and can travel) before the trunk's backward starts
-        self.split_backward = False
+        self.split_backward = 0          # 0 off, 1 cut at the skip convs, 2 also in front of layer3 (ResNet101.cut_layer3)
         self._cut = None
         ops.set_dtype(self, getattr(args, "dtype", "fp32"))      # `-dtype bf16`: bf16-operand MFMA kernels where they exist
 
@@ -65,6 +65,7 @@ class FeatureExtractor(nn.Module):
     def forward(self, x, semseg=False, raw=False):
         if self.training and x.is_cuda:
             self._arm_bn_arena(x.device)
+        self.base.cut_layer3 = int(self.split_backward) >= 2
         x5, x4, x3, x2, x1 = self.base(x)            # model.py:57
         if semseg:
             return x5
@@ -83,17 +84,33 @@ class FeatureExtractor(nn.Module):
         x1_skip = self.bn1(self.sk1(x1))
         return x5_skip, x4_skip, x3_skip, x2_skip, x1_skip
 
-    def backward_trunk(self):
+    def backward_trunk(self, between=None):
         """second half of a split backward (see split_backward): back-propagate the gradients the skip convs left on the leaf
         copies of x5..x1 through the trunk.  The taps of x1..x4 (ops.grad_tap, ResNet101.forward) are the youngest nodes of the
         trunk's graph, so autograd runs them first: they park their gradient for the in-place hand-over exactly as in the
-        unsplit backward."""
+        unsplit backward.  With the second cut (split_backward == 2) this call first runs layers 4-3 down to the leaf copy of x3,
+        flushes their parked weight gradients, calls between("trunk_hi") -- the gradients of layers 3-4 are final -- and then
+        continues through layers 2-1 and the stem."""
         if self._cut is None:
             return False
         roots, leaves = self._cut
         self._cut = None
-        pairs = [(r, l.grad) for r, l in zip(roots, leaves) if l.grad is not None]
-        torch.autograd.backward([r for r, _g in pairs], [g for _r, g in pairs])
+        trip = [(k, r, l.grad) for k, (r, l) in enumerate(zip(roots, leaves)) if l.grad is not None]      # k: x5, x4, x3, x2, x1
+        pairs = [(r, g) for _k, r, g in trip]
+        cut3, self.base._cut3 = self.base._cut3, None
+        if cut3 is None:
+            torch.autograd.backward([r for r, _g in pairs], [g for _r, g in pairs])
+            return True
+        # first half: x5 and the taps of x4 / x3 (the x3 tap sits on the leaf copy) -> layers 4-3; the taps of x2 / x1 wait for the
+        # second half, whose graph (layers 2-1, stem) consumes what they park
+        hi = [(r, g) for k, r, g in trip if k < 3]
+        lo = [(r, g) for k, r, g in trip if k >= 3]
+        torch.autograd.backward([r for r, _g in hi], [g for _r, g in hi])
+        ops.flush_wgrads()
+        if between is not None:
+            between("trunk_hi")
+        lo = [(cut3[0], cut3[1].grad)] + lo
+        torch.autograd.backward([r for r, _g in lo], [g for _r, g in lo])
         return True
 
 

@@ -123,6 +123,11 @@ class ResNet101(nn.Module):
         self.layer4 = self._make_layer(512, 3, stride=2)
         self.fc = nn.Linear(2048, 1000)  # present in reference checkpoints, never used in forward (vision.py:11-21)
         self._slot_x1 = ops.GradSlot()
+        # cut_layer3: cut the autograd graph between layer2 and layer3 (FeatureExtractor.split_backward == 2): the backward of
+        # layers 3-4 (41 M of the trunk's 44.5 M parameters) then ends at a leaf copy of x3 and FeatureExtractor.backward_trunk
+        # continues from it after a callback -- their gradients can travel while layers 2, 1 and the stem back-propagate
+        self.cut_layer3 = False
+        self._cut3 = None
 
     def _make_layer(self, planes, blocks, stride=1):
         downsample = None
@@ -141,7 +146,16 @@ class ResNet101(nn.Module):
         x = ops.maxpool3x3s2(x1, grad_slot=self._slot_x1 if hand else None)   # :15
         x2 = self.layer1(x)
         x3 = self.layer2(x2)
-        x4 = self.layer3(x3)
+        self._cut3 = None
+        if self.cut_layer3 and hand and x3.requires_grad:
+            # (the skip connection of this level then taps the LEAF copy: a tap on x3 itself would make layers 2-1 reachable
+            #  from the first half's roots, and autograd would run them there with undefined gradients)
+            x3_in = x3.detach().requires_grad_(True)
+            self._cut3 = (x3, x3_in)
+            x4 = self.layer3(x3_in)
+            x3 = x3_in
+        else:
+            x4 = self.layer3(x3)
         x5 = self.layer4(x4)
         if self.training:
             # x2..x4 also leave the trunk (skip connections): their outside gradient is parked for the next stage's strided

@@ -69,8 +69,8 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
     sigmoid of all T full-resolution masks (train.py:191) is not computed and outs[0] holds the raw logits.
     do_update=False: stop after the backward (gradients left in the flat buffers; the caller all-reduces them and calls
     apply_update) -- the split GraphedStep uses when a gradient exchange sits between the backward and the optimizer.
-    between: called between the two halves of a split backward (encoder.split_backward: decoder + skip convs first -- their
-    gradients are final when it is called -- then the trunk)."""
+    between: callback of a split backward (encoder.split_backward): between("dec") when the decoder + skip-conv gradients are
+    final and the trunk's backward is about to start, between("trunk_hi") when those of trunk layers 3-4 are (second cut)."""
     from .utils.hungarian import MaskedNLL, StableBalancedMaskedBCE, softIoU
     mask_siou, class_crit, stop_xentropy = crits
     enc_opt, dec_opt = optims
@@ -167,8 +167,8 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
             ops.flush_wgrads()         # the weight gradients parked during backward (ops.wgrad_launch), as grouped launches
             if getattr(encoder, "_cut", None) is not None:            # split backward: the trunk's half
                 if between is not None:
-                    between()
-                encoder.backward_trunk()
+                    between("dec")
+                encoder.backward_trunk(between)
                 ops.flush_wgrads()
         finally:
             ops.DIRECT_GRAD[0] = prev
@@ -238,6 +238,9 @@ def build_optimizers(args, encoder, decoder):
     return enc_opt, dec_opt
 
 
+EXCHANGE_CUTS = int(os.environ.get("RSIS_EXCHANGE_CUTS", "2"))     # 0 / 1 / 2, see GraphedStep
+
+
 class GraphedStep(object):
     """One training iteration (runIter: encoder, T decoder steps, matching, losses, backward, gradient exchange, both Adam
     steps, weight repack) captured ONCE as hipGraphs and replayed: the ~1000 kernel launches of a step cost the host a
@@ -250,34 +253,48 @@ class GraphedStep(object):
     re-allocated inside the capture is read at its OLD address by the part of the graph captured before it (ops.PackedConv._pack_bias;
     found by tests/test_gpu_determinism.py).  The library zero-fills with a kernel, never hipMemsetAsync (common.h rsis_zero_async).
 
-    With a gradient exchange (`reducer` active: one process per GPU) the iteration is THREE graphs, because RCCL refuses stream
+    With a gradient exchange (`reducer` active: one process per GPU) the iteration is SEVERAL graphs, because RCCL refuses stream
     capture on this stack (ProcessGroupNCCL raises hipErrorStreamCaptureUnsupported from its watchdog thread, which terminates the
-    process) and the collectives are therefore launched eagerly BETWEEN graphs, cut where the gradient groups become final:
-        graph A : forward, matching, losses, BPTT through the decoder and the skip convs, their weight-gradient flush
-                  -> the decoder + skip group's flat gradient is final
-        RCCL    : all-reduce of that group, asynchronous (ProcessGroupNCCL's own stream)      ||  graph B
-        graph B : the trunk's backward (FeatureExtractor.backward_trunk) + its weight-gradient flush
-        RCCL    : all-reduce of the trunk group (the exposed part of the exchange)
-        graph C : both Adam steps (gradient scale 1 / world) + the batched weight repack
-    i.e. the bucketed, overlapped schedule of the eager path (optim.BucketedAllReduce) at the granularity the capture allows.
-    `timing = True` brackets the five segments with HIP events (bench.py prints their averages)."""
+    process): the collectives are launched eagerly BETWEEN graphs, cut where a range of the flat gradient buffers becomes final
+    (`cuts`, default RSIS_EXCHANGE_CUTS = 2):
+        graph A  : forward, matching, losses, BPTT through the decoder and the skip convs, their weight-gradient flush
+        RCCL     : all-reduce of the decoder + skip group (24 MB at hidden 128), asynchronous          ||  graph B1
+        graph B1 : backward of trunk layers 4-3 + their weight-gradient flush          (cuts >= 1; with cuts == 1: the whole trunk)
+        RCCL     : all-reduce of the gradients of layers 3-4 (165 of the trunk's 178 MB), asynchronous ||  graph B2
+        graph B2 : backward of layers 2-1 and the stem + flush                         (cuts == 2)
+        RCCL     : wait for both, all-reduce of what is left (5.6 MB: the exposed part of the exchange)
+        graph C  : both Adam steps (gradient scale 1 / world) + the batched weight repack
+    i.e. the bucketed, overlapped schedule of the eager path (optim.BucketedAllReduce) at the granularity a capture allows.  Every
+    cut costs ~0.3 ms per step (a graph-launch bubble and a less well filled weight-gradient group launch); cuts = 0 is the
+    two-graph form (backward | all-reduce of everything, exposed | update).  `timing = True` brackets the segments with HIP events
+    (bench.py prints their averages)."""
 
-    def __init__(self, args, encoder, decoder, crits, optims, reducer=None, warm=2, pool=None):
+    def __init__(self, args, encoder, decoder, crits, optims, reducer=None, warm=2, pool=None, cuts=None):
         self.args, self.encoder, self.decoder, self.crits, self.optims, self.reducer = args, encoder, decoder, crits, optims, reducer
         self.split = reducer is not None and getattr(reducer, "active", False)
+        self.cuts = max(0, min(2, EXCHANGE_CUTS if cuts is None else int(cuts))) if self.split else 0
         if self.split:
             # this schedule all-reduces the flat gradient buffers itself: the reducer's per-bucket hooks must not fire inside
             # these backward passes (they would reduce the first warm-up step's gradients twice)
             reducer.hooks_enabled = False
-            encoder.split_backward = True
+            encoder.split_backward = self.cuts
         self.warm, self.pool = warm, pool
-        self.graph, self.graph_b, self.graph_update, self.static, self.result, self.t_run = None, None, None, None, None, None
+        self.graphs, self.graph_update, self.static, self.result, self.t_run = None, None, None, None, None
         self.stream = torch.cuda.Stream()
         self.n_eager = 0
         self._bns = None
         self.failed = None
         self._in_src = None
         self.timing, self._events = False, []
+
+    # (`graph` is what callers test for "captured": the first graph of the iteration)
+    @property
+    def graph(self):
+        return self.graphs[0] if self.graphs else None
+
+    @property
+    def graph_b(self):
+        return self.graphs[1] if self.graphs and len(self.graphs) > 1 else None
 
     def _run(self, batch, t_run, do_update=True, between=None):
         return runIter(self.args, self.encoder, self.decoder, *batch, self.crits, self.optims, mode="train",
@@ -287,29 +304,39 @@ class GraphedStep(object):
     def _groups(self):
         return [o.group for o in self.optims if isinstance(o, FlatAdam)]
 
-    def _reduce(self, group, async_op=False):
-        """SUM all-reduce of one flat gradient buffer, issued from the current stream (RCCL runs it on its own stream after the
-        work already enqueued here; `wait()` -- or the synchronous form -- makes the current stream wait for it)"""
-        return dist.all_reduce(group.flat_g, op=dist.ReduceOp.SUM, group=self.reducer.pg, async_op=async_op)
+    def _reduce(self, buf, async_op=False):
+        """SUM all-reduce of (a range of) a flat gradient buffer, issued from the current stream (RCCL runs it on its own stream
+        after the work already enqueued here; `wait()` -- or the synchronous form -- makes the current stream wait for it)"""
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.reducer.pg, async_op=async_op)
 
-    def _dec_enc(self):
+    def _plan(self):
+        """flat-gradient ranges that are final after each stage: {"dec": [...], "trunk_hi": [...], "rest": [...]}"""
         enc_g = self.optims[0].group
-        return [g for g in self._groups() if g is not enc_g], enc_g
+        dec = [g.flat_g for g in self._groups() if g is not enc_g]
+        if self.cuts == 0:
+            return {"dec": [], "trunk_hi": [], "rest": dec + [enc_g.flat_g]}
+        if self.cuts == 1:
+            return {"dec": dec, "trunk_hi": [], "rest": [enc_g.flat_g]}
+        first = next(self.encoder.base.layer3.parameters())
+        k = enc_g._index[id(first)]
+        off3 = enc_g.offsets[k][0]                # parameters lie in forward order: [stem, layer1, layer2 | layer3, layer4]
+        return {"dec": dec, "trunk_hi": [enc_g.flat_g[off3:]], "rest": [enc_g.flat_g[:off3]]}
 
     def __call__(self, batch, t_run):
-        if self.graph is None and self.failed is None and self.n_eager >= self.warm:
+        if self.graphs is None and self.failed is None and self.n_eager >= self.warm:
             self._capture(batch, t_run)
-        if self.graph is None:                     # warm-up steps (or capture not possible): plain eager iterations
+        if self.graphs is None:                    # warm-up steps (or capture not possible): plain eager iterations
             self.n_eager += 1
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 if self.split:
-                    dec_gs, enc_g = self._dec_enc()
-                    pending = []
-                    res = self._run(batch, t_run, do_update=False, between=lambda: pending.extend(self._reduce(g, True) for g in dec_gs))
+                    plan, pending = self._plan(), []
+                    res = self._run(batch, t_run, do_update=False,
+                                    between=lambda stage: pending.extend(self._reduce(b, True) for b in plan[stage]))
                     for h in pending:
                         h.wait()
-                    self._reduce(enc_g)
+                    for b in plan["rest"]:
+                        self._reduce(b)
                     apply_update(self.args, self.optims, 1.0 / self.reducer.world)
                 else:
                     res = self._run(batch, t_run)
@@ -328,23 +355,26 @@ class GraphedStep(object):
                     dst.copy_(src, non_blocking=True)
             self._in_src = [(t, t._version) for t in batch]
         if not self.split:
-            self.graph.replay()
+            self.graphs[0].replay()
         else:
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if self.timing else None
+            n = len(self.graphs)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 3)] if self.timing else None
             mark = (lambda k: ev[k].record()) if ev is not None else (lambda k: None)
-            dec_gs, enc_g = self._dec_enc()
+            plan, pending = self._plan(), []
+            stages = ["dec", "trunk_hi"]
             mark(0)
-            self.graph.replay()                                    # A
-            mark(1)
-            pending = [self._reduce(g, True) for g in dec_gs]      # decoder + skip group: travels while graph B runs
-            self.graph_b.replay()                                  # B
-            mark(2)
+            for k, g in enumerate(self.graphs):
+                g.replay()                                         # A, B1, B2 ...
+                mark(k + 1)
+                if k + 1 < n:                                      # this range is final: it travels while the next graph runs
+                    pending.extend(self._reduce(b, True) for b in plan[stages[k]])
             for h in pending:
                 h.wait()
-            self._reduce(enc_g)                                    # trunk group: the exposed part
-            mark(3)
+            for b in plan["rest"]:                                 # the exposed part
+                self._reduce(b)
+            mark(n + 1)
             self.graph_update.replay()                             # C
-            mark(4)
+            mark(n + 2)
             if ev is not None:
                 self._events.append(ev)
 
@@ -356,16 +386,19 @@ class GraphedStep(object):
         return self.result
 
     def segment_ms(self):
-        """average milliseconds of (graph A, graph B incl. the overlapped collective, exposed collective, graph C) over the timed
-        replays so far (`timing`); synchronises"""
+        """average milliseconds per segment over the timed replays so far (`timing`); synchronises"""
         if not self._events:
             return None
         torch.cuda.synchronize()
-        n = len(self._events)
-        seg = [sum(e[k].elapsed_time(e[k + 1]) for e in self._events) / n for k in range(4)]
+        n, ng = len(self._events), len(self.graphs)
+        seg = [sum(e[k].elapsed_time(e[k + 1]) for e in self._events) / n for k in range(ng + 2)]
         self._events = []
-        return {"graph_A_fwd_bptt": seg[0], "graph_B_trunk_bwd_overlapping_allreduce_dec": seg[1], "exposed_allreduce": seg[2],
-                "graph_C_adam_repack": seg[3], "replays": n}
+        names = (["graph_A_fwd_bptt"] + ["graph_B%d_trunk_bwd" % (k + 1) for k in range(ng - 1)])
+        out = {nm: seg[k] for k, nm in enumerate(names)}
+        out["exposed_allreduce"] = seg[ng]
+        out["graph_C_adam_repack"] = seg[ng + 1]
+        out["replays"], out["cuts"] = n, self.cuts
+        return out
 
     def _capture(self, batch, t_run):
         from .modules.vision import HipBatchNorm2d
@@ -376,7 +409,7 @@ class GraphedStep(object):
         groups = self._groups()
         for g in groups:
             g.begin_graph()
-        graph, graph_b, graph_u = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        graphs, graph_u = [torch.cuda.CUDAGraph()], torch.cuda.CUDAGraph()
         try:
             torch.cuda.synchronize()
             if dist.is_initialized():
@@ -391,38 +424,36 @@ class GraphedStep(object):
             # run in six died with hipErrorStreamCaptureUnsupported raised inside the watchdog (the loader's staging threads
             # are the other candidate)
             if not self.split:
-                with torch.cuda.graph(graph, pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
+                with torch.cuda.graph(graphs[0], pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
                     self.result = self._run(self.static, t_run)
             else:
-                # one pass of runIter, cut into graph A | graph B where its split backward calls back (same thread: the callback
-                # runs in runIter between the two backward calls), then graph C; all three share one memory pool (they always
-                # replay in this order, so blocks freed by one may be reused by the next exactly as inside a single capture)
-                state = {"cur": graph}
-
-                def cut():
-                    state["cur"].capture_end()
-                    state["cur"] = graph_b
-                    graph_b.capture_begin(pool=graph.pool(), capture_error_mode="thread_local")
+                # one pass of runIter, cut into graphs where its split backward calls back (same thread: the callback runs in
+                # runIter between the backward calls), then graph C; all share one memory pool (they always replay in this
+                # order, so blocks freed by one may be reused by the next exactly as inside a single capture)
+                def cut(_stage):
+                    graphs[-1].capture_end()
+                    graphs.append(torch.cuda.CUDAGraph())
+                    graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
                 import gc
                 gc.collect()
                 torch.cuda.empty_cache()
                 self.stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.stream):
-                    graph.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+                    graphs[0].capture_begin(pool=self.pool, capture_error_mode="thread_local")
                     try:
                         self.result = self._run(self.static, t_run, do_update=False, between=cut)
-                        if state["cur"] is graph:      # (no split point was reached: the encoder produced no cut)
-                            cut()
                     finally:
-                        state["cur"].capture_end()
-                    graph_u.capture_begin(pool=graph.pool(), capture_error_mode="thread_local")
+                        graphs[-1].capture_end()
+                    graph_u.capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
                     try:
                         apply_update(self.args, self.optims, 1.0 / self.reducer.world)
                     finally:
                         graph_u.capture_end()
                 torch.cuda.current_stream().wait_stream(self.stream)
-                self.graph_b, self.graph_update = graph_b, graph_u
-            self.graph = graph
+                if len(graphs) != self.cuts + 1:
+                    raise RuntimeError("GraphedStep: expected %d cuts of the backward, got %d" % (self.cuts, len(graphs) - 1))
+                self.graph_update = graph_u
+            self.graphs = graphs
         except Exception as e:  # noqa: BLE001  (capture refused: stay eager)
             self.failed = repr(e)
             for g in groups:
@@ -434,7 +465,7 @@ class GraphedStep(object):
     def release(self):
         for g in self._groups():
             g.end_graph()
-        self.graph = self.graph_b = self.graph_update = self.result = self.static = self._in_src = None
+        self.graphs = self.graph_update = self.result = self.static = self._in_src = None
 
 
 def init_dataloaders(args, rank=0, world=1):

@@ -42,8 +42,8 @@ def test_bench_two_ranks_one_json_line_graph_replay():
     assert out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
     assert "hipGraph replay" in out["config"]["launch"], out["config"]["launch"]
     ex = out["config"]["exchange_ms_per_step"]
-    assert ex["replays"] == 3 and all(ex[k] >= 0 for k in ("graph_A_fwd_bptt", "graph_B_trunk_bwd_overlapping_allreduce_dec", "exposed_allreduce",
-                                                          "graph_C_adam_repack"))
+    assert ex["replays"] == 3 and ex["cuts"] == 2
+    assert all(ex[k] >= 0 for k in ("graph_A_fwd_bptt", "graph_B1_trunk_bwd", "graph_B2_trunk_bwd", "exposed_allreduce", "graph_C_adam_repack"))
     assert "communicator size 2" in err and "split-graph schedule" in err
 
 

@@ -135,11 +135,11 @@ def _worker_split_graph(rank, world, port, q):
     batch = synthetic_batch(10 + rank, 2, 64, 64, 5, 3, 7, "cuda")          # a different shard per rank
     t_run = steps_to_run(a, batch[3])
     finals, losses = [], []
-    for graphed in (False, True):
+    for graphed, cuts in ((False, 0), (True, 2), (True, 1), (True, 0)):
         enc, dec = copy.deepcopy(enc0), copy.deepcopy(dec0)
         enc_opt, dec_opt = build_optimizers(a, enc, dec)
         red = BucketedAllReduce([dec_opt.group, enc_opt.group], bucket_bytes=8 << 20)
-        g = GraphedStep(a, enc, dec, crits, [enc_opt, dec_opt], red, warm=1) if graphed else None
+        g = GraphedStep(a, enc, dec, crits, [enc_opt, dec_opt], red, warm=1, cuts=cuts) if graphed else None
         for _ in range(3):
             if graphed:
                 out = g(batch, t_run)
@@ -149,7 +149,7 @@ def _worker_split_graph(rank, world, port, q):
         torch.cuda.synchronize()
         losses.append(float(out[0][0]))
         if graphed:
-            assert g.graph is not None and g.graph_b is not None and g.graph_update is not None, "capture failed: %s" % g.failed
+            assert g.graph is not None and len(g.graphs) == cuts + 1 and g.graph_update is not None, "capture failed: %s" % g.failed
             assert dec_opt.group.steps[0] == 3 and enc_opt.group.steps[0] == 3
         finals.append((torch.cat([dec_opt.group.flat_p, enc_opt.group.flat_p]).clone(),
                        torch.cat([dec_opt.group.flat_g, enc_opt.group.flat_g]).clone()))
@@ -157,8 +157,9 @@ def _worker_split_graph(rank, world, port, q):
             g.release()
         for h in red._hooks:
             h.remove()
-    (pe, ge), (pg, gg) = finals
-    dp, dg = float((pe - pg).abs().max()), float((ge - gg).abs().max())
+    (pe, ge), (pg, gg) = finals[0], finals[1]
+    dp = max(float((pe - f[0]).abs().max()) for f in finals[1:])          # every cut schedule against the eager bucketed one
+    dg = max(float((ge - f[1]).abs().max()) for f in finals[1:])
     moved = float((pe[:1000] - torch.cat([p.detach().reshape(-1) for p in dec0.parameters()])[:1000]).abs().max())
     assert moved > 0, "the optimizer steps did not change the parameters"
     t = pg.double().cpu()
@@ -190,7 +191,7 @@ def test_split_graph_schedule_equals_eager_bucketed_schedule_world2():
         assert p.exitcode == 0
     for r in res:
         assert r[1] == 0.0 and r[2] == 0.0, "rank %d: split-graph vs eager schedule: max |d param| %.3e, max |d grad| %.3e" % (r[0], r[1], r[2])
-        assert r[6][0] == r[6][1] and r[6][0] == r[6][0]
+        assert all(v == r[6][0] for v in r[6]) and r[6][0] == r[6][0]
     a, b = res
     assert a[3] == b[3] and a[4] == b[4] and np.array_equal(a[5], b[5]), "parameters diverged between ranks"
 
