@@ -76,6 +76,7 @@ def gate_kernel_roofline(B, iters, imsize, dtype="fp32", T=10, product_only=Fals
     L = lib()
     dt = ops.DTYPES[dtype]
     rows, tot = [], {"full_flops": 0.0, "full_ms": 0.0, "dyn_flops": 0.0, "dyn_ms": 0.0, "hoist_ms": 0.0, "bytes": 0.0}
+    diag = []        # the five product launches as jobs of ONE rsis_convlstm_fwd_batch call (a steady-state wavefront diagonal)
     for li, (segs, hid, hw) in enumerate(GATE_LAYERS):
         H = W = hw * imsize // 256
         c_skip = segs[-1]
@@ -109,6 +110,7 @@ def gate_kernel_roofline(B, iters, imsize, dtype="fp32", T=10, product_only=Fals
         pd, idd = ptr_array(dsrc), int_array(([c_up] if c_up else []) + [hid])
         ms_dyn = _time_launch(lambda: check(L.rsis_convlstm_fwd(pd, idd, len(dsrc), B, H, W, ptr(wd), None, ptr(G), ptr(c_prev), ptr(h), ptr(c),
                                                                  ptr(act), hid, 3, 1, 0, dt, stream()), "rsis_convlstm_fwd(step)"), iters)
+        diag.append((dsrc, wd, G, c_prev, h, c, act, hid, H, W))
         M = B * H * W
         f_full = 2.0 * M * (cin * 9) * (4 * hid)
         f_dyn = 2.0 * M * ((c_up + hid) * 9) * (4 * hid)
@@ -124,13 +126,30 @@ def gate_kernel_roofline(B, iters, imsize, dtype="fp32", T=10, product_only=Fals
         tot["dyn_ms"] += ms_dyn
         tot["hoist_ms"] += ms_hoist
         tot["bytes"] += byts
+    # ---- the launch the product issues in steady state: the gate kernels of one (level, timestep) diagonal of the decoder's
+    # wavefront -- levels 0..4 at steps t+4..t, one timestep's worth of work -- as ONE rsis_convlstm_fwd_batch call ----
+    from rsis_amd._lib import LstmJob
+    jobs = (LstmJob * len(diag))()
+    for j, (dsrc, wd, G, c_prev, h, c, act, hid, H, W) in zip(jobs, diag):
+        j.nsrc = len(dsrc)
+        for k, s in enumerate(dsrc):
+            j.src[k], j.Csrc[k] = s.data_ptr(), s.shape[1]
+        (j.B, j.H, j.W, j.Wp, j.bias_packed, j.addend, j.c_prev, j.h_out, j.c_out, j.act_out, j.hid, j.ks, j.pad, j.tile, j.dtype) = (
+            B, H, W, wd.data_ptr(), None, G.data_ptr(), c_prev.data_ptr(), h.data_ptr(), c.data_ptr(), act.data_ptr(), hid, 3, 1, 0, dt)
+    ms_diag = _time_launch(lambda: check(L.rsis_convlstm_fwd_batch(jobs, len(diag), stream()), "rsis_convlstm_fwd_batch"), iters)
+    singles_ms = tot["dyn_ms"]
+    tot["dyn_ms"] = ms_diag
     executed = tot["dyn_flops"] / tot["dyn_ms"] / 1e9
     algorithmic = tot["full_flops"] / (tot["dyn_ms"] + tot["hoist_ms"] / T) / 1e9
     full = tot["full_flops"] / tot["full_ms"] / 1e9
-    out = {"kernel": ("conv3x3_direct_kernel<..., EPI_LSTM>" if dtype == "fp32" else "conv_bf16_kernel<3, ..., EPI_LSTM>") +
-                     " (rsis_convlstm_fwd), the 5 pyramid levels of one decoder timestep as rsis_amd.decoder_fused launches them "
-                     "(hoisted skip term as addend, dynamic channels only)",
-           "per_scale": rows, "ms_per_timestep": round(tot["dyn_ms"], 4), "executed_gflop_per_timestep": round(tot["dyn_flops"] / 1e9, 3),
+    out = {"kernel": ("conv3x3_direct_group_kernel<EPI_LSTM>" if dtype == "fp32" else "conv_bf16_kernel<3, ..., EPI_LSTM>") +
+                     " (rsis_convlstm_fwd_batch): the ConvLSTM gate kernels of the 5 pyramid levels -- one decoder timestep's worth of "
+                     "work -- as rsis_amd.decoder_fused.decoder_sequence launches them: the cells of one (level, timestep) wavefront "
+                     "diagonal in ONE call (fp32: one grid; hoisted skip term as addend, dynamic channels only)",
+           "per_scale": rows, "ms_per_timestep": round(tot["dyn_ms"], 4),
+           "ms_per_timestep_as_five_single_launches": round(singles_ms, 4),
+           "tflops_as_five_single_launches": round(tot["dyn_flops"] / singles_ms / 1e9, 2),
+           "executed_gflop_per_timestep": round(tot["dyn_flops"] / 1e9, 3),
            "algorithmic_gflop_per_timestep": round(tot["full_flops"] / 1e9, 3),
            "hoisted_convs_ms_per_iteration": round(tot["hoist_ms"], 4),
            "achieved_executed": round(executed, 2), "achieved_algorithmic": round(algorithmic, 2),
@@ -277,10 +296,12 @@ def cpu_baseline(imsize, T, budget_s=25.0):
 # the fused LSTM epilogue (tests/test_abi.py checks the pattern against the symbols of the built library)
 REAL_STDOUT = 1
 GATE_KERNEL_RE = re.compile(r"conv3x3_direct_kernel<\d+, \d+, \d+, \d+, 1, \d+, \d+>")
+# ... and the grouped launch of one wavefront diagonal (rsis_convlstm_fwd_batch): template argument <EPI>
+GATE_GROUP_RE = re.compile(r"conv3x3_direct_group_kernel<1>")
 
 
 def gate_kernel_traffic(batch, imsize, timeout=150):
-    """HBM bytes of the five gate-kernel launches of one timestep from the memory-side PMC counters: two rocprofv3 passes
+    """HBM bytes of the gate-kernel launch of one timestep (the grouped launch of one wavefront diagonal: five levels) from the memory-side PMC counters: two rocprofv3 passes
     (FETCH_SIZE, then WRITE_SIZE -- they do not fit one pass) over `bench.py --roofline-only` in a child process.
     FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibrated there for 16 B/lane streaming reads; this
     kernel's input patch is fetched 4 B/lane, for which the doubling is an upper bound).  Returns (bytes, detail) or (None, why)."""
@@ -310,10 +331,10 @@ def gate_kernel_traffic(batch, imsize, timeout=150):
             with open(path) as f:
                 for r in csv.DictReader(f):
                     k = r["Kernel_Name"]
-                    if r["Counter_Name"] == counter and GATE_KERNEL_RE.search(k):
+                    if r["Counter_Name"] == counter and GATE_GROUP_RE.search(k):
                         vals.setdefault((k, r["Grid_Size"]), []).append(float(r["Counter_Value"]))
-            if len(vals) != 5:
-                return None, "expected 5 gate-kernel launch shapes in the counter file, found %d" % len(vals)
+            if len(vals) != 1:
+                return None, "expected 1 grouped gate-kernel launch shape in the counter file, found %d" % len(vals)
             per_counter[counter] = sum(statistics.median(v) for v in vals.values()) * 1024.0      # counters are in KiB
     except Exception as e:  # noqa: BLE001  (profiler missing / refused / timed out: the figure stays null)
         return None, "rocprofv3 pass failed: %r" % (e,)
@@ -429,7 +450,7 @@ def main():
             traffic, detail = gate_kernel_traffic(o.batch, o.imsize)
             roof["traffic"] = traffic
             if traffic is not None:
-                roof["traffic_unit"] = ("bytes per timestep (the 5 product launches): 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate "
+                roof["traffic_unit"] = ("bytes per timestep (the grouped launch of the 5 levels): 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate "
                                         "passes; the x2 is the guide's gfx950 correction, re-measured for this kernel's dword LDS-DMA reads in "
                                         "profiles/r02_fetch_calibration.txt")
                 roof["traffic_vs_algorithmic"] = round(traffic / (roof["algorithmic_mbytes_per_timestep"] * 1e6), 3)

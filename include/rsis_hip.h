@@ -122,6 +122,28 @@ int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B,
                       const float* bias_packed, const float* addend, const float* c_prev, float* h_out, float* c_out,
                       float* act_out, int hid, int ks, int pad, int tile, int dtype, void* stream);
 
+/* Several INDEPENDENT rsis_convlstm_fwd calls as ONE launch: the cells (level i, timestep d - i) of one diagonal of the decoder's
+ * (level, timestep) wavefront -- level i at step t needs level i-1 at step t and itself at step t-1 (model.py:129-165 inside the
+ * loop of train.py:85-94 / test.py:37-38), so the cells of a diagonal do not depend on each other.  Exact-f32 3x3 jobs share one
+ * grid (conv3x3_direct_group_kernel: blocks of different jobs have different lengths and phases, so one job's prologue / epilogue
+ * overlaps another's MFMA loop); other jobs, and every job in the deterministic mode, are launched one after the other -- the
+ * results are those of njobs single calls either way (same kernels, same tiles, same summation order).  Fields as the arguments
+ * of rsis_convlstm_fwd (src / Csrc hold nsrc <= 3 entries). */
+typedef struct rsis_lstm_job {
+  const float* src[3];
+  int Csrc[3];
+  int nsrc, B, H, W;
+  const void* Wp;
+  const float* bias_packed;
+  const float* addend;
+  const float* c_prev;
+  float* h_out;
+  float* c_out;
+  float* act_out;
+  int hid, ks, pad, tile, dtype;
+} rsis_lstm_job;
+int rsis_convlstm_fwd_batch(const rsis_lstm_job* jobs, int njobs, void* stream);
+
 /* ---- ConvLSTMCell pointwise backward: (dh + dh2, dc_next, saved act, c_prev, c) -> da (gate pre-activation grads,
  * interleaved rows) and dc_prev.  dh / dh2 / dc_next / c_prev / dc_prev / da_sum may be NULL. da_sum += da if given.
  * dh2: the gradient reaching h through a second consumer (the next timestep's recurrence), summed in the kernel. ---- */

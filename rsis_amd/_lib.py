@@ -30,6 +30,14 @@ class WgradJob(ctypes.Structure):
                [(k, ctypes.c_int) for k in ("B", "Cs", "H", "W", "Cout", "Ho", "Wo", "ks", "stride", "pad", "Ctot", "c_off", "lstm_hid", "dtype")]
 
 
+class LstmJob(ctypes.Structure):
+    """struct rsis_lstm_job of include/rsis_hip.h"""
+    _fields_ = [("src", ctypes.c_void_p * 3), ("Csrc", ctypes.c_int * 3), ("nsrc", ctypes.c_int), ("B", ctypes.c_int), ("H", ctypes.c_int),
+                ("W", ctypes.c_int), ("Wp", ctypes.c_void_p), ("bias_packed", ctypes.c_void_p), ("addend", ctypes.c_void_p),
+                ("c_prev", ctypes.c_void_p), ("h_out", ctypes.c_void_p), ("c_out", ctypes.c_void_p), ("act_out", ctypes.c_void_p),
+                ("hid", ctypes.c_int), ("ks", ctypes.c_int), ("pad", ctypes.c_int), ("tile", ctypes.c_int), ("dtype", ctypes.c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/rsis_hip.h
 SIGNATURES = {
     "rsis_version": (_i, []),
@@ -51,6 +59,7 @@ SIGNATURES = {
     "rsis_conv_out_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_convlstm_fwd": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsis_convlstm_fwd_batch": (_i, [ctypes.POINTER(LstmJob), _i, _vp]),
     "rsis_convlstm_bwd_gates": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "rsis_upsample_bilinear_ac_fwd": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "rsis_upsample_bilinear_ac_bwd": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),

@@ -7,6 +7,7 @@
 int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_tile, hipStream_t st);
 int rsis_launch_conv_wgrad(WgradArgs& a, int ks, hipStream_t st);
 int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st);
+int rsis_launch_convlstm_direct_group(ConvArgs* jobs, int n, const int* force_variant, hipStream_t st);
 int rsis_launch_conv_bf16(ConvArgs& a, int ks, int epi, int force_variant, hipStream_t st);
 bool rsis_wgrad_bf16_supported(const WgradArgs& w, int ks);
 int rsis_launch_conv_wgrad_bf16(const WgradArgs& w, int ks, hipStream_t st);
@@ -434,13 +435,14 @@ int rsis_bias_grad(const float* dy, float* db, int B, int C, int HW, int lstm_hi
   return rsis_l_channel_sum(dy, db, B, C, HW, lstm_hid, (hipStream_t)stream);
 }
 
-int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp,
-                      const float* bias_packed, const float* addend, const float* c_prev, float* h_out, float* c_out,
-                      float* act_out, int hid, int ks, int pad, int tile, int dtype, void* stream) {
-  ConvArgs a = {};
+// argument checks + ConvArgs of one fused ConvLSTM forward; route: 0 bf16 kernel, 1 direct 3x3 (exact f32), 2 implicit GEMM
+static int lstm_fill(ConvArgs& a, int& route, const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp,
+                     const float* bias_packed, const float* addend, const float* c_prev, float* h_out, float* c_out, float* act_out, int hid,
+                     int ks, int pad, int dtype) {
+  a = ConvArgs{};
   int rc = fill_sources(a, src, Csrc, nsrc, ks, /*allow_empty=*/addend != nullptr);   // nsrc == 0: gates = addend only
   if (rc) return rc;
-  if (!Wp || !h_out || !c_out || hid < 1) return RSIS_ERR_ARG;
+  if (!Wp || !h_out || !c_out || hid < 1 || B < 1) return RSIS_ERR_ARG;
   if (2 * pad != ks - 1) return RSIS_ERR_UNSUPPORTED;   // "same" conv only (the state keeps its size)
   // bf16 gates: 3x3 only (the fused-cell epilogue of conv_bf16_kernel); rsis_conv_pack_fwd refuses the same combination, so a
   // bf16-packed buffer can never reach the f32 kernels below
@@ -450,9 +452,49 @@ int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B,
   a.ndst = 1; a.dst[0] = nullptr; a.Cd[0] = 4 * hid;
   a.hid = hid; a.c_prev = c_prev; a.h_out = h_out; a.c_out = c_out; a.act_out = act_out;
   a.ostride = 1; a.oH = H; a.oW = W; a.ksplit = 1;
-  if (use_bf16(dtype, ks, 1, pad, 4 * hid)) return rsis_launch_conv_bf16(a, 3, 1, direct_variant(tile), (hipStream_t)stream);
-  if (use_direct(ks, 1, pad)) return rsis_launch_conv3x3_direct(a, 1, direct_variant(tile), (hipStream_t)stream);
-  return rsis_launch_conv_igemm(a, ks, false, 1, tile, (hipStream_t)stream);
+  route = use_bf16(dtype, ks, 1, pad, 4 * hid) ? 0 : (use_direct(ks, 1, pad) ? 1 : 2);
+  return RSIS_OK;
+}
+static int lstm_launch_one(ConvArgs& a, int route, int ks, int tile, hipStream_t st) {
+  if (route == 0) return rsis_launch_conv_bf16(a, 3, 1, direct_variant(tile), st);
+  if (route == 1) return rsis_launch_conv3x3_direct(a, 1, direct_variant(tile), st);
+  return rsis_launch_conv_igemm(a, ks, false, 1, tile, st);
+}
+
+int rsis_convlstm_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp,
+                      const float* bias_packed, const float* addend, const float* c_prev, float* h_out, float* c_out,
+                      float* act_out, int hid, int ks, int pad, int tile, int dtype, void* stream) {
+  ConvArgs a;
+  int route = 0;
+  const int rc = lstm_fill(a, route, src, Csrc, nsrc, B, H, W, Wp, bias_packed, addend, c_prev, h_out, c_out, act_out, hid, ks, pad, dtype);
+  if (rc) return rc;
+  return lstm_launch_one(a, route, ks, tile, (hipStream_t)stream);
+}
+
+int rsis_convlstm_fwd_batch(const rsis_lstm_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs < 1) return RSIS_ERR_ARG;
+  ConvArgs* grp = (ConvArgs*)malloc(sizeof(ConvArgs) * njobs);
+  int* force = (int*)malloc(sizeof(int) * njobs);
+  if (!grp || !force) { free(grp); free(force); return RSIS_ERR_LAUNCH; }
+  int ng = 0, rc = RSIS_OK;
+  for (int j = 0; j < njobs && rc == RSIS_OK; ++j) {
+    const rsis_lstm_job& q = jobs[j];
+    if (q.nsrc < 0 || q.nsrc > RSIS_MAX_SRC) { rc = RSIS_ERR_ARG; break; }
+    ConvArgs a;
+    int route = 0;
+    rc = lstm_fill(a, route, q.src, q.Csrc, q.nsrc, q.B, q.H, q.W, q.Wp, q.bias_packed, q.addend, q.c_prev, q.h_out, q.c_out, q.act_out,
+                   q.hid, q.ks, q.pad, q.dtype);
+    if (rc) break;
+    // grouped: the exact-f32 direct kernel with 32-bit epilogue addressing (its buffer-descriptor cell update); everything else --
+    // and every job in the deterministic mode, where launches are kept as the single-call path issues them -- one by one
+    const bool groupable = route == 1 && (size_t)q.B * 4 * q.hid * q.H * q.W * 4 < (1ull << 31) && !rsis_deterministic();
+    if (groupable) { force[ng] = direct_variant(q.tile % 100); grp[ng++] = a; }
+    else rc = lstm_launch_one(a, route, q.ks, q.tile, (hipStream_t)stream);
+  }
+  if (rc == RSIS_OK && ng == 1) rc = rsis_launch_conv3x3_direct(grp[0], 1, force[0], (hipStream_t)stream);
+  else if (rc == RSIS_OK && ng > 1) rc = rsis_launch_convlstm_direct_group(grp, ng, force, (hipStream_t)stream);
+  free(grp); free(force);
+  return rc;
 }
 
 int rsis_convlstm_bwd_gates(const float* dh, const float* dh2, const float* dc_next, const float* act, const float* c_prev,

@@ -41,8 +41,19 @@ typedef const f32x4 __attribute__((address_space(1)))* gcf4_t;
 // one wave per SIMD.
 // NWV = 8: a 512-thread block -- twice the pixels against ONE weight stage (the weight chunk is ~60 % of what a 64-row block
 // copies into LDS per chunk, and the LDS-DMA fill rate of a CU, ~25 GB/s, is what two or three co-resident 4-wave blocks run into).
+// floats of LDS one block of a variant needs (two stages of patch + weight chunk)
+template <int BM, int TW, int TH, int NI, int EPI, int NWV>
+constexpr int direct_lds_floats() {
+  constexpr int S = EPI == EPI_F2 ? 2 : 1;
+  constexpr int PW = TW * S + 3 - S, PH = TH * S + 3 - S;
+  constexpr int XS = CK * NI * PH * PW, WS = CK * 9 * BM, NT = NWV * 64;
+  return 2 * ((XS + NT - 1) / NT * NT + WS);
+}
+
+// The block program.  bid: the block's index inside its launch (or inside its job of a grouped launch); kz / ksplit: its slice of
+// the channel chunks (grid split-K); lds: the block's LDS, direct_lds_floats<...>() floats.
 template <int BM, int TW, int TH, int NI, int EPI, int KSP = 1, int NWV = 4>
-__global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs p) {
+__device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int bid, const int kz, const int ksplit, float* const lds) {
 #if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; the buffer-resource builtins do not exist there)
   constexpr int BN = TW * TH * NI;
   constexpr int NT = NWV * 64;                           // threads per block
@@ -59,7 +70,7 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs
   constexpr int NW = (W_F4 + NT - 1) / NT;          // weight float4 loads per thread per chunk
   static_assert(TN >= 1 && BN % (WGN * 32) == 0 && WGM * WGN * KSP == NWV && (CK / 2) % KSP == 0 && (KSP == 1 || EPI != EPI_S2), "tile");
 
-  __shared__ __attribute__((aligned(16))) float lds[2 * (XSP + WS)];
+  static_assert(2 * (XSP + WS) == direct_lds_floats<BM, TW, TH, NI, EPI, NWV>(), "LDS size helper out of sync");
   float* const Xs0 = lds;
   float* const Ws0 = lds + 2 * XSP;
 
@@ -69,7 +80,6 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs
   const int nq_all = q0 + q1 + q2;
   // split-K over the channel chunks (deep-K / few-pixel layers such as sk5: 2048 channels on an 8x8 map): gridDim.y blocks
   // each take a contiguous chunk range and finish with fp32 atomics into the (zeroed) output
-  const int ksplit = gridDim.y, kz = blockIdx.y;
   const int q_begin = (int)((long)nq_all * kz / ksplit), q_end = (int)((long)nq_all * (kz + 1) / ksplit);
   const int nq = q_end - q_begin;
   // H x W: the grid the block tiles walk and the epilogue writes (the output map; == the gathered map except for EPI_F2);
@@ -79,7 +89,6 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs
   const int ldw = p.ldw;
 
   // ---- block -> (co tile, spatial tile); blocks b, b+8, ... share an XCD: a tile's co tiles stay on one L2 ----
-  const int bid = blockIdx.x;
   const int xcd = bid & 7, q = bid >> 3;
   const int co_t = q % p.n_co_tiles;
   const int sp_t = (q / p.n_co_tiles) * 8 + xcd;
@@ -364,6 +373,47 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs
 #endif
 }
 
+template <int BM, int TW, int TH, int NI, int EPI, int KSP = 1, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds[direct_lds_floats<BM, TW, TH, NI, EPI, NWV>()];
+  conv3x3_direct_body<BM, TW, TH, NI, EPI, KSP, NWV>(p, blockIdx.x, blockIdx.y, gridDim.y, lds);
+}
+
+// ---- grouped launch: several INDEPENDENT convs in ONE grid (rsis_convlstm_fwd_batch: the ConvLSTM levels of one diagonal of the
+// decoder's (level, timestep) wavefront -- level i at step t depends on level i-1 at step t and on itself at step t-1, so the cells
+// (i, d - i) of a diagonal d are independent).  Alone, each gate launch pays its ramp, prologue, per-chunk barrier stalls and
+// epilogue with every block of the grid in the same phase (0.53-0.67 of the f32 MFMA peak per level); together the jobs' blocks
+// have different lengths and phases, so one block's prologue / epilogue hides behind another's MFMA loop.  The jobs travel by value
+// in the kernel arguments; block b belongs to the job whose [begin, end) range holds it.  Every job runs one of the 32-row, 256-thread
+// variants {4, 5, 6} (one kernel cannot mix block sizes, and its LDS footprint is the largest variant's: 40 KB, four blocks per CU).
+#define RSIS_DG_MAXJ 8
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+struct DirectGroup {
+  int n;
+  int begin[RSIS_DG_MAXJ + 1];
+  int variant[RSIS_DG_MAXJ];
+  ConvArgs job[RSIS_DG_MAXJ];
+};
+static_assert(sizeof(DirectGroup) <= 4000, "kernel arguments are limited to 4 KB");
+
+template <int EPI>
+__global__ __launch_bounds__(256) void conv3x3_direct_group_kernel(const DirectGroup g) {
+  constexpr int LMAX = cmax(cmax(direct_lds_floats<32, 16, 8, 1, EPI, 4>(), direct_lds_floats<32, 32, 8, 1, EPI, 4>()),
+                            direct_lds_floats<32, 8, 8, 1, EPI, 4>());
+  __shared__ __attribute__((aligned(16))) float lds[LMAX];
+  const int b = blockIdx.x;
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < RSIS_DG_MAXJ; ++k) j += (k < g.n && g.begin[k] <= b) ? 1 : 0;     // (begin[] ascending: the last job whose begin <= b)
+  const ConvArgs& p = g.job[j];
+  const int local = b - g.begin[j];
+  switch (g.variant[j]) {
+    case 4: conv3x3_direct_body<32, 16, 8, 1, EPI>(p, local, 0, 1, lds); break;
+    case 5: conv3x3_direct_body<32, 32, 8, 1, EPI>(p, local, 0, 1, lds); break;
+    default: conv3x3_direct_body<32, 8, 8, 1, EPI, 2>(p, local, 0, 1, lds); break;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int BM, int TW, int TH, int NI, int EPI, int KSP = 1, int NWV = 4>
 static int launch_direct_cfg(ConvArgs& a, hipStream_t st) {
@@ -390,7 +440,7 @@ static int launch_direct_cfg(ConvArgs& a, hipStream_t st) {
 // variant codes: 1 = BM64 8x8x1 (64 px), 2 = BM64 16x8 (128 px), 3 = BM64 32x8 (256 px), 4 = BM32 16x8, 5 = BM32 32x8,
 // 6 = BM32 8x8 with the K range split over two wave pairs; 512-thread blocks: 7 = BM64 32x16 (512 px), 8 = BM32 32x16, 9 = BM64 16x16
 template <int EPI>
-static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
+static int pick_direct_variant(const ConvArgs& a, int force) {
   int v = force;
   if (v <= 0) {
     const bool small_co = a.Cout <= 32;
@@ -423,6 +473,12 @@ static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
   }
   if (EPI == EPI_S2 && v == 3) v = 5;   // 4 accumulator sets: the 256-pixel x 64-row tile would need 256 accumulator registers
   if (EPI == EPI_S2 && v == 6) v = 1;   // (no K-split variant of the 4-accumulator epilogue)
+  return v;
+}
+
+template <int EPI>
+static int launch_direct_epi(ConvArgs& a, hipStream_t st, int force) {
+  const int v = pick_direct_variant<EPI>(a, force);
   switch (v) {
     case 1: return launch_direct_cfg<64, 8, 8, 1, EPI>(a, st);
     case 2: return launch_direct_cfg<64, 16, 8, 1, EPI>(a, st);
@@ -451,4 +507,49 @@ int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStrea
   if (epi == EPI_LSTM) return launch_direct_epi<EPI_LSTM>(a, st, force_variant);
   if (epi == EPI_S2) return launch_direct_epi<EPI_S2>(a, st, force_variant);
   return launch_direct_epi<EPI_PLAIN>(a, st, force_variant);
+}
+
+// n independent 3x3 / stride 1 / pad 1 convs with the fused ConvLSTM cell epilogue in one grid (see conv3x3_direct_group_kernel).
+// Jobs are ordered by decreasing work per block (the long blocks start first: longest-processing-time scheduling of the tail).
+int rsis_launch_convlstm_direct_group(ConvArgs* jobs, int n, const int* force_variant, hipStream_t st) {
+  if (n < 1) return RSIS_OK;
+  for (int j0 = 0; j0 < n; j0 += RSIS_DG_MAXJ) {
+    const int m = n - j0 < RSIS_DG_MAXJ ? n - j0 : RSIS_DG_MAXJ;
+    int order[RSIS_DG_MAXJ], var[RSIS_DG_MAXJ];
+    long work[RSIS_DG_MAXJ];
+    for (int j = 0; j < m; ++j) {
+      ConvArgs& a = jobs[j0 + j];
+      if (a.nsrc < 0 || a.nsrc > RSIS_MAX_SRC) return RSIS_ERR_ARG;
+      int v = pick_direct_variant<EPI_LSTM>(a, force_variant ? force_variant[j0 + j] : 0);
+      // the grouped kernel's variants: 6 (8x8 maps), 4 (16 x 8 tiles), 5 (32 x 8 tiles), all 32 rows x 256 threads
+      if (v == 1) v = 6; else if (v == 2 || v == 9) v = 4; else if (v == 3 || v == 7 || v == 8) v = 5;
+      var[j] = v;
+      int nq = 0;
+      for (int s = 0; s < a.nsrc; ++s) nq += (a.C[s] + RSIS_CK - 1) / RSIS_CK;
+      work[j] = (long)nq * (v == 6 ? 64 : (v == 5 ? 256 : 128));
+      order[j] = j;
+    }
+    for (int x = 1; x < m; ++x)                        // insertion sort, descending work per block
+      for (int y = x; y > 0 && work[order[y]] > work[order[y - 1]]; --y) { const int t = order[y]; order[y] = order[y - 1]; order[y - 1] = t; }
+    DirectGroup g;
+    g.n = m;
+    int blocks = 0;
+    for (int k = 0; k < m; ++k) {
+      const int j = order[k];
+      ConvArgs a = jobs[j0 + j];
+      const int v = var[j];
+      const int bm = 32, tw = v == 6 ? 8 : (v == 5 ? 32 : 16);
+      a.n_co_tiles = rsis_cdiv(a.Cout, bm);
+      a.n_px_tiles = rsis_cdiv(a.W, tw) * rsis_cdiv(a.H, 8) * a.B;
+      a.ksplit = 1;
+      g.begin[k] = blocks;
+      g.variant[k] = v;
+      g.job[k] = a;
+      blocks += a.n_co_tiles * 8 * rsis_cdiv(a.n_px_tiles, 8);
+    }
+    for (int k = m; k <= RSIS_DG_MAXJ; ++k) g.begin[k] = blocks;
+    hipLaunchKernelGGL((conv3x3_direct_group_kernel<EPI_LSTM>), dim3(blocks), dim3(256), 0, st, g);
+    if (rsis_check_launch() != RSIS_OK) return RSIS_ERR_LAUNCH;
+  }
+  return RSIS_OK;
 }

@@ -17,10 +17,30 @@ clstm.py:43-44   gates = W * [x | h_prev] + b   into
 Module surface is unchanged: RSIS.forward(skip_feats, prev_hidden_list) is still called once per timestep; the tape is a
 private per-iteration cache on the module, keyed on the identity of the state tensors it handed out.
 """
+import os
+
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import check, int_array, lib, ptr, ptr_array, require_cuda_f32, stream
+
+# Gate launches parked by _StepFn.forward while decoder_sequence() walks one diagonal of the (level, timestep) wavefront; flushed as
+# ONE rsis_convlstm_fwd_batch call (a grouped launch for the exact-f32 kernels).  None: launch where the node is created.
+_GATE_QUEUE = [None]
+WAVEFRONT = [os.environ.get("RSIS_DECODER_WAVEFRONT", "1") != "0"]
+
+
+def _flush_gates():
+    q, _GATE_QUEUE[0] = _GATE_QUEUE[0], None
+    if not q:
+        return
+    jobs = (_lib.LstmJob * len(q))()
+    for j, (f, _keep) in zip(jobs, q):
+        srcs, segs, j.B, j.H, j.W, j.Wp, j.bias_packed, j.addend, j.c_prev, j.h_out, j.c_out, j.act_out, j.hid, j.ks, j.pad, j.tile, j.dtype = f
+        j.nsrc = len(srcs)
+        for k, (s, c) in enumerate(zip(srcs, segs)):
+            j.src[k], j.Csrc[k] = s, c
+    check(lib().rsis_convlstm_fwd_batch(jobs, len(q), stream()), "rsis_convlstm_fwd_batch")
 
 
 class LevelTape(object):
@@ -149,8 +169,14 @@ class _StepFn(torch.autograd.Function):
         wp = dyn.fwd(weight)
         pa = ptr_array(srcs) if srcs else None
         ia = int_array([s.shape[1] for s in srcs]) if srcs else None
-        check(L.rsis_convlstm_fwd(pa, ia, len(srcs), B, H, W, ptr(wp), None, ptr(G), ptr(c_prev) if h_prev is not None else None,
-                                  ptr(h), ptr(c), ptr(act), hid, tl.ks, tl.pad, ops.FORCE_TILE[0], dyn.dtype, stream()), "rsis_convlstm_fwd(step)")
+        if _GATE_QUEUE[0] is not None:      # decoder_sequence: park the launch, the diagonal's cells go out together
+            _GATE_QUEUE[0].append((([s.data_ptr() for s in srcs], [s.shape[1] for s in srcs], B, H, W, wp.data_ptr(), None, G.data_ptr(),
+                                    c_prev.data_ptr() if h_prev is not None else None, h.data_ptr(), c.data_ptr(),
+                                    act.data_ptr() if act is not None else None, hid, tl.ks, tl.pad, ops.FORCE_TILE[0], dyn.dtype),
+                                   (srcs, wp, G, c_prev, h, c, act)))
+        else:
+            check(L.rsis_convlstm_fwd(pa, ia, len(srcs), B, H, W, ptr(wp), None, ptr(G), ptr(c_prev) if h_prev is not None else None,
+                                      ptr(h), ptr(c), ptr(act), hid, tl.ks, tl.pad, ops.FORCE_TILE[0], dyn.dtype, stream()), "rsis_convlstm_fwd(step)")
         ctx.tl, ctx.t, ctx.stacked = tl, t, stacked
         ctx.wparam = weight
         ctx.has_up, ctx.has_state = up is not None, h_prev is not None
@@ -389,3 +415,58 @@ def decoder_levels(decoder, skip_feats, prev_hidden_list):
         side_feats.append(side)
     tape.t += 1
     return hidden_list, side_feats, up
+
+
+def sequence_supported(decoder, skip_feats, T):
+    """the wavefront schedule covers what the fused per-step path covers, for sequences that fit the tape"""
+    need_grad = torch.is_grad_enabled() and (any(f.requires_grad for f in skip_feats) or
+                                            any(p.requires_grad for p in decoder.clstm_list.parameters()))
+    return (WAVEFRONT[0] and decoder.fused and decoder.skip_mode == "concat" and decoder.dropout == 0 and
+            len(skip_feats) == len(decoder.clstm_list) and T >= 1 and (T <= decoder._tcap or not need_grad))
+
+
+def decoder_sequence(decoder, skip_feats, T):
+    """T decoder timesteps from the zero state (the loop of reference train.py:85-94 / test.py:37-38 around RSIS.forward,
+    model.py:122-184) in WAVEFRONT order.  Cell (level i, step t) needs up(h[i-1][t]) and (h, c)[i][t-1] only, so the cells
+    (i, d - i) of diagonal d are independent: their gate kernels are issued as ONE rsis_convlstm_fwd_batch call per diagonal
+    (T + 4 grouped launches instead of 5 T; include/rsis_hip.h).  Same autograd nodes, same kernels per cell and therefore the same
+    results as T calls of RSIS.forward; only the launch order and the grouping differ.  Returns the per-step outputs
+    [(out_mask, class_probs, stop_probs)] and the final hidden_list."""
+    need_grad = torch.is_grad_enabled() and (any(f.requires_grad for f in skip_feats) or
+                                            any(p.requires_grad for p in decoder.clstm_list.parameters()))
+    if decoder._tape is not None:          # a previous sequence that was never back-propagated: drop its cycles explicitly
+        for old in decoder._tape.levels:
+            old.release()
+    tape = decoder._tape = DecoderTape(decoder, skip_feats, need_grad)
+    n = len(tape.levels)
+    Hs = [[None] * T for _ in range(n)]
+    Cs = [[None] * T for _ in range(n)]
+    UP = [[None] * T for _ in range(n + 1)]          # UP[i][t]: the up-sampled hidden state level i consumes at step t (i >= 1)
+    SIDE = [[None] * T for _ in range(n)]
+    outs = [None] * T
+    for d in range(T + n - 1):
+        cells = [(i, d - i) for i in range(n) if 0 <= d - i < T]
+        _GATE_QUEUE[0] = []
+        try:
+            for i, t in cells:
+                tl = tape.levels[i]
+                h_prev, c_prev = (Hs[i][t - 1], Cs[i][t - 1]) if t > 0 else (None, None)
+                Hs[i][t], Cs[i][t] = _StepFn.apply(tl, t, UP[i][t] if i > 0 else None, h_prev, c_prev, tl.G, tl.cell.Gates.weight)
+            _flush_gates()
+        finally:
+            _GATE_QUEUE[0] = None
+        for i, t in cells:
+            h = Hs[i][t]
+            if i + 1 < n:
+                nxt = tape.levels[i + 1]
+                into = nxt if (nxt.UP is not None and t < nxt.cap) else None
+                SIDE[i][t], UP[i + 1][t] = _SideUpFn.apply(into, t, h, tuple(skip_feats[i + 1].shape[-2:]))     # model.py:143,149-150
+            else:
+                SIDE[i][t], UP[n][t] = _SideUpFn.apply(None, t, h, (h.shape[-2] * 2, h.shape[-1] * 2))          # model.py:143,163-164
+                hidden_list = [[Hs[k][t], Cs[k][t]] for k in range(n)]
+                outs[t] = decoder._heads(UP[n][t], [SIDE[k][t] for k in range(n)], hidden_list)[:3]
+                UP[n][t] = None
+    for i, tl in enumerate(tape.levels):
+        tl.last_h, tl.last_c = Hs[i][T - 1], Cs[i][T - 1]
+    tape.t = T
+    return outs, [[Hs[k][T - 1], Cs[k][T - 1]] for k in range(n)]

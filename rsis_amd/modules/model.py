@@ -169,6 +169,20 @@ class RSIS(nn.Module):
         class_probs = torch.softmax(class_feats, dim=1 if class_feats.dim() == 2 else 0)
         return out_mask, class_probs, stop_probs, hidden_list            # model.py:184
 
+    def forward_sequence(self, skip_feats, T):
+        """T timesteps from the zero state: what `hidden = None; for t in range(T): out_mask, cls, stop, hidden = decoder(feats, hidden)`
+        computes (reference train.py:85-94, test.py:37-38), returned as ([(out_mask, class_probs, stop_probs)] * T, hidden_list).
+        Runs the (level, timestep) wavefront schedule of rsis_amd.decoder_fused.decoder_sequence where it applies, the plain loop
+        over forward() otherwise."""
+        # (an instance whose forward() has been wrapped -- tests that record per-step intermediates -- sees every step through it)
+        if "forward" not in self.__dict__ and decoder_fused.sequence_supported(self, skip_feats, T):
+            return decoder_fused.decoder_sequence(self, skip_feats, T)
+        hidden, outs = None, []
+        for _t in range(T):
+            out_mask, out_class, out_stop, hidden = self.forward(skip_feats, hidden)
+            outs.append((out_mask, out_class, out_stop))
+        return outs, hidden
+
     def forward(self, skip_feats, prev_hidden_list):
         if self.fused and self.skip_mode == "concat" and self.dropout == 0 and len(skip_feats) == len(self.clstm_list):
             res = decoder_fused.decoder_levels(self, skip_feats, prev_hidden_list)

@@ -17,8 +17,8 @@ def test(args, encoder, decoder, x, return_logits=False):
     encoder.eval()
     decoder.eval()
     feats = encoder(x)                                                  # test.py:35
-    for _t in range(0, T):
-        out_mask, out_class, out_stop, hidden = decoder(feats, hidden)  # test.py:38
+    steps, hidden = decoder.forward_sequence(feats, T)                  # test.py:37-38 (the T decoder steps, wavefront order)
+    for out_mask, out_class, out_stop in steps:
         out_mask = ops.upsample_bilinear_ac(out_mask, (x.size()[-2], x.size()[-1]))   # test.py:39-40
         out_masks.append(out_mask)
         out_classes.append(out_class)

@@ -87,8 +87,10 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
     out_masks, out_classes, out_stops = [], [], []
     with torch.set_grad_enabled(train):
         feats = encoder(x)                                           # train.py:77 (once per iteration)
-        for _t in range(t_run):                                      # train.py:85
-            out_mask, out_class, out_stop, hidden = decoder(feats, hidden)                  # :94
+        # train.py:85-94: t_run decoder steps from the zero state -- RSIS.forward_sequence runs them in wavefront order with the
+        # gate kernels of a (level, step) diagonal in one launch; same nodes, same results as t_run calls of decoder(feats, hidden)
+        steps, hidden = decoder.forward_sequence(feats, t_run)
+        for out_mask, out_class, out_stop in steps:                  # train.py:85
             out_mask = ops.upsample_bilinear_ac(out_mask, (x.size(-2), x.size(-1)))         # :96-97
             out_masks.append(out_mask.reshape(out_mask.size(0), -1))                        # :98
             out_classes.append(out_class)

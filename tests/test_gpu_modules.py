@@ -292,6 +292,61 @@ def test_fused_decoder_equals_unfused(tcap):
         assert_close("grad." + k, q, p, 1e-4 * max(1.0, float(p.abs().max())), 1e-4)
 
 
+@pytest.mark.parametrize("shape", ["odd", "pow2"])
+def test_wavefront_sequence_equals_per_step_loop(shape):
+    """RSIS.forward_sequence (the (level, timestep) wavefront with the gate kernels of a diagonal in ONE rsis_convlstm_fwd_batch call)
+    against T calls of RSIS.forward (reference train.py:85-94): the same autograd nodes and the same kernel per cell, only the
+    launch order and the grouping differ -- outputs, final states and every gradient must agree to fp32 summation-order noise
+    (the grouped kernel may pick another pixel-tile shape than the single launch; the K order per output element is the same).
+    `odd`: ragged maps (partial tiles at every level); `pow2`: 8..128-pixel maps at hidden 128, batch 4 (every level of the product's
+    variant table, incl. the K-split 8x8 variant and the 32-wide tiles)."""
+    from oracle import filler
+    from rsis_amd.modules import RSIS
+    if shape == "odd":
+        hs, B, T, sizes = 32, 2, 4, [(3, 4), (5, 7), (10, 13), (19, 25), (37, 50)]
+    else:
+        hs, B, T, sizes = 128, 4, 3, [(8, 8), (16, 16), (32, 32), (64, 64), (128, 128)]
+    chans = [hs, hs, hs // 2, hs // 4, hs // 8]
+    a = mk_args(hidden_size=hs, maxseqlen=T)
+    torch.manual_seed(1)
+    dec = RSIS(a).cuda()
+    res = []
+    for seq in (False, True):
+        dec.zero_grad()
+        feats = [filler.tensor(7, "wf.f%d" % i, (B, chans[i]) + sizes[i]).cuda().requires_grad_() for i in range(5)]
+        if seq:
+            steps, hidden = dec.forward_sequence(feats, T)
+        else:
+            hidden, steps = None, []
+            for t in range(T):
+                m, c, s, hidden = dec(feats, hidden)
+                steps.append((m, c, s))
+        loss, outs = 0.0, []
+        for t, (m, c, s) in enumerate(steps):
+            outs += [m, c, s]
+            loss = loss + (m * filler.tensor(7, "wf.gm%d" % t, m.shape).cuda()).sum() + (c * c).sum() + s.sum()
+        loss = loss + sum((h * h).mean() + c.mean() for h, c in hidden)
+        outs += [t_ for st in hidden for t_ in st]
+        loss.backward()
+        res.append(([o.detach().clone() for o in outs], [f.grad.clone() for f in feats], {k: p.grad.clone() for k, p in dec.named_parameters()}))
+    for i, (p, q) in enumerate(zip(res[0][0], res[1][0])):
+        assert_close("out%d" % i, q, p, 1e-6 * max(1.0, float(p.abs().max())), 1e-6)
+    for i, (p, q) in enumerate(zip(res[0][1], res[1][1])):
+        assert_close("dfeat%d" % i, q, p, 1e-4 * max(1.0, float(p.abs().max())), 1e-4)
+    for k in res[0][2]:
+        p, q = res[0][2][k], res[1][2][k]
+        assert_close("grad." + k, q, p, 1e-4 * max(1.0, float(p.abs().max())), 1e-4)
+    # inference (no tape, no saved gates): bit-for-bit the per-step loop's outputs
+    with torch.no_grad():
+        feats = [filler.tensor(7, "wf.f%d" % i, (B, chans[i]) + sizes[i]).cuda() for i in range(5)]
+        steps, _hid = dec.forward_sequence(feats, T)
+        hidden = None
+        for t in range(T):
+            m, c, s, hidden = dec(feats, hidden)
+            assert_close("inf.mask%d" % t, steps[t][0], m, 1e-6 * max(1.0, float(m.abs().max())), 1e-6)
+            assert_close("inf.class%d" % t, steps[t][1], c, 1e-6)
+
+
 @pytest.mark.parametrize("train_bn", [True, False])
 def test_direct_grad_accumulation_equals_autograd(train_bn):
     """ops.DIRECT_GRAD (wgrad kernels accumulate straight into the zeroed flat .grad views) == plain autograd grads.
