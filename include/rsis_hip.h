@@ -178,6 +178,11 @@ int rsis_bn_bwd(const float* dy, const float* x, const float* y, const float* sa
                 const float* gamma, double* stats, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C,
                 int HW, int relu, void* stream);
 
+/* ---- y[bc][ho][wo] = x[bc][ho * stride][wo * stride], y is [BC][(H-1)/stride+1][(W-1)/stride+1]: the dense input of a
+ * 1x1 / stride-s conv (torchvision Bottleneck downsample, layers 2-4; reference vision.py:16-19) -- x[:, :, ::s, ::s].contiguous().
+ * The conv then runs as its stride-1 form (rsis_conv2d_fwd on y) and y is what its weight gradient reads. ---- */
+int rsis_subsample2d(const float* x, float* y, long BC, int H, int W, int stride, void* stream);
+
 /* ---- nn.MaxPool2d(3, stride 2, padding 1) of the ResNet stem (vision.py:15) ---- */
 int rsis_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* argmax, long BC, int H, int W, int Ho, int Wo,
                           void* stream);

@@ -32,6 +32,7 @@ int rsis_l_bn_fwd(const float*, const float*, float*, double*, const float*, con
 int rsis_l_bn_bwd(const float*, const float*, const float*, const float*, const float*, const float*, double*, float*, float*,
                   float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_maxpool_fwd(const float*, float*, unsigned char*, long, int, int, int, int, hipStream_t);
+int rsis_l_subsample(const float*, float*, long, int, int, int, int, int, hipStream_t);
 int rsis_l_maxpool_bwd(const float*, const unsigned char*, float*, long, int, int, int, int, int, hipStream_t);
 int rsis_l_channel_sum(const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_adam(float*, const float*, float*, float*, long, float, float, float, float, float, int, float, const int*, hipStream_t);
@@ -543,6 +544,10 @@ int rsis_bn_bwd(const float* dy, const float* x, const float* y, const float* sa
   if ((relu & 1) && !y) return RSIS_ERR_ARG;
   return rsis_l_bn_bwd(dy, x, y, save_mean, save_rstd, gamma, stats, dx, dres, dgamma, dbeta, B, C, HW, relu,
                        (hipStream_t)stream);
+}
+int rsis_subsample2d(const float* x, float* y, long BC, int H, int W, int stride, void* stream) {
+  if (!x || !y || x == y || BC < 1 || H < 1 || W < 1 || stride < 1) return RSIS_ERR_ARG;
+  return rsis_l_subsample(x, y, BC, H, W, (H - 1) / stride + 1, (W - 1) / stride + 1, stride, (hipStream_t)stream);
 }
 int rsis_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* argmax, long BC, int H, int W, int Ho, int Wo,
                           void* stream) {

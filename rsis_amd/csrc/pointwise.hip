@@ -637,6 +637,32 @@ __global__ __launch_bounds__(NT) void bn_bwd_fused_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// y[bc][ho][wo] = x[bc][ho * s][wo * s]: the input of a 1x1 / stride-s conv (the downsample convs of ResNet layers 2-4, torchvision
+// Bottleneck; reference vision.py:16-19) as a dense map, so that the conv itself runs as a stride-1 GEMM on the LDS-DMA path and
+// the same copy serves its weight gradient.  One thread per 4 output pixels of a row: s = 2 reads two float4 (every other element
+// of 8 consecutive inputs), writes one float4.
+// ------------------------------------------------------------------------------------------------
+__global__ void subsample_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int Ho, int Wo, int s, long total4) {
+  const int wq = (Wo + 3) / 4;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total4; e += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(e % wq);
+    const long t = e / wq;
+    const int ho = (int)(t % Ho);
+    const long bc = t / Ho;
+    const float* xr = x + (bc * H + (long)ho * s) * W;
+    float* yr = y + (bc * Ho + ho) * (long)Wo + 4 * q;
+    if (s == 2 && (W & 3) == 0 && 4 * q + 3 < Wo && 8 * q + 7 < W) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 8 * q), b = *reinterpret_cast<const f32x4*>(xr + 8 * q + 4);
+      const f32x4 o = {a[0], a[2], b[0], b[2]};
+      if ((Wo & 3) == 0) *reinterpret_cast<f32x4*>(yr) = o;
+      else { yr[0] = o[0]; yr[1] = o[1]; yr[2] = o[2]; yr[3] = o[3]; }
+    } else {
+      for (int k = 0; k < 4 && 4 * q + k < Wo; ++k) yr[k] = xr[(long)(4 * q + k) * s];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // MaxPool2d(3, stride 2, pad 1) of the ResNet stem (torchvision; reference vision.py:15)
 // ------------------------------------------------------------------------------------------------
 __global__ void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ arg,
@@ -1031,6 +1057,11 @@ int rsis_l_bn_bwd(const float* dy, const float* x, const float* y, const float* 
 }
 int rsis_l_gmax_bwd_add(const float* dy, const int* arg, float* dx, long BC, int HW, hipStream_t st) {
   hipLaunchKernelGGL(global_maxpool_bwd_add_kernel, dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, st, dy, arg, dx, HW, BC);
+  return rsis_check_launch();
+}
+int rsis_l_subsample(const float* x, float* y, long BC, int H, int W, int Ho, int Wo, int s, hipStream_t st) {
+  const long total4 = BC * Ho * ((Wo + 3) / 4);
+  hipLaunchKernelGGL(subsample_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, y, H, W, Ho, Wo, s, total4);
   return rsis_check_launch();
 }
 int rsis_l_maxpool_fwd(const float* x, float* y, unsigned char* arg, long BC, int H, int W, int Ho, int Wo, hipStream_t st) {

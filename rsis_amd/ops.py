@@ -339,7 +339,9 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.in_shape = None
         if ks == 1 and stride > 1 and pad == 0 and nsrc == 1 and (SUBSAMPLE_1X1[0] or pack.dtype == DTYPE_BF16):
             ctx.in_shape = tuple(srcs[0].shape)
-            srcs = [srcs[0][:, :, ::stride, ::stride].contiguous()]
+            sub = torch.empty((B, srcs[0].shape[1], Ho, Wo), dtype=torch.float32, device=weight.device)
+            check(L.rsis_subsample2d(ptr(srcs[0]), ptr(sub), B * srcs[0].shape[1], H, W, stride, stream()), "rsis_subsample2d")
+            srcs = [sub]
             H, W, stride_k = Ho, Wo, 1
         else:
             stride_k = stride

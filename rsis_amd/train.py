@@ -66,7 +66,8 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
     """Runs forward, computes loss and (if train mode) updates parameters for the provided batch (train.py:54-197).
     Returns (losses [total, iou, stop, class], outs [sigmoid(masks), class probs], perms [y_mask_perm, y_class_perm]).
     want_outs=False (training loops that only log the losses, as the reference's trainIters does: train.py:344-356): the
-    sigmoid of all T full-resolution masks (train.py:191) is not computed and outs[0] holds the raw logits.
+    sigmoid of all T full-resolution masks (train.py:191) is not computed and outs[0] holds the raw logits; the permuted GT masks
+    (train.py:140, 84 MB of gather per step at batch 32) are not materialised either: perms[0] is None, perms[1] is y_class_perm.
     do_update=False: stop after the backward (gradients left in the flat buffers; the caller all-reduces them and calls
     apply_update) -- the split GraphedStep uses when a gradient exchange sits between the backward and the optimizer.
     between: callback of a split backward (encoder.split_backward): between("dec") when the decoder + skip-conv gradients are
@@ -116,7 +117,10 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
         else:
             perm = torch.from_numpy(match_indices(scores)).to(x.device)                           # more than 64 GT slots: host assignment (scipy), as the reference does
         idx = perm[:, 0:t]
-        y_mask_perm = torch.gather(y_mask, 1, idx.unsqueeze(-1).expand(-1, -1, y_mask.size(2)))   # :140
+        # :140 -- the permuted GT masks are a RETURN value here (the matched loss below reads y_mask through `perm`): 84 MB of
+        # gather per step that a training loop which only logs the losses (want_outs=False) does not need; the fallback loss does
+        need_perm_masks = want_outs or not fused_iou
+        y_mask_perm = torch.gather(y_mask, 1, idx.unsqueeze(-1).expand(-1, -1, y_mask.size(2))) if need_perm_masks else None
         y_class_perm = torch.gather(y_class, 1, idx)                                               # :141
     sw_mask_t = sw_mask[:, 0:t].contiguous()                         # :147
     sw_class_t = sw_class[:, 0:t].contiguous()                       # :148

@@ -172,6 +172,20 @@ def test_global_maxpool(shape):
     assert_close("bwd", xd.grad, x.grad, 0)
 
 
+@pytest.mark.parametrize("shape", [(2, 4, 8, 8), (3, 5, 9, 11), (1, 2, 16, 6), (2, 3, 7, 7), (2, 8, 56, 56), (1, 3, 13, 30), (2, 16, 64, 64)])
+@pytest.mark.parametrize("stride", [2, 3])
+def test_subsample2d(shape, stride):
+    """rsis_subsample2d: x[:, :, ::s, ::s] as a dense map (the input of the strided 1x1 downsample convs), bit-exact copy; even /
+    odd / ragged widths (vector and scalar paths)"""
+    from rsis_amd._lib import check, lib, ptr, stream
+    x = _dev(_rng_t(70, shape))
+    B, C, H, W = shape
+    want = x[:, :, ::stride, ::stride].contiguous()
+    y = torch.full_like(want, float("nan"))
+    check(lib().rsis_subsample2d(ptr(x), ptr(y), B * C, H, W, stride, stream()), "rsis_subsample2d")
+    assert torch.equal(y, want)
+
+
 @pytest.mark.parametrize("shape", [(2, 4, 8, 8), (3, 5, 9, 11), (1, 2, 16, 6), (2, 3, 7, 7), (2, 3, 12, 20), (1, 2, 10, 4), (2, 8, 32, 64)])
 @pytest.mark.parametrize("ties", [False, True])
 def test_maxpool3x3s2(shape, ties):
