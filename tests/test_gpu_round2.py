@@ -437,6 +437,39 @@ def test_config4_geometry_training_steps(dtype):
     g.release()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_config2_geometry_training_steps(dtype):
+    """BASELINE configs[2] (and the per-GPU workload of configs[3]) -- 224x224, T = 10, batch 32, ResNet-101 -- as the training
+    driver runs it: five iterations (two eager, three replayed as a hipGraph) under either dtype: finite, decreasing loss; and the
+    bf16 curve stays within 5 % of the fp32 one at every step (same initial weights, same batch: bf16 is operand rounding only)."""
+    import bench
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import GraphedStep, build_optimizers, steps_to_run
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    B, S, T = 32, 224, 10
+    a = bench.bench_args(B, S, T, dtype)
+    torch.manual_seed(0)
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    opts = list(build_optimizers(a, enc, dec))
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(0.5)]
+    batch = synthetic_batch(2, B, S, S, a.gt_maxseqlen, 12, a.num_classes, "cuda")
+    t_run = steps_to_run(a, batch[3])
+    assert t_run == T
+    g = GraphedStep(a, enc, dec, crits, opts, None, warm=2)
+    ls = [float(g(batch, t_run)[0][0]) for _ in range(5)]
+    assert g.graph is not None, g.failed
+    g.release()
+    assert all(v == v and abs(v) < 1e3 for v in ls) and ls[-1] < ls[0], ls
+    _CONFIG2_CURVES[dtype] = ls
+    if len(_CONFIG2_CURVES) == 2:
+        f, b = _CONFIG2_CURVES["fp32"], _CONFIG2_CURVES["bf16"]
+        assert all(abs(x - y) <= 0.05 * abs(x) for x, y in zip(f, b)), (f, b)
+
+
+_CONFIG2_CURVES = {}
+
+
 def test_ragged_targets_match_the_oracle():
     """Edge cases of the target side (reference train.py:85-176): a batch whose images hold 0, 1, 3 and T+2 instances -- an image
     without any ground truth, images that run out of instances before the last step, one with more instances than steps -- at
