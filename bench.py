@@ -298,13 +298,17 @@ REAL_STDOUT = 1
 GATE_KERNEL_RE = re.compile(r"conv3x3_direct_kernel<\d+, \d+, \d+, \d+, 1, \d+, \d+>")
 # ... and the grouped launch of one wavefront diagonal (rsis_convlstm_fwd_batch): template argument <EPI>
 GATE_GROUP_RE = re.compile(r"conv3x3_direct_group_kernel<1>")
+# ... and its bf16 twin, conv_bf16_kernel<KS, BM, TW, TH, EPI, CKB, V4> with KS == 3 and EPI == 1 (five single launches per diagonal)
+GATE_BF16_RE = re.compile(r"conv_bf16_kernel<3, \d+, \d+, \d+, 1, \d+, \w+>")
 
 
-def gate_kernel_traffic(batch, imsize, timeout=150):
+def gate_kernel_traffic(batch, imsize, dtype="fp32", timeout=150):
     """HBM bytes of the gate-kernel launch of one timestep (the grouped launch of one wavefront diagonal: five levels) from the memory-side PMC counters: two rocprofv3 passes
     (FETCH_SIZE, then WRITE_SIZE -- they do not fit one pass) over `bench.py --roofline-only` in a child process.
-    FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibrated there for 16 B/lane streaming reads; this
-    kernel's input patch is fetched 4 B/lane, for which the doubling is an upper bound).  Returns (bytes, detail) or (None, why)."""
+    FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (re-measured for this library's load flavours in
+    profiles/r02_fetch_calibration.txt).  fp32: ONE launch shape (the grouped kernel); bf16: the five single launches of the
+    diagonal, summed.  Returns (bytes, detail) or (None, why)."""
+    name_re, n_shapes = (GATE_GROUP_RE, 1) if dtype == "fp32" else (GATE_BF16_RE, 5)
     import csv
     import shutil
     import statistics
@@ -318,7 +322,7 @@ def gate_kernel_traffic(batch, imsize, timeout=150):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", counter.lower(), "--",
                    sys.executable, os.path.abspath(__file__), "--roofline-only", "--product-only", "--kernel-iters", "4", "--batch", str(batch),
-                   "--imsize", str(imsize)]
+                   "--imsize", str(imsize), "--dtype", dtype]
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
             path = None
             for root, _d, files in os.walk(tmp):
@@ -331,10 +335,10 @@ def gate_kernel_traffic(batch, imsize, timeout=150):
             with open(path) as f:
                 for r in csv.DictReader(f):
                     k = r["Kernel_Name"]
-                    if r["Counter_Name"] == counter and GATE_GROUP_RE.search(k):
+                    if r["Counter_Name"] == counter and name_re.search(k):
                         vals.setdefault((k, r["Grid_Size"]), []).append(float(r["Counter_Value"]))
-            if len(vals) != 1:
-                return None, "expected 1 grouped gate-kernel launch shape in the counter file, found %d" % len(vals)
+            if len(vals) != n_shapes:
+                return None, "expected %d gate-kernel launch shape(s) in the counter file, found %d" % (n_shapes, len(vals))
             per_counter[counter] = sum(statistics.median(v) for v in vals.values()) * 1024.0      # counters are in KiB
     except Exception as e:  # noqa: BLE001  (profiler missing / refused / timed out: the figure stays null)
         return None, "rocprofv3 pass failed: %r" % (e,)
@@ -447,10 +451,10 @@ def main():
         note("roofline_kernels: %s" % "; ".join("%s %.1f TF/s" % (r["family"], r["tflops"]) for r in roof_kernels))
         if world == 1 and not o.skip_traffic:
             t0 = time.time()
-            traffic, detail = gate_kernel_traffic(o.batch, o.imsize)
+            traffic, detail = gate_kernel_traffic(o.batch, o.imsize, o.dtype)
             roof["traffic"] = traffic
             if traffic is not None:
-                roof["traffic_unit"] = ("bytes per timestep (the grouped launch of the 5 levels): 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate "
+                roof["traffic_unit"] = ("bytes per timestep (the gate launches of the 5 levels): 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate "
                                         "passes; the x2 is the guide's gfx950 correction, re-measured for this kernel's dword LDS-DMA reads in "
                                         "profiles/r02_fetch_calibration.txt")
                 roof["traffic_vs_algorithmic"] = round(traffic / (roof["algorithmic_mbytes_per_timestep"] * 1e6), 3)
@@ -536,18 +540,23 @@ def main():
             note("cpu baseline: %s" % (cpu,))
         secondary = None
         if world == 1 and o.dtype == "fp32" and not o.skip_secondary:
-            # BASELINE configs[2] (224x224, T=10, batch 32, bf16) as a secondary record: own process, same harness
+            # BASELINE configs[2] (224x224, T=10, batch 32, bf16) as a secondary record, and the SAME geometry under fp32 next to it
+            # (so that the speed-up of the bf16 kernels is stated on equal geometry): own processes, same harness
             import subprocess
-            try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", "bf16", "--imsize", "224", "--batch", str(o.batch), "--T",
-                                    str(o.T), "--steps", str(o.steps), "--warmup", str(o.warmup), "--skip-cpu", "--skip-traffic",
-                                    "--skip-secondary", "--kernel-iters", str(o.kernel_iters)], capture_output=True, text=True, timeout=600)
-                sj = json.loads(r.stdout.strip().splitlines()[-1])
-                sj["config"]["workload"] = sj["config"]["workload"].replace("configs[1]", "configs[2]")
-                secondary = [{k: sj[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "roofline_kernels")}]
-            except Exception as ex:  # noqa: BLE001
-                secondary = [{"error": repr(ex)}]
-            note("secondary (bf16, 224x224): %s" % (secondary[0].get("value"),))
+            secondary = []
+            for sd, extra in (("bf16", []), ("fp32", ["--skip-traffic"])):
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", sd, "--imsize", "224", "--batch", str(o.batch), "--T",
+                                        str(o.T), "--steps", str(o.steps), "--warmup", str(o.warmup), "--skip-cpu", "--skip-secondary",
+                                        "--kernel-iters", str(o.kernel_iters)] + extra, capture_output=True, text=True, timeout=600)
+                    sj = json.loads(r.stdout.strip().splitlines()[-1])
+                    sj["config"]["workload"] = sj["config"]["workload"].replace("configs[1]", "configs[2] geometry" if sd == "fp32" else "configs[2]")
+                    secondary.append({k: sj[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "roofline_kernels")})
+                except Exception as ex:  # noqa: BLE001
+                    secondary.append({"dtype": sd, "error": repr(ex)})
+            if all("value" in s_ for s_ in secondary):
+                secondary[0]["speedup_over_fp32_same_geometry"] = round(secondary[0]["value"] / secondary[1]["value"], 3)
+            note("secondary (224x224): bf16 %s images/s, fp32 %s images/s" % (secondary[0].get("value"), secondary[1].get("value")))
         value = world * o.batch * o.steps / dt
         out = {"metric": "training images/sec at %dx%d, T=%d, batch=%d per GPU" % (o.imsize, o.imsize, o.T, o.batch),
                "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": o.steps, "warmup": o.warmup,

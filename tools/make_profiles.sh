@@ -1,0 +1,39 @@
+#!/bin/bash
+# Regenerates the rocprofv3 summaries committed under profiles/ for one round (run on the GPU box: `gpurun -- bash tools/make_profiles.sh r03`).
+# Everything is written under gpurun_out/<tag>/ ; copy the *.txt / *.json you want judged into profiles/.
+set -u
+TAG=${1:-r03}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+cd $R
+STEP="--steps 3 --warmup 3 --skip-cpu --skip-roofline --skip-secondary --no-settle"
+prof() {   # name, then the command
+  local name=$1; shift
+  rm -rf $OUT/raw_$name
+  rocprofv3 --kernel-trace --stats -d $OUT/raw_$name -- "$@" > /dev/null 2> $OUT/${name}.err
+  find $OUT/raw_$name -name "*results.db" | head -1
+}
+# one replayed training step, fp32 256^2 and bf16 224^2
+db=$(prof step_fp32 python bench.py $STEP);                  python tools/prof_summary.py $db laststep > $OUT/bench_fp32_step.txt
+db=$(prof step_bf16 python bench.py $STEP --dtype bf16 --imsize 224); python tools/prof_summary.py $db laststep > $OUT/bench_bf16_224_step.txt
+# the roofline leg: the launches `roofline.achieved` is computed from, one row per (kernel, grid)
+db=$(prof roof_fp32 python bench.py --roofline-only --product-only)
+python tools/prof_by_grid.py $db conv3x3_direct_group_kernel "conv3x3_direct_kernel<" > $OUT/roofline_leg_fp32.txt
+db=$(prof roof_bf16 python bench.py --roofline-only --product-only --dtype bf16 --imsize 224)
+python tools/prof_by_grid.py $db "conv_bf16_kernel<3" > $OUT/roofline_leg_bf16_224.txt
+# HBM counters of the gate launches (separate passes per counter: they do not fit one), both dtypes
+for dt in fp32 bf16; do
+  sz=256; [ $dt = bf16 ] && sz=224
+  csvs=""
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $OUT/raw_pmc_${dt}_$c
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/raw_pmc_${dt}_$c -o pmc -- python bench.py --roofline-only --product-only --kernel-iters 4 --dtype $dt --imsize $sz > /dev/null 2>&1
+    csvs="$csvs $(find $OUT/raw_pmc_${dt}_$c -name '*counter_collection.csv' | head -1)"
+  done
+  pat="conv3x3_direct_group_kernel"; [ $dt = bf16 ] && pat="conv_bf16_kernel<3"
+  python tools/pmc_summary.py "$pat" $csvs > $OUT/gate_pmc_$dt.txt
+done
+rm -rf $OUT/raw_*
+ls -la $OUT
