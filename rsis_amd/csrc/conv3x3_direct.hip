@@ -26,6 +26,9 @@
 // immediate offset per MFMA (2-way LDS bank conflicts from the pixel stride of 2), plain epilogue on the output grid.
 #include "common.h"
 #include <stdlib.h>
+#ifndef XCD_CHUNKED
+#define XCD_CHUNKED 1
+#endif
 
 enum { EPI_PLAIN = 0, EPI_LSTM = 1, EPI_S2 = 2, EPI_F2 = 3 };
 typedef __attribute__((address_space(3))) void* lds_vp_t;
@@ -91,7 +94,11 @@ __device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int
   // ---- block -> (co tile, spatial tile); blocks b, b+8, ... share an XCD: a tile's co tiles stay on one L2 ----
   const int xcd = bid & 7, q = bid >> 3;
   const int co_t = q % p.n_co_tiles;
-  const int sp_t = (q / p.n_co_tiles) * 8 + xcd;
+  // (XCD x owns the contiguous range [x * chunk, (x + 1) * chunk) of the spatial tiles: blocks b, b + 8, ... -- the ones this XCD
+  //  runs one after the other -- are NEIGHBOURING tiles, so the halo rows / columns two tiles share are L2 hits instead of a
+  //  second fetch from HBM by another XCD.  Measured against the round-robin map `(q / n_co_tiles) * 8 + xcd` (a build with
+  //  -DXCD_CHUNKED=0): the bf16 gate launch of the 112 x 112 level 48.4 -> 33.6 us, the fp32 128 x 128 level 83.7 -> 79.3 us.)
+  const int sp_t = XCD_CHUNKED ? xcd * ((p.n_px_tiles + 7) >> 3) + q / p.n_co_tiles : (q / p.n_co_tiles) * 8 + xcd;
   if (sp_t >= p.n_px_tiles) return;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int tx = sp_t % tiles_x;

@@ -21,6 +21,9 @@
 // flight per CU and one pass over the input, not MFMA utilisation.
 #include "common.h"
 #include <stdlib.h>
+#ifndef XCD_CHUNKED
+#define XCD_CHUNKED 1
+#endif
 
 enum { EPI_PLAIN = 0, EPI_LSTM = 1 };
 typedef __attribute__((address_space(3))) void* lds_vp_t;
@@ -76,7 +79,11 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgs p) {
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q = bid >> 3;
   const int co_t = q % p.n_co_tiles;
-  const int sp_t = (q / p.n_co_tiles) * 8 + xcd;
+  // (XCD x owns the contiguous range [x * chunk, (x + 1) * chunk) of the spatial tiles: blocks b, b + 8, ... -- the ones this XCD
+  //  runs one after the other -- are NEIGHBOURING tiles, so the halo rows / columns two tiles share are L2 hits instead of a
+  //  second fetch from HBM by another XCD.  Measured against the round-robin map `(q / n_co_tiles) * 8 + xcd` (a build with
+  //  -DXCD_CHUNKED=0): the bf16 gate launch of the 112 x 112 level 48.4 -> 33.6 us, the fp32 128 x 128 level 83.7 -> 79.3 us.)
+  const int sp_t = XCD_CHUNKED ? xcd * ((p.n_px_tiles + 7) >> 3) + q / p.n_co_tiles : (q / p.n_co_tiles) * 8 + xcd;
   if (sp_t >= p.n_px_tiles) return;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int tx = sp_t % tiles_x;
@@ -408,7 +415,11 @@ __global__ __launch_bounds__(256) void conv1x1_bf16_ring_kernel(const ConvArgs p
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q = bid >> 3;
   const int co_t = q % p.n_co_tiles;
-  const int sp_t = (q / p.n_co_tiles) * 8 + xcd;
+  // (XCD x owns the contiguous range [x * chunk, (x + 1) * chunk) of the spatial tiles: blocks b, b + 8, ... -- the ones this XCD
+  //  runs one after the other -- are NEIGHBOURING tiles, so the halo rows / columns two tiles share are L2 hits instead of a
+  //  second fetch from HBM by another XCD.  Measured against the round-robin map `(q / n_co_tiles) * 8 + xcd` (a build with
+  //  -DXCD_CHUNKED=0): the bf16 gate launch of the 112 x 112 level 48.4 -> 33.6 us, the fp32 128 x 128 level 83.7 -> 79.3 us.)
+  const int sp_t = XCD_CHUNKED ? xcd * ((p.n_px_tiles + 7) >> 3) + q / p.n_co_tiles : (q / p.n_co_tiles) * 8 + xcd;
   if (sp_t >= p.n_px_tiles) return;
   const int tiles_x = (HW + BN - 1) / BN;
   const int tx = sp_t % tiles_x, b0 = sp_t / tiles_x;
