@@ -379,35 +379,50 @@ __global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const WgradBf16Args p)
   wgrad1_bf16_body<BM, BN, WGM, WGN, TW, V4>(p, blockIdx.x, blockIdx.y);
 }
 
-#define RSIS_WGB_MAXJ 48
+// XCD placement of a grouped launch.  A (job, range of consecutive splits) ITEM -- all dW tiles of one job over one range of its
+// spatial tiles -- runs on ONE XCD: its blocks re-read the same dy / x pixels once per dW tile (4-16 times each), and only inside
+// one L2 are those re-reads hits.  With consecutive block indices spread round-robin over the eight XCDs every XCD fetched the pixels
+// again: the bf16 1x1 group read 6.1 GB where 1.5 GB are needed and ran AT the fabric's rate (6 TB/s; rocprofv3 --pmc FETCH_SIZE per
+// kernel, tools/step_traffic.py) -- with the MFMA 16x faster than in fp32 these launches are what the memory system lets them be.
+// Hardware sends block b to XCD b % 8, so the grid is eight interleaved LANES: lane x is the blocks b = 8 k + x and holds a list of
+// items (k ranges); the host balances the lanes by work (longest item first).  (The exact-f32 weight gradients are MFMA-bound: the
+// same placement halved their reads and changed their time by nothing, NOTES.md (21).)
+#define RSIS_WGB_MAXJ 32
+#define RSIS_WGB_LANE_ITEMS 28
 struct WgradBf16Group {
   int n;
-  int begin[RSIS_WGB_MAXJ + 1];
+  int lane_n[8];
+  int lane_start[8][RSIS_WGB_LANE_ITEMS + 1];     // first k of each item of a lane, ascending; [lane_n] = the lane's block count
+  unsigned short lane_split0[8][RSIS_WGB_LANE_ITEMS];   // an item covers the consecutive splits split0, split0 + 1, ... of its job
+  unsigned char lane_job[8][RSIS_WGB_LANE_ITEMS];
   WgradBf16Args job[RSIS_WGB_MAXJ];
 };
 static_assert(sizeof(WgradBf16Group) <= 4000, "kernel arguments are limited to 4 KB");
 
-__device__ __forceinline__ int wgb_find(const WgradBf16Group& g, int b) {
-  int lo = 0, hi = g.n - 1;
-  while (lo < hi) {                       // last job whose begin <= b (uniform: scalar code)
-    const int mid = (lo + hi + 1) >> 1;
-    if (g.begin[mid] <= b) lo = mid; else hi = mid - 1;
-  }
-  return lo;
+// block -> (job, tile, split); false: a padding block of a short lane
+__device__ __forceinline__ bool wgb_find(const WgradBf16Group& g, int& job, int& tile, int& split) {
+  const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const int nl = g.lane_n[x];
+  if (k >= g.lane_start[x][nl]) return false;
+  int i = 0;
+  while (i + 1 < nl && g.lane_start[x][i + 1] <= k) ++i;        // (uniform: scalar code)
+  job = g.lane_job[x][i];
+  const int kl = k - g.lane_start[x][i], ntile = g.job[job].n_co_tiles * g.job[job].n_n_tiles;
+  tile = kl % ntile;
+  split = g.lane_split0[x][i] + kl / ntile;
+  return true;
 }
 template <int BM, int TW, bool V4>
 __global__ __launch_bounds__(256) void wgrad3_bf16_group_kernel(const WgradBf16Group g) {
-  const int j = wgb_find(g, blockIdx.x);
-  const WgradBf16Args& p = g.job[j];
-  const int local = blockIdx.x - g.begin[j], ntile = p.n_co_tiles * p.n_n_tiles;
-  wgrad3_bf16_body<BM, TW, V4>(p, local % ntile, local / ntile);
+  int j, tile, split;
+  if (!wgb_find(g, j, tile, split)) return;
+  wgrad3_bf16_body<BM, TW, V4>(g.job[j], tile, split);
 }
 template <int BM, int BN, int WGM, int WGN, int TW, bool V4>
 __global__ __launch_bounds__(256) void wgrad1_bf16_group_kernel(const WgradBf16Group g) {
-  const int j = wgb_find(g, blockIdx.x);
-  const WgradBf16Args& p = g.job[j];
-  const int local = blockIdx.x - g.begin[j], ntile = p.n_co_tiles * p.n_n_tiles;
-  wgrad1_bf16_body<BM, BN, WGM, WGN, TW, V4>(p, local % ntile, local / ntile);
+  int j, tile, split;
+  if (!wgb_find(g, j, tile, split)) return;
+  wgrad1_bf16_body<BM, BN, WGM, WGN, TW, V4>(g.job[j], tile, split);
 }
 
 static void split_plan(WgradBf16Args& a, int TW, int ntile, int slots) {
@@ -523,23 +538,51 @@ static int wgb_launch_bucket(WgradBf16Args* jobs, int n, const WgbKey& k, Launch
   long L = (total + target_blocks - 1) / target_blocks;
   if (L < 2) L = 2;
   if (rsis_deterministic()) L = 1L << 40;
-  for (int j0 = 0; j0 < n; j0 += RSIS_WGB_MAXJ) {
-    WgradBf16Group g;
-    g.n = n - j0 < RSIS_WGB_MAXJ ? n - j0 : RSIS_WGB_MAXJ;
-    int blocks = 0;
-    for (int j = 0; j < g.n; ++j) {
-      WgradBf16Args a = jobs[j0 + j];
+  int j0 = 0;
+  while (j0 < n) {
+    WgradBf16Group g = {};
+    // items of this launch: a job with up to 8 splits is one item per split, a job with more is 8 items of consecutive splits
+    struct Item { int job, split, blocks; long work; };
+    Item items[8 * RSIS_WGB_LANE_ITEMS];
+    int ni = 0, nj = 0;
+    while (j0 + nj < n && nj < RSIS_WGB_MAXJ) {
+      WgradBf16Args a = jobs[j0 + nj];
       int nsplit = rsis_cdiv(a.n_sp_tiles, L);
       if (nsplit < 1) nsplit = 1;
+      if (nsplit > 60000) nsplit = 60000;
       a.tiles_per_split = rsis_cdiv(a.n_sp_tiles, nsplit);
       nsplit = rsis_cdiv(a.n_sp_tiles, a.tiles_per_split);
-      g.begin[j] = blocks;
-      g.job[j] = a;
-      blocks += a.n_co_tiles * a.n_n_tiles * nsplit;
+      const int nit = nsplit < 8 ? nsplit : 8;
+      if (ni + nit > 8 * RSIS_WGB_LANE_ITEMS) break;            // (nj >= 1 here: one job is at most 8 items)
+      const int ntile = a.n_co_tiles * a.n_n_tiles;
+      for (int it = 0; it < nit; ++it) {
+        const int s0 = (int)((long)nsplit * it / nit), s1 = (int)((long)nsplit * (it + 1) / nit);
+        const long tiles = (long)(s1 < nsplit ? (long)s1 * a.tiles_per_split : a.n_sp_tiles) - (long)s0 * a.tiles_per_split;
+        items[ni++] = Item{nj, s0, ntile * (s1 - s0), (long)ntile * tiles};
+      }
+      g.job[nj++] = a;
     }
-    g.begin[g.n] = blocks;
-    launch(g, blocks);
+    g.n = nj;
+    for (int x = 1; x < ni; ++x)           // longest item first onto the least loaded lane that still has a free slot
+      for (int y = x; y > 0 && items[y].work > items[y - 1].work; --y) { const Item t = items[y]; items[y] = items[y - 1]; items[y - 1] = t; }
+    long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int blocks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < ni; ++i) {
+      int best = -1;
+      for (int x = 0; x < 8; ++x)
+        if (g.lane_n[x] < RSIS_WGB_LANE_ITEMS && (best < 0 || load[x] < load[best])) best = x;
+      const int e = g.lane_n[best]++;
+      g.lane_start[best][e] = blocks[best];
+      g.lane_job[best][e] = (unsigned char)items[i].job;
+      g.lane_split0[best][e] = (unsigned short)items[i].split;
+      blocks[best] += items[i].blocks;
+      load[best] += items[i].work;
+    }
+    int maxb = 0;
+    for (int x = 0; x < 8; ++x) { g.lane_start[x][g.lane_n[x]] = blocks[x]; if (blocks[x] > maxb) maxb = blocks[x]; }
+    launch(g, 8 * maxb);
     if (rsis_check_launch() != RSIS_OK) return RSIS_ERR_LAUNCH;
+    j0 += nj;
   }
   return RSIS_OK;
 }
