@@ -62,12 +62,18 @@ __global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restri
 // (row -> bc, ho).  Same arithmetic per element as upsample_fwd_kernel (bit-identical results).
 __global__ __launch_bounds__(256) void upsample_fwd_v4_kernel(const float* __restrict__ x, float* __restrict__ y, int Hi, int Wi,
                                                               int Ho, int Wo, float sh, float sw, long rows, int Wq, int wq_shift) {
-  // wq_shift >= 0: Wq is a power of two <= 256 and a block spans 256 >> wq_shift rows; otherwise blockIdx.y walks the row
+  // wq_shift >= 0: Wq is a power of two <= 256 and a block spans 256 >> wq_shift rows; -2: any Wq <= 256, the (row, float4)
+  // space is walked flat (one division per thread: the 7 / 14 / 28-float4 rows of the 224 x 224 pyramid had one 256-thread block
+  // per ROW before, 3-11 % of the lanes active: 22 us per launch instead of 6); otherwise blockIdx.y walks the row
   long row;
   int wq;
   if (wq_shift >= 0) {
     row = (long)blockIdx.x * (256 >> wq_shift) + (threadIdx.x >> wq_shift);
     wq = threadIdx.x & (Wq - 1);
+  } else if (wq_shift == -2) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    row = e / Wq;
+    wq = (int)(e - row * Wq);
   } else {
     row = blockIdx.x;
     wq = blockIdx.y * 256 + threadIdx.x;
@@ -955,7 +961,9 @@ int rsis_l_upsample_fwd(const float* x, float* y, long BC, int Hi, int Wi, int H
     const long rows = BC * Ho;
     int shift = -1;
     if (Wq <= 256 && (Wq & (Wq - 1)) == 0) { shift = 0; while ((1 << shift) < Wq) ++shift; }
-    const dim3 grid = shift >= 0 ? dim3((unsigned)((rows + (256 >> shift) - 1) / (256 >> shift))) : dim3((unsigned)rows, (Wq + 255) / 256);
+    if (shift < 0 && Wq <= 256) shift = -2;
+    const dim3 grid = shift >= 0 ? dim3((unsigned)((rows + (256 >> shift) - 1) / (256 >> shift)))
+                                 : (shift == -2 ? dim3((unsigned)((rows * Wq + 255) / 256)) : dim3((unsigned)rows, (Wq + 255) / 256));
     hipLaunchKernelGGL(upsample_fwd_v4_kernel, grid, dim3(256), 0, st, x, y, Hi, Wi, Ho, Wo, ac_scale(Hi, Ho), ac_scale(Wi, Wo), rows,
                        Wq, shift);
   } else {
