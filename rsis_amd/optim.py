@@ -7,6 +7,8 @@ flat fp32 buffer (so are their grads): the Adam step is a single fused HIP kerne
 bucket, launched from autograd hooks as soon as a bucket's gradients are final (decoder + skip bucket first -- it
 overlaps the whole encoder backward).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -231,6 +233,9 @@ class BucketedAllReduce(object):
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = dist.is_initialized() and (self.world > 1 or force)   # force: exercise the collective path at world 1
         self.hooks_enabled = True
+        # staged: train.runIter exchanges the gradients itself at the cuts of a split backward (three ranges, three collectives)
+        # instead of through the per-bucket hooks below; RSIS_EXCHANGE=hooks (or staged = False) selects the hooks
+        self.staged = os.environ.get("RSIS_EXCHANGE", "staged") != "hooks"
         self.buckets = []      # (flat_g view, n_params)
         self._pending = []
         self._handles = []

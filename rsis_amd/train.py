@@ -76,6 +76,18 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
     mask_siou, class_crit, stop_xentropy = crits
     enc_opt, dec_opt = optims
     train = mode == "train"
+    # gradient exchange of an eager step (one process per GPU): STAGED by default -- the backward is cut where a range of the flat
+    # gradient buffers becomes final (exchange_plan: decoder + skip group | trunk layers 3-4 | the rest) and each range is
+    # all-reduced asynchronously while the next part of the backward runs: three weight-gradient flushes and three collectives per
+    # step, the same schedule (and the same arithmetic) as the cut hipGraphs of GraphedStep.  reducer.staged = False
+    # (RSIS_EXCHANGE=hooks) keeps the hook-driven bucketed exchange of optim.BucketedAllReduce (one flush per completed bucket).
+    staged = bool(train and do_update and between is None and reducer is not None and getattr(reducer, "active", False)
+                  and getattr(reducer, "staged", False) and hasattr(encoder, "split_backward"))
+    if staged:
+        encoder.split_backward, reducer.hooks_enabled = EXCHANGE_CUTS, False
+        plan, pending = exchange_plan(encoder, optims, EXCHANGE_CUTS), []
+        between = lambda stage: pending.extend(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=reducer.pg, async_op=True)   # noqa: E731
+                                               for b in plan[stage])
     encoder.train(train)                                             # train.py:71-76
     decoder.train(train)
     y_mask = y_mask.float()
@@ -180,7 +192,13 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
             ops.DIRECT_GRAD[0] = prev
             ops.WGRAD_DEFER[0] = prev_defer
             del ops._WGRAD_QUEUE[:]
-        if do_update:
+        if staged:
+            for h in pending:
+                h.wait()
+            for b in plan["rest"]:
+                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=reducer.pg)
+            apply_update(args, optims, 1.0 / reducer.world)
+        elif do_update:
             apply_update(args, optims, reducer.finish() if reducer is not None else 1.0)
 
     losses = [loss.detach(), loss_mask_iou.detach(), loss_stop.detach(), loss_class.detach()]
@@ -245,6 +263,22 @@ def build_optimizers(args, encoder, decoder):
 
 
 EXCHANGE_CUTS = int(os.environ.get("RSIS_EXCHANGE_CUTS", "2"))     # 0 / 1 / 2, see GraphedStep
+
+
+def exchange_plan(encoder, optims, cuts):
+    """flat-gradient ranges that are final after each stage of a split backward (encoder.split_backward = cuts):
+    {"dec": [...], "trunk_hi": [...], "rest": [...]} -- "dec" when BPTT and the skip convs are done, "trunk_hi" when trunk layers
+    4-3 are, "rest" at the end.  optims = [enc_opt, dec_opt] (FlatAdam)."""
+    groups = [o.group for o in optims if isinstance(o, FlatAdam)]
+    enc_g = optims[0].group
+    dec = [g.flat_g for g in groups if g is not enc_g]
+    if cuts <= 0:
+        return {"dec": [], "trunk_hi": [], "rest": dec + [enc_g.flat_g]}
+    if cuts == 1:
+        return {"dec": dec, "trunk_hi": [], "rest": [enc_g.flat_g]}
+    first = next(encoder.base.layer3.parameters())
+    off3 = enc_g.offsets[enc_g._index[id(first)]][0]      # parameters lie in forward order: [stem, layer1, layer2 | layer3, layer4]
+    return {"dec": dec, "trunk_hi": [enc_g.flat_g[off3:]], "rest": [enc_g.flat_g[:off3]]}
 
 
 class GraphedStep(object):
@@ -316,17 +350,7 @@ class GraphedStep(object):
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.reducer.pg, async_op=async_op)
 
     def _plan(self):
-        """flat-gradient ranges that are final after each stage: {"dec": [...], "trunk_hi": [...], "rest": [...]}"""
-        enc_g = self.optims[0].group
-        dec = [g.flat_g for g in self._groups() if g is not enc_g]
-        if self.cuts == 0:
-            return {"dec": [], "trunk_hi": [], "rest": dec + [enc_g.flat_g]}
-        if self.cuts == 1:
-            return {"dec": dec, "trunk_hi": [], "rest": [enc_g.flat_g]}
-        first = next(self.encoder.base.layer3.parameters())
-        k = enc_g._index[id(first)]
-        off3 = enc_g.offsets[k][0]                # parameters lie in forward order: [stem, layer1, layer2 | layer3, layer4]
-        return {"dec": dec, "trunk_hi": [enc_g.flat_g[off3:]], "rest": [enc_g.flat_g[:off3]]}
+        return exchange_plan(self.encoder, self.optims, self.cuts)
 
     def __call__(self, batch, t_run):
         if self.graphs is None and self.failed is None and self.n_eager >= self.warm:

@@ -202,3 +202,40 @@ def test_host_loss_math_matches_golden():
     m, c, perm = Hn.match([ym, None], [yc, None], scores)
     assert (perm == g["match_perm"]).all() and (c.numpy() == g["match_class"]).all()
     assert np.allclose(m.sum(-1).numpy(), g["match_mask_sum"])
+
+
+def test_exchange_plan_partitions_the_flat_gradient_buffers():
+    """train.exchange_plan (the gradient ranges that become final at the cuts of a split backward -- what GraphedStep and the staged
+    eager exchange all-reduce, and when): for every cut count the ranges are disjoint views that together cover both flat gradient
+    buffers exactly once; with two cuts the trunk splits in front of layer3 (parameters lie in forward order), layers 3-4 holding
+    the bulk of the trunk's parameters."""
+    from helpers import mk_args
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.optim import FlatAdam
+    from rsis_amd.train import exchange_plan
+    from rsis_amd.utils.utils import get_base_params, get_skip_params
+    a = mk_args()
+    enc, dec = FeatureExtractor(a), RSIS(a)
+    dec_opt = FlatAdam(list(dec.parameters()) + list(get_skip_params(enc)), lr=1e-3, name="dec")
+    enc_opt = FlatAdam(list(get_base_params(a, enc)), lr=1e-6, name="enc")
+    n_enc, n_dec = enc_opt.group.flat_g.numel(), dec_opt.group.flat_g.numel()
+    for cuts in (0, 1, 2):
+        plan = exchange_plan(enc, [enc_opt, dec_opt], cuts)
+        spans = []
+        for stage in ("dec", "trunk_hi", "rest"):
+            for t in plan[stage]:
+                base = enc_opt.group.flat_g if t.untyped_storage().data_ptr() == enc_opt.group.flat_g.untyped_storage().data_ptr() else dec_opt.group.flat_g
+                spans.append((id(base), t.storage_offset(), t.storage_offset() + t.numel()))
+        by = {}
+        for b, lo, hi in spans:
+            by.setdefault(b, []).append((lo, hi))
+        assert sorted(by[id(enc_opt.group.flat_g)]) and sum(hi - lo for lo, hi in by[id(enc_opt.group.flat_g)]) == n_enc
+        assert sum(hi - lo for lo, hi in by[id(dec_opt.group.flat_g)]) == n_dec
+        for v in by.values():
+            v.sort()
+            assert v[0][0] == 0 and all(x[1] == y[0] for x, y in zip(v, v[1:]))
+        assert (len(plan["dec"]) > 0) == (cuts >= 1) and (len(plan["trunk_hi"]) > 0) == (cuts == 2)
+    hi = exchange_plan(enc, [enc_opt, dec_opt], 2)["trunk_hi"][0]
+    first3 = next(enc.base.layer3.parameters())
+    assert hi.data_ptr() == first3.grad.data_ptr()                       # the range starts at layer3's first parameter
+    assert hi.numel() > 0.9 * n_enc                                      # layers 3-4: 41 M of the trunk's 42.5 M optimised parameters

@@ -107,10 +107,11 @@ def test_runiter_world2_gradients_and_parameters_agree():
 
 
 def _worker_split_graph(rank, world, port, q):
-    """the three-graph overlapped schedule of train.GraphedStep (graph A | all-reduce(decoder group) || graph B | all-reduce(trunk) |
-    graph C) against the eager bucketed schedule (optim.BucketedAllReduce hooks), both ranks on the one GPU over gloo, library in
-    its deterministic mode: the two schedules are the same arithmetic, so after three steps from identical replicas on different
-    shards every parameter must be BIT-identical between them -- and between the ranks"""
+    """the cut-graph schedules of train.GraphedStep (graph A | all-reduce(decoder group) || graph B1 | all-reduce(layers 3-4) ||
+    graph B2 | all-reduce(rest) | graph C, with 2 / 1 / 0 cuts) and the staged exchange of an eager step against the hook-driven
+    bucketed exchange (optim.BucketedAllReduce), both ranks on the one GPU over gloo, library in its deterministic mode: all of
+    them are the same arithmetic, so after three steps from identical replicas on different shards every parameter must be
+    BIT-identical between them -- and between the ranks"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
                       RSIS_DETERMINISTIC="1")
     import torch.distributed as dist
@@ -135,10 +136,12 @@ def _worker_split_graph(rank, world, port, q):
     batch = synthetic_batch(10 + rank, 2, 64, 64, 5, 3, 7, "cuda")          # a different shard per rank
     t_run = steps_to_run(a, batch[3])
     finals, losses = [], []
-    for graphed, cuts in ((False, 0), (True, 2), (True, 1), (True, 0)):
+    # legs: the hook-driven bucketed exchange (eager) | the staged exchange of an eager step (runIter's default) | the cut hipGraphs
+    for graphed, cuts, staged in ((False, 0, False), (False, 2, True), (True, 2, True), (True, 1, True), (True, 0, True)):
         enc, dec = copy.deepcopy(enc0), copy.deepcopy(dec0)
         enc_opt, dec_opt = build_optimizers(a, enc, dec)
         red = BucketedAllReduce([dec_opt.group, enc_opt.group], bucket_bytes=8 << 20)
+        red.staged = staged
         g = GraphedStep(a, enc, dec, crits, [enc_opt, dec_opt], red, warm=1, cuts=cuts) if graphed else None
         for _ in range(3):
             if graphed:
