@@ -142,7 +142,7 @@ def test_trainstep_fp32_losses_outputs_gradients_and_adam_step():
     level, of the deeper levels it feeds and of the trunk are held to 15 % relative L2 instead of the fixed-k rule."""
     g, losses, outs, perms, named, pre, (B, T, H, W), flipped = _train_step("fp32")
     for k, v in zip(("loss", "loss_mask_iou", "loss_stop", "loss_class"), losses):
-        assert_close(k, v, g[k], 1e-4)
+        assert_close(k, v, g[k], 1e-4, 1e-4)       # (1e-4 absolute + 1e-4 relative, as in _check_bench_step below)
     assert (perms[1].cpu().numpy() == g["y_class_perm"]).all()
     assert_close("out_masks", outs[0].view(B, T, H, W)[:, :, ::4, ::4], g["out_masks_sub"], 1e-4)
     f64c = torch.from_numpy(g["f64.out_classes"])
@@ -304,8 +304,12 @@ def _bench_config_oracle():
 
 
 def _check_bench_step(o, losses, perm, grads):
+    # losses: 1e-4 absolute + 1e-4 relative.  The class loss is 4.3 here (random weights, 21 classes): two runs of THIS step already
+    # differ by ~5e-5 on it (train-mode split-K sums and BatchNorm statistics end in atomics whose order varies), and 1 run in 4 on
+    # fresh boxes landed 1.2e-4 from the oracle's fp32 value -- 2.8e-5 relative, 60 fp32 ulps after ~110 layers.  The bar for O(1)
+    # quantities (mask logits, probabilities, the IoU / stop losses) stays 1e-4 absolute.
     for k, got in zip(("loss", "loss_mask_iou", "loss_stop", "loss_class"), losses):
-        assert_close(k, got, o["losses"][k], 1e-4)
+        assert_close(k, got, o["losses"][k], 1e-4, 1e-4)
     assert (perm.cpu().numpy() == o["perm"]).all()
     errs = []
     for k, g32 in o["grads"].items():
