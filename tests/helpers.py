@@ -31,6 +31,10 @@ def assert_close(what, got, want, atol, rtol=0.0):
         return
     err = (got - want).abs()
     tol = atol + rtol * want.abs()
+    if os.environ.get("RSIS_TEST_MARGINS"):        # margin survey: worst err / tol of every comparison, one line per call
+        with open(os.environ["RSIS_TEST_MARGINS"], "a") as f:
+            ratio = float((err / tol.clamp_min(1e-300)).max()) if tol.numel() else 0.0
+            f.write("%.4f\t%s\t%s\n" % (ratio, os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], what))
     bad = err > tol
     if bad.any() or torch.isnan(got).any():
         i = int(torch.argmax(err - tol))
