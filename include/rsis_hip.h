@@ -141,6 +141,11 @@ typedef struct rsis_lstm_job {
   float* c_out;
   float* act_out;
   int hid, ks, pad, tile, dtype;
+  /* optional [B][hid] 64-bit keys, ZEROED by the caller: the global max-pool of h (model.py:143, the side feature) is then taken in
+   * the kernel's epilogue -- every half wave adds its best (value, pixel) with an atomic max; key = order-preserving bits of the
+   * value << 32 | (0x7FFFFFFF - flat pixel index); order-independent, so bit-reproducible.  rsis_heads_fwd_keys decodes them.
+   * 3x3 gates only (RSIS_ERR_UNSUPPORTED otherwise). */
+  unsigned long long* side_key;
 } rsis_lstm_job;
 int rsis_convlstm_fwd_batch(const rsis_lstm_job* jobs, int njobs, void* stream);
 
@@ -251,6 +256,12 @@ int rsis_softiou_bwd(const float* logits, const float* y, const long long* perm,
  * K <= 2048, ncls <= 64; rsis_heads_bwd: B <= 64 (the parameter gradients are reduced over the batch in-kernel, no atomics). ---- */
 int rsis_heads_fwd(const float* const* side, const int* Cside, int nside, int B, const float* Wc, const float* bc, int ncls,
                    const float* Ws, const float* bs, float* class_probs, float* stop, void* stream);
+/* rsis_heads_fwd with the pooled side features given as the keys of rsis_lstm_job.side_key (one [B][Cside[i]] key array per level):
+ * decodes them, ALSO writes the float features to side_out[i] and the arg-max pixels to arg_out[i] (what rsis_global_maxpool_fwd
+ * would have produced: the backward passes read those), then computes the heads as rsis_heads_fwd does. */
+int rsis_heads_fwd_keys(const unsigned long long* const* keys, float* const* side_out, int* const* arg_out, const int* Cside, int nside,
+                        int B, const float* Wc, const float* bc, int ncls, const float* Ws, const float* bs, float* class_probs, float* stop,
+                        void* stream);
 int rsis_heads_bwd(const float* const* side, const int* Cside, int nside, int B, const float* Wc, int ncls, const float* Ws,
                    const float* class_probs, const float* dprobs, const float* dstop, float* const* dside, float* dWc, float* dbc,
                    float* dWs, float* dbs, void* stream);

@@ -404,7 +404,9 @@ def softIoULoss(y_true, y_pred, sw):
 # restates its arithmetic on top of the pieces above, each of which IS pinned against the
 # imported reference).  Returns the loss tensors and leaves .backward()/optimizer to the caller.
 # ----------------------------------------------------------------------------------
-def run_iter_forward(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, mode="train"):
+def run_iter_forward(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, mode="train", assignment=None):
+    """assignment: None = the Hungarian matching of train.py:137; or a (B, gt_maxseqlen) integer array perm[b, prediction] = GT slot
+    to evaluate the iteration under a GIVEN assignment (tests: an assignment that ties with the optimum inside fp32 noise)."""
     T = args.maxseqlen
     hidden = None
     out_masks, out_classes, out_stops = [], [], []
@@ -440,7 +442,12 @@ def run_iter_forward(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_cla
     sw_t = sw_mask[:, 0:args.maxseqlen].unsqueeze(-1).repeat(1, 1, args.gt_maxseqlen).permute(0, 2, 1).bool()
     valid = (sw_g & sw_t).float()
     scores = scores * valid + (1 - valid) * 10
-    y_mask_perm, y_class_perm, _ = match([y_mask, out_masks], [y_class, out_classes], scores)  # :137
+    if assignment is None:
+        y_mask_perm, y_class_perm, perm_idx = match([y_mask, out_masks], [y_class, out_classes], scores)  # :137
+    else:
+        perm_idx = np.asarray(assignment).astype(int)
+        y_mask_perm = np.stack([y_mask[b].detach().numpy()[perm_idx[b]] for b in range(y_mask.size(0))])
+        y_class_perm = np.stack([y_class[b].detach().numpy()[perm_idx[b]] for b in range(y_class.size(0))])
     y_mask_perm = torch.from_numpy(y_mask_perm[:, 0:t])             # :140-141
     y_class_perm = torch.from_numpy(y_class_perm[:, 0:t])
     sw_mask_t = sw_mask[:, 0:t].contiguous().float()                # :147-148
@@ -458,4 +465,4 @@ def run_iter_forward(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_cla
         loss = loss + args.stop_weight * loss_stop                  # :175-176
     return dict(loss=loss, loss_mask_iou=loss_mask_iou, loss_stop=loss_stop, loss_class=loss_class,
                 out_masks=out_masks, out_classes=out_classes, out_stops=out_stops,
-                y_mask_perm=y_mask_perm, y_class_perm=y_class_perm, scores=scores)
+                y_mask_perm=y_mask_perm, y_class_perm=y_class_perm, scores=scores, assignment=perm_idx)

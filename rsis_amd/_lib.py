@@ -35,7 +35,8 @@ class LstmJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p * 3), ("Csrc", ctypes.c_int * 3), ("nsrc", ctypes.c_int), ("B", ctypes.c_int), ("H", ctypes.c_int),
                 ("W", ctypes.c_int), ("Wp", ctypes.c_void_p), ("bias_packed", ctypes.c_void_p), ("addend", ctypes.c_void_p),
                 ("c_prev", ctypes.c_void_p), ("h_out", ctypes.c_void_p), ("c_out", ctypes.c_void_p), ("act_out", ctypes.c_void_p),
-                ("hid", ctypes.c_int), ("ks", ctypes.c_int), ("pad", ctypes.c_int), ("tile", ctypes.c_int), ("dtype", ctypes.c_int)]
+                ("hid", ctypes.c_int), ("ks", ctypes.c_int), ("pad", ctypes.c_int), ("tile", ctypes.c_int), ("dtype", ctypes.c_int),
+                ("side_key", ctypes.c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/rsis_hip.h
@@ -74,6 +75,7 @@ SIGNATURES = {
     "rsis_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp]),
     "rsis_assign_min_cost": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "rsis_heads_fwd": (_i, [_vpp, _ip, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rsis_heads_fwd_keys": (_i, [_vpp, _vpp, _vpp, _ip, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "rsis_heads_bwd": (_i, [_vpp, _ip, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vpp, _vp, _vp, _vp, _vp, _vp]),
     "rsis_loss_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rsis_softiou_sums": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _vp]),

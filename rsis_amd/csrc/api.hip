@@ -47,7 +47,7 @@ int rsis_l_rle_encode(const unsigned char*, int, long, unsigned int*, int, int*,
 int rsis_l_rle_to_string(const unsigned int*, int, char*, int);
 int rsis_l_largest_component(const unsigned char*, unsigned char*, int*, int*, int*, int, int, int, hipStream_t);
 int rsis_l_heads_fwd(const float* const*, const int*, int, int, const float*, const float*, int, const float*, const float*, float*, float*,
-                     hipStream_t);
+                     hipStream_t, const unsigned long long* const* keys = nullptr, float* const* side_out = nullptr, int* const* arg_out = nullptr);
 int rsis_l_heads_bwd(const float* const*, const int*, int, int, const float*, int, const float*, const float*, const float*, const float*,
                      float* const*, float*, float*, float*, float*, hipStream_t);
 int rsis_l_loss_tail(const float*, const long long*, const float*, const float*, const float*, const float*, const float*, int, int, float,
@@ -439,7 +439,7 @@ int rsis_bias_grad(const float* dy, float* db, int B, int C, int HW, int lstm_hi
 // argument checks + ConvArgs of one fused ConvLSTM forward; route: 0 bf16 kernel, 1 direct 3x3 (exact f32), 2 implicit GEMM
 static int lstm_fill(ConvArgs& a, int& route, const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp,
                      const float* bias_packed, const float* addend, const float* c_prev, float* h_out, float* c_out, float* act_out, int hid,
-                     int ks, int pad, int dtype) {
+                     int ks, int pad, int dtype, unsigned long long* side_key = nullptr) {
   a = ConvArgs{};
   int rc = fill_sources(a, src, Csrc, nsrc, ks, /*allow_empty=*/addend != nullptr);   // nsrc == 0: gates = addend only
   if (rc) return rc;
@@ -454,6 +454,8 @@ static int lstm_fill(ConvArgs& a, int& route, const float* const* src, const int
   a.hid = hid; a.c_prev = c_prev; a.h_out = h_out; a.c_out = c_out; a.act_out = act_out;
   a.ostride = 1; a.oH = H; a.oW = W; a.ksplit = 1;
   route = use_bf16(dtype, ks, 1, pad, 4 * hid) ? 0 : (use_direct(ks, 1, pad) ? 1 : 2);
+  a.side_key = side_key;
+  if (side_key && (route == 2 || (long)H * W >= 0x7FFFFFFFL)) return RSIS_ERR_UNSUPPORTED;   // the fused side max-pool lives in the 3x3 epilogues
   return RSIS_OK;
 }
 static int lstm_launch_one(ConvArgs& a, int route, int ks, int tile, hipStream_t st) {
@@ -484,7 +486,7 @@ int rsis_convlstm_fwd_batch(const rsis_lstm_job* jobs, int njobs, void* stream) 
     ConvArgs a;
     int route = 0;
     rc = lstm_fill(a, route, q.src, q.Csrc, q.nsrc, q.B, q.H, q.W, q.Wp, q.bias_packed, q.addend, q.c_prev, q.h_out, q.c_out, q.act_out,
-                   q.hid, q.ks, q.pad, q.dtype);
+                   q.hid, q.ks, q.pad, q.dtype, q.side_key);
     if (rc) break;
     // grouped: the exact-f32 direct kernel with 32-bit epilogue addressing (its buffer-descriptor cell update); everything else --
     // and every job in the deterministic mode, where launches are kept as the single-call path issues them -- one by one
@@ -605,6 +607,15 @@ int rsis_heads_fwd(const float* const* side, const int* Cside, int nside, int B,
                    const float* Ws, const float* bs, float* class_probs, float* stop, void* stream) {
   if (!side || !Cside || !Wc || !bc || !Ws || !bs || !class_probs || !stop || B < 1) return RSIS_ERR_ARG;
   return rsis_l_heads_fwd(side, Cside, nside, B, Wc, bc, ncls, Ws, bs, class_probs, stop, (hipStream_t)stream);
+}
+
+int rsis_heads_fwd_keys(const unsigned long long* const* keys, float* const* side_out, int* const* arg_out, const int* Cside, int nside,
+                        int B, const float* Wc, const float* bc, int ncls, const float* Ws, const float* bs, float* class_probs, float* stop,
+                        void* stream) {
+  if (!keys || !side_out || !arg_out || !Cside || !Wc || !bc || !Ws || !bs || !class_probs || !stop || B < 1) return RSIS_ERR_ARG;
+  for (int i = 0; i < nside; ++i) if (!keys[i] || !side_out[i] || !arg_out[i]) return RSIS_ERR_ARG;
+  return rsis_l_heads_fwd((const float* const*)side_out, Cside, nside, B, Wc, bc, ncls, Ws, bs, class_probs, stop, (hipStream_t)stream, keys,
+                          side_out, arg_out);
 }
 
 int rsis_heads_bwd(const float* const* side, const int* Cside, int nside, int B, const float* Wc, int ncls, const float* Ws,

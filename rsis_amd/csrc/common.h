@@ -74,7 +74,33 @@ struct ConvArgs {
   float* h_out;                    // [B][hid][Ho][Wo]
   float* c_out;                    // [B][hid][Ho][Wo]
   float* act_out;                  // [B][4*hid][Ho][Wo] post-nonlinearity gates (interleaved rows) or null
+  unsigned long long* side_key;    // [B][hid] or null: global max-pool of h fused into the epilogue (rsis_side_key, zeroed by the caller)
 };
+
+// ---- global max-pool of the hidden state (reference model.py:143) fused into the ConvLSTM epilogue ----
+// key = (order-preserving bits of the value) << 32 | (0x7FFFFFFF - pixel index): the LARGEST key is the largest value and, among
+// equal values, the smallest pixel index (the first maximum in scan order); 0 = "no value yet" (every real key is > 0).  Blocks
+// combine their candidates with a 64-bit atomic max on [B][hid] keys -- order-independent, hence bit-reproducible.
+__device__ __forceinline__ unsigned long long rsis_side_key(float v, int idx) {
+  unsigned u = __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (unsigned)(0x7FFFFFFF - idx);
+}
+__device__ __forceinline__ float rsis_side_value(unsigned long long k) {
+  unsigned u = (unsigned)(k >> 32);
+  u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ int rsis_side_index(unsigned long long k) { return 0x7FFFFFFF - (int)(unsigned)(k & 0xFFFFFFFFull); }
+// max over the 32 lanes of a half wave (xor offsets < 32 stay inside the half)
+__device__ __forceinline__ unsigned long long rsis_key_max32(unsigned long long k) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_xor(k, o, 64);
+    k = t > k ? t : k;
+  }
+  return k;
+}
 
 // Arguments of the split-K weight-gradient kernel (conv_wgrad.hip).
 struct WgradArgs {

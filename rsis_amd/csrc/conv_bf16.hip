@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgs p) {
   // ---- epilogue (fp32; same accumulator layout as the f32 MFMA kernels: column = pixel l31, rows (r&3) + 8 (r>>2) + 4 hi) ----
   const int co_base = co_t * BM + wm * 32;
   const gcf_t bias = (gcf_t)p.bias, addend = (gcf_t)p.addend;
+  unsigned long long best[4] = {0ull, 0ull, 0ull, 0ull};      // EPI_LSTM + side_key: this lane's best (h, pixel) per hidden channel
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int pp = (wn * TN + j) * 32 + l31;
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgs p) {
           const float gi = rsis_sigmoid(ai), gf = rsis_sigmoid(af), go = rsis_sigmoid(ao), gg = tanhf(ag);
           const float c = gf * cpv[r4] + gi * gg;  // clstm.py:57
           const float h = go * tanhf(c);           // clstm.py:58
+          if (p.side_key && ok) { const unsigned long long k = rsis_side_key(h, osp); best[r4] = k > best[r4] ? k : best[r4]; }
           const unsigned os = ok ? vs + 2 * r4 * rowb : 0x7FFFFFF0u, og = ok ? vg + 8 * r4 * rowb : 0x7FFFFFF0u;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), r_c, os, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), r_h, os, 0, 0);
@@ -365,12 +367,24 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgs p) {
         const float cp = c_prev ? c_prev[sidx] : 0.f;
         const float c = gf * cp + gi * gg;       // clstm.py:57
         const float h = go * tanhf(c);           // clstm.py:58
+        if (p.side_key) { const unsigned long long k = rsis_side_key(h, osp); best[r4] = k > best[r4] ? k : best[r4]; }
         c_out[sidx] = c;
         h_out[sidx] = h;
         if (act_out) {
           act_out[gidx] = gi; act_out[gidx + HW] = gf;
           act_out[gidx + 2 * (size_t)HW] = go; act_out[gidx + 3 * (size_t)HW] = gg;
         }
+      }
+    }
+  }
+  if constexpr (EPI == EPI_LSTM) {
+    // the side feature of model.py:143 (as in conv3x3_direct.hip): one 64-bit atomic max per hidden channel and half wave
+    if (p.side_key) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const unsigned long long k = rsis_key_max32(best[r4]);
+        const int jh = (co_base >> 2) + 2 * r4 + hi;
+        if (l31 == 0 && k != 0ull && jh < p.hid) atomicMax(p.side_key + (size_t)b0 * p.hid + jh, k);
       }
     }
   }

@@ -106,12 +106,25 @@ int rsis_l_softiou_bwd(const float* logits, const float* y, const long long* per
 // ------------------------------------------------------------------------------------------------
 #define HEADS_MAXK 2048
 #define HEADS_MAXC 64
-struct HeadSides { const float* p[5]; float* d[5]; int C[5]; int n; };
+struct HeadSides { const float* p[5]; float* d[5]; int C[5]; int n; const unsigned long long* key[5]; float* so[5]; int* ao[5]; };
 
+// side features of image b -> sv.  key[i] set (forward only): source i comes as the packed (value, pixel) keys the ConvLSTM epilogue
+// left with its atomic max (common.h rsis_side_key); decode them and write the float feature and the arg-max pixel the backward
+// passes read (what rsis_global_maxpool_fwd would have written)
 __device__ __forceinline__ void heads_load_side(const HeadSides& s, int b, float* sv) {
   int base = 0;
   for (int i = 0; i < s.n; ++i) {
-    for (int k = threadIdx.x; k < s.C[i]; k += blockDim.x) sv[base + k] = s.p[i][(size_t)b * s.C[i] + k];
+    if (s.key[i]) {
+      for (int k = threadIdx.x; k < s.C[i]; k += blockDim.x) {
+        const unsigned long long kk = s.key[i][(size_t)b * s.C[i] + k];
+        const float v = rsis_side_value(kk);
+        sv[base + k] = v;
+        s.so[i][(size_t)b * s.C[i] + k] = v;
+        s.ao[i][(size_t)b * s.C[i] + k] = rsis_side_index(kk);
+      }
+    } else {
+      for (int k = threadIdx.x; k < s.C[i]; k += blockDim.x) sv[base + k] = s.p[i][(size_t)b * s.C[i] + k];
+    }
     base += s.C[i];
   }
 }
@@ -226,15 +239,21 @@ static int heads_sides(HeadSides& s, const float* const* side, float* const* dsi
   if (n < 1 || n > 5) return -1;
   int K = 0;
   s.n = n;
-  for (int i = 0; i < 5; ++i) { s.p[i] = i < n ? side[i] : nullptr; s.d[i] = (i < n && dside) ? dside[i] : nullptr; s.C[i] = i < n ? C[i] : 0; K += s.C[i]; }
+  for (int i = 0; i < 5; ++i) {
+    s.p[i] = i < n ? side[i] : nullptr; s.d[i] = (i < n && dside) ? dside[i] : nullptr; s.C[i] = i < n ? C[i] : 0; K += s.C[i];
+    s.key[i] = nullptr; s.so[i] = nullptr; s.ao[i] = nullptr;
+  }
   return K;
 }
 
 int rsis_l_heads_fwd(const float* const* side, const int* C, int n, int B, const float* Wc, const float* bc, int ncls, const float* Ws,
-                     const float* bs, float* probs, float* stop, hipStream_t st) {
+                     const float* bs, float* probs, float* stop, hipStream_t st, const unsigned long long* const* keys,
+                     float* const* side_out, int* const* arg_out) {
   HeadSides s;
   const int K = heads_sides(s, side, nullptr, C, n);
   if (K < 1 || K > HEADS_MAXK || ncls < 1 || ncls > HEADS_MAXC) return RSIS_ERR_UNSUPPORTED;
+  if (keys)
+    for (int i = 0; i < n; ++i) { s.key[i] = keys[i]; s.so[i] = side_out[i]; s.ao[i] = arg_out[i]; }
   hipLaunchKernelGGL(heads_fwd_kernel, dim3(B), dim3(256), 0, st, s, K, Wc, bc, ncls, Ws, bs, probs, stop);
   return rsis_check_launch();
 }

@@ -28,6 +28,10 @@ from ._lib import check, int_array, lib, ptr, ptr_array, require_cuda_f32, strea
 # ONE rsis_convlstm_fwd_batch call (a grouped launch for the exact-f32 kernels).  None: launch where the node is created.
 _GATE_QUEUE = [None]
 WAVEFRONT = [os.environ.get("RSIS_DECODER_WAVEFRONT", "1") != "0"]
+# The global max-pool of every hidden state (the side features of model.py:143) taken in the gate kernel's epilogue as packed
+# (value, pixel) keys (rsis_lstm_job.side_key) and decoded by the heads kernel, instead of one rsis_global_maxpool_fwd launch per cell
+# that re-reads h.  Wavefront path only.
+FUSED_POOL = [os.environ.get("RSIS_FUSED_POOL", "1") != "0"]
 
 
 def _flush_gates():
@@ -36,7 +40,7 @@ def _flush_gates():
         return
     jobs = (_lib.LstmJob * len(q))()
     for j, (f, _keep) in zip(jobs, q):
-        srcs, segs, j.B, j.H, j.W, j.Wp, j.bias_packed, j.addend, j.c_prev, j.h_out, j.c_out, j.act_out, j.hid, j.ks, j.pad, j.tile, j.dtype = f
+        srcs, segs, j.B, j.H, j.W, j.Wp, j.bias_packed, j.addend, j.c_prev, j.h_out, j.c_out, j.act_out, j.hid, j.ks, j.pad, j.tile, j.dtype, j.side_key = f
         j.nsrc = len(srcs)
         for k, (s, c) in enumerate(zip(srcs, segs)):
             j.src[k], j.Csrc[k] = s, c
@@ -57,6 +61,11 @@ class LevelTape(object):
         self.n_bwd = 0
         self.last_h = self.last_c = None
         self.need_grad = False
+        self.KEY = self.SIDE = self.ARG = None       # decoder_sequence with FUSED_POOL: per-step [T][B][hid] keys / features / arg-max
+
+    def pooled(self, t):
+        """(side feature, arg-max pixel) buffers of step t that the heads kernel fills from the keys, or None"""
+        return None if self.KEY is None else (self.SIDE[t], self.ARG[t])
 
     def release(self):
         """Drop every tensor the level holds.  tl -> G / last_h -> grad_fn -> ctx -> tl is a reference CYCLE: without this
@@ -65,6 +74,7 @@ class LevelTape(object):
         self.H = self.C = self.ACT = self.UP = self.DA = self.da_sum = None
         self.DHP, self.dhp_t = None, -1
         self.G = self.last_h = self.last_c = None
+        self.KEY = self.SIDE = self.ARG = None
 
     def alloc_forward(self, B, Hh, Ww, device, need_grad):
         hid, cap = self.hid, self.cap
@@ -172,7 +182,8 @@ class _StepFn(torch.autograd.Function):
         if _GATE_QUEUE[0] is not None:      # decoder_sequence: park the launch, the diagonal's cells go out together
             _GATE_QUEUE[0].append((([s.data_ptr() for s in srcs], [s.shape[1] for s in srcs], B, H, W, wp.data_ptr(), None, G.data_ptr(),
                                     c_prev.data_ptr() if h_prev is not None else None, h.data_ptr(), c.data_ptr(),
-                                    act.data_ptr() if act is not None else None, hid, tl.ks, tl.pad, ops.FORCE_TILE[0], dyn.dtype),
+                                    act.data_ptr() if act is not None else None, hid, tl.ks, tl.pad, ops.FORCE_TILE[0], dyn.dtype,
+                                    tl.KEY[t].data_ptr() if tl.KEY is not None else None),
                                    (srcs, wp, G, c_prev, h, c, act)))
         else:
             check(L.rsis_convlstm_fwd(pa, ia, len(srcs), B, H, W, ptr(wp), None, ptr(G), ptr(c_prev) if h_prev is not None else None,
@@ -337,13 +348,16 @@ class _SideUpFn(torch.autograd.Function):
     letting autograd add the two."""
 
     @staticmethod
-    def forward(ctx, tl, t, x, size):
+    def forward(ctx, tl, t, x, size, pooled=None):
         x = x if x.is_contiguous() else x.contiguous()
         B, C, Hi, Wi = x.shape
         L = lib()
-        side = torch.empty((B, C, 1, 1), dtype=torch.float32, device=x.device)
-        arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
-        check(L.rsis_global_maxpool_fwd(ptr(x), ptr(side), ptr(arg), B * C, Hi * Wi, stream()), "rsis_global_maxpool_fwd")
+        if pooled is not None:      # the gate kernel left (value, pixel) keys: the heads launch of this timestep fills both (ops._HeadsFn)
+            side, arg = pooled
+        else:
+            side = torch.empty((B, C, 1, 1), dtype=torch.float32, device=x.device)
+            arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
+            check(L.rsis_global_maxpool_fwd(ptr(x), ptr(side), ptr(arg), B * C, Hi * Wi, stream()), "rsis_global_maxpool_fwd")
         if tl is not None:
             y = tl.UP[t]                      # straight into the next level's stacked buffer
         else:
@@ -366,7 +380,7 @@ class _SideUpFn(torch.autograd.Function):
             dx = torch.empty((B, C, Hi, Wi), dtype=torch.float32, device=dy.device)
             check(L.rsis_upsample_maxpool_bwd(ptr(dy), ptr(dside), ptr(arg), ptr(dx), B * C, Hi, Wi, Ho, Wo, stream()),
                   "rsis_upsample_maxpool_bwd")
-            return None, None, dx, None
+            return None, None, dx, None, None
         if dy is not None:
             dy = dy if dy.is_contiguous() else dy.contiguous()
             dx = torch.empty((B, C, Hi, Wi), dtype=torch.float32, device=dy.device)
@@ -378,7 +392,7 @@ class _SideUpFn(torch.autograd.Function):
                 check(L.rsis_global_maxpool_bwd(ptr(dside), ptr(arg), ptr(dx), B * C, Hi * Wi, stream()), "rsis_global_maxpool_bwd")
             else:
                 check(L.rsis_global_maxpool_bwd_add(ptr(dside), ptr(arg), ptr(dx), B * C, Hi * Wi, stream()), "rsis_global_maxpool_bwd_add")
-        return None, None, dx, None
+        return None, None, dx, None, None
 
 
 def decoder_levels(decoder, skip_feats, prev_hidden_list):
@@ -439,6 +453,23 @@ def decoder_sequence(decoder, skip_feats, T):
             old.release()
     tape = decoder._tape = DecoderTape(decoder, skip_feats, need_grad)
     n = len(tape.levels)
+    B = skip_feats[0].shape[0]
+    fused_pool = (FUSED_POOL[0] and all(tl.ks == 3 and tl.pad == 1 for tl in tape.levels) and decoder.dropout_cls == 0 and
+                  decoder.dropout_stop == 0 and ops.heads_supported([skip_feats[0]] * n, decoder.fc_class, decoder.fc_stop) and
+                  sum(tl.hid for tl in tape.levels) == decoder.fc_class.weight.shape[1])
+    if fused_pool:                     # one zeroed key buffer (and its decoded twins) for the whole sequence: a single fill launch
+        tot = sum(tl.hid for tl in tape.levels)
+        dev = skip_feats[0].device
+        KEY = torch.zeros(T * B * tot, dtype=torch.int64, device=dev)
+        SIDE = torch.empty(T * B * tot, dtype=torch.float32, device=dev)
+        ARG = torch.empty(T * B * tot, dtype=torch.int32, device=dev)
+        off = 0
+        for tl in tape.levels:
+            m = T * B * tl.hid
+            tl.KEY = KEY[off:off + m].view(T, B, tl.hid)
+            tl.SIDE = SIDE[off:off + m].view(T, B, tl.hid, 1, 1)
+            tl.ARG = ARG[off:off + m].view(T, B, tl.hid)
+            off += m
     Hs = [[None] * T for _ in range(n)]
     Cs = [[None] * T for _ in range(n)]
     UP = [[None] * T for _ in range(n + 1)]          # UP[i][t]: the up-sampled hidden state level i consumes at step t (i >= 1)
@@ -460,11 +491,12 @@ def decoder_sequence(decoder, skip_feats, T):
             if i + 1 < n:
                 nxt = tape.levels[i + 1]
                 into = nxt if (nxt.UP is not None and t < nxt.cap) else None
-                SIDE[i][t], UP[i + 1][t] = _SideUpFn.apply(into, t, h, tuple(skip_feats[i + 1].shape[-2:]))     # model.py:143,149-150
+                SIDE[i][t], UP[i + 1][t] = _SideUpFn.apply(into, t, h, tuple(skip_feats[i + 1].shape[-2:]), tape.levels[i].pooled(t))     # model.py:143,149-150
             else:
-                SIDE[i][t], UP[n][t] = _SideUpFn.apply(None, t, h, (h.shape[-2] * 2, h.shape[-1] * 2))          # model.py:143,163-164
+                SIDE[i][t], UP[n][t] = _SideUpFn.apply(None, t, h, (h.shape[-2] * 2, h.shape[-1] * 2), tape.levels[i].pooled(t))          # model.py:143,163-164
                 hidden_list = [[Hs[k][t], Cs[k][t]] for k in range(n)]
-                outs[t] = decoder._heads(UP[n][t], [SIDE[k][t] for k in range(n)], hidden_list)[:3]
+                keys = ([tl.KEY[t] for tl in tape.levels], [tl.ARG[t] for tl in tape.levels]) if fused_pool else None
+                outs[t] = decoder._heads(UP[n][t], [SIDE[k][t] for k in range(n)], hidden_list, keys)[:3]
                 UP[n][t] = None
     for i, tl in enumerate(tape.levels):
         tl.last_h, tl.last_c = Hs[i][T - 1], Cs[i][T - 1]

@@ -149,11 +149,14 @@ class RSIS(nn.Module):
         ops.set_dtype(self, getattr(args, "dtype", "fp32"))
         self.fused = os.environ.get("RSIS_DECODER_FUSED", "1") != "0"
 
-    def _heads(self, clstm_in, side_feats, hidden_list):
+    def _heads(self, clstm_in, side_feats, hidden_list, keys=None):
+        # keys: (per-level max-pool keys, per-level arg-max buffers) when the gate kernels pooled the hidden states themselves
+        # (decoder_fused.decoder_sequence); the heads launch then decodes them into side_feats' own storage first
         out_mask = self.conv_out(clstm_in)                               # model.py:167
         if self.dropout_cls == 0 and self.dropout_stop == 0 and ops.heads_supported(side_feats, self.fc_class, self.fc_stop):
-            class_probs, stop_probs = ops.heads(side_feats, self.fc_class, self.fc_stop)   # model.py:169-182 in one launch
+            class_probs, stop_probs = ops.heads(side_feats, self.fc_class, self.fc_stop, keys)   # model.py:169-182 in one launch
             return out_mask, class_probs, stop_probs, hidden_list
+        assert keys is None, "pooled keys need the fused heads kernel"
         side_feats = torch.cat(side_feats, 1).squeeze()                  # model.py:169 (drops the batch dim at B == 1)
         if self.dropout_cls > 0:
             class_feats = nn.functional.dropout(side_feats, self.dropout_cls, training=True)

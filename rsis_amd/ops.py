@@ -758,15 +758,26 @@ class _HeadsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, n, *tensors):
-        sides = [_contig(t).reshape(t.shape[0], -1) for t in tensors[:n]]
+        keys = tensors[n + 4] if len(tensors) > n + 4 else None
+        if keys is not None:          # the features arrive as max-pool keys; this launch writes them (and the arg-max) into place
+            assert all(t.is_contiguous() for t in tensors[:n])
+            sides = [t.view(t.shape[0], -1) for t in tensors[:n]]
+        else:
+            sides = [_contig(t).reshape(t.shape[0], -1) for t in tensors[:n]]
         Wc, bc, Ws, bs = tensors[n:n + 4]
         require_cuda_f32(Wc, bc, Ws, bs, *sides)
         B, ncls = sides[0].shape[0], Wc.shape[0]
         probs = torch.empty((B, ncls), dtype=torch.float32, device=Wc.device)
         stop = torch.empty((B, 1), dtype=torch.float32, device=Wc.device)
-        check(lib().rsis_heads_fwd(ptr_array(sides), int_array([s.shape[1] for s in sides]), n, B, ptr(Wc.detach()), ptr(bc.detach()),
-                                   ncls, ptr(Ws.detach()), ptr(bs.detach()), ptr(probs), ptr(stop), stream()), "rsis_heads_fwd")
+        if keys is not None:
+            check(lib().rsis_heads_fwd_keys(ptr_array(keys[0]), ptr_array(sides), ptr_array(keys[1]), int_array([s.shape[1] for s in sides]),
+                                            n, B, ptr(Wc.detach()), ptr(bc.detach()), ncls, ptr(Ws.detach()), ptr(bs.detach()), ptr(probs),
+                                            ptr(stop), stream()), "rsis_heads_fwd_keys")
+        else:
+            check(lib().rsis_heads_fwd(ptr_array(sides), int_array([s.shape[1] for s in sides]), n, B, ptr(Wc.detach()), ptr(bc.detach()),
+                                       ncls, ptr(Ws.detach()), ptr(bs.detach()), ptr(probs), ptr(stop), stream()), "rsis_heads_fwd")
         ctx.n = n
+        ctx.extra = len(tensors) - (n + 4)
         ctx.shapes = [tuple(t.shape) for t in tensors[:n]]
         ctx.params = (Wc, bc, Ws, bs)
         ctx.save_for_backward(probs, Wc, Ws, *sides)
@@ -795,7 +806,7 @@ class _HeadsFn(torch.autograd.Function):
                                    ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), stream()), "rsis_heads_bwd")
         grads = [d.reshape(sh) if d is not None else None for d, sh in zip(dsides, ctx.shapes)]
         grads += [None if t is not None else o for t, o in zip(tgts, outs)]
-        return (None,) + tuple(grads)
+        return (None,) + tuple(grads) + (None,) * ctx.extra
 
 
 def heads_supported(sides, fc_class, fc_stop):
@@ -803,8 +814,12 @@ def heads_supported(sides, fc_class, fc_stop):
             fc_class.weight.shape[0] <= 64 and fc_stop.weight.shape[0] == 1 and fc_class.bias is not None and fc_stop.bias is not None)
 
 
-def heads(sides, fc_class, fc_stop):
-    """(class_probs (B, ncls), stop logits (B, 1)) of reference RSIS.forward's tail from the list of pooled side features"""
+def heads(sides, fc_class, fc_stop, keys=None):
+    """(class_probs (B, ncls), stop logits (B, 1)) of reference RSIS.forward's tail from the list of pooled side features.
+    keys = (per-level [B][C] int64 max-pool keys, per-level [B][C] int32 arg-max buffers): the features are still packed keys
+    (rsis_lstm_job.side_key); the launch decodes them into `sides` / the arg-max buffers before it uses them."""
+    if keys is not None:
+        return _HeadsFn.apply(len(sides), *sides, fc_class.weight, fc_class.bias, fc_stop.weight, fc_stop.bias, keys)
     return _HeadsFn.apply(len(sides), *sides, fc_class.weight, fc_class.bias, fc_stop.weight, fc_stop.bias)
 
 

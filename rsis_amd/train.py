@@ -64,7 +64,7 @@ def apply_update(args, optims, gscale=1.0):
 def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits, optims, mode="train", reducer=None,
             sync_losses=True, t_run=None, want_outs=True, do_update=True, between=None):
     """Runs forward, computes loss and (if train mode) updates parameters for the provided batch (train.py:54-197).
-    Returns (losses [total, iou, stop, class], outs [sigmoid(masks), class probs], perms [y_mask_perm, y_class_perm]).
+    Returns (losses [total, iou, stop, class], outs [sigmoid(masks), class probs], perms [y_mask_perm, y_class_perm, assignment]).
     want_outs=False (training loops that only log the losses, as the reference's trainIters does: train.py:344-356): the
     sigmoid of all T full-resolution masks (train.py:191) is not computed and outs[0] holds the raw logits; the permuted GT masks
     (train.py:140, 84 MB of gather per step at batch 32) are not materialised either: perms[0] is None, perms[1] is y_class_perm.
@@ -205,7 +205,7 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
     if sync_losses:
         losses = [float(v) for v in torch.stack(losses).cpu()]        # :189 (one D2H for all four)
     outs = [torch.sigmoid(out_masks.detach()) if want_outs else out_masks.detach(), out_classes.detach()]  # :191-192
-    perms = [y_mask_perm, y_class_perm]
+    perms = [y_mask_perm, y_class_perm, perm]     # (+ the assignment itself: perm[b, prediction] = matched GT slot; hungarian.py:110)
     return losses, outs, perms
 
 

@@ -347,6 +347,54 @@ def test_wavefront_sequence_equals_per_step_loop(shape):
             assert_close("inf.class%d" % t, steps[t][1], c, 1e-6)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", ["odd", "pow2"])
+def test_pool_fused_into_gate_kernel_is_bit_identical(shape, dtype):
+    """The side features of reference model.py:143 (global max-pool of every hidden state) taken inside the ConvLSTM gate kernels as
+    packed (value, first pixel) keys merged by a 64-bit atomic max and decoded by the heads launch (rsis_lstm_job.side_key +
+    rsis_heads_fwd_keys, decoder_fused.FUSED_POOL) against the separate rsis_global_maxpool_fwd launches: the maximum of a set does
+    not depend on the order it is taken in and ties keep the first pixel in both, so outputs AND gradients (the arg-max routes the
+    pooled gradient) must be bit-identical in the deterministic mode."""
+    from oracle import filler
+    from rsis_amd import decoder_fused, ops
+    from rsis_amd.modules import RSIS
+    if shape == "odd":
+        hs, B, T, sizes = 32, 2, 4, [(3, 4), (5, 7), (10, 13), (19, 25), (37, 50)]
+    else:
+        hs, B, T, sizes = 128, 4, 3, [(8, 8), (16, 16), (32, 32), (64, 64), (128, 128)]
+    chans = [hs, hs, hs // 2, hs // 4, hs // 8]
+    a = mk_args(hidden_size=hs, maxseqlen=T, dtype=dtype)
+    torch.manual_seed(1)
+    dec = RSIS(a).cuda()
+    res = []
+    was, det = decoder_fused.FUSED_POOL[0], ops.is_deterministic()
+    ops.set_deterministic(True)
+    try:
+        for fused in (False, True):
+            decoder_fused.FUSED_POOL[0] = fused
+            dec.zero_grad()
+            feats = [filler.tensor(7, "wf.f%d" % i, (B, chans[i]) + sizes[i]).cuda().requires_grad_() for i in range(5)]
+            steps, hidden = dec.forward_sequence(feats, T)
+            loss, outs = 0.0, []
+            for t, (m, c, s) in enumerate(steps):
+                outs += [m, c, s]
+                loss = loss + (m * filler.tensor(7, "wf.gm%d" % t, m.shape).cuda()).sum() + (c * c).sum() * 50 + s.sum()
+            loss = loss + sum((h * h).mean() + c.mean() for h, c in hidden)
+            loss.backward()
+            res.append(([o.detach().clone() for o in outs], [f.grad.clone() for f in feats], {k: p.grad.clone() for k, p in dec.named_parameters()}))
+    finally:
+        decoder_fused.FUSED_POOL[0] = was
+        ops.set_deterministic(det)
+    for i, (p, q) in enumerate(zip(res[0][0], res[1][0])):
+        assert torch.equal(p, q), "out%d differs by %g" % (i, float((p - q).abs().max()))
+    for i, (p, q) in enumerate(zip(res[0][1], res[1][1])):
+        assert torch.equal(p, q), "dfeat%d differs by %g" % (i, float((p - q).abs().max()))
+    for k in res[0][2]:
+        p, q = res[0][2][k], res[1][2][k]
+        assert torch.equal(p, q), "grad.%s differs by %g" % (k, float((p - q).abs().max()))
+    assert float(res[0][2]["fc_class.weight"].abs().max()) > 0
+
+
 @pytest.mark.parametrize("train_bn", [True, False])
 def test_direct_grad_accumulation_equals_autograd(train_bn):
     """ops.DIRECT_GRAD (wgrad kernels accumulate straight into the zeroed flat .grad views) == plain autograd grads.

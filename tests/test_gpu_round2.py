@@ -295,23 +295,42 @@ def _bench_config_oracle():
         odec = filler.fill_module(O.RSIS(a), seed=72)
         batch = synthetic_batch(7, 32, 256, 256, a.gt_maxseqlen, 12, a.num_classes, "cpu")
         sd = (copy.deepcopy(oenc.state_dict()), copy.deepcopy(odec.state_dict()))
-        r = O.run_iter_forward(a, oenc, odec, *batch, mode="train")
-        r["loss"].backward()
-        ref = {("dec." + k): p.grad.detach().clone() for k, p in odec.named_parameters()}
-        ref.update({("enc." + k): p.grad.detach().clone() for k, p in oenc.named_parameters() if not k.startswith("base.")})
-        _BENCH_ORACLE.update(batch=batch, sd=sd, grads=ref, perm=r["y_class_perm"].numpy().copy(),
-                             losses={k: float(r[k]) for k in ("loss", "loss_mask_iou", "loss_stop", "loss_class")})
+        _BENCH_ORACLE.update(batch=batch, sd=sd, args=a, modules=(oenc, odec))
+        _BENCH_ORACLE.update(_bench_oracle_eval(_BENCH_ORACLE, None))
     return _BENCH_ORACLE
 
 
-def _check_bench_step(o, losses, perm, grads):
+def _bench_oracle_eval(o, assignment):
+    """losses, gradients, cost matrix and matching of the oracle's iteration (under a given assignment if not None)"""
+    from oracle import rsis_oracle as O
+    oenc, odec = o["modules"]
+    oenc.zero_grad()
+    odec.zero_grad()
+    r = O.run_iter_forward(o["args"], oenc, odec, *o["batch"], mode="train", assignment=assignment)
+    r["loss"].backward()
+    ref = {("dec." + k): p.grad.detach().clone() for k, p in odec.named_parameters()}
+    ref.update({("enc." + k): p.grad.detach().clone() for k, p in oenc.named_parameters() if not k.startswith("base.")})
+    return dict(grads=ref, perm=r["y_class_perm"].numpy().copy(), scores=r["scores"].numpy().copy(),
+                losses={k: float(r[k]) for k in ("loss", "loss_mask_iou", "loss_stop", "loss_class")})
+
+
+def _check_bench_step(o, losses, perms, grads):
+    from helpers import same_matching
+    # the matching first: equal to the oracle's, or tied with it inside 1e-5 under the oracle's own costs (every image of this batch has
+    # its second-best assignment within ~1e-6 of the optimum: helpers.same_matching) -- then the oracle is evaluated under the
+    # product's assignment, so that losses and gradients are compared like with like
+    if not same_matching("bench step", perms[2], perms[1], o["scores"], o["perm"]):
+        key = perms[2].cpu().numpy().tobytes()
+        if key not in o.setdefault("tied", {}):
+            o["tied"][key] = _bench_oracle_eval(o, perms[2].cpu().numpy())
+        o = dict(o, **o["tied"][key])
     # losses: 1e-4 absolute + 1e-4 relative.  The class loss is 4.3 here (random weights, 21 classes): two runs of THIS step already
     # differ by ~5e-5 on it (train-mode split-K sums and BatchNorm statistics end in atomics whose order varies), and 1 run in 4 on
     # fresh boxes landed 1.2e-4 from the oracle's fp32 value -- 2.8e-5 relative, 60 fp32 ulps after ~110 layers.  The bar for O(1)
     # quantities (mask logits, probabilities, the IoU / stop losses) stays 1e-4 absolute.
     for k, got in zip(("loss", "loss_mask_iou", "loss_stop", "loss_class"), losses):
         assert_close(k, got, o["losses"][k], 1e-4, 1e-4)
-    assert (perm.cpu().numpy() == o["perm"]).all()
+    assert (perms[1].cpu().numpy() == o["perm"]).all()
     errs = []
     for k, g32 in o["grads"].items():
         if k.startswith("enc.sk") and k.endswith("bias"):
@@ -360,7 +379,7 @@ def test_training_step_at_the_bench_configuration_matches_the_oracle():
     pre = dec.clstm_list[0].Gates.weight.detach().clone()
     losses, _outs, perms = runIter(a, enc, dec, *dbatch, crits, opts, mode="train", sync_losses=True, t_run=t_run, want_outs=False)
     assert float((dec.clstm_list[0].Gates.weight.detach() - pre).abs().max()) > 0          # the optimizer step happened
-    _check_bench_step(o, losses, perms[1], _grads_of(enc, dec))
+    _check_bench_step(o, losses, perms, _grads_of(enc, dec))
 
 
 def test_first_replayed_step_at_the_bench_configuration_matches_the_oracle():
@@ -399,7 +418,7 @@ def test_first_replayed_step_at_the_bench_configuration_matches_the_oracle():
     assert g.graph is not None, "capture failed: %s" % g.failed
     torch.cuda.synchronize()
     losses = [float(v) for v in losses]
-    _check_bench_step(o, losses, perms[1], _grads_of(enc, dec))
+    _check_bench_step(o, losses, perms, _grads_of(enc, dec))
     assert all(st == 1 for grp in groups for st in grp.steps), "Adam step counts after one replay: %s" % sorted({st for grp in groups for st in grp.steps})
     for grp, p0, lr in zip(groups, snap_p, (a.lr_cnn, a.lr)):
         d = float((grp.flat_p - p0).abs().max())
@@ -512,7 +531,11 @@ def test_ragged_targets_match_the_oracle():
     crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
     losses, _outs, perms = runIter(a, enc, dec, *dbatch, crits, opts, mode="train", sync_losses=True, t_run=t_run, want_outs=False)
     a.use_gpu = False
-    r = O.run_iter_forward(a, oenc, odec, *batch, mode="train")
+    from helpers import same_matching
+    with torch.no_grad():
+        r = O.run_iter_forward(a, oenc, odec, *batch, mode="train")
+        if not same_matching("ragged step", perms[2], perms[1], r["scores"].numpy(), r["y_class_perm"].numpy()):
+            r = O.run_iter_forward(a, oenc, odec, *batch, mode="train", assignment=perms[2].cpu().numpy())   # tie: like with like
     for k, got, want in (("loss", losses[0], r["loss"]), ("loss_mask_iou", losses[1], r["loss_mask_iou"]), ("loss_stop", losses[2], r["loss_stop"]),
                          ("loss_class", losses[3], r["loss_class"])):
         want = float(want.detach())

@@ -104,6 +104,19 @@ def test_runiter_matches_reference():
         assert_close("runiter." + k, r[k], g[k], 2e-5, 1e-5)
     assert (r["y_class_perm"].numpy() == g["y_class_perm"]).all()
     assert_close("gnorm sk5", dict(enc.named_parameters())["sk5.weight"].grad.norm(), g["gnorm.enc.sk5.weight"], 0, 1e-3)
+    # the tie-handling of the GPU parity tests (helpers.same_matching + run_iter_forward(assignment=...)): the oracle under its OWN
+    # assignment is the same iteration; another assignment is accepted only if it costs the same under the oracle's scores
+    from helpers import same_matching
+    r2 = O.run_iter_forward(a, enc, dec, x, y_mask, y_class, sw_mask, sw_class, mode="train", assignment=r["assignment"])
+    assert float(r2["loss"]) == float(r["loss"]) and (r2["y_class_perm"].numpy() == r["y_class_perm"].numpy()).all()
+    assert same_matching("own", r["assignment"], r["y_class_perm"], r["scores"].numpy(), r["y_class_perm"].numpy()) is True
+    swapped = r["assignment"].copy()
+    swapped[0, [0, 1]] = swapped[0, [1, 0]]
+    cls = np.stack([y_class[b].numpy()[swapped[b]] for b in range(B)])[:, :T]
+    if (cls != r["y_class_perm"].numpy()).any():
+        import pytest
+        with pytest.raises(AssertionError):
+            same_matching("swapped", swapped, cls, r["scores"].numpy(), r["y_class_perm"].numpy())
 
 
 def test_e2e_256_matches_reference():
