@@ -296,6 +296,21 @@ int rsis_rle_to_string(const unsigned int* counts, int m, char* out, int cap);
 int rsis_largest_component(const unsigned char* mask, unsigned char* out, int* labels, int* counts, int* best, int n, int h, int w,
                            void* stream);
 
+/* ---- channel-blocked bf16 activations: the storage half of the bf16 path (BASELINE.json configs[2..4]) --------------------------
+ * A logical [B][C][H][W] tensor stored as bf16 [B][C/8][H][W][8] ("blk": the 8 channels of a pixel are one 16-byte cell, C % 8 == 0).
+ * The reference has no counterpart (fp32 NCHW throughout); these entry points serve the ResNet-101 trunk of
+ * src/modules/vision.py:12-19 under -dtype bf16. */
+
+/* fp32 NCHW -> blk (round-to-nearest-even) and back (exact) */
+int rsis_blk_from_nchw(const float* x, void* y_blk, int B, int C, int H, int W, void* stream);
+int rsis_blk_to_nchw(const void* x_blk, float* y, int B, int C, int H, int W, void* stream);
+
+/* out_blk[B][Cout] = conv(x_blk[B][C], W), ks in {1, 3}, stride 1, "same" padding, no bias (torchvision's trunk convs have none);
+ * Wp: the bf16 pack rsis_conv_pack_fwd (forward) or rsis_conv_pack_dgrad (data gradient: x = dy, out = dx) produce for dtype
+ * RSIS_DTYPE_BF16.  fp32 accumulation, one rounding to bf16 at the store.  variant: 0 = pick a tile, > 0 force (tests). */
+int rsis_blk_conv2d(const void* x_blk, int B, int C, int H, int W, const void* Wp, int Cout, int ks, void* out_blk, int variant,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

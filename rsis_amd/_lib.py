@@ -76,6 +76,9 @@ SIGNATURES = {
     "rsis_assign_min_cost": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "rsis_heads_fwd": (_i, [_vpp, _ip, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "rsis_heads_fwd_keys": (_i, [_vpp, _vpp, _vpp, _ip, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rsis_blk_from_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsis_blk_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsis_blk_conv2d": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "rsis_heads_bwd": (_i, [_vpp, _ip, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vpp, _vp, _vp, _vp, _vp, _vp]),
     "rsis_loss_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rsis_softiou_sums": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _vp]),

@@ -9,6 +9,9 @@ int rsis_launch_conv_wgrad(WgradArgs& a, int ks, hipStream_t st);
 int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st);
 int rsis_launch_convlstm_direct_group(ConvArgs* jobs, int n, const int* force_variant, hipStream_t st);
 int rsis_launch_conv_bf16(ConvArgs& a, int ks, int epi, int force_variant, hipStream_t st);
+int rsis_launch_conv_blk(ConvArgs& a, int ks, int variant, hipStream_t st);
+int rsis_l_blk_from_nchw(const float*, void*, int, int, int, hipStream_t);
+int rsis_l_blk_to_nchw(const void*, float*, int, int, int, hipStream_t);
 bool rsis_wgrad_bf16_supported(const WgradArgs& w, int ks);
 int rsis_launch_conv_wgrad_bf16(const WgradArgs& w, int ks, hipStream_t st);
 int rsis_launch_conv_wgrad_bf16_group(const WgradArgs* w, int n, int ks, hipStream_t st);
@@ -547,6 +550,26 @@ int rsis_bn_bwd(const float* dy, const float* x, const float* y, const float* sa
   return rsis_l_bn_bwd(dy, x, y, save_mean, save_rstd, gamma, stats, dx, dres, dgamma, dbeta, B, C, HW, relu,
                        (hipStream_t)stream);
 }
+// ---- channel-blocked bf16 activations (conv_blk.hip) ----
+int rsis_blk_conv2d(const void* x, int B, int C, int H, int W, const void* Wp, int Cout, int ks, void* out, int variant, void* stream) {
+  if (!x || !Wp || !out || x == out || B < 1 || C < 8 || H < 1 || W < 1 || Cout < 8) return RSIS_ERR_ARG;
+  if (ks != 1 && ks != 3) return RSIS_ERR_UNSUPPORTED;
+  ConvArgs a = {};
+  a.nsrc = 1; a.src[0] = a.src[1] = a.src[2] = (const float*)x; a.C[0] = C; a.K = C * ks * ks;
+  a.B = B; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.stride = 1; a.pad = ks / 2;
+  a.wp = (const float*)Wp; a.ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN); a.Cout = Cout;
+  a.dst[0] = (float*)out; a.Cd[0] = Cout; a.ndst = 1; a.ostride = 1; a.oH = H; a.oW = W; a.ksplit = 1;
+  return rsis_launch_conv_blk(a, ks, variant, (hipStream_t)stream);
+}
+int rsis_blk_from_nchw(const float* x, void* y, int B, int C, int H, int W, void* stream) {
+  if (!x || !y || B < 1 || C < 8 || (C & 7) || H < 1 || W < 1) return RSIS_ERR_ARG;
+  return rsis_l_blk_from_nchw(x, y, B, C, H * W, (hipStream_t)stream);
+}
+int rsis_blk_to_nchw(const void* x, float* y, int B, int C, int H, int W, void* stream) {
+  if (!x || !y || B < 1 || C < 8 || (C & 7) || H < 1 || W < 1) return RSIS_ERR_ARG;
+  return rsis_l_blk_to_nchw(x, y, B, C, H * W, (hipStream_t)stream);
+}
+
 int rsis_subsample2d(const float* x, float* y, long BC, int H, int W, int stride, void* stream) {
   if (!x || !y || x == y || BC < 1 || H < 1 || W < 1 || stride < 1) return RSIS_ERR_ARG;
   return rsis_l_subsample(x, y, BC, H, W, (H - 1) / stride + 1, (W - 1) / stride + 1, stride, (hipStream_t)stream);

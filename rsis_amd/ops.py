@@ -857,3 +857,33 @@ class _LossTailFn(torch.autograd.Function):
 def loss_tail(probs, y_class, stop, siou, sw_mask, sw_class, cls_w, bw, w_iou, w_cls, w_stop):
     """bw: BCE balance weight or None (taken from the targets); cls_w: per-class weights tensor or None"""
     return _LossTailFn.apply(probs, y_class, stop, siou, sw_mask, sw_class, cls_w, -1.0 if bw is None else bw, w_iou, w_cls, w_stop)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# channel-blocked bf16 activations ("blk": logical [B][C][H][W] stored as bf16 [B][C/8][H][W][8]; csrc/conv_blk.hip) -- raw ops
+# (no autograd): the blocked trunk's autograd functions are built on them
+# ---------------------------------------------------------------------------------------------------------------------------
+def blk_from_nchw(x):
+    require_cuda_f32(x)
+    x = _contig(x)
+    B, C, H, W = x.shape
+    y = torch.empty((B, C // 8, H, W, 8), dtype=torch.bfloat16, device=x.device)
+    check(lib().rsis_blk_from_nchw(ptr(x), ptr(y), B, C, H, W, stream()), "rsis_blk_from_nchw")
+    return y
+
+
+def blk_to_nchw(x):
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 5 and x.shape[-1] == 8
+    B, Cb, H, W, _ = x.shape
+    y = torch.empty((B, Cb * 8, H, W), dtype=torch.float32, device=x.device)
+    check(lib().rsis_blk_to_nchw(ptr(x), ptr(y), B, Cb * 8, H, W, stream()), "rsis_blk_to_nchw")
+    return y
+
+
+def blk_conv2d(x, wp, cout, ks, variant=0):
+    """conv (stride 1, same padding, no bias) of a blk tensor with a bf16 pack (PackedConv(dtype=DTYPE_BF16).fwd / .dgrad)"""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 5 and x.shape[-1] == 8 and cout % 8 == 0
+    B, Cb, H, W, _ = x.shape
+    y = torch.empty((B, cout // 8, H, W, 8), dtype=torch.bfloat16, device=x.device)
+    check(lib().rsis_blk_conv2d(ptr(x), B, Cb * 8, H, W, ptr(wp), cout, ks, ptr(y), int(variant), stream()), "rsis_blk_conv2d")
+    return y
