@@ -36,6 +36,10 @@ extern "C" {
  *                    gradients) run their f32 kernel under either dtype; rsis_conv_uses_bf16 tells which. */
 #define RSIS_DTYPE_F32 0
 #define RSIS_DTYPE_BF16 1
+/* rsis_conv2d_wgrad / rsis_wgrad_job.dtype only: dy and x are channel-blocked bf16 tensors (the "blk" layout of the entry points at
+ * the end of this header), dW is fp32 in the reference layout as always; ks in {1, 3}, stride 1, "same" padding, Cout % 8 == 0 and
+ * Cs % 8 == 0 (RSIS_ERR_UNSUPPORTED otherwise) */
+#define RSIS_DTYPE_BF16_BLK 2
 
 int rsis_version(void);
 const char* rsis_error_string(int code);
@@ -307,9 +311,29 @@ int rsis_blk_to_nchw(const void* x_blk, float* y, int B, int C, int H, int W, vo
 
 /* out_blk[B][Cout] = conv(x_blk[B][C], W), ks in {1, 3}, stride 1, "same" padding, no bias (torchvision's trunk convs have none);
  * Wp: the bf16 pack rsis_conv_pack_fwd (forward) or rsis_conv_pack_dgrad (data gradient: x = dy, out = dx) produce for dtype
- * RSIS_DTYPE_BF16.  fp32 accumulation, one rounding to bf16 at the store.  variant: 0 = pick a tile, > 0 force (tests). */
-int rsis_blk_conv2d(const void* x_blk, int B, int C, int H, int W, const void* Wp, int Cout, int ks, void* out_blk, int variant,
-                    void* stream);
+ * RSIS_DTYPE_BF16.  addend_blk (optional, the output's shape; may alias out_blk) is added in fp32 before the ONE rounding to bf16 at
+ * the store.  variant: 0 = pick a tile, > 0 force (tests). */
+int rsis_blk_conv2d(const void* x_blk, int B, int C, int H, int W, const void* Wp, int Cout, int ks, const void* addend_blk,
+                    void* out_blk, int variant, void* stream);
+
+/* BatchNorm2d (+ residual add) (+ ReLU) on blk tensors: y = relu?((x - mean) * rstd * gamma + beta (+ res)).  train != 0: batch
+ * statistics (saved to save_mean / save_rstd for the backward; run_mean / run_var, if given, updated with `momentum` and the unbiased
+ * variance, as nn.BatchNorm2d does); train == 0: normalises with run_mean / run_var.  scratch: rsis_blk_bn_scratch_doubles(C) doubles
+ * (per-split partial sums: the reduction order is fixed, results are bit-reproducible). */
+long rsis_blk_bn_scratch_doubles(int C);
+int rsis_blk_bn_fwd(const void* x_blk, const void* res_blk, void* y_blk, double* scratch, const float* gamma, const float* beta,
+                    float* run_mean, float* run_var, float* save_mean, float* save_rstd, int B, int C, int H, int W, float eps,
+                    float momentum, int relu, int train, void* stream);
+/* backward of the train-mode forward: g = dy * [y > 0] if relu (y_blk = the forward output; NULL: the mask is recomputed from x -- only
+ * valid without a residual), dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)), dres_blk (optional) = g, the gradient of the
+ * residual branch; dgamma / dbeta (optional) = sum g * xhat / sum g, added to the buffers if accumulate != 0, stored otherwise. */
+int rsis_blk_bn_bwd(const void* dy_blk, const void* x_blk, const void* y_blk, double* scratch, const float* gamma, const float* beta,
+                    const float* save_mean, const float* save_rstd, void* dx_blk, void* dres_blk, float* dgamma, float* dbeta,
+                    int accumulate, int B, int C, int H, int W, int relu, void* stream);
+/* y[oh][ow] = x[oh * stride][ow * stride] (a strided conv = the stride-1 conv, then this) and its transpose (dx of H x W: dy at the
+ * multiples of stride, zero elsewhere) */
+int rsis_blk_subsample2d(const void* x_blk, void* y_blk, int B, int C, int H, int W, int stride, void* stream);
+int rsis_blk_upscatter2d(const void* dy_blk, void* dx_blk, int B, int C, int H, int W, int stride, void* stream);
 
 #ifdef __cplusplus
 }

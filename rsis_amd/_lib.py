@@ -78,7 +78,12 @@ SIGNATURES = {
     "rsis_heads_fwd_keys": (_i, [_vpp, _vpp, _vpp, _ip, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "rsis_blk_from_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_blk_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "rsis_blk_conv2d": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
+    "rsis_blk_bn_scratch_doubles": (ctypes.c_long, [_i]),
+    "rsis_blk_bn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp]),
+    "rsis_blk_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsis_blk_subsample2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsis_blk_upscatter2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsis_blk_conv2d": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "rsis_heads_bwd": (_i, [_vpp, _ip, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vpp, _vp, _vp, _vp, _vp, _vp]),
     "rsis_loss_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rsis_softiou_sums": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _vp]),

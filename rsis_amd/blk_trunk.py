@@ -1,0 +1,202 @@
+"""Layers 1-4 of the ResNet-101 trunk on channel-blocked bf16 activations -- the storage half of `-dtype bf16` (BASELINE.json
+configs[2..4]; the layers are torchvision's bottlenecks behind reference src/modules/vision.py:12-19).
+
+Under `-dtype bf16` the convs already multiply bf16 operands, but every activation, BatchNorm and gradient tensor of the trunk was
+fp32 NCHW: the convs spent their time converting while staging and BatchNorm moved 4-byte elements.  Here a logical [B][C][H][W]
+tensor lives as bf16 [B][C/8][H][W][8] ("blk", csrc/conv_blk.hip): conv forward / data gradient are LDS-DMA rings over 16-byte
+cells, BatchNorm (+ residual + ReLU) works on cells, the weight gradients transpose 8 x 8 blocks in registers while staging.
+Parameters, their gradients, the BatchNorm statistics and the optimizer stay fp32; so do the stem (3 input channels), the max-pool
+and everything outside the trunk -- the five feature maps leave as fp32 NCHW.
+
+A layer (nn.Sequential of Bottlenecks) is ONE autograd node with a hand-written backward: no per-op autograd bookkeeping, the
+gradient of a block's input is the first conv's data gradient with the identity / downsample branch's gradient as its addend, and
+parameter gradients are accumulated by the kernels -- straight into the flat gradient buffers when ops.DIRECT_GRAD is on (weight
+gradients parked for the grouped launch of ops.flush_wgrads, as the fp32-storage path does).
+
+Strided layers (the first block of layers 2-4): a stride-s conv is the stride-1 conv followed by a sub-sampling -- with the bf16
+MFMA the 4x extra work of three convs costs less than a second kernel family -- and its gradients use the zero-inserted dy.
+"""
+import os
+
+import torch
+
+from . import ops
+from ._lib import lib
+
+# RSIS_BF16_STORAGE=0: keep fp32 NCHW activations under -dtype bf16 (the round-2 path)
+ENABLED = [os.environ.get("RSIS_BF16_STORAGE", "1") != "0"]
+
+
+class _ToBlkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.blk_from_nchw(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.blk_to_nchw(dy.contiguous())
+
+
+class _ToNchwFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.blk_to_nchw(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.blk_from_nchw(dy)
+
+
+def to_blk(x):
+    return _ToBlkFn.apply(x)
+
+
+def to_nchw(x):
+    return _ToNchwFn.apply(x)
+
+
+def _pack(conv):
+    """the stride-1 bf16 pack of a conv's weight (forward and data-gradient copies), whatever the conv's own stride"""
+    pk = getattr(conv, "_blk_pack", None)
+    if pk is None:
+        ks = conv.kernel_size
+        pk = conv._blk_pack = ops.PackedConv(ks, [conv.in_channels], stride=1, pad=ks // 2, dtype=ops.DTYPE_BF16)
+    return pk
+
+
+def _conv(conv, x):
+    return ops.blk_conv2d(x, _pack(conv).fwd(conv.weight), conv.out_channels, conv.kernel_size)
+
+
+def _dgrad(conv, dy, addend=None):
+    return ops.blk_conv2d(dy, _pack(conv).dgrad(conv.weight), conv.in_channels, conv.kernel_size, addend=addend)
+
+
+def _bn(bn, x, res, relu):
+    if bn.training:
+        bn._nbt_pending += 1
+    y, sm, sr = ops.blk_bn_fwd(x, res, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu,
+                               bn.training)
+    return y, (sm, sr)
+
+
+def _acc(p, g):
+    """parameter gradient outside DIRECT_GRAD: what autograd's accumulation would do"""
+    if p.grad is None:
+        p.grad = g
+    else:
+        p.grad += g
+
+
+def _bn_bwd(bn, dy, x, y, stats, relu, want_dres):
+    tg, tb = ops._direct_target(bn.weight), ops._direct_target(bn.bias)
+    direct = tg is not None and tb is not None
+    need = bn.weight.requires_grad
+    dx, dres, dg, db = ops.blk_bn_bwd(dy, x, y, bn.weight.detach(), bn.bias.detach(), stats[0], stats[1], relu, want_dres,
+                                      dgamma=tg if direct else None, dbeta=tb if direct else None, accumulate=direct)
+    if need and not direct:
+        _acc(bn.weight, dg)
+        _acc(bn.bias, db)
+    return dx, dres
+
+
+def _wgrad(conv, dy, x):
+    """dW of a stride-1 'same' conv from blk dy / x: into the flat gradient buffer (parked for the grouped launch) or a new tensor"""
+    w = conv.weight
+    if not w.requires_grad:
+        return
+    B, _cb, H, W, _ = dy.shape
+    tgt = ops._direct_target(w)
+    dW = tgt if tgt is not None else torch.zeros_like(w)
+    ks = conv.kernel_size
+    ops.wgrad_launch(lib(), dy, x, dW, B, conv.in_channels, H, W, conv.out_channels, H, W, ks, 1, ks // 2, conv.in_channels, 0, 0,
+                     ops.DTYPE_BF16_BLK, "rsis_conv2d_wgrad(blk)", tgt is not None)
+    if tgt is None:
+        _acc(w, dW)
+
+
+def _block_forward(blk, x, keep):
+    s = blk.stride
+    a1 = _conv(blk.conv1, x)
+    y1, m1 = _bn(blk.bn1, a1, None, True)
+    a2 = _conv(blk.conv2, y1)
+    if s != 1:
+        a2 = ops.blk_subsample(a2, s)
+    y2, m2 = _bn(blk.bn2, a2, None, True)
+    a3 = _conv(blk.conv3, y2)
+    xs = ad = md = None
+    if blk.downsample is None:
+        res = x
+    else:
+        xs = x if s == 1 else ops.blk_subsample(x, s)
+        ad = _conv(blk.downsample[0], xs)
+        res, md = _bn(blk.downsample[1], ad, None, False)
+    out, m3 = _bn(blk.bn3, a3, res, True)
+    if keep:
+        return out, (x, a1, y1, m1, a2, y2, m2, a3, m3, out, xs, ad, md)
+    return out, None
+
+
+def _block_backward(blk, dout, saved):
+    x, a1, y1, m1, a2, y2, m2, a3, m3, out, xs, ad, md = saved
+    s = blk.stride
+    da3, dres = _bn_bwd(blk.bn3, dout, a3, out, m3, True, True)
+    _wgrad(blk.conv3, da3, y2)
+    dy2 = _dgrad(blk.conv3, da3)
+    da2, _ = _bn_bwd(blk.bn2, dy2, a2, None, m2, True, False)
+    if s != 1:
+        da2 = ops.blk_upscatter(da2, y1.shape[2], y1.shape[3], s)
+    _wgrad(blk.conv2, da2, y1)
+    dy1 = _dgrad(blk.conv2, da2)
+    da1, _ = _bn_bwd(blk.bn1, dy1, a1, None, m1, True, False)
+    _wgrad(blk.conv1, da1, x)
+    if blk.downsample is None:
+        return _dgrad(blk.conv1, da1, addend=dres)
+    dad, _ = _bn_bwd(blk.downsample[1], dres, ad, None, md, False, False)
+    _wgrad(blk.downsample[0], dad, xs)
+    dxs = _dgrad(blk.downsample[0], dad)
+    if s != 1:
+        dxs = ops.blk_upscatter(dxs, x.shape[2], x.shape[3], s)
+    return _dgrad(blk.conv1, da1, addend=dxs)
+
+
+class _LayerFn(torch.autograd.Function):
+    """one `layerN` (nn.Sequential of Bottlenecks): blk in, blk out; the parameters are read from the modules"""
+
+    @staticmethod
+    def forward(ctx, layer, x, _anchor):
+        keep = any(ctx.needs_input_grad)          # (grad mode is off inside forward: this is "somebody will call backward")
+        tape = []
+        for blk in layer:
+            x, saved = _block_forward(blk, x, keep)
+            tape.append(saved)
+        ctx.layer, ctx.tape = layer, tape
+        return x
+
+    @staticmethod
+    def backward(ctx, dout):
+        layer, tape = ctx.layer, ctx.tape
+        ctx.tape = None
+        if not layer[0].bn1.training:
+            raise RuntimeError("blk trunk: the backward exists for train-mode BatchNorm only (eval-mode trunks keep fp32 activations)")
+        dx = dout.contiguous()
+        for blk, saved in zip(reversed(list(layer)), reversed(tape)):
+            dx = _block_backward(blk, dx, saved)
+        return None, dx, None
+
+
+def layer_forward(layer, x):
+    """x (blk) through one layer.  The anchor keeps the node in the graph when x itself carries no gradient (a frozen stem in front
+    of a trainable layer): any parameter of the layer that requires grad."""
+    anchor = None
+    if torch.is_grad_enabled() and not x.requires_grad:
+        for p in layer.parameters():
+            if p.requires_grad:
+                anchor = p
+                break
+    return _LayerFn.apply(layer, x, anchor)
+
+
+def usable(trunk, x):
+    """blk storage applies: enabled, bf16 kernels selected, and no backward through eval-mode BatchNorm (no blk kernel for that)"""
+    return bool(ENABLED[0] and getattr(trunk, "_blk", False) and x.is_cuda and (trunk.training or not torch.is_grad_enabled()))

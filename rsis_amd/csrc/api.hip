@@ -12,6 +12,13 @@ int rsis_launch_conv_bf16(ConvArgs& a, int ks, int epi, int force_variant, hipSt
 int rsis_launch_conv_blk(ConvArgs& a, int ks, int variant, hipStream_t st);
 int rsis_l_blk_from_nchw(const float*, void*, int, int, int, hipStream_t);
 int rsis_l_blk_to_nchw(const void*, float*, int, int, int, hipStream_t);
+long rsis_l_blk_bn_scratch(int);
+int rsis_l_blk_bn_fwd(const void*, const void*, void*, double*, const float*, const float*, float*, float*, float*, float*, int, int, int, float,
+                      float, int, int, hipStream_t);
+int rsis_l_blk_bn_bwd(const void*, const void*, const void*, double*, const float*, const float*, const float*, const float*, void*, void*,
+                      float*, float*, int, int, int, int, int, hipStream_t);
+int rsis_l_blk_subsample(const void*, void*, long, int, int, int, int, int, hipStream_t);
+int rsis_l_blk_upscatter(const void*, void*, long, int, int, int, int, int, hipStream_t);
 bool rsis_wgrad_bf16_supported(const WgradArgs& w, int ks);
 int rsis_launch_conv_wgrad_bf16(const WgradArgs& w, int ks, hipStream_t st);
 int rsis_launch_conv_wgrad_bf16_group(const WgradArgs* w, int n, int ks, hipStream_t st);
@@ -371,7 +378,11 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const vo
 }
 
 // route of one weight gradient: 0 conv_out vector kernel, 1 bf16 tiled, 2 exact-f32 LDS-DMA tiled, 3 generic split-K implicit GEMM
-static int wgrad_route(const WgradArgs& a, int ks, int lstm_hid, int dtype) {
+static int wgrad_route(WgradArgs& a, int ks, int lstm_hid, int dtype) {
+  if (dtype == RSIS_DTYPE_BF16_BLK) {     // dy / x are channel-blocked bf16 tensors: the bf16 kernels with the blk staging, or nothing
+    a.blk = 1;
+    return rsis_wgrad_bf16_supported(a, ks) ? 1 : -1;
+  }
   if (use_direct(ks, a.stride, a.pad) && a.Cout == 1 && lstm_hid == 0 && rsis_c1_supported(a.Cs) && a.H == a.Ho && a.W == a.Wo && a.W % 4 == 0)
     return 0;
   // stride-1 "same" convs on tile-aligned maps: the LDS-DMA tiled kernel (conv_wgrad_tiled.hip); RSIS_WGRAD_TILED=0 forces the
@@ -403,7 +414,9 @@ int rsis_conv2d_wgrad(const float* dy, const float* x, float* dW, int B, int Cs,
   WgradArgs a;
   const int rc = wgrad_fill(a, dy, x, dW, B, Cs, H, W, Cout, Ho, Wo, ks, stride, pad, Ctot, c_off, lstm_hid);
   if (rc) return rc;
-  return wgrad_launch_one(a, wgrad_route(a, ks, lstm_hid, dtype), ks, (hipStream_t)stream);
+  const int route = wgrad_route(a, ks, lstm_hid, dtype);
+  if (route < 0) return RSIS_ERR_UNSUPPORTED;
+  return wgrad_launch_one(a, route, ks, (hipStream_t)stream);
 }
 
 int rsis_conv2d_wgrad_batch(const rsis_wgrad_job* jobs, int njobs, void* stream) {
@@ -419,6 +432,7 @@ int rsis_conv2d_wgrad_batch(const rsis_wgrad_job* jobs, int njobs, void* stream)
     rc = wgrad_fill(a, q.dy, q.x, q.dW, q.B, q.Cs, q.H, q.W, q.Cout, q.Ho, q.Wo, q.ks, q.stride, q.pad, q.Ctot, q.c_off, q.lstm_hid);
     if (rc) break;
     const int route = wgrad_route(a, q.ks, q.lstm_hid, q.dtype);
+    if (route < 0) { rc = RSIS_ERR_UNSUPPORTED; break; }
     // (deterministic mode: one launch per job, in order -- several jobs may accumulate into the SAME dW (a conv applied at every
     //  decoder timestep), and inside one grid their atomics would land in a run-dependent order)
     if ((route == 1 || route == 2) && (q.ks == 1 || q.ks == 3) && !rsis_deterministic()) {      // grouped below
@@ -551,13 +565,14 @@ int rsis_bn_bwd(const float* dy, const float* x, const float* y, const float* sa
                        (hipStream_t)stream);
 }
 // ---- channel-blocked bf16 activations (conv_blk.hip) ----
-int rsis_blk_conv2d(const void* x, int B, int C, int H, int W, const void* Wp, int Cout, int ks, void* out, int variant, void* stream) {
+int rsis_blk_conv2d(const void* x, int B, int C, int H, int W, const void* Wp, int Cout, int ks, const void* addend, void* out, int variant,
+                    void* stream) {
   if (!x || !Wp || !out || x == out || B < 1 || C < 8 || H < 1 || W < 1 || Cout < 8) return RSIS_ERR_ARG;
   if (ks != 1 && ks != 3) return RSIS_ERR_UNSUPPORTED;
   ConvArgs a = {};
   a.nsrc = 1; a.src[0] = a.src[1] = a.src[2] = (const float*)x; a.C[0] = C; a.K = C * ks * ks;
   a.B = B; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.stride = 1; a.pad = ks / 2;
-  a.wp = (const float*)Wp; a.ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN); a.Cout = Cout;
+  a.wp = (const float*)Wp; a.ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN); a.Cout = Cout; a.addend = (const float*)addend;
   a.dst[0] = (float*)out; a.Cd[0] = Cout; a.ndst = 1; a.ostride = 1; a.oH = H; a.oW = W; a.ksplit = 1;
   return rsis_launch_conv_blk(a, ks, variant, (hipStream_t)stream);
 }
@@ -568,6 +583,31 @@ int rsis_blk_from_nchw(const float* x, void* y, int B, int C, int H, int W, void
 int rsis_blk_to_nchw(const void* x, float* y, int B, int C, int H, int W, void* stream) {
   if (!x || !y || B < 1 || C < 8 || (C & 7) || H < 1 || W < 1) return RSIS_ERR_ARG;
   return rsis_l_blk_to_nchw(x, y, B, C, H * W, (hipStream_t)stream);
+}
+
+long rsis_blk_bn_scratch_doubles(int C) { return C >= 8 && !(C & 7) ? rsis_l_blk_bn_scratch(C) : 0; }
+int rsis_blk_bn_fwd(const void* x, const void* res, void* y, double* scratch, const float* gamma, const float* beta, float* run_mean,
+                    float* run_var, float* save_mean, float* save_rstd, int B, int C, int H, int W, float eps, float momentum, int relu,
+                    int train, void* stream) {
+  if (!x || !y || !gamma || !beta || B < 1 || C < 8 || (C & 7) || H < 1 || W < 1) return RSIS_ERR_ARG;
+  if (train ? (!scratch || !save_mean || !save_rstd || (!run_mean != !run_var)) : (!run_mean || !run_var)) return RSIS_ERR_ARG;
+  return rsis_l_blk_bn_fwd(x, res, y, scratch, gamma, beta, run_mean, run_var, save_mean, save_rstd, B, C, H * W, eps, momentum, relu ? 1 : 0,
+                           train ? 1 : 0, (hipStream_t)stream);
+}
+int rsis_blk_bn_bwd(const void* dy, const void* x, const void* y, double* scratch, const float* gamma, const float* beta,
+                    const float* save_mean, const float* save_rstd, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate, int B,
+                    int C, int H, int W, int relu, void* stream) {
+  if (!dy || !x || !scratch || !gamma || !beta || !save_mean || !save_rstd || !dx || B < 1 || C < 8 || (C & 7) || H < 1 || W < 1) return RSIS_ERR_ARG;
+  return rsis_l_blk_bn_bwd(dy, x, y, scratch, gamma, beta, save_mean, save_rstd, dx, dres, dgamma, dbeta, accumulate ? 1 : 0, B, C, H * W,
+                           relu ? 1 : 0, (hipStream_t)stream);
+}
+int rsis_blk_subsample2d(const void* x, void* y, int B, int C, int H, int W, int stride, void* stream) {
+  if (!x || !y || x == y || B < 1 || C < 8 || (C & 7) || H < 1 || W < 1 || stride < 1) return RSIS_ERR_ARG;
+  return rsis_l_blk_subsample(x, y, (long)B * (C >> 3), H, W, (H - 1) / stride + 1, (W - 1) / stride + 1, stride, (hipStream_t)stream);
+}
+int rsis_blk_upscatter2d(const void* dy, void* dx, int B, int C, int H, int W, int stride, void* stream) {
+  if (!dy || !dx || dx == dy || B < 1 || C < 8 || (C & 7) || H < 1 || W < 1 || stride < 1) return RSIS_ERR_ARG;
+  return rsis_l_blk_upscatter(dy, dx, (long)B * (C >> 3), H, W, (H - 1) / stride + 1, (W - 1) / stride + 1, stride, (hipStream_t)stream);
 }
 
 int rsis_subsample2d(const float* x, float* y, long BC, int H, int W, int stride, void* stream) {

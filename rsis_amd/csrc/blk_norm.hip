@@ -1,0 +1,329 @@
+// BatchNorm (+ residual add + ReLU) and the small layout helpers on channel-blocked bf16 activations (conv_blk.hip: logical
+// [B][C][H][W] stored as bf16 [B][C/8][H][W][8], one 16-byte cell = the 8 channels of a pixel).
+// Reference: nn.BatchNorm2d / ReLU / the residual add of the torchvision bottlenecks behind src/modules/vision.py:12-19 (train-mode
+// batch statistics, running-statistics update with the unbiased variance; eval mode normalises with the running statistics).
+//
+// A thread works on whole cells: eight per-channel fp32 accumulators (statistics) or eight scale / shift pairs (apply), 16-byte
+// loads and stores, half the bytes of the fp32 NCHW kernels of pointwise.hip.  Statistics and the two backward sums are reduced
+// in two levels -- S partial sums per channel written by the grid (double), summed again by every block of the apply pass (8
+// threads x S adds) -- so the result does not depend on the order blocks run in: bit-reproducible without atomics.
+// The arithmetic is fp32 on the exact bf16 inputs, with ONE rounding to bf16 at each store.
+#include "common.h"
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void cell_unpack(const u32x4 c, float* v) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[2 * k] = __uint_as_float(c[k] << 16);
+    v[2 * k + 1] = __uint_as_float(c[k] & 0xFFFF0000u);
+  }
+}
+__device__ __forceinline__ u32x4 cell_pack(const float* v) {
+  u32x4 c;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x2 f = {v[2 * k], v[2 * k + 1]};
+    c[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+  }
+  return c;
+}
+// cell index of element n = b * HW + sp of channel block cb
+__device__ __forceinline__ size_t cell_index(long n, int cb, int Cb, int HW) {
+  const long b = n / HW;
+  return ((size_t)b * Cb + cb) * HW + (size_t)(n - b * HW);
+}
+
+// sum of 16 per-thread values over the 256 threads of the block -> out[16] (double), written by threads 0..15
+__device__ __forceinline__ void block_sum16(float* a, double* out) {
+  __shared__ float red[4][16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float v = a[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    a[k] = v;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) red[wave][k] = a[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) out[threadIdx.x] = (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
+}
+
+// ---- statistics: part[s][cb][0..7] = sum x, [8..15] = sum x^2 over split s of the B * HW cells of channel block cb ----
+__global__ __launch_bounds__(256) void blk_bn_stats_kernel(const u32x4* __restrict__ x, double* __restrict__ part, int Cb, int HW, long N, long per) {
+  const int cb = blockIdx.y, s = blockIdx.x;
+  const long n0 = s * per, n1 = min(N, n0 + per);
+  float a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = 0.f;
+  for (long n = n0 + threadIdx.x; n < n1; n += 1024) {
+    u32x4 c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long nn = n + u * 256;
+      c[u] = nn < n1 ? x[cell_index(nn, cb, Cb, HW)] : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v[8];
+      cell_unpack(c[u], v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { a[k] += v[k]; a[8 + k] += v[k] * v[k]; }
+    }
+  }
+  block_sum16(a, part + ((size_t)s * Cb + cb) * 16);
+}
+
+// ---- y = relu?( (x - mean) * rstd * gamma + beta (+ res) ) ----
+template <int U>
+__global__ __launch_bounds__(256) void blk_bn_apply_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ res, u32x4* __restrict__ y,
+                                                           const double* __restrict__ part, int S, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                           float* __restrict__ run_var, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_rstd, int Cb, int HW, long N, float eps, float momentum,
+                                                           int relu, int train) {
+  __shared__ float sc[8], sh[8];
+  const int cb = blockIdx.y;
+  if (threadIdx.x < 8) {
+    const int k = threadIdx.x, c = cb * 8 + k;
+    float mean, rstd;
+    if (train) {
+      double s = 0.0, q = 0.0;
+      for (int i = 0; i < S; ++i) { s += part[((size_t)i * Cb + cb) * 16 + k]; q += part[((size_t)i * Cb + cb) * 16 + 8 + k]; }
+      const double m = s / (double)N;
+      double var = q / (double)N - m * m;
+      if (var < 0.0) var = 0.0;
+      mean = (float)m;
+      rstd = rsqrtf((float)var + eps);
+      if (blockIdx.x == 0) {
+        save_mean[c] = mean;
+        save_rstd[c] = rstd;
+        if (run_mean) {
+          const float unb = N > 1 ? (float)(var * (double)N / (double)(N - 1)) : (float)var;
+          run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+          run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+        }
+      }
+    } else {
+      mean = run_mean[c];
+      rstd = rsqrtf(run_var[c] + eps);
+    }
+    const float g = gamma[c] * rstd;
+    sc[k] = g;
+    sh[k] = beta[c] - mean * g;
+  }
+  __syncthreads();
+  float scv[8], shv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { scv[k] = sc[k]; shv[k] = sh[k]; }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long n = ((long)blockIdx.x * U + u) * 256 + threadIdx.x;
+    if (n >= N) continue;
+    const size_t idx = cell_index(n, cb, Cb, HW);
+    float v[8];
+    cell_unpack(x[idx], v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = v[k] * scv[k] + shv[k];
+    if (res) {
+      float r[8];
+      cell_unpack(res[idx], r);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += r[k];
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    y[idx] = cell_pack(v);
+  }
+}
+
+// ---- backward.  g = dy * [y > 0] (relu; y = the forward output.  Without y the mask is recomputed from x: no residual then);
+//      part[s][cb][0..7] = sum g, [8..15] = sum g * xhat ----
+__device__ __forceinline__ void bn_bwd_g(const u32x4 dyc, const u32x4 xc, const bool has_y, const u32x4 yc, const float* mean, const float* rstd,
+                                         const float* gam, const float* bet, const int relu, float* g, float* xh) {
+  float dv[8], xv[8], yv[8];
+  cell_unpack(dyc, dv);
+  cell_unpack(xc, xv);
+  if (has_y) cell_unpack(yc, yv);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    xh[k] = (xv[k] - mean[k]) * rstd[k];
+    bool on = true;
+    if (relu) on = has_y ? (yv[k] > 0.f) : (xh[k] * gam[k] + bet[k] > 0.f);
+    g[k] = on ? dv[k] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void blk_bn_bwd_reduce_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x, const u32x4* __restrict__ y,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                                double* __restrict__ part, int Cb, int HW, long N, long per, int relu) {
+  const int cb = blockIdx.y, s = blockIdx.x;
+  const long n0 = s * per, n1 = min(N, n0 + per);
+  float mean[8], rstd[8], gam[8], bet[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { mean[k] = save_mean[cb * 8 + k]; rstd[k] = save_rstd[cb * 8 + k]; gam[k] = gamma[cb * 8 + k]; bet[k] = beta[cb * 8 + k]; }
+  float a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = 0.f;
+  const bool has_y = y != nullptr;
+  for (long n = n0 + threadIdx.x; n < n1; n += 512) {
+    u32x4 dc[2], xc[2], yc[2];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long nn = n + u * 256;
+      ok[u] = nn < n1;
+      const size_t idx = ok[u] ? cell_index(nn, cb, Cb, HW) : 0;
+      dc[u] = ok[u] ? dy[idx] : u32x4{0u, 0u, 0u, 0u};
+      xc[u] = x[idx];
+      yc[u] = has_y ? y[idx] : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float g[8], xh[8];
+      bn_bwd_g(dc[u], xc[u], has_y, yc[u], mean, rstd, gam, bet, relu, g, xh);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { a[k] += g[k]; a[8 + k] += g[k] * xh[k]; }
+    }
+  }
+  block_sum16(a, part + ((size_t)s * Cb + cb) * 16);
+}
+
+// dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat));  dres = g (the gradient of the residual branch);  dgamma / dbeta
+template <int U>
+__global__ __launch_bounds__(256) void blk_bn_bwd_apply_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x, const u32x4* __restrict__ y,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                               const double* __restrict__ part, int S, u32x4* __restrict__ dx,
+                                                               u32x4* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               int accumulate, int Cb, int HW, long N, int relu) {
+  __shared__ float sm[6][8];
+  const int cb = blockIdx.y;
+  if (threadIdx.x < 8) {
+    const int k = threadIdx.x, c = cb * 8 + k;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < S; ++i) { s += part[((size_t)i * Cb + cb) * 16 + k]; q += part[((size_t)i * Cb + cb) * 16 + 8 + k]; }
+    if (blockIdx.x == 0) {
+      if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+      if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
+    }
+    sm[0][k] = save_mean[c]; sm[1][k] = save_rstd[c]; sm[2][k] = gamma[c]; sm[3][k] = beta[c];
+    sm[4][k] = (float)(s / (double)N); sm[5][k] = (float)(q / (double)N);
+  }
+  __syncthreads();
+  float mean[8], rstd[8], gam[8], bet[8], c1[8], c2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { mean[k] = sm[0][k]; rstd[k] = sm[1][k]; gam[k] = sm[2][k]; bet[k] = sm[3][k]; c1[k] = sm[4][k]; c2[k] = sm[5][k]; }
+  const bool has_y = y != nullptr;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long n = ((long)blockIdx.x * U + u) * 256 + threadIdx.x;
+    if (n >= N) continue;
+    const size_t idx = cell_index(n, cb, Cb, HW);
+    float g[8], xh[8], o[8];
+    bn_bwd_g(dy[idx], x[idx], has_y, has_y ? y[idx] : u32x4{0u, 0u, 0u, 0u}, mean, rstd, gam, bet, relu, g, xh);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = gam[k] * rstd[k] * (g[k] - c1[k] - xh[k] * c2[k]);
+    dx[idx] = cell_pack(o);
+    if (dres) dres[idx] = cell_pack(g);
+  }
+}
+
+// ---- spatial helpers for the strided layers (a stride-s conv = the stride-1 conv followed by this sub-sampling) ----
+__global__ __launch_bounds__(256) void blk_subsample_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int H, int W, int Ho, int Wo,
+                                                            int stride, long cells) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= cells) return;
+  const int ow = (int)(e % Wo);
+  const long t = e / Wo;
+  const int oh = (int)(t % Ho);
+  const long bc = t / Ho;
+  y[e] = x[((size_t)bc * H + oh * stride) * W + ow * stride];
+}
+// the transpose: dx[h][w] = dy[h / s][w / s] where both are multiples of s, zero elsewhere
+__global__ __launch_bounds__(256) void blk_upscatter_kernel(const u32x4* __restrict__ dy, u32x4* __restrict__ dx, int H, int W, int Ho, int Wo,
+                                                            int stride, long cells) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= cells) return;
+  const int w = (int)(e % W);
+  const long t = e / W;
+  const int h = (int)(t % H);
+  const long bc = t / H;
+  const int oh = h / stride, ow = w / stride;
+  const bool on = oh * stride == h && ow * stride == w && oh < Ho && ow < Wo;
+  dx[e] = on ? dy[((size_t)bc * Ho + oh) * Wo + ow] : u32x4{0u, 0u, 0u, 0u};
+}
+
+// ------------------------------------------------------------------------------------------------
+static void bn_splits(int Cb, long N, int& S, long& per) {
+  // ~2048 blocks over the grid, at least 2048 cells per block, at most 64 splits
+  long s = 2048 / (Cb > 0 ? Cb : 1);
+  if (s < 1) s = 1;
+  const long smax = (N + 2047) / 2048;
+  if (s > smax) s = smax;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  per = (N + s - 1) / s;
+  per = (per + 255) / 256 * 256;
+  S = (int)((N + per - 1) / per);
+}
+
+// scratch: >= rsis_blk_bn_scratch_doubles(C) doubles
+long rsis_l_blk_bn_scratch(int C) { return (long)64 * C * 2; }
+
+int rsis_l_blk_bn_fwd(const void* x, const void* res, void* y, double* scratch, const float* gamma, const float* beta, float* run_mean,
+                      float* run_var, float* save_mean, float* save_rstd, int B, int C, int HW, float eps, float momentum, int relu, int train,
+                      hipStream_t st) {
+  const int Cb = C >> 3;
+  const long N = (long)B * HW;
+  int S = 1;
+  long per = N;
+  if (train) {
+    bn_splits(Cb, N, S, per);
+    hipLaunchKernelGGL(blk_bn_stats_kernel, dim3(S, Cb), dim3(256), 0, st, (const u32x4*)x, scratch, Cb, HW, N, per);
+  }
+  constexpr int U = 4;
+  hipLaunchKernelGGL((blk_bn_apply_kernel<U>), dim3((unsigned)((N + 256 * U - 1) / (256 * U)), Cb), dim3(256), 0, st, (const u32x4*)x,
+                     (const u32x4*)res, (u32x4*)y, scratch, S, gamma, beta, run_mean, run_var, save_mean, save_rstd, Cb, HW, N, eps, momentum,
+                     relu, train);
+  return rsis_check_launch();
+}
+
+int rsis_l_blk_bn_bwd(const void* dy, const void* x, const void* y, double* scratch, const float* gamma, const float* beta,
+                      const float* save_mean, const float* save_rstd, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate,
+                      int B, int C, int HW, int relu, hipStream_t st) {
+  const int Cb = C >> 3;
+  const long N = (long)B * HW;
+  int S = 1;
+  long per = N;
+  bn_splits(Cb, N, S, per);
+  hipLaunchKernelGGL(blk_bn_bwd_reduce_kernel, dim3(S, Cb), dim3(256), 0, st, (const u32x4*)dy, (const u32x4*)x, (const u32x4*)y, gamma, beta,
+                     save_mean, save_rstd, scratch, Cb, HW, N, per, relu);
+  constexpr int U = 4;
+  hipLaunchKernelGGL((blk_bn_bwd_apply_kernel<U>), dim3((unsigned)((N + 256 * U - 1) / (256 * U)), Cb), dim3(256), 0, st, (const u32x4*)dy,
+                     (const u32x4*)x, (const u32x4*)y, gamma, beta, save_mean, save_rstd, scratch, S, (u32x4*)dx, (u32x4*)dres, dgamma, dbeta,
+                     accumulate, Cb, HW, N, relu);
+  return rsis_check_launch();
+}
+
+int rsis_l_blk_subsample(const void* x, void* y, long BCb, int H, int W, int Ho, int Wo, int stride, hipStream_t st) {
+  const long cells = BCb * Ho * Wo;
+  hipLaunchKernelGGL(blk_subsample_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, (const u32x4*)x, (u32x4*)y, H, W, Ho, Wo,
+                     stride, cells);
+  return rsis_check_launch();
+}
+int rsis_l_blk_upscatter(const void* dy, void* dx, long BCb, int H, int W, int Ho, int Wo, int stride, hipStream_t st) {
+  const long cells = BCb * H * W;
+  hipLaunchKernelGGL(blk_upscatter_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, (const u32x4*)dy, (u32x4*)dx, H, W, Ho, Wo,
+                     stride, cells);
+  return rsis_check_launch();
+}

@@ -113,4 +113,5 @@ struct WgradArgs {
   int interleave_hid;  // >0: dy rows are 4*j+gate -> dW row gate*hid + j
   int chunk;         // px per split (multiple of BKW)
   int n_co_tiles, n_n_tiles;
+  int blk;           // bf16 kernels only: dy and x are channel-blocked bf16 tensors (conv_blk.hip)
 };

@@ -163,6 +163,11 @@ __global__ __launch_bounds__(256) void conv_blk_kernel(const ConvArgs p) {
   const int Cbo = p.Cout >> 3;
   char* const obase = (char*)p.dst[0] + (size_t)b0 * Cbo * HW * 16;
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, Cbo * HW * 16, 0x00020000);
+  // optional blk addend of the output's shape (the data gradient of a residual block's first conv + the gradient of the identity
+  // branch): added in fp32 before the one rounding
+  const bool has_add = p.addend != nullptr;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(has_add ? (const char*)p.addend + (size_t)b0 * Cbo * HW * 16 : obase), 0, has_add ? Cbo * HW * 16 : 0, 0x00020000);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int pp = (wn * TN + j) * 32 + l31;
@@ -173,7 +178,13 @@ __global__ __launch_bounds__(256) void conv_blk_kernel(const ConvArgs p) {
     for (int g = 0; g < 4; ++g) {
       const int cbo = (co_base >> 3) + g;
       const unsigned off = (in && cbo < Cbo) ? (unsigned)(cbo * HW + osp) * 16u + 8u * hi : RSIS_OOB;
-      const u32x2 v = {blk_pack2(acc[j][4 * g], acc[j][4 * g + 1]), blk_pack2(acc[j][4 * g + 2], acc[j][4 * g + 3])};
+      float o0 = acc[j][4 * g], o1 = acc[j][4 * g + 1], o2 = acc[j][4 * g + 2], o3 = acc[j][4 * g + 3];
+      if (has_add) {
+        const u32x2 av = __builtin_amdgcn_raw_buffer_load_b64(ra, off, 0, 0);
+        o0 += __uint_as_float(av[0] << 16); o1 += __uint_as_float(av[0] & 0xFFFF0000u);
+        o2 += __uint_as_float(av[1] << 16); o3 += __uint_as_float(av[1] & 0xFFFF0000u);
+      }
+      const u32x2 v = {blk_pack2(o0, o1), blk_pack2(o2, o3)};
       __builtin_amdgcn_raw_buffer_store_b64(v, ro, off, 0, 0);
     }
   }

@@ -3,7 +3,10 @@
 //     dW[co][ci][r][s] += sum_{b,y,x} dy[b][co][y][x] * x[b][ci][y+r-pad][x+s-pad]
 // (autograd of nn.Conv2d in reference src/modules/clstm.py:17,44 -- the ConvLSTM gates, time-batched over T*B images --
 //  model.py:43-47 and the 1x1 / 3x3 convs of the torchvision bottlenecks).  dy, x and dW are fp32 (NCHW / reference layout);
-//  the operands are rounded to bf16 while they are staged into LDS.
+//  the operands are rounded to bf16 while they are staged into LDS.  IN = 2: dy and x are channel-blocked bf16 tensors
+//  (conv_blk.hip: cells of 8 channels x 1 pixel) -- a staging task then fetches the 8 cells of 8 consecutive pixels (whole 16-byte
+//  loads whatever the map width: no ragged-row slow path), transposes the 8 x 8 block in registers and writes the 8 pixel-major
+//  cells [channel][8 px] the MFMA operands are read from.
 //
 // The PIXELS are the reduction axis, and NCHW has them contiguous: a lane's 8 K values are 8 consecutive pixels of one row,
 // i.e. one 16-byte LDS cell, for dy (A operand, rows = co) and for x (B operand) alike.
@@ -30,7 +33,9 @@ struct WgradBf16Args {
   const float* x;    // [B][Cs][H][W]
   float* dw;         // [Cout][ldo]
   int B, Cs, H, W, Cout;
-  int ldo, n_off, interleave_hid;
+  int ldo, n_off;
+  short interleave_hid;
+  short blk;         // dy and x are channel-blocked bf16 tensors (IN = 2)
   int n_co_tiles, n_n_tiles, n_sp_tiles, tiles_per_split;
 };
 
@@ -67,11 +72,36 @@ struct Task8 {
   }
 };
 
+// IN = 2 staging: the 8 x 8 (pixel x channel) block held as 8 cells `in[px]` -> the pixel-major cell of channel c
+__device__ __forceinline__ u32x4 blk_tr_cell(const u32x4* in, const int c) {
+  u32x4 o;
+  const int k = c >> 1;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+    o[m] = (c & 1) ? ((in[2 * m][k] >> 16) | (in[2 * m + 1][k] & 0xFFFF0000u)) : ((in[2 * m][k] & 0xFFFFu) | (in[2 * m + 1][k] << 16));
+  return o;
+}
+// One blk staging task: 8 channels (one channel block) x 8 consecutive pixels of a row.
+struct BlkTask {
+  int off;        // cell offset of pixel 0 inside the descriptor at tile (0, 0), or -1: never valid
+  int y, x;       // position inside the tile (may be negative: halo)
+  int lds;        // byte offset of channel 0's cell inside a stage
+};
+__device__ __forceinline__ void blk_task_load(u32x4* rc, const BlkTask& t, const __amdgpu_buffer_rsrc_t r, const int tsc, const int y0, const int x0,
+                                              const int H, const int W) {
+  const bool row_ok = t.off >= 0 && (unsigned)(y0 + t.y) < (unsigned)H;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool ok = row_ok && (unsigned)(x0 + t.x + j) < (unsigned)W;
+    rc[j] = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)(t.off + tsc + j) * 16u : RSIS_OOB, 0, 0);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 3x3: block = BM dy rows x 32 input channels x 9 taps; wave = 32 rows x 32 channels x 9 taps, the 4 / (BM / 32) wave copies of a
 // row group take alternate 16-pixel reduction steps.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int TW, bool V4>
+template <int BM, int TW, int IN>
 __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const int bx, const int by) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int TP = 64, TH = TP / TW, GPR = TW / 8, NG = TP / 8, KSTEPS = NG / 2;
@@ -119,6 +149,58 @@ __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const i
     x_lds[i] = cl * CHSB + (py * PWP + xg * 8) * 2;
   }
 
+  // ---- IN = 2: super tasks (channel block, 8-pixel group): dy first (padded to whole waves), then the patch ----
+  constexpr int NSA = BM / 8 * NG, NSAP = (NSA + 63) / 64 * 64, NSX = 4 * PH * XG, NTS = (NSAP + NSX + 255) / 256;
+  BlkTask bt[IN == 2 ? NTS : 1];
+  bool bt_a[IN == 2 ? NTS : 1];
+  if constexpr (IN == 2) {
+#pragma unroll
+    for (int i = 0; i < NTS; ++i) {
+      const int e = tid + i * 256;
+      bt_a[i] = __builtin_amdgcn_readfirstlane(e) < NSAP;       // (NSAP % 64 == 0: a wave's tasks are all dy or all patch)
+      if (bt_a[i]) {
+        const int cbl = e / NG, G = e % NG;
+        bt[i].y = G / GPR; bt[i].x = (G % GPR) * 8;
+        bt[i].off = (e < NSA && co0 + cbl * 8 < Cout) ? cbl * HW + bt[i].y * W + bt[i].x : -1;
+        bt[i].lds = cbl * 8 * ARS + G * 16;
+      } else {
+        const int idx = e - NSAP;
+        const int cbl = idx / (PH * XG), rem = idx - cbl * (PH * XG);
+        const int py = rem / XG, xg = rem - py * XG;
+        bt[i].y = py - 1; bt[i].x = (xg - 1) * 8;
+        bt[i].off = (idx < NSX && ci0 + cbl * 8 < Cs) ? cbl * HW + bt[i].y * W + bt[i].x : -1;
+        bt[i].lds = A_BYTES + cbl * 8 * CHSB + (py * PWP + xg * 8) * 2;
+      }
+    }
+  }
+  u32x4 rc[IN == 2 ? NTS : 1][8];
+#define W3B_LOAD()                                                                                                 \
+  {                                                                                                                \
+    const int y0 = ty * TH, x0 = tx * TW;                                                                          \
+    const int tsc = y0 * W + x0;                                                                                   \
+    const char* ab = (const char*)p.dy + ((size_t)tb * (Cout >> 3) + (co0 >> 3)) * HW * 16;                        \
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, ((Cout - co0) >> 3) * HW * 16, 0x00020000); \
+    const char* xb = (const char*)p.x + ((size_t)tb * (Cs >> 3) + (ci0 >> 3)) * HW * 16;                            \
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, ((Cs - ci0) >> 3) * HW * 16, 0x00020000); \
+    _Pragma("unroll") for (int i = 0; i < NTS; ++i) {                                                              \
+      if (bt_a[i]) blk_task_load(rc[i], bt[i], ra_, tsc, y0, x0, H, W);                                            \
+      else blk_task_load(rc[i], bt[i], rx_, tsc, y0, x0, H, W);                                                    \
+    }                                                                                                              \
+    if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++tb; } }                                        \
+  }
+#define W3B_STORE(BUF)                                                                                             \
+  {                                                                                                                \
+    char* st = lds + (BUF) * ST_BYTES;                                                                             \
+    _Pragma("unroll") for (int i = 0; i < NTS; ++i) {                                                              \
+      if ((NSAP + NSX) % 256 == 0 || tid + i * 256 < NSAP + NSX) {                                                 \
+        const int rs = bt_a[i] ? ARS : CHSB;                                                                       \
+        if (!bt_a[i] || tid + i * 256 < NSA) {                                                                     \
+          _Pragma("unroll") for (int c = 0; c < 8; ++c) *(u32x4*)(st + bt[i].lds + c * rs) = blk_tr_cell(rc[i], c); \
+        }                                                                                                          \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
+
   // ---- per-lane LDS read bases (bytes) ----
   const int a_base = (wm * 32 + l31) * ARS + hi * 16;
   // step g covers groups 2g (lanes 0-31) and 2g+1 (lanes 32-63): pixel (y, x8*8) of the tile, patch column 8 + x8*8
@@ -140,7 +222,7 @@ __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const i
   int trem = t_begin - tb * (tiles_x * tiles_y);
   int ty = trem / tiles_x, tx = trem - ty * tiles_x;
 
-  Task8<V4> ra[NTA], rxp[NTX];
+  Task8<IN == 1> ra[IN == 2 ? 1 : NTA], rxp[IN == 2 ? 1 : NTX];
 #define W3_LOAD()                                                                                                  \
   {                                                                                                                \
     const int y0 = ty * TH, x0 = tx * TW;                                                                          \
@@ -163,13 +245,12 @@ __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const i
       if (XT % 256 == 0 || tid + i * 256 < XT) *(u32x4*)(st + A_BYTES + x_lds[i]) = rxp[i].cell();                 \
   }
 
-  W3_LOAD()
-  W3_STORE(0)
+  if constexpr (IN == 2) { W3B_LOAD() W3B_STORE(0) } else { W3_LOAD() W3_STORE(0) }
   __syncthreads();
   const int ntl = t_end - t_begin;
   for (int t = 0; t < ntl; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntl) W3_LOAD()
+    if (t + 1 < ntl) { if constexpr (IN == 2) W3B_LOAD() else W3_LOAD() }
     {
       const char* As = lds + cur * ST_BYTES + a_base;
       const char* Xs = lds + cur * ST_BYTES + A_BYTES;
@@ -192,11 +273,13 @@ __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const i
         }
       }
     }
-    if (t + 1 < ntl) W3_STORE(cur ^ 1)
+    if (t + 1 < ntl) { if constexpr (IN == 2) W3B_STORE(cur ^ 1) else W3_STORE(cur ^ 1) }
     __syncthreads();
   }
 #undef W3_LOAD
 #undef W3_STORE
+#undef W3B_LOAD
+#undef W3B_STORE
 
   // ---- epilogue: the KSPW wave copies of a row group first sum their partial tiles in LDS (fewer same-address atomics: they are
   // serialised by the L2), 8 rows x 288 columns at a time; the rows are then split over the copies and added to dW with the lanes
@@ -239,7 +322,7 @@ __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const i
 // ------------------------------------------------------------------------------------------------
 // 1x1: D[co][ci] = sum_px dy[co][px] x[ci][px]; block tile BM x BN, waves WGM x WGN, TM x TN MFMA tiles per wave.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int TW, bool V4>
+template <int BM, int BN, int WGM, int WGN, int TW, int IN>
 __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const int bx, const int by) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int TP = 64, TH = TP / TW, GPR = TW / 8, NG = TP / 8, KSTEPS = NG / 2;
@@ -279,6 +362,48 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
     b_off[i] = n0 + row < Cs ? row * HW + b_y[i] * W + b_x[i] : -1;
     b_lds[i] = row * ARS + G * 16;
   }
+  // ---- IN = 2: super tasks (channel block, 8-pixel group): the dy tile, then the x tile ----
+  constexpr int NSA = BM / 8 * NG, NSB = BN / 8 * NG, NTS = (NSA + NSB + 255) / 256;
+  static_assert(NSA % 64 == 0, "a wave's tasks are all dy or all x");
+  BlkTask bt[IN == 2 ? NTS : 1];
+  bool bt_a[IN == 2 ? NTS : 1];
+  if constexpr (IN == 2) {
+#pragma unroll
+    for (int i = 0; i < NTS; ++i) {
+      const int e = tid + i * 256;
+      bt_a[i] = __builtin_amdgcn_readfirstlane(e) < NSA;
+      const int idx = bt_a[i] ? e : e - NSA;
+      const int cbl = idx / NG, G = idx % NG;
+      bt[i].y = G / GPR; bt[i].x = (G % GPR) * 8;
+      const bool ok = bt_a[i] ? (co0 + cbl * 8 < Cout) : (idx < NSB && n0 + cbl * 8 < Cs);
+      bt[i].off = ok ? cbl * HW + bt[i].y * W + bt[i].x : -1;
+      bt[i].lds = (bt_a[i] ? 0 : A_BYTES) + cbl * 8 * ARS + G * 16;
+    }
+  }
+  u32x4 rc[IN == 2 ? NTS : 1][8];
+#define W1B_LOAD()                                                                                                 \
+  {                                                                                                                \
+    const int y0 = ty * TH, x0 = tx * TW;                                                                          \
+    const int tsc = y0 * W + x0;                                                                                   \
+    const char* ab = (const char*)p.dy + ((size_t)tb * (Cout >> 3) + (co0 >> 3)) * HW * 16;                        \
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, ((Cout - co0) >> 3) * HW * 16, 0x00020000); \
+    const char* xb = (const char*)p.x + ((size_t)tb * (Cs >> 3) + (n0 >> 3)) * HW * 16;                             \
+    const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, ((Cs - n0) >> 3) * HW * 16, 0x00020000); \
+    _Pragma("unroll") for (int i = 0; i < NTS; ++i) {                                                              \
+      if (bt_a[i]) blk_task_load(rc[i], bt[i], ra_, tsc, y0, x0, H, W);                                            \
+      else blk_task_load(rc[i], bt[i], rb_, tsc, y0, x0, H, W);                                                    \
+    }                                                                                                              \
+    if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++tb; } }                                        \
+  }
+#define W1B_STORE(BUF)                                                                                             \
+  {                                                                                                                \
+    char* st = lds + (BUF) * ST_BYTES;                                                                             \
+    _Pragma("unroll") for (int i = 0; i < NTS; ++i) {                                                              \
+      if ((NSA + NSB) % 256 == 0 || tid + i * 256 < NSA + NSB) {                                                   \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) *(u32x4*)(st + bt[i].lds + c * ARS) = blk_tr_cell(rc[i], c); \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
   const int a_base = (wm * TM * 32 + l31) * ARS + hi * 16;
   const int b_base = (wn * TN * 32 + l31) * ARS + hi * 16;
 
@@ -294,7 +419,7 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
   int trem = t_begin - tb * (tiles_x * tiles_y);
   int ty = trem / tiles_x, tx = trem - ty * tiles_x;
 
-  Task8<V4> ra[NTA], rb[NTB];
+  Task8<IN == 1> ra[IN == 2 ? 1 : NTA], rb[IN == 2 ? 1 : NTB];
 #define W1_LOAD()                                                                                                  \
   {                                                                                                                \
     const int y0 = ty * TH, x0 = tx * TW;                                                                          \
@@ -316,13 +441,12 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
     _Pragma("unroll") for (int i = 0; i < NTB; ++i) *(u32x4*)(st + A_BYTES + b_lds[i]) = rb[i].cell();             \
   }
 
-  W1_LOAD()
-  W1_STORE(0)
+  if constexpr (IN == 2) { W1B_LOAD() W1B_STORE(0) } else { W1_LOAD() W1_STORE(0) }
   __syncthreads();
   const int ntl = t_end - t_begin;
   for (int t = 0; t < ntl; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntl) W1_LOAD()
+    if (t + 1 < ntl) { if constexpr (IN == 2) W1B_LOAD() else W1_LOAD() }
     {
       const char* As = lds + cur * ST_BYTES + a_base;
       const char* Bs = lds + cur * ST_BYTES + A_BYTES + b_base;
@@ -339,11 +463,13 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
           for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (t + 1 < ntl) W1_STORE(cur ^ 1)
+    if (t + 1 < ntl) { if constexpr (IN == 2) W1B_STORE(cur ^ 1) else W1_STORE(cur ^ 1) }
     __syncthreads();
   }
 #undef W1_LOAD
 #undef W1_STORE
+#undef W1B_LOAD
+#undef W1B_STORE
 
   // (buffer atomics, as in conv_wgrad_tiled.hip)
   const __amdgpu_buffer_rsrc_t rdw = __builtin_amdgcn_make_buffer_rsrc((void*)p.dw, 0, (unsigned)((size_t)Cout * p.ldo * 4), 0x00020000);
@@ -372,11 +498,11 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
 // ------------------------------------------------------------------------------------------------
 // single launches, and grouped launches: the weight gradients of many layers in one grid (rsis_conv2d_wgrad_batch; see
 // conv_wgrad_tiled.hip).  The jobs travel by value in the kernel arguments.
-template <int BM, int TW, bool V4>
-__global__ __launch_bounds__(256) void wgrad3_bf16_kernel(const WgradBf16Args p) { wgrad3_bf16_body<BM, TW, V4>(p, blockIdx.x, blockIdx.y); }
-template <int BM, int BN, int WGM, int WGN, int TW, bool V4>
+template <int BM, int TW, int IN>
+__global__ __launch_bounds__(256) void wgrad3_bf16_kernel(const WgradBf16Args p) { wgrad3_bf16_body<BM, TW, IN>(p, blockIdx.x, blockIdx.y); }
+template <int BM, int BN, int WGM, int WGN, int TW, int IN>
 __global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const WgradBf16Args p) {
-  wgrad1_bf16_body<BM, BN, WGM, WGN, TW, V4>(p, blockIdx.x, blockIdx.y);
+  wgrad1_bf16_body<BM, BN, WGM, WGN, TW, IN>(p, blockIdx.x, blockIdx.y);
 }
 
 // XCD placement of a grouped launch.  A (job, range of consecutive splits) ITEM -- all dW tiles of one job over one range of its
@@ -412,17 +538,17 @@ __device__ __forceinline__ bool wgb_find(const WgradBf16Group& g, int& job, int&
   split = g.lane_split0[x][i] + kl / ntile;
   return true;
 }
-template <int BM, int TW, bool V4>
+template <int BM, int TW, int IN>
 __global__ __launch_bounds__(256) void wgrad3_bf16_group_kernel(const WgradBf16Group g) {
   int j, tile, split;
   if (!wgb_find(g, j, tile, split)) return;
-  wgrad3_bf16_body<BM, TW, V4>(g.job[j], tile, split);
+  wgrad3_bf16_body<BM, TW, IN>(g.job[j], tile, split);
 }
-template <int BM, int BN, int WGM, int WGN, int TW, bool V4>
+template <int BM, int BN, int WGM, int WGN, int TW, int IN>
 __global__ __launch_bounds__(256) void wgrad1_bf16_group_kernel(const WgradBf16Group g) {
   int j, tile, split;
   if (!wgb_find(g, j, tile, split)) return;
-  wgrad1_bf16_body<BM, BN, WGM, WGN, TW, V4>(g.job[j], tile, split);
+  wgrad1_bf16_body<BM, BN, WGM, WGN, TW, IN>(g.job[j], tile, split);
 }
 
 static void split_plan(WgradBf16Args& a, int TW, int ntile, int slots) {
@@ -445,8 +571,9 @@ static int launch_w3(WgradBf16Args& a, hipStream_t st) {
   const int ntile = a.n_co_tiles * a.n_n_tiles;
   split_plan(a, TW, ntile, 256);
   const dim3 grid(ntile, rsis_cdiv(a.n_sp_tiles, a.tiles_per_split));
-  if (a.W % 4 == 0) hipLaunchKernelGGL((wgrad3_bf16_kernel<BM, TW, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((wgrad3_bf16_kernel<BM, TW, false>), grid, dim3(256), 0, st, a);
+  if (a.blk) hipLaunchKernelGGL((wgrad3_bf16_kernel<BM, TW, 2>), grid, dim3(256), 0, st, a);
+  else if (a.W % 4 == 0) hipLaunchKernelGGL((wgrad3_bf16_kernel<BM, TW, 1>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad3_bf16_kernel<BM, TW, 0>), grid, dim3(256), 0, st, a);
   return rsis_check_launch();
 }
 
@@ -466,8 +593,9 @@ static int launch_w1(WgradBf16Args& a, hipStream_t st) {
   const int ntile = a.n_co_tiles * a.n_n_tiles;
   split_plan(a, TW, ntile, 256);
   const dim3 grid(ntile, rsis_cdiv(a.n_sp_tiles, a.tiles_per_split));
-  if (a.W % 4 == 0) hipLaunchKernelGGL((wgrad1_bf16_kernel<BM, BN, WGM, WGN, TW, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((wgrad1_bf16_kernel<BM, BN, WGM, WGN, TW, false>), grid, dim3(256), 0, st, a);
+  if (a.blk) hipLaunchKernelGGL((wgrad1_bf16_kernel<BM, BN, WGM, WGN, TW, 2>), grid, dim3(256), 0, st, a);
+  else if (a.W % 4 == 0) hipLaunchKernelGGL((wgrad1_bf16_kernel<BM, BN, WGM, WGN, TW, 1>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad1_bf16_kernel<BM, BN, WGM, WGN, TW, 0>), grid, dim3(256), 0, st, a);
   return rsis_check_launch();
 }
 
@@ -483,6 +611,7 @@ static int launch_w1_tw(WgradBf16Args& a, hipStream_t st) {
 bool rsis_wgrad_bf16_supported(const WgradArgs& w, int ks) {
   if (!(ks == 1 || ks == 3) || w.stride != 1 || w.pad != ks / 2 || w.H != w.Ho || w.W != w.Wo) return false;
   if (w.Cout == 1) return false;          // conv_out: HBM-bound VALU kernel (conv_c1.hip)
+  if (w.blk && ((w.Cout & 7) || (w.Cs & 7))) return false;
   const long img = (long)w.H * w.W * 4;
   return (long)w.Cout * img < (1L << 30) && (long)w.Cs * img < (1L << 30);
 }
@@ -490,7 +619,7 @@ bool rsis_wgrad_bf16_supported(const WgradArgs& w, int ks) {
 int rsis_launch_conv_wgrad_bf16(const WgradArgs& w, int ks, hipStream_t st) {
   WgradBf16Args a = {};
   a.dy = w.dy; a.x = w.x; a.dw = w.dw; a.B = w.B; a.Cs = w.Cs; a.H = w.H; a.W = w.W; a.Cout = w.Cout;
-  a.ldo = w.ldo; a.n_off = w.n_off; a.interleave_hid = w.interleave_hid;
+  a.ldo = w.ldo; a.n_off = w.n_off; a.interleave_hid = (short)w.interleave_hid; a.blk = (short)w.blk;
   const int tw = w.W > 16 ? 32 : (w.W > 8 ? 16 : 8);     // widest 64-pixel tile the map fills
   if (ks == 3) {
     if (tw == 32) return launch_w3_tw<32>(a, st);
@@ -517,7 +646,7 @@ static WgbKey wgb_key(const WgradBf16Args& a, int ks) {      // the rules of lau
     k.bm = a.Cout <= 64 ? 64 : 128;
     k.bn = a.Cs <= 64 ? 64 : 128;
   }
-  k.v4 = a.W % 4 == 0;
+  k.v4 = a.blk ? 2 : (a.W % 4 == 0 ? 1 : 0);      // the IN template argument
   return k;
 }
 static inline bool wgb_same(const WgbKey& a, const WgbKey& b) { return a.ks == b.ks && a.bm == b.bm && a.bn == b.bn && a.tw == b.tw && a.v4 == b.v4; }
@@ -589,17 +718,21 @@ static int wgb_launch_bucket(WgradBf16Args* jobs, int n, const WgbKey& k, Launch
 
 #define WGB3(BMv, TWv)                                                                                             \
   if (k.bm == BMv && k.tw == TWv) {                                                                                \
-    if (k.v4) return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                      \
-      hipLaunchKernelGGL((wgrad3_bf16_group_kernel<BMv, TWv, true>), dim3(blocks), dim3(256), 0, st, g); });       \
+    if (k.v4 == 2) return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                 \
+      hipLaunchKernelGGL((wgrad3_bf16_group_kernel<BMv, TWv, 2>), dim3(blocks), dim3(256), 0, st, g); });          \
+    if (k.v4 == 1) return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                 \
+      hipLaunchKernelGGL((wgrad3_bf16_group_kernel<BMv, TWv, 1>), dim3(blocks), dim3(256), 0, st, g); });          \
     return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                                \
-      hipLaunchKernelGGL((wgrad3_bf16_group_kernel<BMv, TWv, false>), dim3(blocks), dim3(256), 0, st, g); });      \
+      hipLaunchKernelGGL((wgrad3_bf16_group_kernel<BMv, TWv, 0>), dim3(blocks), dim3(256), 0, st, g); });          \
   }
 #define WGB1(BMv, BNv)                                                                                             \
   if (k.bm == BMv && k.bn == BNv) {                                                                                \
-    if (k.v4) return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                      \
-      hipLaunchKernelGGL((wgrad1_bf16_group_kernel<BMv, BNv, 2, 2, 64, true>), dim3(blocks), dim3(256), 0, st, g); });   \
+    if (k.v4 == 2) return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                 \
+      hipLaunchKernelGGL((wgrad1_bf16_group_kernel<BMv, BNv, 2, 2, 64, 2>), dim3(blocks), dim3(256), 0, st, g); });      \
+    if (k.v4 == 1) return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                 \
+      hipLaunchKernelGGL((wgrad1_bf16_group_kernel<BMv, BNv, 2, 2, 64, 1>), dim3(blocks), dim3(256), 0, st, g); });      \
     return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                                \
-      hipLaunchKernelGGL((wgrad1_bf16_group_kernel<BMv, BNv, 2, 2, 64, false>), dim3(blocks), dim3(256), 0, st, g); });  \
+      hipLaunchKernelGGL((wgrad1_bf16_group_kernel<BMv, BNv, 2, 2, 64, 0>), dim3(blocks), dim3(256), 0, st, g); });      \
   }
 static int wgb_dispatch(WgradBf16Args* jobs, int n, const WgbKey& k, hipStream_t st) {
   if (k.ks == 3) {
@@ -622,7 +755,7 @@ int rsis_launch_conv_wgrad_bf16_group(const WgradArgs* w, int n, int ks, hipStre
   for (int j = 0; j < n; ++j) {
     WgradBf16Args a = {};
     a.dy = w[j].dy; a.x = w[j].x; a.dw = w[j].dw; a.B = w[j].B; a.Cs = w[j].Cs; a.H = w[j].H; a.W = w[j].W; a.Cout = w[j].Cout;
-    a.ldo = w[j].ldo; a.n_off = w[j].n_off; a.interleave_hid = w[j].interleave_hid;
+    a.ldo = w[j].ldo; a.n_off = w[j].n_off; a.interleave_hid = (short)w[j].interleave_hid; a.blk = (short)w[j].blk;
     if (ks == 1) { a.W = w[j].H * w[j].W; a.H = 1; }      // 1x1: the flattened map
     all[j] = a;
     key[j] = wgb_key(a, ks);

@@ -880,10 +880,92 @@ def blk_to_nchw(x):
     return y
 
 
-def blk_conv2d(x, wp, cout, ks, variant=0):
-    """conv (stride 1, same padding, no bias) of a blk tensor with a bf16 pack (PackedConv(dtype=DTYPE_BF16).fwd / .dgrad)"""
+def blk_conv2d(x, wp, cout, ks, variant=0, addend=None):
+    """conv (stride 1, same padding, no bias) of a blk tensor with a bf16 pack (PackedConv(dtype=DTYPE_BF16).fwd / .dgrad);
+    addend: a blk tensor of the output's shape, added before the rounding"""
     assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 5 and x.shape[-1] == 8 and cout % 8 == 0
     B, Cb, H, W, _ = x.shape
     y = torch.empty((B, cout // 8, H, W, 8), dtype=torch.bfloat16, device=x.device)
-    check(lib().rsis_blk_conv2d(ptr(x), B, Cb * 8, H, W, ptr(wp), cout, ks, ptr(y), int(variant), stream()), "rsis_blk_conv2d")
+    assert addend is None or (addend.dtype == torch.bfloat16 and addend.is_contiguous() and tuple(addend.shape) == tuple(y.shape))
+    check(lib().rsis_blk_conv2d(ptr(x), B, Cb * 8, H, W, ptr(wp), cout, ks, ptr(addend), ptr(y), int(variant), stream()), "rsis_blk_conv2d")
     return y
+
+
+def _blk_ok(*ts):
+    for t in ts:
+        assert t is None or (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.dim() == 5 and t.shape[-1] == 8), "blk tensor expected"
+
+
+_BLK_SCRATCH = {}
+
+
+def _blk_scratch(C, device):
+    """per-split partial sums of the blk BatchNorm kernels: one buffer per (device, stream) -- launches on a stream are ordered"""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    n = lib().rsis_blk_bn_scratch_doubles(int(C))
+    buf = _BLK_SCRATCH.get(key)
+    if buf is None or buf.numel() < n:
+        buf = _BLK_SCRATCH[key] = torch.empty(max(n, 64 * 2048 * 2), dtype=torch.float64, device=device)
+    return buf
+
+
+def blk_bn_fwd(x, res, gamma, beta, run_mean, run_var, eps, momentum, relu, train):
+    """(y, save_mean, save_rstd) -- BatchNorm2d (+ res) (+ ReLU) on a blk tensor (rsis_blk_bn_fwd)"""
+    _blk_ok(x, res)
+    B, Cb, H, W, _ = x.shape
+    C = Cb * 8
+    y = torch.empty_like(x)
+    sm = torch.empty(C, dtype=torch.float32, device=x.device) if train else None
+    sr = torch.empty(C, dtype=torch.float32, device=x.device) if train else None
+    check(lib().rsis_blk_bn_fwd(ptr(x), ptr(res), ptr(y), ptr(_blk_scratch(C, x.device)) if train else None, ptr(gamma), ptr(beta), ptr(run_mean),
+                                ptr(run_var), ptr(sm), ptr(sr), B, C, H, W, float(eps), float(momentum), int(bool(relu)), int(bool(train)),
+                                stream()), "rsis_blk_bn_fwd")
+    return y, sm, sr
+
+
+def blk_bn_bwd(dy, x, y, gamma, beta, save_mean, save_rstd, relu, want_dres, dgamma=None, dbeta=None, accumulate=False):
+    """(dx, dres or None, dgamma, dbeta) of the train-mode blk BatchNorm (rsis_blk_bn_bwd)"""
+    _blk_ok(dy, x, y)
+    B, Cb, H, W, _ = x.shape
+    C = Cb * 8
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    if dgamma is None:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        accumulate = False
+    check(lib().rsis_blk_bn_bwd(ptr(dy), ptr(x), ptr(y), ptr(_blk_scratch(C, x.device)), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_rstd),
+                                ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), int(bool(accumulate)), B, C, H, W, int(bool(relu)), stream()),
+          "rsis_blk_bn_bwd")
+    return dx, dres, dgamma, dbeta
+
+
+def blk_subsample(x, stride):
+    _blk_ok(x)
+    B, Cb, H, W, _ = x.shape
+    y = torch.empty((B, Cb, (H - 1) // stride + 1, (W - 1) // stride + 1, 8), dtype=torch.bfloat16, device=x.device)
+    check(lib().rsis_blk_subsample2d(ptr(x), ptr(y), B, Cb * 8, H, W, int(stride), stream()), "rsis_blk_subsample2d")
+    return y
+
+
+def blk_upscatter(dy, H, W, stride):
+    _blk_ok(dy)
+    B, Cb, Ho, Wo, _ = dy.shape
+    assert Ho == (H - 1) // stride + 1 and Wo == (W - 1) // stride + 1
+    dx = torch.empty((B, Cb, H, W, 8), dtype=torch.bfloat16, device=dy.device)
+    check(lib().rsis_blk_upscatter2d(ptr(dy), ptr(dx), B, Cb * 8, H, W, int(stride), stream()), "rsis_blk_upscatter2d")
+    return dx
+
+
+DTYPE_BF16_BLK = 2      # rsis_conv2d_wgrad / rsis_wgrad_job.dtype: dy and x are blk tensors
+
+
+def blk_conv_wgrad(dy, x, dW, ks):
+    """dW[Cout][Cin][ks][ks] += the weight gradient of the stride-1 'same' conv from blk dy / x (fp32 accumulation and output)"""
+    _blk_ok(dy, x)
+    B, Cbo, H, W, _ = dy.shape
+    Cin = x.shape[1] * 8
+    assert tuple(x.shape[2:4]) == (H, W) and tuple(dW.shape) == (Cbo * 8, Cin, ks, ks) and dW.dtype == torch.float32 and dW.is_contiguous()
+    check(lib().rsis_conv2d_wgrad(ptr(dy), ptr(x), ptr(dW), B, Cin, H, W, Cbo * 8, H, W, ks, 1, ks // 2, Cin, 0, 0, DTYPE_BF16_BLK, stream()),
+          "rsis_conv2d_wgrad(blk)")
+    return dW

@@ -69,3 +69,160 @@ def test_blk_conv_forward_and_data_gradient(shape, variant):
     dx = from_blk(ops.blk_conv2d(to_blk(dy), pk.dgrad(w), Cin, ks, variant))
     dref = torch.nn.functional.conv_transpose2d(dy.double(), _bf16(w).double(), padding=ks // 2)
     assert_close("dgrad", dx, dref, 1e-5 * float(dref.abs().max()), HALF_ULP)
+    if variant == 0:      # + addend (the identity branch's gradient joining a residual block's first data gradient)
+        add = _bf16(torch.randn(B, Cin, H, W, device="cuda"))
+        dx2 = from_blk(ops.blk_conv2d(to_blk(dy), pk.dgrad(w), Cin, ks, 0, addend=to_blk(add)))
+        ref2 = dref + add.double()
+        assert_close("dgrad+addend", dx2, ref2, 1e-5 * float(ref2.abs().max()), HALF_ULP)
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 14, 14), (2, 256, 28, 28), (32, 16, 7, 7), (3, 24, 5, 9), (2, 8, 1, 1), (8, 64, 56, 56)],
+                         ids=lambda s: "x".join(str(v) for v in s))
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+def test_blk_batchnorm_forward_backward(shape, relu, res):
+    """Train-mode nn.BatchNorm2d (+ residual) (+ ReLU) on blk tensors -- the bn1 / bn2 / bn3 + add + relu of a torchvision bottleneck
+    (vision.py:12-19) -- against the same graph in float64 on the same bf16-valued inputs: output and gradients within half a bf16
+    ulp + fp32 noise, batch statistics / running statistics / parameter gradients (fp32 outputs) to 1e-5 relative."""
+    from rsis_amd import ops
+    B, C, H, W = shape
+    torch.manual_seed(C + H)
+    x = _bf16(torch.randn(B, C, H, W, device="cuda") * 2 + 0.5)
+    r = _bf16(torch.randn(B, C, H, W, device="cuda")) if res else None
+    gamma = torch.rand(C, device="cuda") + 0.5
+    beta = torch.randn(C, device="cuda") * 0.3
+    rm, rv = torch.randn(C, device="cuda") * 0.1, torch.rand(C, device="cuda") + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    y, sm, sr = ops.blk_bn_fwd(to_blk(x), to_blk(r) if res else None, gamma, beta, rm, rv, 1e-5, 0.1, relu, True)
+    xd = x.double().requires_grad_()
+    rd = r.double().requires_grad_() if res else None
+    gd, bd = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    rmd, rvd = rm0.double(), rv0.double()
+    ref = torch.nn.functional.batch_norm(xd, rmd, rvd, gd, bd, True, 0.1, 1e-5)
+    if res:
+        ref = ref + rd
+    if relu:
+        ref = torch.relu(ref)
+    scale = float(ref.detach().abs().max()) + 1e-6
+    assert_close("y", from_blk(y), ref, 2e-5 * scale, HALF_ULP)
+    N = B * H * W
+    if N > 1:
+        assert_close("save_mean", sm, x.double().mean((0, 2, 3)), 1e-5, 1e-5)
+        assert_close("save_rstd", sr, 1.0 / torch.sqrt(x.double().var((0, 2, 3), unbiased=False) + 1e-5), 1e-5, 1e-4)
+        assert_close("running_mean", rm, rmd, 1e-5, 1e-5)
+        assert_close("running_var", rv, rvd, 1e-5, 1e-4)
+    # backward: the mask of the reference is taken from the PRODUCT's rounded output (y == 0 exactly where the bf16 result is 0)
+    dy = _bf16(torch.randn(B, C, H, W, device="cuda"))
+    dx, dres, dg, db = ops.blk_bn_bwd(to_blk(dy), to_blk(x), y if (relu and res) else None, gamma, beta, sm, sr, relu, res)
+    ref.backward(dy.double())
+    gs = float(xd.grad.abs().max()) + 1e-6
+    # elements whose pre-activation is within rounding of 0 may fall on either side of the ReLU: compare where |pre| is clear of 0
+    pre = torch.nn.functional.batch_norm(x.double(), None, None, gd.detach(), bd.detach(), True, 0.0, 1e-5) + (r.double() if res else 0)
+    clear = (pre.abs() > 2.0 ** -7 * (pre.abs() + 1)).float() if relu else torch.ones_like(pre).float()
+    frac = float(clear.mean())
+    assert frac > 0.9
+    # sums over the batch see the few flipped elements: bars scale with their count
+    nflip = float((1 - clear).sum())
+    # (2 x 8 x 1 x 1: two samples per channel, dx is pure cancellation -- the absolute bar is fp32 noise of the terms that cancel)
+    cancel = 1e-5 * float((gamma * sr).max()) * float(dy.abs().max())
+    assert_close("dx", from_blk(dx) * clear, xd.grad * clear, 2e-4 * gs + 8.0 * nflip / max(N, 1) * gs + cancel, 2 * HALF_ULP)
+    if res:
+        assert_close("dres", from_blk(dres) * clear, rd.grad * clear, 1e-6, HALF_ULP)
+    tol = 1e-4 * (float(gd.grad.abs().max()) + float(bd.grad.abs().max()) + 1) + 4.0 * nflip
+    assert_close("dgamma", dg, gd.grad, tol, 1e-4)
+    assert_close("dbeta", db, bd.grad, tol, 1e-4)
+
+
+def test_blk_batchnorm_eval_mode_and_reproducibility():
+    from rsis_amd import ops
+    torch.manual_seed(3)
+    B, C, H, W = 4, 32, 9, 9
+    x = _bf16(torch.randn(B, C, H, W, device="cuda"))
+    gamma, beta = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda")
+    rm, rv = torch.randn(C, device="cuda") * 0.1, torch.rand(C, device="cuda") + 0.5
+    y, _sm, _sr = ops.blk_bn_fwd(to_blk(x), None, gamma, beta, rm.clone(), rv.clone(), 1e-5, 0.1, True, False)
+    ref = torch.relu(torch.nn.functional.batch_norm(x.double(), rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.1, 1e-5))
+    assert_close("eval y", from_blk(y), ref, 2e-5 * float(ref.abs().max()), HALF_ULP)
+    outs = [ops.blk_bn_fwd(to_blk(x), None, gamma, beta, rm.clone(), rv.clone(), 1e-5, 0.1, True, True) for _ in range(3)]
+    assert all(torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2]) for o in outs[1:])
+
+
+@pytest.mark.parametrize("hw", [(8, 8), (7, 7), (9, 14)])
+def test_blk_subsample_and_its_transpose(hw):
+    from rsis_amd import ops
+    H, W = hw
+    torch.manual_seed(1)
+    x = _bf16(torch.randn(2, 16, H, W, device="cuda"))
+    y = ops.blk_subsample(to_blk(x), 2)
+    assert torch.equal(from_blk(y), x[:, :, ::2, ::2])
+    dy = _bf16(torch.randn_like(x[:, :, ::2, ::2]))
+    dx = from_blk(ops.blk_upscatter(to_blk(dy.contiguous()), H, W, 2))
+    want = torch.zeros_like(x)
+    want[:, :, ::2, ::2] = dy
+    assert torch.equal(dx, want)
+
+
+@pytest.mark.parametrize("shape", SHAPES + [(32, 256, 256, 14, 14, 3), (32, 64, 64, 56, 56, 1), (4, 32, 64, 28, 28, 3), (4, 24, 40, 17, 9, 3)],
+                         ids=lambda s: "x".join(str(v) for v in s))
+def test_blk_conv_weight_gradient(shape):
+    """dW of the stride-1 convs from blk dy / x (rsis_conv2d_wgrad, RSIS_DTYPE_BF16_BLK: 8 x 8 register transposition at staging)
+    against float64 on the same bf16-valued operands: fp32 accumulation only -- 1e-5 of the gradient scale + 1e-4 relative
+    (split-K partial sums meet in fp32 atomics) -- and a second call accumulates."""
+    from rsis_amd import ops
+    B, Cin, Cout, H, W, ks = shape
+    torch.manual_seed(sum(shape) + 1)
+    x = _bf16(torch.randn(B, Cin, H, W, device="cuda"))
+    dy = _bf16(torch.randn(B, Cout, H, W, device="cuda"))
+    dW = torch.zeros(Cout, Cin, ks, ks, device="cuda")
+    ops.blk_conv_wgrad(to_blk(dy), to_blk(x), dW, ks)
+    xd = x.double()
+    wd = torch.zeros(Cout, Cin, ks, ks, dtype=torch.float64, device="cuda", requires_grad=True)
+    torch.nn.functional.conv2d(xd, wd, padding=ks // 2).backward(dy.double())
+    scale = float(wd.grad.abs().max())
+    assert_close("dW", dW, wd.grad, 2e-5 * scale, 1e-4)
+    ops.blk_conv_wgrad(to_blk(dy), to_blk(x), dW, ks)
+    assert_close("dW x2", dW, 2 * wd.grad, 4e-5 * scale, 1e-4)
+
+
+def _rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_blk_trunk_against_fp32_storage_bf16_trunk():
+    """The whole ResNet-101 trunk (vision.py:11-21), train mode, forward + backward, with layers 1-4 on blk activations
+    (rsis_amd/blk_trunk.py) against the SAME bf16 kernels on fp32 NCHW activations (blk_trunk.ENABLED = False): same weights, same
+    input.  Bars (stated before measuring): a bf16 rounding is 2^-9 relative per element and layer, ~100 layers deep -> feature maps
+    within 3 % relative L2, parameter gradients within 10 % relative L2 (median over the tensors within 5 %), running statistics
+    within 1 %."""
+    from rsis_amd import blk_trunk, ops
+    from rsis_amd.modules.vision import ResNet101
+    torch.manual_seed(0)
+    net = ResNet101().cuda().train()
+    ops.set_dtype(net, "bf16")
+    x = torch.randn(4, 3, 128, 128, device="cuda")
+    gys = None
+    res = []
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    was = blk_trunk.ENABLED[0]
+    try:
+        for on in (False, True):
+            blk_trunk.ENABLED[0] = on
+            net.load_state_dict(sd0)
+            net.zero_grad(set_to_none=True)
+            outs = net(x)
+            if gys is None:
+                gys = [torch.randn_like(o) / o.numel() ** 0.5 for o in outs]
+            torch.autograd.backward(list(outs), gys)
+            res.append(([o.detach().clone() for o in outs], {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
+                        {k: v.clone() for k, v in net.state_dict().items() if "running_" in k}))
+    finally:
+        blk_trunk.ENABLED[0] = was
+    (o0, g0, s0), (o1, g1, s1) = res
+    for i, (a, b) in enumerate(zip(o1, o0)):
+        assert _rel_l2(a, b) < 3e-2, "feature map %d: rel L2 %.3g" % (i, _rel_l2(a, b))
+    assert set(g0) == set(g1) and len(g0) > 300
+    errs = sorted((_rel_l2(g1[k], g0[k]), k) for k in g0)
+    assert errs[-1][0] < 0.10, "worst parameter gradients: %s" % errs[-5:]
+    assert errs[len(errs) // 2][0] < 0.05, errs[len(errs) // 2]
+    for k in s0:
+        assert _rel_l2(s1[k], s0[k]) < 1e-2, (k, _rel_l2(s1[k], s0[k]))

@@ -52,7 +52,7 @@ def main():
         yb = torch.empty((B, cout // 8, h, h, 8), dtype=torch.bfloat16, device="cuda")
 
         def new(v=0):
-            check(L.rsis_blk_conv2d(ptr(xb), B, cin, h, h, ptr(wp), cout, ks, ptr(yb), v, stream()), "blk")
+            check(L.rsis_blk_conv2d(ptr(xb), B, cin, h, h, ptr(wp), cout, ks, None, ptr(yb), v, stream()), "blk")
         t_old, t_new = timeit(old), timeit(new)
         byts = (cin + cout) * B * h * h * 2 + cin * cout * ks * ks * 2
         fl = 2.0 * cin * cout * ks * ks * B * h * h
