@@ -83,13 +83,14 @@ __device__ __forceinline__ u32x4 blk_tr_cell(const u32x4* in, const int c) {
 }
 // One blk staging task: 8 channels (one channel block) x 8 consecutive pixels of a row.
 struct BlkTask {
-  int off;        // cell offset of pixel 0 inside the descriptor at tile (0, 0), or -1: never valid
+  int off;        // cell offset of pixel 0 inside the descriptor at tile (0, 0) (negative for halo cells), or BLK_NEVER
   int y, x;       // position inside the tile (may be negative: halo)
   int lds;        // byte offset of channel 0's cell inside a stage
 };
+#define BLK_NEVER 0x40000000
 __device__ __forceinline__ void blk_task_load(u32x4* rc, const BlkTask& t, const __amdgpu_buffer_rsrc_t r, const int tsc, const int y0, const int x0,
                                               const int H, const int W) {
-  const bool row_ok = t.off >= 0 && (unsigned)(y0 + t.y) < (unsigned)H;
+  const bool row_ok = t.off < 0x20000000 && (unsigned)(y0 + t.y) < (unsigned)H;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const bool ok = row_ok && (unsigned)(x0 + t.x + j) < (unsigned)W;
@@ -161,14 +162,14 @@ __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const i
       if (bt_a[i]) {
         const int cbl = e / NG, G = e % NG;
         bt[i].y = G / GPR; bt[i].x = (G % GPR) * 8;
-        bt[i].off = (e < NSA && co0 + cbl * 8 < Cout) ? cbl * HW + bt[i].y * W + bt[i].x : -1;
+        bt[i].off = (e < NSA && co0 + cbl * 8 < Cout) ? cbl * HW + bt[i].y * W + bt[i].x : BLK_NEVER;
         bt[i].lds = cbl * 8 * ARS + G * 16;
       } else {
         const int idx = e - NSAP;
         const int cbl = idx / (PH * XG), rem = idx - cbl * (PH * XG);
         const int py = rem / XG, xg = rem - py * XG;
         bt[i].y = py - 1; bt[i].x = (xg - 1) * 8;
-        bt[i].off = (idx < NSX && ci0 + cbl * 8 < Cs) ? cbl * HW + bt[i].y * W + bt[i].x : -1;
+        bt[i].off = (idx < NSX && ci0 + cbl * 8 < Cs) ? cbl * HW + bt[i].y * W + bt[i].x : BLK_NEVER;
         bt[i].lds = A_BYTES + cbl * 8 * CHSB + (py * PWP + xg * 8) * 2;
       }
     }
@@ -376,7 +377,7 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
       const int cbl = idx / NG, G = idx % NG;
       bt[i].y = G / GPR; bt[i].x = (G % GPR) * 8;
       const bool ok = bt_a[i] ? (co0 + cbl * 8 < Cout) : (idx < NSB && n0 + cbl * 8 < Cs);
-      bt[i].off = ok ? cbl * HW + bt[i].y * W + bt[i].x : -1;
+      bt[i].off = ok ? cbl * HW + bt[i].y * W + bt[i].x : BLK_NEVER;
       bt[i].lds = (bt_a[i] ? 0 : A_BYTES) + cbl * 8 * ARS + G * 16;
     }
   }

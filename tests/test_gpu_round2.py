@@ -196,8 +196,10 @@ def test_trainstep_fp32_losses_outputs_gradients_and_adam_step():
     assert n_cmp > 5000
 
 
-def test_bf16_training_tracks_fp32():
-    """Under `-dtype bf16` a train-mode gradient parity check against the fp32 reference is meaningless on the filler-weight
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_bf16_training_tracks_fp32(storage):
+    """(storage: the trunk's activations as fp32 NCHW -- bf16 operands only, RSIS_BF16_STORAGE=0 -- or as channel-blocked bf16,
+    rsis_amd/blk_trunk.py, the default.)  Under `-dtype bf16` a train-mode gradient parity check against the fp32 reference is meaningless on the filler-weight
     fixtures: train-mode BatchNorm over ~100 samples already amplifies fp32 rounding to 3-20 % gradient noise in the reference
     itself (tests/golden/trainstep_160.npz, f64.* vs fp32), i.e. a condition number ~1e6, so a 2^-9 operand rounding de-correlates
     the deep features completely (tools/exp/trainstep_flip_diag.py: 80 % of the deepest planes move their arg-max).  What is
@@ -208,10 +210,30 @@ def test_bf16_training_tracks_fp32():
     from rsis_amd.synthetic import synthetic_batch
     from rsis_amd.train import build_optimizers, runIter
     from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    from rsis_amd import blk_trunk
+    was = blk_trunk.ENABLED[0]
+    blk_trunk.ENABLED[0] = storage == "bf16"
+    try:
+        _bf16_training_tracks_fp32(storage)
+    finally:
+        blk_trunk.ENABLED[0] = was
+
+
+def _bf16_training_tracks_fp32(storage):
+    import copy
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import build_optimizers, runIter
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
     g, losses, _outs, _perms, _named, _pre, _dims, _flipped = _train_step("bf16")
     for k, v in zip(("loss", "loss_mask_iou", "loss_stop", "loss_class"), losses):
-        assert_close(k, v, g[k], 1e-2, 2e-2)       # 2 % of the value + 1e-2 (the stop loss is ~0.15: atomics-order noise alone moves it 2e-3,
-        #                                            and a fresh-box survey measured it 5.1e-3 from the reference's fp32 value)
+        # fp32 activations: 2 % of the value + 1e-2 (the stop loss is ~0.15: atomics-order noise alone moves it 2e-3, and a fresh-box
+        # survey measured it 5.1e-3 from the reference's fp32 value).  bf16 activations put a 2^-9 rounding on every stored tensor of
+        # this condition-number-1e6 fixture: 15 % + 2e-2 -- the bar that means something for them is the loss curve below
+        if storage == "bf16":
+            assert_close(k, v, g[k], 2e-2, 0.15)
+        else:
+            assert_close(k, v, g[k], 1e-2, 2e-2)
     batch = synthetic_batch(5, 8, 64, 64, 20, 3, 21, "cuda")
     crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(0.5)]
     torch.manual_seed(0)
