@@ -55,6 +55,110 @@ __device__ __forceinline__ void block_sum16(float* a, double* out) {
   if (threadIdx.x < 16) out[threadIdx.x] = (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
 }
 
+// the same over the NW waves of a larger block, result in LDS (tot[16], valid after the barrier for every thread)
+template <int NW>
+__device__ __forceinline__ void block_sum16_lds(float* a, double* tot) {
+  __shared__ float redw[NW][16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float v = a[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    a[k] = v;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) redw[wave][k] = a[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += (double)redw[w][threadIdx.x];
+    tot[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+// ---- small maps (B * HW <= 4096 cells per channel block: layer 4 at batch 32; more cells per thread spill): ONE block of 512 threads per channel block does
+//      the statistics pass and the apply pass with its <= 8 cells per thread held in registers (every load issued before the first
+//      use: a loop with one load per iteration pays a memory round trip per iteration).  One launch instead of two -- the trunk has
+//      ~80 such BatchNorms per step, each way -- one read of the inputs, no partial-sum round trip. ----
+template <int NPT>
+__global__ __launch_bounds__(512) void blk_bn_fwd_block_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ res, u32x4* __restrict__ y,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                float* __restrict__ save_mean, float* __restrict__ save_rstd, int Cb, int HW,
+                                                                int N, float eps, float momentum, int relu) {
+  __shared__ double tot[16];
+  __shared__ float sc[8], sh[8];
+  const int cb = blockIdx.x;
+  // the thread's NPT cells stay in registers between the two passes: all loads are issued before the first use
+  u32x4 c[NPT];
+#pragma unroll
+  for (int u = 0; u < NPT; ++u) {
+    const int n = threadIdx.x + u * 512;
+    c[u] = n < N ? x[cell_index(n, cb, Cb, HW)] : u32x4{0u, 0u, 0u, 0u};
+  }
+  float a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = 0.f;
+#pragma unroll
+  for (int u = 0; u < NPT; ++u) {
+    float v[8];
+    cell_unpack(c[u], v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a[k] += v[k]; a[8 + k] += v[k] * v[k]; }
+  }
+  u32x4 r[NPT];
+  if (res) {      // (the residual's loads overlap the reduction)
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) r[u] = threadIdx.x + u * 512 < N ? res[cell_index(threadIdx.x + u * 512, cb, Cb, HW)] : u32x4{0u, 0u, 0u, 0u};
+  }
+  block_sum16_lds<8>(a, tot);
+  if (threadIdx.x < 8) {
+    const int k = threadIdx.x, ch = cb * 8 + k;
+    const double m = tot[k] / (double)N;
+    double var = tot[8 + k] / (double)N - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)m, rstd = rsqrtf((float)var + eps);
+    save_mean[ch] = mean;
+    save_rstd[ch] = rstd;
+    if (run_mean) {
+      const float unb = N > 1 ? (float)(var * (double)N / (double)(N - 1)) : (float)var;
+      run_mean[ch] = (1.f - momentum) * run_mean[ch] + momentum * mean;
+      run_var[ch] = (1.f - momentum) * run_var[ch] + momentum * unb;
+    }
+    const float g = gamma[ch] * rstd;
+    sc[k] = g;
+    sh[k] = beta[ch] - mean * g;
+  }
+  __syncthreads();
+  float scv[8], shv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { scv[k] = sc[k]; shv[k] = sh[k]; }
+#pragma unroll
+  for (int u = 0; u < NPT; ++u) {
+    if (threadIdx.x + u * 512 >= N) continue;
+    float v[8];
+    cell_unpack(c[u], v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = v[k] * scv[k] + shv[k];
+    if (res) {
+      float rv[8];
+      cell_unpack(r[u], rv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += rv[k];
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    y[cell_index(threadIdx.x + u * 512, cb, Cb, HW)] = cell_pack(v);
+  }
+}
+
 // ---- statistics: part[s][cb][0..7] = sum x, [8..15] = sum x^2 over split s of the B * HW cells of channel block cb ----
 __global__ __launch_bounds__(256) void blk_bn_stats_kernel(const u32x4* __restrict__ x, double* __restrict__ part, int Cb, int HW, long N, long per) {
   const int cb = blockIdx.y, s = blockIdx.x;
@@ -90,6 +194,16 @@ __global__ __launch_bounds__(256) void blk_bn_apply_kernel(const u32x4* __restri
                                                            int relu, int train) {
   __shared__ float sc[8], sh[8];
   const int cb = blockIdx.y;
+  // the block's cells are requested BEFORE the per-channel prologue (a chain of dependent loads and double arithmetic on 8 threads):
+  // their latency hides behind it
+  u32x4 xc[U], rc[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long n = ((long)blockIdx.x * U + u) * 256 + threadIdx.x;
+    const size_t idx = cell_index(n < N ? n : 0, cb, Cb, HW);
+    xc[u] = x[idx];
+    rc[u] = res ? res[idx] : u32x4{0u, 0u, 0u, 0u};
+  }
   if (threadIdx.x < 8) {
     const int k = threadIdx.x, c = cb * 8 + k;
     float mean, rstd;
@@ -128,12 +242,12 @@ __global__ __launch_bounds__(256) void blk_bn_apply_kernel(const u32x4* __restri
     if (n >= N) continue;
     const size_t idx = cell_index(n, cb, Cb, HW);
     float v[8];
-    cell_unpack(x[idx], v);
+    cell_unpack(xc[u], v);
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = v[k] * scv[k] + shv[k];
     if (res) {
       float r[8];
-      cell_unpack(res[idx], r);
+      cell_unpack(rc[u], r);
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] += r[k];
     }
@@ -208,6 +322,16 @@ __global__ __launch_bounds__(256) void blk_bn_bwd_apply_kernel(const u32x4* __re
                                                                int accumulate, int Cb, int HW, long N, int relu) {
   __shared__ float sm[6][8];
   const int cb = blockIdx.y;
+  const bool has_y = y != nullptr;
+  u32x4 dcv[U], xcv[U], ycv[U];       // requested before the prologue, as in blk_bn_apply_kernel
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long n = ((long)blockIdx.x * U + u) * 256 + threadIdx.x;
+    const size_t idx = cell_index(n < N ? n : 0, cb, Cb, HW);
+    dcv[u] = dy[idx];
+    xcv[u] = x[idx];
+    ycv[u] = has_y ? y[idx] : u32x4{0u, 0u, 0u, 0u};
+  }
   if (threadIdx.x < 8) {
     const int k = threadIdx.x, c = cb * 8 + k;
     double s = 0.0, q = 0.0;
@@ -223,18 +347,72 @@ __global__ __launch_bounds__(256) void blk_bn_bwd_apply_kernel(const u32x4* __re
   float mean[8], rstd[8], gam[8], bet[8], c1[8], c2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { mean[k] = sm[0][k]; rstd[k] = sm[1][k]; gam[k] = sm[2][k]; bet[k] = sm[3][k]; c1[k] = sm[4][k]; c2[k] = sm[5][k]; }
-  const bool has_y = y != nullptr;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const long n = ((long)blockIdx.x * U + u) * 256 + threadIdx.x;
     if (n >= N) continue;
     const size_t idx = cell_index(n, cb, Cb, HW);
     float g[8], xh[8], o[8];
-    bn_bwd_g(dy[idx], x[idx], has_y, has_y ? y[idx] : u32x4{0u, 0u, 0u, 0u}, mean, rstd, gam, bet, relu, g, xh);
+    bn_bwd_g(dcv[u], xcv[u], has_y, ycv[u], mean, rstd, gam, bet, relu, g, xh);
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = gam[k] * rstd[k] * (g[k] - c1[k] - xh[k] * c2[k]);
     dx[idx] = cell_pack(o);
     if (dres) dres[idx] = cell_pack(g);
+  }
+}
+
+// one block per channel block (small maps, see blk_bn_fwd_block_kernel)
+template <int NPT, bool HAS_Y>
+__global__ __launch_bounds__(512) void blk_bn_bwd_block_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x, const u32x4* __restrict__ y,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                                u32x4* __restrict__ dx, u32x4* __restrict__ dres, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int accumulate, int Cb, int HW, int N, int relu) {
+  __shared__ double tot[16];
+  const int cb = blockIdx.x;
+  constexpr bool has_y = HAS_Y;
+  u32x4 dc[NPT], xc[NPT], yc[HAS_Y ? NPT : 1];
+#pragma unroll
+  for (int u = 0; u < NPT; ++u) {
+    const int n = threadIdx.x + u * 512;
+    const bool ok = n < N;
+    const size_t id = cell_index(ok ? n : 0, cb, Cb, HW);
+    dc[u] = ok ? dy[id] : u32x4{0u, 0u, 0u, 0u};
+    xc[u] = x[id];
+    if constexpr (HAS_Y) yc[u] = y[id];
+  }
+  float mean[8], rstd[8], gam[8], bet[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { mean[k] = save_mean[cb * 8 + k]; rstd[k] = save_rstd[cb * 8 + k]; gam[k] = gamma[cb * 8 + k]; bet[k] = beta[cb * 8 + k]; }
+  float a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = 0.f;
+#pragma unroll
+  for (int u = 0; u < NPT; ++u) {
+    float g[8], xh[8];
+    bn_bwd_g(dc[u], xc[u], has_y, yc[HAS_Y ? u : 0], mean, rstd, gam, bet, relu, g, xh);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a[k] += g[k]; a[8 + k] += g[k] * xh[k]; }
+  }
+  block_sum16_lds<8>(a, tot);
+  if (threadIdx.x < 8) {
+    const int ch = cb * 8 + threadIdx.x;
+    if (dbeta) dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)tot[threadIdx.x];
+    if (dgamma) dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)tot[8 + threadIdx.x];
+  }
+  float c1[8], c2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { c1[k] = (float)(tot[k] / (double)N); c2[k] = (float)(tot[8 + k] / (double)N); }
+#pragma unroll
+  for (int u = 0; u < NPT; ++u) {
+    if (threadIdx.x + u * 512 >= N) continue;
+    float g[8], xh[8], o[8];
+    bn_bwd_g(dc[u], xc[u], has_y, yc[HAS_Y ? u : 0], mean, rstd, gam, bet, relu, g, xh);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = gam[k] * rstd[k] * (g[k] - c1[k] - xh[k] * c2[k]);
+    const size_t id = cell_index(threadIdx.x + u * 512, cb, Cb, HW);
+    dx[id] = cell_pack(o);
+    if (dres) dres[id] = cell_pack(g);
   }
 }
 
@@ -264,6 +442,12 @@ __global__ __launch_bounds__(256) void blk_upscatter_kernel(const u32x4* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+#define BLK_BN_BLOCK_MAX 4096      // cells per channel block up to which one 512-thread block does both passes
+#include <stdlib.h>
+static bool bn_block_ok() {        // RSIS_BLK_BN_BLOCK=0: always the two-level grid kernels (A/B)
+  static const bool ok = !(getenv("RSIS_BLK_BN_BLOCK") && getenv("RSIS_BLK_BN_BLOCK")[0] == '0');
+  return ok;
+}
 static void bn_splits(int Cb, long N, int& S, long& per) {
   // ~2048 blocks over the grid, at least 2048 cells per block, at most 64 splits
   long s = 2048 / (Cb > 0 ? Cb : 1);
@@ -287,6 +471,13 @@ int rsis_l_blk_bn_fwd(const void* x, const void* res, void* y, double* scratch, 
   const long N = (long)B * HW;
   int S = 1;
   long per = N;
+  if (train && N <= BLK_BN_BLOCK_MAX && bn_block_ok()) {
+#define BN_FB(NPT) hipLaunchKernelGGL((blk_bn_fwd_block_kernel<NPT>), dim3(Cb), dim3(512), 0, st, (const u32x4*)x, (const u32x4*)res, (u32x4*)y, \
+                                     gamma, beta, run_mean, run_var, save_mean, save_rstd, Cb, HW, (int)N, eps, momentum, relu)
+    if (N <= 2048) BN_FB(4); else BN_FB(8);
+#undef BN_FB
+    return rsis_check_launch();
+  }
   if (train) {
     bn_splits(Cb, N, S, per);
     hipLaunchKernelGGL(blk_bn_stats_kernel, dim3(S, Cb), dim3(256), 0, st, (const u32x4*)x, scratch, Cb, HW, N, per);
@@ -303,6 +494,14 @@ int rsis_l_blk_bn_bwd(const void* dy, const void* x, const void* y, double* scra
                       int B, int C, int HW, int relu, hipStream_t st) {
   const int Cb = C >> 3;
   const long N = (long)B * HW;
+  if (N <= BLK_BN_BLOCK_MAX && bn_block_ok()) {
+#define BN_BB(NPT, HY) hipLaunchKernelGGL((blk_bn_bwd_block_kernel<NPT, HY>), dim3(Cb), dim3(512), 0, st, (const u32x4*)dy, (const u32x4*)x, \
+                                         (const u32x4*)y, gamma, beta, save_mean, save_rstd, (u32x4*)dx, (u32x4*)dres, dgamma, dbeta, accumulate, Cb, HW, (int)N, relu)
+    if (y) { if (N <= 2048) BN_BB(4, true); else BN_BB(8, true); }
+    else { if (N <= 2048) BN_BB(4, false); else BN_BB(8, false); }
+#undef BN_BB
+    return rsis_check_launch();
+  }
   int S = 1;
   long per = N;
   bn_splits(Cb, N, S, per);
