@@ -544,18 +544,22 @@ def main():
             # (so that the speed-up of the bf16 kernels is stated on equal geometry): own processes, same harness
             import subprocess
             secondary = []
-            for sd, extra in (("bf16", []), ("fp32", ["--skip-traffic"])):
+            # (third record: bf16 operands on fp32 NCHW activations, RSIS_BF16_STORAGE=0 -- what the blocked bf16 trunk is measured against)
+            for sd, extra, env in (("bf16", [], {}), ("fp32", ["--skip-traffic"], {}),
+                                   ("bf16", ["--skip-traffic", "--skip-roofline"], {"RSIS_BF16_STORAGE": "0"})):
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", sd, "--imsize", "224", "--batch", str(o.batch), "--T",
                                         str(o.T), "--steps", str(o.steps), "--warmup", str(o.warmup), "--skip-cpu", "--skip-secondary",
-                                        "--kernel-iters", str(o.kernel_iters)] + extra, capture_output=True, text=True, timeout=600)
+                                        "--kernel-iters", str(o.kernel_iters)] + extra, capture_output=True, text=True, timeout=600,
+                                       env=dict(os.environ, **env))
                     sj = json.loads(r.stdout.strip().splitlines()[-1])
                     sj["config"]["workload"] = sj["config"]["workload"].replace("configs[1]", "configs[2] geometry" if sd == "fp32" else "configs[2]")
-                    secondary.append({k: sj[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "roofline_kernels")})
+                    secondary.append({k: sj.get(k) for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "roofline_kernels")})
                 except Exception as ex:  # noqa: BLE001
                     secondary.append({"dtype": sd, "error": repr(ex)})
-            if all("value" in s_ for s_ in secondary):
+            if all(s_.get("value") for s_ in secondary):
                 secondary[0]["speedup_over_fp32_same_geometry"] = round(secondary[0]["value"] / secondary[1]["value"], 3)
+                secondary[0]["speedup_over_bf16_operands_on_fp32_activations"] = round(secondary[0]["value"] / secondary[2]["value"], 3)
             note("secondary (224x224): bf16 %s images/s, fp32 %s images/s" % (secondary[0].get("value"), secondary[1].get("value")))
         value = world * o.batch * o.steps / dt
         out = {"metric": "training images/sec at %dx%d, T=%d, batch=%d per GPU" % (o.imsize, o.imsize, o.T, o.batch),
@@ -568,6 +572,10 @@ def main():
                           "launch": "hipGraph replay of the captured iteration" if (gstep is not None and gstep.graph is not None)
                                     else "eager (one Python launch per kernel)"},
                "roofline": roof, "roofline_kernels": roof_kernels, "cpu_baseline": cpu, "secondary": secondary}
+        if o.dtype != "fp32":
+            from rsis_amd import blk_trunk
+            out["config"]["activations"] = ("trunk layers 1-4: channel-blocked bf16 (rsis_amd/blk_trunk.py); stem, skip convs, decoder: fp32 NCHW"
+                                            if blk_trunk.ENABLED[0] else "fp32 NCHW everywhere (RSIS_BF16_STORAGE=0: bf16 operands only)")
         if seg is not None:
             out["config"]["exchange_ms_per_step"] = {k: round(v, 3) for k, v in seg.items()}
     # RCCL prints a banner (version, library path) through C stdio, which on a pipe is flushed only at exit, i.e. AFTER anything

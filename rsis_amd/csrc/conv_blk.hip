@@ -213,7 +213,7 @@ int rsis_launch_conv_blk(ConvArgs& a, int ks, int variant, hipStream_t st) {
       const long t64_8 = (long)a.B * rsis_cdiv(a.H, 8) * rsis_cdiv(a.W, 8);
       if (a.W <= 8) v = a.Cout >= 128 && t64_8 * rsis_cdiv(a.Cout, 128) >= 256 ? 6 : 1;
       else if (a.W <= 16) v = (long)a.B * rsis_cdiv(a.H, 8) * rsis_cdiv(a.Cout, 64) >= 512 ? 2 : 4;
-      else v = a.Cout <= 32 ? 5 : 3;
+      else v = a.Cout <= 128 ? 5 : 3;       // (tools/blk_bench.py --variants, batch 32: 64 / 128 rows fill the chip better as 32-row tiles)
     }
     switch (v) {
       case 1: return launch_blk<3, 64, 8, 8, 16, 3>(a, st);
@@ -226,10 +226,11 @@ int rsis_launch_conv_blk(ConvArgs& a, int ks, int variant, hipStream_t st) {
     }
   }
   if (ks == 1) {
-    if (v <= 0) {
+    if (v <= 0) {      // measured on the trunk's shapes at batch 32, 224^2 and 256^2 inputs (tools/blk_bench.py --variants)
       const long t128 = (long)a.B * rsis_cdiv(px, 128);
-      if (a.Cout >= 128 && t128 * rsis_cdiv(a.Cout, 128) >= 512) v = 1;
-      else if (t128 * rsis_cdiv(a.Cout, 64) >= 512) v = 2;
+      if (px <= 64) v = a.Cout >= 1024 ? 3 : 4;                                   // 7x7 / 8x8 maps: 64-pixel tiles
+      else if (a.Cout >= 128 && t128 * rsis_cdiv(a.Cout, 128) >= 256) v = 1;       // one block per CU or more with the big tile
+      else if (t128 * rsis_cdiv(a.Cout, 64) >= 256) v = 2;
       else v = 4;
     }
     switch (v) {
