@@ -35,5 +35,16 @@ for dt in fp32 bf16; do
   pat="conv3x3_direct_group_kernel"; [ $dt = bf16 ] && pat="conv_bf16_kernel<3"
   python tools/pmc_summary.py "$pat" $csvs > $OUT/gate_pmc_$dt.txt
 done
+# per-kernel HBM traffic of one EAGER bf16 224^2 step (blocked bf16 trunk), two PMC passes joined by tools/step_traffic.py
+csvs=""
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $OUT/raw_st_$c
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/raw_st_$c -o pmc -- python bench.py --no-graph --steps 2 --warmup 2 --skip-cpu --skip-roofline --skip-secondary --no-settle --dtype bf16 --imsize 224 > /dev/null 2>&1
+  csvs="$csvs $(find $OUT/raw_st_$c -name '*counter_collection.csv' | head -1)"
+done
+python tools/step_traffic.py $csvs > $OUT/step_traffic_bf16_224.txt
+# blocked bf16 conv against the fp32-storage bf16 conv on the trunk's shapes
+python tools/blk_bench.py --imsize 224 --variants > $OUT/blk_conv_bench_224.txt 2>/dev/null
+python tools/blk_bench.py --imsize 256 > $OUT/blk_conv_bench_256.txt 2>/dev/null
 rm -rf $OUT/raw_*
 ls -la $OUT
