@@ -169,6 +169,7 @@ def gate_kernel_roofline(B, iters, imsize, dtype="fp32", T=10, product_only=Fals
 
 
 # (Cin, Cout, ks, out HxW at 256^2, layers of that shape in ResNet-101 + skip convs) -- SURVEY.md Appendix A
+N_TRUNK_SHAPES = 11      # the first 11 are trunk layers (blocked bf16 activations under -dtype bf16), the last three the skip convs
 TRUNK_SHAPES = [(256, 256, 3, 16, 22), (256, 1024, 1, 16, 23), (1024, 256, 1, 16, 22), (64, 64, 3, 64, 3), (128, 128, 3, 32, 3),
                 (512, 512, 3, 8, 2), (64, 256, 1, 64, 4), (128, 512, 1, 32, 4), (512, 128, 1, 32, 3), (512, 2048, 1, 8, 3),
                 (2048, 512, 1, 8, 2), (2048, 128, 3, 8, 1), (1024, 128, 3, 16, 1), (64, 16, 3, 128, 1)]
@@ -180,12 +181,34 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
     1x1) -- on the stride-1 layer shapes of the ResNet-101 trunk and the skip convs, weighted by how many layers have each shape."""
     from rsis_amd import ops
     from rsis_amd._lib import check, int_array, lib, ptr, ptr_array, stream
+    from rsis_amd import blk_trunk
     L = lib()
     dt = ops.DTYPES[dtype]
+    blk_on = dtype != "fp32" and blk_trunk.ENABLED[0]      # the trunk's layers then run on channel-blocked bf16 tensors (conv_blk.hip)
     fam = {}
-    for cin, cout, ks, hw, count in TRUNK_SHAPES:
+    for si, (cin, cout, ks, hw, count) in enumerate(TRUNK_SHAPES):
         hw = hw * imsize // 256
         pad = ks // 2
+        if blk_on and si < N_TRUNK_SHAPES:
+            xb = ops.blk_from_nchw(torch.randn(B, cin, hw, hw, device="cuda"))
+            yb = ops.blk_from_nchw(torch.randn(B, cout, hw, hw, device="cuda"))
+            w = torch.randn(cout, cin, ks, ks, device="cuda") / (ks * cin ** 0.5)
+            pack = ops.PackedConv(ks, [cin], stride=1, pad=pad, dtype=dt)
+            wp, wd = pack.fwd(w), pack.dgrad(w)
+            ob, dxb, dW = torch.empty_like(yb), torch.empty_like(xb), torch.zeros_like(w)
+            fl = 2.0 * B * hw * hw * cin * ks * ks * cout
+            ms_f = _time_launch(lambda: check(L.rsis_blk_conv2d(ptr(xb), B, cin, hw, hw, ptr(wp), cout, ks, None, ptr(ob), 0, stream()), "blk fwd"), iters)
+            ms_d = _time_launch(lambda: check(L.rsis_blk_conv2d(ptr(yb), B, cout, hw, hw, ptr(wd), cin, ks, None, ptr(dxb), 0, stream()), "blk dgrad"), iters)
+            ms_w = _time_launch(lambda: check(L.rsis_conv2d_wgrad(ptr(yb), ptr(xb), ptr(dW), B, cin, hw, hw, cout, hw, hw, ks, 1, pad, cin, 0, 0,
+                                                                  ops.DTYPE_BF16_BLK, stream()), "blk wgrad"), iters)
+            act_bytes = 2.0 * B * hw * hw * (cin + cout)
+            for name, ms, n in (("conv%dx%d fwd+dgrad" % (ks, ks), ms_f + ms_d, 2), ("conv%dx%d wgrad" % (ks, ks), ms_w, 1)):
+                f = fam.setdefault(name, {"flops": 0.0, "ms": 0.0, "bytes": 0.0, "launches": 0})
+                f["flops"] += n * fl * count
+                f["ms"] += ms * count
+                f["bytes"] += n * act_bytes * count
+                f["launches"] += n * count
+            continue
         x = torch.randn(B, cin, hw, hw, device="cuda")
         w = torch.randn(cout, cin, ks, ks, device="cuda") / (ks * cin ** 0.5)
         pack = ops.PackedConv(ks, [cin], stride=1, pad=pad, dtype=dt)
@@ -212,29 +235,34 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
     from rsis_amd._lib import WgradJob
     for ksz in (3, 1):
         jobs, keep, fl, by = [], [], 0.0, 0.0
-        for cin, cout, ks, hw, count in TRUNK_SHAPES:
+        for si, (cin, cout, ks, hw, count) in enumerate(TRUNK_SHAPES):
             if ks != ksz:
                 continue
             hw = hw * imsize // 256
             x = torch.randn(B, cin, hw, hw, device="cuda")
             y = torch.randn(B, cout, hw, hw, device="cuda")
+            jdt, ebytes = dt, 4.0
+            if blk_on and si < N_TRUNK_SHAPES:
+                x, y, jdt, ebytes = ops.blk_from_nchw(x), ops.blk_from_nchw(y), ops.DTYPE_BF16_BLK, 2.0
             keep += [x, y]
             for _ in range(count):
                 dW = torch.zeros(cout, cin, ks, ks, device="cuda")
                 keep.append(dW)
                 j = WgradJob()
                 (j.dy, j.x, j.dW, j.B, j.Cs, j.H, j.W, j.Cout, j.Ho, j.Wo, j.ks, j.stride, j.pad, j.Ctot, j.c_off, j.lstm_hid, j.dtype) = (
-                    y.data_ptr(), x.data_ptr(), dW.data_ptr(), B, cin, hw, hw, cout, hw, hw, ks, 1, ks // 2, cin, 0, 0, dt)
+                    y.data_ptr(), x.data_ptr(), dW.data_ptr(), B, cin, hw, hw, cout, hw, hw, ks, 1, ks // 2, cin, 0, 0, jdt)
                 jobs.append(j)
                 fl += 2.0 * B * hw * hw * cin * ks * ks * cout
-                by += 4.0 * B * hw * hw * (cin + cout)
+                by += ebytes * B * hw * hw * (cin + cout)
         arr = (WgradJob * len(jobs))(*jobs)
         ms = _time_launch(lambda: check(L.rsis_conv2d_wgrad_batch(arr, len(jobs), stream()), "wgrad_batch"), max(2, iters // 2))
         f = fam["conv%dx%d wgrad" % (ksz, ksz)]
         f.update({"flops": fl, "ms": ms, "bytes": by, "launches": len(jobs), "grouped": True})
         del keep
-    kern = {"conv1x1 fwd+dgrad": ("conv_igemm_kernel<..., V4>", "conv_bf16_kernel<1, ...>"),
-            "conv3x3 fwd+dgrad": ("conv3x3_direct_kernel<..., EPI_PLAIN>", "conv_bf16_kernel<3, ..., EPI_PLAIN>"),
+    kern = {"conv1x1 fwd+dgrad": ("conv_igemm_kernel<..., V4>", "conv_blk_kernel<1, ...> on blocked bf16 activations" if blk_on else "conv_bf16_kernel<1, ...>"),
+            "conv3x3 fwd+dgrad": ("conv3x3_direct_kernel<..., EPI_PLAIN>",
+                                  "conv_blk_kernel<3, ...> (trunk, blocked bf16) + conv_bf16_kernel<3, ..., EPI_PLAIN> (skip convs, fp32 activations)"
+                                  if blk_on else "conv_bf16_kernel<3, ..., EPI_PLAIN>"),
             "conv1x1 wgrad": ("conv_wgrad_tiled_group_kernel<..., 1, ...> (rsis_conv2d_wgrad_batch)", "wgrad1_bf16_group_kernel (rsis_conv2d_wgrad_batch)"),
             "conv3x3 wgrad": ("conv_wgrad_tiled_group_kernel<..., 3, ...> (rsis_conv2d_wgrad_batch)", "wgrad3_bf16_group_kernel (rsis_conv2d_wgrad_batch)")}
     out = []
