@@ -76,7 +76,7 @@ def test_blk_conv_forward_and_data_gradient(shape, variant):
         assert_close("dgrad+addend", dx2, ref2, 1e-5 * float(ref2.abs().max()), HALF_ULP)
 
 
-@pytest.mark.parametrize("shape", [(4, 64, 14, 14), (2, 256, 28, 28), (32, 16, 7, 7), (3, 24, 5, 9), (2, 8, 1, 1), (8, 64, 56, 56)],
+@pytest.mark.parametrize("shape", [(4, 64, 14, 14), (2, 256, 28, 28), (32, 16, 7, 7), (3, 24, 5, 9), (2, 8, 1, 1), (8, 64, 56, 56), (32, 24, 14, 14)],
                          ids=lambda s: "x".join(str(v) for v in s))
 @pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
 def test_blk_batchnorm_forward_backward(shape, relu, res):
