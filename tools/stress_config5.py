@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Shape stress: BASELINE.json configs[4] geometry (512x1024, T=20, batch 8 per GPU, 9 classes) in fp32 -- a few training steps
-through the same kernels (large maps: 256x512 at the finest pyramid level), finite losses, step time."""
+"""Shape stress: BASELINE.json configs[4] geometry (512x1024, T=20, batch 8 per GPU, 9 classes) -- a few eager training steps
+through the same kernels (large maps: 256x512 at the finest pyramid level), finite losses, step time.
+usage: tools/stress_config5.py [fp32|bf16]   (bf16: configs[4] as named; RSIS_BF16_STORAGE=0 for fp32 activations)"""
 import os
 import sys
 import time
@@ -15,7 +16,8 @@ from rsis_amd.train import build_optimizers, runIter  # noqa: E402
 from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss  # noqa: E402
 
 B, H, W, T = 8, 512, 1024, 20
-a = bench.bench_args(B, H, T)
+DTYPE = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+a = bench.bench_args(B, H, T, DTYPE)
 a.num_classes, a.gt_maxseqlen, a.maxseqlen = 9, 20, T
 enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
 opts = list(build_optimizers(a, enc, dec))
@@ -28,4 +30,4 @@ for i in range(5):
     torch.cuda.synchronize()
     print("step %d: %.1f ms  losses %s" % (i, (time.time() - t0) * 1e3, ["%.4f" % v for v in losses]))
     assert all(v == v and abs(v) < 1e6 for v in losses)
-print("peak memory %.1f GB; %.1f images/s at 512x1024, T=20, B=8 (fp32)" % (torch.cuda.max_memory_allocated() / 2**30, B / (time.time() - t0)))
+print("peak memory %.1f GB; %.1f images/s at 512x1024, T=20, B=8 (%s)" % (torch.cuda.max_memory_allocated() / 2**30, B / (time.time() - t0), DTYPE))
