@@ -379,8 +379,8 @@ def gate_kernel_traffic(batch, imsize, dtype="fp32", timeout=150):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)      # (2 s of timed region at the headline configuration)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     ap.add_argument("--imsize", type=int, default=256)
     ap.add_argument("--T", type=int, default=10)

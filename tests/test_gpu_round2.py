@@ -172,7 +172,11 @@ def test_trainstep_fp32_losses_outputs_gradients_and_adam_step():
         # the full-vector norm as well (catches an error outside the sub-sample)
         n64, n32 = float(g["f64.gnorm." + k]), float(g["gnorm." + k])
         assert abs(float(flat.double().norm()) - n64) <= K_FLOOR * abs(n32 - n64) + 2e-4 * n64 + 1e-7, "gnorm " + k
+    # (visible with -rP / on failure: how many tensors were held to the strict float64-floor rule -- all of them unless an arg-max flipped)
+    print("trainstep fp32: %d gradient tensors checked, %d by the strict rule, arg-max flips at levels %s" % (checked, strict, flipped))
     assert checked > 300 and strict >= 20
+    if not flipped:
+        assert strict == checked, "no arg-max flip, yet %d tensors took the relaxed branch" % (checked - strict)
     # one Adam step (torch.optim.Adam, lr 1e-3 / 1e-6, weight decay 1e-6): first-step update = -lr * g / (|g| + eps), which is
     # insensitive to the size of g wherever |g| >> eps -- compare where the gradient is well above its own fp32 noise
     n_cmp = 0
