@@ -217,6 +217,9 @@ WGRAD_DEFER_DEFAULT = [os.environ.get("RSIS_WGRAD_DEFER", "1") != "0"]
 
 def init_distributed():
     """one process per GPU; torchrun provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*."""
+    # (before the first HIP call of the process: the host driver of this stack supports dmabuf IPC only, and without this RCCL fails
+    #  with `hipIpcGetMemHandle: invalid argument`)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -238,8 +241,6 @@ def init_distributed():
             pass
     force = os.environ.get("RSIS_FORCE_DIST", "") == "1"      # test hook: run the collective path even at world size 1
     if (world > 1 or force) and not dist.is_initialized():
-        # (the host driver of this stack supports dmabuf IPC only: without this RCCL fails with `hipIpcGetMemHandle: invalid argument`)
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = os.environ.get("RSIS_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
