@@ -159,6 +159,19 @@ __global__ __launch_bounds__(512) void blk_bn_fwd_block_kernel(const u32x4* __re
   }
 }
 
+// sum of the S per-split partials of channel block cb (part[s][cb][16]) by the whole block: 16 lanes per value, each adds the splits
+// i = j, j + 16, ... and the 16 lanes fold by shuffles -- a fixed order.  Result in tot[16] (LDS), valid for every thread on return.
+// (The 8 threads that used to add S partials one after the other waited one L2 round trip per partial.)
+__device__ __forceinline__ void partial_sums16(const double* __restrict__ part, int S, int cb, int Cb, double* tot) {
+  const int v = threadIdx.x >> 4, j = threadIdx.x & 15;       // 256 threads: value v = 0..15, lane j of its 16
+  double s = 0.0;
+  for (int i = j; i < S; i += 16) s += part[((size_t)i * Cb + cb) * 16 + v];
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (j == 0) tot[v] = s;
+  __syncthreads();
+}
+
 // ---- statistics: part[s][cb][0..7] = sum x, [8..15] = sum x^2 over split s of the B * HW cells of channel block cb ----
 __global__ __launch_bounds__(256) void blk_bn_stats_kernel(const u32x4* __restrict__ x, double* __restrict__ part, int Cb, int HW, long N, long per) {
   const int cb = blockIdx.y, s = blockIdx.x;
@@ -193,6 +206,7 @@ __global__ __launch_bounds__(256) void blk_bn_apply_kernel(const u32x4* __restri
                                                            float* __restrict__ save_rstd, int Cb, int HW, long N, float eps, float momentum,
                                                            int relu, int train) {
   __shared__ float sc[8], sh[8];
+  __shared__ double ptot[16];
   const int cb = blockIdx.y;
   // the block's cells are requested BEFORE the per-channel prologue (a chain of dependent loads and double arithmetic on 8 threads):
   // their latency hides behind it
@@ -204,12 +218,12 @@ __global__ __launch_bounds__(256) void blk_bn_apply_kernel(const u32x4* __restri
     xc[u] = x[idx];
     rc[u] = res ? res[idx] : u32x4{0u, 0u, 0u, 0u};
   }
+  if (train) partial_sums16(part, S, cb, Cb, ptot);
   if (threadIdx.x < 8) {
     const int k = threadIdx.x, c = cb * 8 + k;
     float mean, rstd;
     if (train) {
-      double s = 0.0, q = 0.0;
-      for (int i = 0; i < S; ++i) { s += part[((size_t)i * Cb + cb) * 16 + k]; q += part[((size_t)i * Cb + cb) * 16 + 8 + k]; }
+      const double s = ptot[k], q = ptot[8 + k];
       const double m = s / (double)N;
       double var = q / (double)N - m * m;
       if (var < 0.0) var = 0.0;
@@ -321,6 +335,7 @@ __global__ __launch_bounds__(256) void blk_bn_bwd_apply_kernel(const u32x4* __re
                                                                u32x4* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                int accumulate, int Cb, int HW, long N, int relu) {
   __shared__ float sm[6][8];
+  __shared__ double ptot[16];
   const int cb = blockIdx.y;
   const bool has_y = y != nullptr;
   u32x4 dcv[U], xcv[U], ycv[U];       // requested before the prologue, as in blk_bn_apply_kernel
@@ -332,10 +347,10 @@ __global__ __launch_bounds__(256) void blk_bn_bwd_apply_kernel(const u32x4* __re
     xcv[u] = x[idx];
     ycv[u] = has_y ? y[idx] : u32x4{0u, 0u, 0u, 0u};
   }
+  partial_sums16(part, S, cb, Cb, ptot);
   if (threadIdx.x < 8) {
     const int k = threadIdx.x, c = cb * 8 + k;
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < S; ++i) { s += part[((size_t)i * Cb + cb) * 16 + k]; q += part[((size_t)i * Cb + cb) * 16 + 8 + k]; }
+    const double s = ptot[k], q = ptot[8 + k];
     if (blockIdx.x == 0) {
       if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
       if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
@@ -449,7 +464,7 @@ static bool bn_block_ok() {        // RSIS_BLK_BN_BLOCK=0: always the two-level 
   return ok;
 }
 static void bn_splits(int Cb, long N, int& S, long& per) {
-  // ~2048 blocks over the grid, at least 2048 cells per block, at most 64 splits
+  // ~2048 blocks over the grid, at least 2048 cells per block (512 / 1024 measured: no better, NOTES (27)), at most 64 splits
   long s = 2048 / (Cb > 0 ? Cb : 1);
   if (s < 1) s = 1;
   const long smax = (N + 2047) / 2048;
