@@ -303,11 +303,12 @@ __global__ __launch_bounds__(256) void blk_bn_bwd_reduce_kernel(const u32x4* __r
 #pragma unroll
   for (int k = 0; k < 16; ++k) a[k] = 0.f;
   const bool has_y = y != nullptr;
-  for (long n = n0 + threadIdx.x; n < n1; n += 512) {
-    u32x4 dc[2], xc[2], yc[2];
-    bool ok[2];
+  constexpr int RB = 4;        // cells requested per thread before the first use (a split is 2048+ cells: 8+ per thread)
+  for (long n = n0 + threadIdx.x; n < n1; n += 256 * RB) {
+    u32x4 dc[RB], xc[RB], yc[RB];
+    bool ok[RB];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < RB; ++u) {
       const long nn = n + u * 256;
       ok[u] = nn < n1;
       const size_t idx = ok[u] ? cell_index(nn, cb, Cb, HW) : 0;
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void blk_bn_bwd_reduce_kernel(const u32x4* __r
       yc[u] = has_y ? y[idx] : u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < RB; ++u) {
       float g[8], xh[8];
       bn_bwd_g(dc[u], xc[u], has_y, yc[u], mean, rstd, gam, bet, relu, g, xh);
 #pragma unroll
