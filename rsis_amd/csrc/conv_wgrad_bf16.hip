@@ -497,10 +497,14 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
 }
 
 // ------------------------------------------------------------------------------------------------
+// (the 3x3 kernels are compiled for TWO waves per SIMD -- `__launch_bounds__(256, 2)`: 9 accumulator tiles + staging registers came
+//  to 150-190 VGPRs + 144 AGPRs, one wave per SIMD, and a loop whose every s_waitcnt / barrier stalls the whole SIMD; held to 256
+//  registers (no AGPRs, at most 9 spilled in three fp32-operand variants) two blocks share a CU and the bf16 224^2 step went
+//  19.66 -> 18.80 ms.  LDS allows two blocks in every variant.)
 // single launches, and grouped launches: the weight gradients of many layers in one grid (rsis_conv2d_wgrad_batch; see
 // conv_wgrad_tiled.hip).  The jobs travel by value in the kernel arguments.
 template <int BM, int TW, int IN>
-__global__ __launch_bounds__(256) void wgrad3_bf16_kernel(const WgradBf16Args p) { wgrad3_bf16_body<BM, TW, IN>(p, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256, 2) void wgrad3_bf16_kernel(const WgradBf16Args p) { wgrad3_bf16_body<BM, TW, IN>(p, blockIdx.x, blockIdx.y); }
 template <int BM, int BN, int WGM, int WGN, int TW, int IN>
 __global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const WgradBf16Args p) {
   wgrad1_bf16_body<BM, BN, WGM, WGN, TW, IN>(p, blockIdx.x, blockIdx.y);
@@ -540,7 +544,7 @@ __device__ __forceinline__ bool wgb_find(const WgradBf16Group& g, int& job, int&
   return true;
 }
 template <int BM, int TW, int IN>
-__global__ __launch_bounds__(256) void wgrad3_bf16_group_kernel(const WgradBf16Group g) {
+__global__ __launch_bounds__(256, 2) void wgrad3_bf16_group_kernel(const WgradBf16Group g) {
   int j, tile, split;
   if (!wgb_find(g, j, tile, split)) return;
   wgrad3_bf16_body<BM, TW, IN>(g.job[j], tile, split);
