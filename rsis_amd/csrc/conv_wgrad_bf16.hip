@@ -668,7 +668,9 @@ static int wgb_launch_bucket(WgradBf16Args* jobs, int n, const WgbKey& k, Launch
     total += (long)a.n_co_tiles * a.n_n_tiles * a.n_sp_tiles;
   }
   static const int env_tb = getenv("RSIS_WGB_GROUP_BLOCKS") ? atoi(getenv("RSIS_WGB_GROUP_BLOCKS")) : 0;     // tuning knob
-  const long target_blocks = env_tb > 0 ? env_tb : 1024;
+  // (swept at the bench geometry, 224^2 / batch 32, with two blocks per CU resident: 640 18.77 ms per step, 768 18.51, 896 18.43,
+  //  1024 18.79, 1280 18.53, 1536 18.52, 1792 18.52 -- twice each, reproducible to 0.02; 1024 happens to cut the layer-3 jobs badly)
+  const long target_blocks = env_tb > 0 ? env_tb : 896;
   long L = (total + target_blocks - 1) / target_blocks;
   if (L < 2) L = 2;
   if (rsis_deterministic()) L = 1L << 40;
