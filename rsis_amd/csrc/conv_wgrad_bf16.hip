@@ -88,13 +88,19 @@ struct BlkTask {
   int lds;        // byte offset of channel 0's cell inside a stage
 };
 #define BLK_NEVER 0x40000000
+// PS: pixel stride between the task's 8 cells.  1 = 8 consecutive pixels (3x3: the taps need neighbours in a lane).  8 (1x1, where the
+// reduction over pixels has no spatial structure and ANY assignment of pixels to K slots works as long as dy and x use the same):
+// task G takes pixels G, G + 8, ..., G + 56 of the 64-pixel tile, so that load j of the 8 tasks of a channel block -- 8 neighbouring
+// lanes -- reads 8 ADJACENT cells = one 128-byte line per instruction instead of 16 bytes out of each of 8 lines (measured with one
+// block per dW tile, tools/exp/wgrad_step_latency.py: the consecutive form took 1.46 us per tile, the fp32 loader 1.21).
+template <int PS>
 __device__ __forceinline__ void blk_task_load(u32x4* rc, const BlkTask& t, const __amdgpu_buffer_rsrc_t r, const int tsc, const int y0, const int x0,
                                               const int H, const int W) {
   const bool row_ok = t.off < 0x20000000 && (unsigned)(y0 + t.y) < (unsigned)H;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const bool ok = row_ok && (unsigned)(x0 + t.x + j) < (unsigned)W;
-    rc[j] = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)(t.off + tsc + j) * 16u : RSIS_OOB, 0, 0);
+    const bool ok = row_ok && (unsigned)(x0 + t.x + j * PS) < (unsigned)W;
+    rc[j] = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)(t.off + tsc + j * PS) * 16u : RSIS_OOB, 0, 0);
   }
 }
 
@@ -184,8 +190,8 @@ __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const i
     const char* xb = (const char*)p.x + ((size_t)tb * (Cs >> 3) + (ci0 >> 3)) * HW * 16;                            \
     const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, ((Cs - ci0) >> 3) * HW * 16, 0x00020000); \
     _Pragma("unroll") for (int i = 0; i < NTS; ++i) {                                                              \
-      if (bt_a[i]) blk_task_load(rc[i], bt[i], ra_, tsc, y0, x0, H, W);                                            \
-      else blk_task_load(rc[i], bt[i], rx_, tsc, y0, x0, H, W);                                                    \
+      if (bt_a[i]) blk_task_load<1>(rc[i], bt[i], ra_, tsc, y0, x0, H, W);                                         \
+      else blk_task_load<1>(rc[i], bt[i], rx_, tsc, y0, x0, H, W);                                                 \
     }                                                                                                              \
     if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++tb; } }                                        \
   }
@@ -375,7 +381,8 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
       bt_a[i] = __builtin_amdgcn_readfirstlane(e) < NSA;
       const int idx = bt_a[i] ? e : e - NSA;
       const int cbl = idx / NG, G = idx % NG;
-      bt[i].y = G / GPR; bt[i].x = (G % GPR) * 8;
+      static_assert(IN != 2 || (TW == 64 && NG == 8), "blk 1x1: the flattened map, 64-pixel tiles, task G = pixels G + 8 j");
+      bt[i].y = 0; bt[i].x = G;
       const bool ok = bt_a[i] ? (co0 + cbl * 8 < Cout) : (idx < NSB && n0 + cbl * 8 < Cs);
       bt[i].off = ok ? cbl * HW + bt[i].y * W + bt[i].x : BLK_NEVER;
       bt[i].lds = (bt_a[i] ? 0 : A_BYTES) + cbl * 8 * ARS + G * 16;
@@ -391,8 +398,8 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
     const char* xb = (const char*)p.x + ((size_t)tb * (Cs >> 3) + (n0 >> 3)) * HW * 16;                             \
     const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, ((Cs - n0) >> 3) * HW * 16, 0x00020000); \
     _Pragma("unroll") for (int i = 0; i < NTS; ++i) {                                                              \
-      if (bt_a[i]) blk_task_load(rc[i], bt[i], ra_, tsc, y0, x0, H, W);                                            \
-      else blk_task_load(rc[i], bt[i], rb_, tsc, y0, x0, H, W);                                                    \
+      if (bt_a[i]) blk_task_load<8>(rc[i], bt[i], ra_, tsc, y0, x0, H, W);                                         \
+      else blk_task_load<8>(rc[i], bt[i], rb_, tsc, y0, x0, H, W);                                                 \
     }                                                                                                              \
     if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++tb; } }                                        \
   }
