@@ -32,6 +32,8 @@ WAVEFRONT = [os.environ.get("RSIS_DECODER_WAVEFRONT", "1") != "0"]
 # (value, pixel) keys (rsis_lstm_job.side_key) and decoded by the heads kernel, instead of one rsis_global_maxpool_fwd launch per cell
 # that re-reads h.  Wavefront path only.
 FUSED_POOL = [os.environ.get("RSIS_FUSED_POOL", "1") != "0"]
+# bf16: time-batched weight gradients of the levels with ragged rows (W % 4 != 0) from channel-blocked bf16 copies of their operands
+_BLK_WGRAD = [os.environ.get("RSIS_DECODER_BLK_WGRAD", "1") != "0"]
 
 
 def _flush_gates():
@@ -279,12 +281,27 @@ class _StepFn(torch.autograd.Function):
                     raise RuntimeError("fused RSIS decoder: %d of %d timesteps were back-propagated" % (tl.n_bwd, n))
                 if dW is None:
                     dW = tgt if tgt is not None else torch.zeros_like(weight)
-                if tl.c_up > 0:
-                    ops.wgrad_launch(L, tl.DA, tl.UP, dW, n * B, tl.c_up, H, W, 4 * hid, H, W, ks, 1, pad, Ctot, 0, hid, dyn.dtype,
-                                     "rsis_conv2d_wgrad(batched up)", tgt is not None)
-                if n > 1:
-                    ops.wgrad_launch(L, tl.DA[1], tl.H, dW, (n - 1) * B, hid, H, W, 4 * hid, H, W, ks, 1, pad, Ctot, h_off, hid, dyn.dtype,
-                                     "rsis_conv2d_wgrad(batched h)", tgt is not None)
+                # bf16, maps whose rows are not a multiple of 4 pixels (the 7 / 14-pixel levels of a 224 x 224 input): the fp32 loader of
+                # the bf16 weight-gradient kernel goes dword by dword there (4x the load instructions: 0.82 ms per step for the two
+                # smallest levels).  Their stacks are small: convert them to channel-blocked bf16 once (the same rounding the kernel
+                # applies while staging) and use the whole-cell loader (conv_wgrad_bf16.hip, IN = 2).
+                as_blk = (dyn.dtype == ops.DTYPE_BF16 and _BLK_WGRAD[0] and ks == 3 and W % 4 != 0 and hid % 8 == 0 and tl.c_up % 8 == 0)
+                if as_blk:
+                    da_b = ops.blk_from_nchw(tl.DA[:n].reshape(n * B, 4 * hid, H, W))
+                    if tl.c_up > 0:
+                        ops.wgrad_launch(L, da_b, ops.blk_from_nchw(tl.UP[:n].reshape(n * B, tl.c_up, H, W)), dW, n * B, tl.c_up, H, W, 4 * hid,
+                                         H, W, ks, 1, pad, Ctot, 0, hid, ops.DTYPE_BF16_BLK, "rsis_conv2d_wgrad(batched up, blk)", tgt is not None)
+                    if n > 1:
+                        ops.wgrad_launch(L, da_b[B:], ops.blk_from_nchw(tl.H[:n - 1].reshape((n - 1) * B, hid, H, W)), dW, (n - 1) * B, hid, H, W,
+                                         4 * hid, H, W, ks, 1, pad, Ctot, h_off, hid, ops.DTYPE_BF16_BLK, "rsis_conv2d_wgrad(batched h, blk)",
+                                         tgt is not None)
+                else:
+                    if tl.c_up > 0:
+                        ops.wgrad_launch(L, tl.DA, tl.UP, dW, n * B, tl.c_up, H, W, 4 * hid, H, W, ks, 1, pad, Ctot, 0, hid, dyn.dtype,
+                                         "rsis_conv2d_wgrad(batched up)", tgt is not None)
+                    if n > 1:
+                        ops.wgrad_launch(L, tl.DA[1], tl.H, dW, (n - 1) * B, hid, H, W, 4 * hid, H, W, ks, 1, pad, Ctot, h_off, hid, dyn.dtype,
+                                         "rsis_conv2d_wgrad(batched h)", tgt is not None)
         if tgt is not None:
             dW = None   # accumulated straight into weight.grad
         if t == 0:
