@@ -43,3 +43,12 @@ for C in (256, 1024):
     print("  blk_bn_fwd train (statistics + apply: 2 launches) %6.2f us per call" % chain(lambda: ops.blk_bn_fwd(x, None, gamma, beta, rm, rv, 1e-5, 0.1, True, True)))
     print("  blk_bn_fwd eval  (apply only: 1 launch)           %6.2f us per call" % chain(lambda: ops.blk_bn_fwd(x, None, gamma, beta, rm, rv, 1e-5, 0.1, True, False)))
     print("  blk_conv2d 1x1 C -> C                             %6.2f us per call" % chain(lambda: ops.blk_conv2d(x, wp, C, 1)))
+    if C == 256:
+        w3 = torch.randn(C, C, 3, 3, device="cuda") / (9 * C) ** 0.5
+        pk3 = ops.PackedConv(3, [C], stride=1, pad=1, dtype=ops.DTYPE_BF16)
+        wp3 = pk3.fwd(w3)
+        print("  blk_conv2d 3x3 C -> C                             %6.2f us per call" % chain(lambda: ops.blk_conv2d(x, wp3, C, 3)))
+    yb, sm, sr = ops.blk_bn_fwd(x, None, gamma, beta, rm, rv, 1e-5, 0.1, True, True)
+    dy = ops.blk_from_nchw(torch.randn(32, C, 14, 14, device="cuda"))
+    print("  blk_bn_bwd (sums + apply: 2 launches), mask from x %6.2f us per call" % chain(lambda: ops.blk_bn_bwd(dy, x, None, gamma, beta, sm, sr, True, False)))
+    print("  blk_bn_bwd with y and the residual gradient        %6.2f us per call" % chain(lambda: ops.blk_bn_bwd(dy, x, yb, gamma, beta, sm, sr, True, True)))
