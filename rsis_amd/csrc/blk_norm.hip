@@ -31,9 +31,11 @@ __device__ __forceinline__ u32x4 cell_pack(const float* v) {
   return c;
 }
 // cell index of element n = b * HW + sp of channel block cb
+// (n < B * HW < 2^31, checked by the launchers: ONE 32-bit division per cell -- the 64-bit one this replaced is ~80 instructions, and
+//  an apply thread does four of them before it can request its first cell)
 __device__ __forceinline__ size_t cell_index(long n, int cb, int Cb, int HW) {
-  const long b = n / HW;
-  return ((size_t)b * Cb + cb) * HW + (size_t)(n - b * HW);
+  const unsigned un = (unsigned)n, b = un / (unsigned)HW;
+  return ((size_t)b * Cb + cb) * HW + (size_t)(un - b * (unsigned)HW);
 }
 
 // sum of 16 per-thread values over the 256 threads of the block -> out[16] (double), written by threads 0..15
@@ -485,6 +487,7 @@ int rsis_l_blk_bn_fwd(const void* x, const void* res, void* y, double* scratch, 
                       hipStream_t st) {
   const int Cb = C >> 3;
   const long N = (long)B * HW;
+  if (N >= (1L << 31)) return RSIS_ERR_UNSUPPORTED;      // (cell_index divides in 32 bits)
   int S = 1;
   long per = N;
   if (train && N <= BLK_BN_BLOCK_MAX && bn_block_ok()) {
@@ -510,6 +513,7 @@ int rsis_l_blk_bn_bwd(const void* dy, const void* x, const void* y, double* scra
                       int B, int C, int HW, int relu, hipStream_t st) {
   const int Cb = C >> 3;
   const long N = (long)B * HW;
+  if (N >= (1L << 31)) return RSIS_ERR_UNSUPPORTED;
   if (N <= BLK_BN_BLOCK_MAX && bn_block_ok()) {
 #define BN_BB(NPT, HY) hipLaunchKernelGGL((blk_bn_bwd_block_kernel<NPT, HY>), dim3(Cb), dim3(512), 0, st, (const u32x4*)dy, (const u32x4*)x, \
                                          (const u32x4*)y, gamma, beta, save_mean, save_rstd, (u32x4*)dx, (u32x4*)dres, dgamma, dbeta, accumulate, Cb, HW, (int)N, relu)
