@@ -6,16 +6,17 @@ batch (B=32 per GPU, 256x256x3, fp32, ResNet-101, hidden 128): encoder fwd, 10 d
 matching, the three losses, backward (BPTT + encoder), gradient all-reduce (N>1), two Adam steps.  Nothing is skipped.
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  "roofline":     ConvLSTM gate kernel (rsis_convlstm_fwd, the 5 pyramid scales of one timestep, B=32):
-                  achieved = algorithmic FLOPs (2*M*K*N with the reference's full K) / HIP-event
-                  time of the launches, against the 157.3 TFLOP/s exact-f32 MFMA peak;
+  "roofline":     ConvLSTM gate kernel (rsis_convlstm_fwd_batch: the 5 pyramid levels of one timestep as the product launches
+                  them, B=32): achieved = EXECUTED FLOPs of that launch (hoisted skip term not credited: 31.41 GFLOP at 256x256) /
+                  its HIP-event time, against the 157.3 TFLOP/s exact-f32 MFMA peak; `achieved_algorithmic` (the reference's full-K
+                  53.15 GFLOP / the product's time) and `full_k` (the un-hoisted launch) are reported next to it, labelled;
   "cpu_baseline": the CPU oracle (port of the reference op graph, oracle/rsis_oracle.py) timed on this box's host cores
                   on a bounded sample of the same workload (rank 0, N=1 only).
 
 After the W warm-up steps an untimed "settle" phase keeps stepping until the step time is stable (cold-box power
 management; see main()); the timed region is still EXACTLY K steps between barrier + synchronize.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1 without WORLD_SIZE: launches its own N ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -376,6 +377,45 @@ def gate_kernel_traffic(batch, imsize, dtype="fp32", timeout=150):
     return fetch + write, {"fetch_bytes_x2": fetch, "write_bytes": write}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def visible_devices():
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def check_world(gpus):
+    """`--gpus N` means N ranks, one per GPU (replaces nn.DataParallel, /root/reference src/train.py:269-274).  A launch whose world size
+    is not N, or that sees fewer than N devices (unless the test hook RSIS_SHARE_GPU=1 puts several gloo ranks on one GPU), exits
+    non-zero instead of printing a line labelled with another GPU count."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus %d` (self-launching) or "
+                 "`python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d`" % (gpus, world, gpus, gpus, gpus))
+    ndev = visible_devices()
+    if ndev < gpus and os.environ.get("RSIS_SHARE_GPU", "") != "1":
+        sys.exit("bench.py: --gpus %d but only %d device(s) visible (one rank per GPU; no N-rank run is faked)" % (gpus, ndev))
+
+
+def self_launch(gpus):
+    """plain `python bench.py --gpus N` (the shape of the driver's N=1 command): become `torch.distributed.run --standalone` with N ranks
+    of this very command line.  Rank 0 of the child job prints the JSON line; the launcher adds nothing to stdout."""
+    ndev = visible_devices()
+    if ndev < gpus and os.environ.get("RSIS_SHARE_GPU", "") != "1":
+        sys.exit("bench.py: --gpus %d but only %d device(s) visible (one rank per GPU; no N-rank run is faked)" % (gpus, ndev))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] self-launch: %s" % " ".join(cmd), file=sys.stderr, flush=True)
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -409,6 +449,9 @@ def main():
         print(json.dumps(gate_kernel_roofline(o.batch, o.kernel_iters, o.imsize, o.dtype, o.T, product_only=o.product_only)))
         return
 
+    if o.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(o.gpus)              # (does not return: the process becomes the launcher of N ranks)
+
     from rsis_amd.train import GraphedStep, build_optimizers, init_distributed, runIter
     from rsis_amd.modules import FeatureExtractor, RSIS
     from rsis_amd.optim import BucketedAllReduce
@@ -421,9 +464,9 @@ def main():
     sys.stdout.flush()
     REAL_STDOUT = os.dup(1)
     os.dup2(2, 1)
-    rank, local_rank, world = init_distributed()
-    assert world == o.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % o.gpus
     assert torch.cuda.is_available(), "bench.py needs the GPU (there is no CPU path)"
+    check_world(o.gpus)                  # never a mislabelled line: --gpus N runs N ranks on N devices or exits non-zero
+    rank, local_rank, world = init_distributed()
     a = bench_args(o.batch, o.imsize, o.T, o.dtype)
     torch.manual_seed(a.seed)
     encoder, decoder = FeatureExtractor(a).cuda(), RSIS(a).cuda()

@@ -54,3 +54,41 @@ def test_bench_two_ranks_eager_bucketed_exchange():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
     assert "eager" in out["config"]["launch"]
+
+
+def _run_plain(gpus, extra, env_extra, timeout=600):
+    """plain `python bench.py --gpus N ...` -- the shape of the command the driver runs for N = 1 -- with no launcher around it"""
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "3", "--batch", "4", "--T", "3",
+           "--imsize", "128", "--skip-cpu", "--skip-roofline", "--skip-secondary", "--no-settle"] + extra
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+
+
+def test_plain_bench_gpus_2_launches_two_ranks_by_itself():
+    r = _run_plain(2, [], {"RSIS_SHARE_GPU": "1", "RSIS_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, "plain bench.py --gpus 2 failed:\n%s\n%s" % (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, "stdout must hold exactly one line, got %d: %s" % (len(lines), lines[:3])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
+    assert "self-launch" in r.stderr and "communicator size 2" in r.stderr
+
+
+def test_plain_bench_refuses_more_ranks_than_devices():
+    """one rank per GPU: on a box with fewer than 8 devices `bench.py --gpus 8` exits non-zero and prints no JSON line (it used to run
+    one rank and label the line n_gpus 1)"""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("8 devices visible: the refusal does not apply")
+    r = _run_plain(8, [], {}, timeout=300)
+    assert r.returncode != 0
+    assert not r.stdout.strip(), r.stdout[-500:]
+    assert "device(s) visible" in r.stderr
+    # ... and a launcher that provides another world size than --gpus is refused as well
+    env = {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--skip-cpu", "--skip-roofline",
+           "--skip-secondary", "--no-settle"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(os.environ, **env))
+    assert r.returncode != 0 and not r.stdout.strip() and "WORLD_SIZE=1" in r.stderr
