@@ -234,6 +234,21 @@ int rsis_conv_pack_batch(const rsis_pack_job* jobs_dev, int njobs, int total_blo
  * [1][Cin][3][3]) and db[1] (may be NULL) are ACCUMULATED.  Cin in {4, 8, 16}, W % 4 == 0, else RSIS_ERR_UNSUPPORTED. ---- */
 int rsis_conv_out_wgrad(const float* dy, const float* x, float* dW, float* db, int B, int Cin, int H, int W, void* stream);
 
+/* ---- conv_out over ALL T timesteps of a decoded sequence in one launch each way (model.py:167 inside the loop of train.py:85-94:
+ * out_mask_t = conv_out(upsampled hidden state of the last level at step t); the T applications are independent).  The Cin-channel
+ * tensors are [T][B][Cin][H][W] (the decoder's stacked per-step buffers), the one-channel tensors are [B][T][H*W] -- the (B, T, N)
+ * layout train.py:118 stacks the mask logits into, so no torch.stack copy is needed.  Same kernels and per-image arithmetic as
+ * rsis_conv2d_fwd / _dgrad / rsis_conv_out_wgrad on one timestep.  Cin in {4, 8, 16}, W % 4 == 0, else RSIS_ERR_UNSUPPORTED.
+ * Wp / Wd: the RSIS_DTYPE_F32 packs of conv_out's weight (rsis_conv_pack_fwd / _dgrad; conv_out keeps its f32 kernels under
+ * RSIS_DTYPE_BF16); dW / db are ACCUMULATED. ---- */
+int rsis_conv_out_seq_fwd(const float* x, const void* Wp, const float* bias, float* y, int T, int B, int Cin, int H, int W, void* stream);
+int rsis_conv_out_seq_dgrad(const float* dy, const void* Wd, float* dx, int T, int B, int Cin, int H, int W, void* stream);
+int rsis_conv_out_seq_wgrad(const float* dy, const float* x, float* dW, float* db, int T, int B, int Cin, int H, int W, void* stream);
+
+/* ---- y[n] = sum_t x[t][n], t ascending (fixed order): sum over the timesteps of the stacked gate gradients, i.e. the gradient of a
+ * ConvLSTM level's time-invariant gate term (autograd's accumulation over the T uses of the skip features, train.py:85-94) ---- */
+int rsis_sum_leading(const float* x, float* y, int T, long n, void* stream);
+
 /* ---- data-layer augmentation: nearest-neighbour affine warp (dataloader/transforms/utils.py:67-147 th_affine2d(mode='nearest',
  * center=True); applied by transforms.py:23-142 RandomAffine to the image, the instance map and the class map of a sample).
  * x, y: [N][C][H][W] float32 (y != x); mat: [N][mat_rows][3] float32 in DEVICE memory, mat_rows = 3 (the reference's 3x3, last

@@ -58,6 +58,10 @@ SIGNATURES = {
     "rsis_conv2d_wgrad_batch": (_i, [ctypes.POINTER(WgradJob), _i, _vp]),
     "rsis_affine_nearest": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsis_conv_out_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsis_conv_out_seq_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsis_conv_out_seq_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsis_conv_out_seq_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsis_sum_leading": (_i, [_vp, _vp, _i, _l, _vp]),
     "rsis_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_convlstm_fwd": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsis_convlstm_fwd_batch": (_i, [ctypes.POINTER(LstmJob), _i, _vp]),

@@ -26,9 +26,10 @@ bool rsis_wgrad_tiled_supported(const WgradArgs& w, int ks);
 int rsis_launch_conv_wgrad_tiled(const WgradArgs& w, int ks, hipStream_t st);
 int rsis_launch_conv_wgrad_tiled_group(const WgradArgs* w, int n, int ks, hipStream_t st);
 bool rsis_c1_supported(int Cin);
-int rsis_l_c1_fwd(const float*, const float*, int, const float*, float*, int, int, int, int, hipStream_t);
-int rsis_l_c1_dgrad(const float*, const float*, int, float*, int, int, int, int, hipStream_t);
-int rsis_l_c1_wgrad(const float*, const float*, float*, float*, int, int, int, int, hipStream_t);
+int rsis_l_c1_fwd(const float*, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
+int rsis_l_c1_dgrad(const float*, const float*, int, float*, int, int, int, int, int, hipStream_t);
+int rsis_l_c1_wgrad(const float*, const float*, float*, float*, int, int, int, int, int, hipStream_t);
+int rsis_l_sum_leading(const float*, float*, int, long, hipStream_t);
 int rsis_l_pack(int, const float*, void*, int, int, int, int, const int*, const int*, int, int, int, hipStream_t);
 
 int rsis_l_lstm_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
@@ -205,7 +206,31 @@ int rsis_conv_pack_dgrad(const float* W, void* Wd, int Cout, int Ctot, int ks, i
 int rsis_conv_out_wgrad(const float* dy, const float* x, float* dW, float* db, int B, int Cin, int H, int W, void* stream) {
   if (!dy || !x || !dW || B < 1) return RSIS_ERR_ARG;
   if (!rsis_c1_supported(Cin) || W % 4 != 0) return RSIS_ERR_UNSUPPORTED;
-  return rsis_l_c1_wgrad(dy, x, dW, db, B, Cin, H, W, (hipStream_t)stream);
+  return rsis_l_c1_wgrad(dy, x, dW, db, B, Cin, H, W, 1, (hipStream_t)stream);
+}
+
+// conv_out over all T timesteps of a decoded sequence, one launch each way (rsis_hip.h)
+static inline bool c1_seq_ok(int T, int B, int Cin, int H, int W) {
+  return T >= 1 && B >= 1 && rsis_c1_supported(Cin) && W % 4 == 0 && (long)T * B * Cin * H * W < (1L << 40);
+}
+int rsis_conv_out_seq_fwd(const float* x, const void* Wp, const float* bias, float* y, int T, int B, int Cin, int H, int W, void* stream) {
+  if (!x || !Wp || !y) return RSIS_ERR_ARG;
+  if (!c1_seq_ok(T, B, Cin, H, W)) return RSIS_ERR_UNSUPPORTED;
+  return rsis_l_c1_fwd(x, (const float*)Wp, rsis_roundup(1, RSIS_LDW_ALIGN), bias, y, T * B, Cin, H, W, T, (hipStream_t)stream);
+}
+int rsis_conv_out_seq_dgrad(const float* dy, const void* Wd, float* dx, int T, int B, int Cin, int H, int W, void* stream) {
+  if (!dy || !Wd || !dx) return RSIS_ERR_ARG;
+  if (!c1_seq_ok(T, B, Cin, H, W)) return RSIS_ERR_UNSUPPORTED;
+  return rsis_l_c1_dgrad(dy, (const float*)Wd, rsis_roundup(Cin, RSIS_LDW_ALIGN), dx, T * B, Cin, H, W, T, (hipStream_t)stream);
+}
+int rsis_conv_out_seq_wgrad(const float* dy, const float* x, float* dW, float* db, int T, int B, int Cin, int H, int W, void* stream) {
+  if (!dy || !x || !dW) return RSIS_ERR_ARG;
+  if (!c1_seq_ok(T, B, Cin, H, W)) return RSIS_ERR_UNSUPPORTED;
+  return rsis_l_c1_wgrad(dy, x, dW, db, T * B, Cin, H, W, T, (hipStream_t)stream);
+}
+int rsis_sum_leading(const float* x, float* y, int T, long n, void* stream) {
+  if (!x || !y || T < 1 || n < 1) return RSIS_ERR_ARG;
+  return rsis_l_sum_leading(x, y, T, n, (hipStream_t)stream);
 }
 
 int rsis_affine_nearest(const float* x, float* y, const float* mat, int mat_rows, int N, int C, int H, int W, void* stream) {
@@ -282,7 +307,7 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
     return rsis_launch_conv_bf16(a, ks, 0, direct_variant(tile), (hipStream_t)stream);
   }
   if (use_direct(ks, stride, pad) && Cout == 1 && nsrc == 1 && !addend && rsis_c1_supported(Csrc[0]) && W % 4 == 0)   // conv_out: HBM-bound VALU kernel
-    return rsis_l_c1_fwd(src[0], (const float*)Wp, a.ldw, bias, out, B, Csrc[0], H, W, (hipStream_t)stream);
+    return rsis_l_c1_fwd(src[0], (const float*)Wp, a.ldw, bias, out, B, Csrc[0], H, W, 1, (hipStream_t)stream);
   if (use_direct(ks, stride, pad)) {
     // deep-K convs on tiny maps (sk5: 2048x9 deep, 64 blocks) are split over the channel chunks: zero the output here and let
     // the launcher decide (a.ksplit = 0 means "split allowed, output is zeroed")
@@ -347,7 +372,7 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const vo
   if (use_direct(ks, stride, pad)) {
     if (Hx != Hy || Wx != Wy) return RSIS_ERR_ARG;
     if (Cout == 1 && ndst == 1 && Cin_packed == Cdx[0] && rsis_c1_supported(Cdx[0]) && !addend)
-      return rsis_l_c1_dgrad(dy, (const float*)Wd, a.ldw, dx[0], B, Cdx[0], Hx, Wx, (hipStream_t)stream);
+      return rsis_l_c1_dgrad(dy, (const float*)Wd, a.ldw, dx[0], B, Cdx[0], Hx, Wx, 1, (hipStream_t)stream);
     {  // deep-K data gradients on tiny maps (ConvLSTM level 0: 512 gate rows x 9 taps on 8x8): split over the channel chunks
       const bool splitk_ok = conv_splitk_ok();
       const int nq = (Cout + RSIS_CK - 1) / RSIS_CK;
@@ -402,7 +427,7 @@ static int wgrad_fill(WgradArgs& a, const float* dy, const float* x, float* dW, 
 }
 static int wgrad_launch_one(WgradArgs& a, int route, int ks, hipStream_t st) {
   switch (route) {
-    case 0: return rsis_l_c1_wgrad(a.dy, a.x, a.dw + a.n_off, nullptr, a.B, a.Cs, a.H, a.W, st);
+    case 0: return rsis_l_c1_wgrad(a.dy, a.x, a.dw + a.n_off, nullptr, a.B, a.Cs, a.H, a.W, 1, st);
     case 1: return rsis_launch_conv_wgrad_bf16(a, ks, st);
     case 2: return rsis_launch_conv_wgrad_tiled(a, ks, st);
     default: return rsis_launch_conv_wgrad(a, ks, st);

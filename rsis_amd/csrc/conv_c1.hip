@@ -33,6 +33,14 @@ template <int TW, int TH> struct C1Tile {
   static constexpr int CGMAX = TW == 64 ? 8 : 4; // channels staged per pass (~42 KB of LDS)
 };
 
+// time-batched launches (rsis_conv_out_seq_*): the Cin-channel tensor holds the images of seqT timesteps in [t][b] order, the
+// one-channel tensor (logits / their gradient) is [b][t] -- image t * (B / seqT) + b of the former pairs with image b * seqT + t
+__device__ __forceinline__ int c1_ymap(int img, int B, int seqT) {
+  if (seqT <= 1) return img;
+  const int Bn = B / seqT;
+  return (img % Bn) * seqT + img / Bn;
+}
+
 template <int CG, int TW, int TH>
 __device__ __forceinline__ void c1_stage_patch(float* __restrict__ patch, gcf_t xb, int H, int W, int y0, int x0) {
   using T = C1Tile<TW, TH>;
@@ -60,7 +68,7 @@ __device__ __forceinline__ void c1_stage_patch(float* __restrict__ patch, gcf_t 
 template <int CIN, int TW, int TH>
 __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restrict__ x_, const float* __restrict__ wp, int ldw,
                                                           const float* __restrict__ bias, float* __restrict__ y_, int B, int H,
-                                                          int W) {
+                                                          int W, int seqT) {
   using T = C1Tile<TW, TH>;
   constexpr int CG = CIN < T::CGMAX ? CIN : T::CGMAX;
   __shared__ __attribute__((aligned(16))) float patch[CG * T::PH * T::PW];
@@ -110,13 +118,13 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const float* __restric
 #pragma unroll
   for (int o = 0; o < T::NOUT; ++o) {
     const int oy = y0 + ty + o * T::RPP, ox = x0 + tx * 4;
-    if (oy < H && ox < W) *(f32x4 __attribute__((address_space(1)))*)(y + (size_t)b * HW + (size_t)oy * W + ox) = acc[o];
+    if (oy < H && ox < W) *(f32x4 __attribute__((address_space(1)))*)(y + (size_t)c1_ymap(b, B, seqT) * HW + (size_t)oy * W + ox) = acc[o];
   }
 }
 
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_c1_dgrad_kernel(const float* __restrict__ dy_, const float* __restrict__ wd, int ldw,
-                                                            float* __restrict__ dx_, int B, int H, int W) {
+                                                            float* __restrict__ dx_, int B, int H, int W, int seqT) {
   const gcf_t dy = (gcf_t)dy_;
   const gf_t dx = (gf_t)dx_;
   const int HW = H * W;
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256) void conv_c1_dgrad_kernel(const float* __restr
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int b = (int)(e / HW), sp = (int)(e - (long)b * HW);
     const int yy = sp / W, xx = sp - yy * W;
-    const gcf_t gb = dy + (size_t)b * HW;
+    const gcf_t gb = dy + (size_t)c1_ymap(b, B, seqT) * HW;
     float g[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -151,7 +159,8 @@ __global__ __launch_bounds__(256) void conv_c1_dgrad_kernel(const float* __restr
 // accumulators per thread, 18 atomics per block; the dy tile is re-read once per channel pair).
 template <int CIN, int TW, int TH>
 __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restrict__ dy_, const float* __restrict__ x_,
-                                                            float* __restrict__ dw, float* __restrict__ db, int B, int H, int W) {
+                                                            float* __restrict__ dw, float* __restrict__ db, int B, int H, int W,
+                                                            int seqT) {
   using T = C1Tile<TW, TH>;
   constexpr int CGW = 2, S = CIN / CGW;
   __shared__ __attribute__((aligned(16))) float patch[CGW * T::PH * T::PW];
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
     for (int o = 0; o < T::NOUT; ++o) {
       const int oy = y0 + ty + o * T::RPP, ox = x0 + tx * 4;
       g[o] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (oy < H && ox < W) g[o] = *(const f32x4 __attribute__((address_space(1)))*)(dy + (size_t)b * HW + (size_t)oy * W + ox);
+      if (oy < H && ox < W) g[o] = *(const f32x4 __attribute__((address_space(1)))*)(dy + (size_t)c1_ymap(b, B, seqT) * HW + (size_t)oy * W + ox);
       gsum += (g[o][0] + g[o][1]) + (g[o][2] + g[o][3]);
     }
     __syncthreads();
@@ -247,20 +256,21 @@ bool rsis_c1_supported(int Cin) { return Cin == 4 || Cin == 8 || Cin == 16; }   
   else if (W > 64) C1_TILED(KERNEL, 128, 16, GRIDCAP, PER_TILE, __VA_ARGS__)                                 \
   else C1_TILED(KERNEL, 64, 16, GRIDCAP, PER_TILE, __VA_ARGS__)
 
-int rsis_l_c1_fwd(const float* x, const float* wp, int ldw, const float* bias, float* y, int B, int Cin, int H, int W,
+// seqT > 1: B = seqT * batch images, the Cin-channel tensor in [t][b] order, the one-channel tensor in [b][t] order (c1_ymap)
+int rsis_l_c1_fwd(const float* x, const float* wp, int ldw, const float* bias, float* y, int B, int Cin, int H, int W, int seqT,
                   hipStream_t st) {
-  C1_BY_WIDTH(conv_c1_fwd_kernel, 0, 1, x, wp, ldw, bias, y, B, H, W)
+  C1_BY_WIDTH(conv_c1_fwd_kernel, 0, 1, x, wp, ldw, bias, y, B, H, W, seqT)
   return rsis_check_launch();
 }
-int rsis_l_c1_dgrad(const float* dy, const float* wd, int ldw, float* dx, int B, int Cin, int H, int W, hipStream_t st) {
+int rsis_l_c1_dgrad(const float* dy, const float* wd, int ldw, float* dx, int B, int Cin, int H, int W, int seqT, hipStream_t st) {
   const int grid = c1_grid((long)B * H * W, 16);
-  C1_DISPATCH(conv_c1_dgrad_kernel, grid, dy, wd, ldw, dx, B, H, W)
+  C1_DISPATCH(conv_c1_dgrad_kernel, grid, dy, wd, ldw, dx, B, H, W, seqT)
   return rsis_check_launch();
 }
-int rsis_l_c1_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int Cin, int H, int W, hipStream_t st) {
+int rsis_l_c1_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int Cin, int H, int W, int seqT, hipStream_t st) {
   // one block per (tile, channel pair) up to the cap (a multiple of every Cin / 2), persistent beyond it
   // (deterministic mode: ONE persistent block per channel pair, so every dW / db address has a single contributor)
   const int cap = rsis_deterministic() ? Cin / 2 : 512;
-  C1_BY_WIDTH(conv_c1_wgrad_kernel, cap, Cin / 2, dy, x, dw, db, B, H, W)     // measured: 256 -> 39 us, 512 -> 29 us, 1024 -> 30 us, 2048 -> 43 us
+  C1_BY_WIDTH(conv_c1_wgrad_kernel, cap, Cin / 2, dy, x, dw, db, B, H, W, seqT)     // measured: 256 -> 39 us, 512 -> 29 us, 1024 -> 30 us, 2048 -> 43 us
   return rsis_check_launch();
 }

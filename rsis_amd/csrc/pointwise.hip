@@ -1088,6 +1088,27 @@ int rsis_l_maxpool_bwd(const float* dy, const unsigned char* arg, float* dx, lon
   hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dy, arg, dx, H, W, Ho, Wo, total, accumulate);
   return rsis_check_launch();
 }
+// y[e] = sum_t x[t][e] (t ascending, one thread per float4 / float: a fixed order, bit-reproducible): the sum over the timesteps of
+// the stacked gate gradients d(gates_t) that the time-invariant skip term of a ConvLSTM level receives (decoder_seq.py)
+__global__ __launch_bounds__(256) void sum_leading_kernel(const float* __restrict__ x, float* __restrict__ y, int T, long n, long n4) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < n4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(x) + e;
+    f32x4 acc = p[0];
+    for (int t = 1; t < T; ++t) { const f32x4 v = p[(size_t)t * (n / 4)]; acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3]; }
+    reinterpret_cast<f32x4*>(y)[e] = acc;
+  } else {
+    const long i = 4 * n4 + (e - n4);
+    if (i < n) { float acc = x[i]; for (int t = 1; t < T; ++t) acc += x[(size_t)t * n + i]; y[i] = acc; }
+  }
+}
+int rsis_l_sum_leading(const float* x, float* y, int T, long n, hipStream_t st) {
+  const bool v4 = (n % 4 == 0) && ((((size_t)x | (size_t)y) & 15) == 0);
+  const long n4 = v4 ? n / 4 : 0, threads = n4 + (n - 4 * n4);
+  hipLaunchKernelGGL(sum_leading_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, x, y, T, n, n4);
+  return rsis_check_launch();
+}
+
 int rsis_l_channel_sum(const float* dy, float* db, int B, int C, int HW, int hid, hipStream_t st) {
   const long N = (long)B * HW;
   int S = chan_splits(C, N);

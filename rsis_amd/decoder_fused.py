@@ -270,7 +270,11 @@ class _StepFn(torch.autograd.Function):
             if ctx.stacked:
                 if tl.n_bwd < tl.n_fwd:       # (a step without a gradient would leave its DA slot unwritten)
                     raise RuntimeError("fused RSIS decoder: %d of %d timesteps were back-propagated" % (tl.n_bwd, tl.n_fwd))
-                dG = tl.DA[0] if tl.n_fwd == 1 else tl.DA[:tl.n_fwd].sum(dim=0)
+                if tl.n_fwd == 1:
+                    dG = tl.DA[0]
+                else:       # sum over the timesteps, t ascending (fixed order; no torch reduction kernel on the path)
+                    dG = torch.empty_like(tl.DA[0])
+                    check(L.rsis_sum_leading(ptr(tl.DA), ptr(dG), tl.n_fwd, dG.numel(), stream()), "rsis_sum_leading")
                 if tl.da_sum is not None:     # steps beyond the tape capacity accumulated theirs in the kernel
                     dG = dG + tl.da_sum
             else:

@@ -1,0 +1,354 @@
+"""The T-step recurrent decoder as ONE autograd node with an explicit back-propagation through time.
+
+What it computes is the loop of reference train.py:85-94 / test.py:37-38 around RSIS.forward (model.py:122-184) from the zero
+state: per timestep five ConvLSTM levels (clstm.py:19-62), the global max-pool side features (model.py:143), the align-corners
+upsamples between levels (:149-150, :163-164), conv_out (:167) and the class / stop heads (:169-182).
+
+`decoder_fused.decoder_sequence` already walks the (level, timestep) grid by diagonals in the FORWARD pass (cell (i, t) needs
+up(h[i-1][t]) and (h, c)[i][t-1], so the cells of a diagonal d = i + t are independent and their gate kernels go out as one
+grouped launch), but leaves the backward to autograd: one node per cell, run one by one.  Here the backward is written out:
+
+  * the reverse wavefront -- cell (i, t) needs d(up[i+1][t]) from cell (i+1, t) and (dh, dc) through the recurrence from cell
+    (i, t+1), both on diagonal d + 1 -- so per diagonal there are three grouped steps: the gradient of every hidden state
+    through its upsample + side max-pool, the LSTM pointwise backward, the data gradient of the gate conv;
+  * everything that is independent of the recurrence runs ONCE over all T timesteps: conv_out forward / data gradient / weight
+    gradient on the stacked [T][B] images (rsis_conv_out_seq_*: 3 launches instead of 3 T), the mask logits written straight into
+    the (B, T, N) layout train.py:118 stacks them into, the sum over t of d(gates) for the time-invariant skip term
+    (rsis_sum_leading), the time-batched weight gradients of the recurrent channels (as decoder_fused does).
+
+Arithmetic and kernels per cell are those of the per-step path (tests/test_gpu_modules.py compares them); only the launch
+schedule differs.  The per-timestep `RSIS.forward` stays for callers that thread the state themselves.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _lib, decoder_fused, ops
+from ._lib import check, int_array, lib, ptr, ptr_array, stream
+
+ENABLED = [os.environ.get("RSIS_DECODER_SEQ", "1") != "0"]
+
+
+def supported(decoder, skip_feats, T):
+    """the explicit sequence covers the product configuration: concat skips, 3x3 gates, no dropout, the fused heads kernel"""
+    n = len(decoder.clstm_list)
+    if not (ENABLED[0] and decoder_fused.WAVEFRONT[0] and decoder_fused.FUSED_POOL[0] and decoder.fused and decoder.skip_mode == "concat" and decoder.dropout == 0 and decoder.dropout_cls == 0 and
+            decoder.dropout_stop == 0 and len(skip_feats) == n and T >= 1 and "forward" not in decoder.__dict__):
+        return False
+    if not all(f.is_cuda and f.dtype == torch.float32 and f.dim() == 4 for f in skip_feats):
+        return False
+    if not all(c.kernel_size == 3 and c.padding == 1 for c in decoder.clstm_list):
+        return False
+    if decoder.conv_out.kernel_size != 3 or decoder.conv_out.padding != 1 or decoder.conv_out.bias is None:
+        return False
+    hs = [c.hidden_size for c in decoder.clstm_list]
+    if sum(hs) != decoder.fc_class.weight.shape[1] or not ops.heads_supported([skip_feats[0]] * n, decoder.fc_class, decoder.fc_stop):
+        return False
+    for i, c in enumerate(decoder.clstm_list):      # the channel pyramid of model.py:98-106 (level i consumes up(h[i-1]) | skip[i])
+        c_up = 0 if i == 0 else hs[i - 1]
+        if c.input_size != c_up + skip_feats[i].shape[1]:
+            return False
+    return True
+
+
+class _Level(object):
+    __slots__ = ("cell", "hid", "c_up", "c_skip", "H", "W", "hoist", "dyn", "G", "Hs", "Cs", "ACT", "UP", "KEY", "SIDE", "ARG")
+
+
+def _conv_out_seq_ok(Cin, W):
+    return Cin in (4, 8, 16) and W % 4 == 0
+
+
+class _DecoderSeqFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, decoder, T, keep, *tensors):
+        L = lib()
+        n = len(decoder.clstm_list)
+        feats = [t if t.is_contiguous() else t.contiguous() for t in tensors[:n]]
+        params = tensors[n:]
+        gates_w = [params[2 * i] for i in range(n)]
+        gates_b = [params[2 * i + 1] for i in range(n)]
+        co_w, co_b, Wc, bc, Ws, bs = params[2 * n:2 * n + 6]
+        _lib.require_cuda_f32(*feats, *params)
+        need_grad = bool(keep) and any(ctx.needs_input_grad)     # (grad mode is off inside forward: the caller says whether a backward may follow)
+        dev = feats[0].device
+        B = feats[0].shape[0]
+        hs = [c.hidden_size for c in decoder.clstm_list]
+        tot = sum(hs)
+        f32 = dict(dtype=torch.float32, device=dev)
+        # one zeroed key buffer for the side max-pools of the whole sequence (rsis_lstm_job.side_key), decoded by the heads launches
+        KEY = torch.zeros(T * B * tot, dtype=torch.int64, device=dev)
+        SIDE = torch.empty(T * B * tot, **f32)
+        ARG = torch.empty(T * B * tot, dtype=torch.int32, device=dev)
+        levels, off = [], 0
+        for i, cell in enumerate(decoder.clstm_list):
+            lv = _Level()
+            lv.cell, lv.hid, lv.c_up, lv.c_skip = cell, hs[i], (0 if i == 0 else hs[i - 1]), feats[i].shape[1]
+            lv.H, lv.W = feats[i].shape[2], feats[i].shape[3]
+            lv.hoist, lv.dyn = decoder_fused._packs(cell, lv.c_up, lv.c_skip)
+            # G_i = W[:, skip channels] * skip_i + b, once per iteration (the skip features do not depend on t)
+            wp = lv.hoist.fwd(gates_w[i], gates_b[i])
+            lv.G = torch.empty((B, 4 * lv.hid, lv.H, lv.W), **f32)
+            check(L.rsis_conv2d_fwd(ptr_array([feats[i]]), int_array([lv.c_skip]), 1, B, lv.H, lv.W, ptr(wp), 4 * lv.hid, 3, 1, 1,
+                                    ptr(lv.hoist.bias_p), None, ptr(lv.G), lv.H, lv.W, ops.FORCE_TILE[0], lv.hoist.dtype, stream()),
+                  "rsis_conv2d_fwd(hoist)")
+            lv.Hs = torch.empty((T, B, lv.hid, lv.H, lv.W), **f32)
+            lv.Cs = torch.empty((T, B, lv.hid, lv.H, lv.W), **f32)
+            lv.ACT = torch.empty((T, B, 4 * lv.hid, lv.H, lv.W), **f32) if need_grad else None
+            lv.UP = torch.empty((T, B, lv.c_up, lv.H, lv.W), **f32) if lv.c_up > 0 else None
+            m = T * B * lv.hid
+            lv.KEY, lv.SIDE, lv.ARG = KEY[off:off + m].view(T, B, lv.hid), SIDE[off:off + m].view(T, B, lv.hid), ARG[off:off + m].view(T, B, lv.hid)
+            off += m
+            levels.append(lv)
+        last = levels[-1]
+        H5, W5 = 2 * last.H, 2 * last.W
+        UP5 = torch.empty((T, B, last.hid, H5, W5), **f32)            # model.py:163-164, all timesteps
+        ncls = Wc.shape[0]
+        probs_tb = torch.empty((T, B, ncls), **f32)
+        stop_tb = torch.empty((T, B, 1), **f32)
+        wps = [lv.dyn.fwd(gates_w[i]) for i, lv in enumerate(levels)]
+        Wc_d, bc_d, Ws_d, bs_d = Wc.detach(), bc.detach(), Ws.detach(), bs.detach()
+
+        for d in range(T + n - 1):
+            cells = [(i, d - i) for i in range(n) if 0 <= d - i < T]
+            jobs = (_lib.LstmJob * len(cells))()
+            for j, (i, t) in zip(jobs, cells):
+                lv = levels[i]
+                srcs = ([lv.UP[t]] if lv.c_up > 0 else []) + ([lv.Hs[t - 1]] if t > 0 else [])
+                j.nsrc = len(srcs)
+                for k, s in enumerate(srcs):
+                    j.src[k], j.Csrc[k] = s.data_ptr(), s.shape[1]
+                (j.B, j.H, j.W, j.Wp, j.bias_packed, j.addend, j.c_prev, j.h_out, j.c_out, j.act_out, j.hid, j.ks, j.pad, j.tile, j.dtype,
+                 j.side_key) = (B, lv.H, lv.W, wps[i].data_ptr(), None, lv.G.data_ptr(), lv.Cs[t - 1].data_ptr() if t > 0 else None,
+                                lv.Hs[t].data_ptr(), lv.Cs[t].data_ptr(), lv.ACT[t].data_ptr() if lv.ACT is not None else None, lv.hid, 3, 1,
+                                ops.FORCE_TILE[0], lv.dyn.dtype, lv.KEY[t].data_ptr())
+            check(L.rsis_convlstm_fwd_batch(jobs, len(cells), stream()), "rsis_convlstm_fwd_batch")
+            for i, t in cells:
+                lv = levels[i]
+                if i + 1 < n:
+                    nx = levels[i + 1]
+                    if (nx.H, nx.W) == (lv.H, lv.W):          # align-corners resize to the same size is the identity (ops.upsample_bilinear_ac)
+                        nx.UP[t].copy_(lv.Hs[t])
+                    else:
+                        check(L.rsis_upsample_bilinear_ac_fwd(ptr(lv.Hs[t]), ptr(nx.UP[t]), B * lv.hid, lv.H, lv.W, nx.H, nx.W, stream()),
+                              "rsis_upsample_fwd")
+                else:
+                    check(L.rsis_upsample_bilinear_ac_fwd(ptr(lv.Hs[t]), ptr(UP5[t]), B * lv.hid, lv.H, lv.W, H5, W5, stream()), "rsis_upsample_fwd")
+                    # the heads of step t: decode the keys of all five levels (writes SIDE / ARG), two linears + softmax
+                    check(L.rsis_heads_fwd_keys(ptr_array([v.KEY[t] for v in levels]), ptr_array([v.SIDE[t] for v in levels]),
+                                                ptr_array([v.ARG[t] for v in levels]), int_array(hs), n, B, ptr(Wc_d), ptr(bc_d), ncls,
+                                                ptr(Ws_d), ptr(bs_d), ptr(probs_tb[t]), ptr(stop_tb[t]), stream()), "rsis_heads_fwd_keys")
+        # conv_out (model.py:167) on every timestep at once, logits straight into (B, T, N)
+        out_masks = torch.empty((B, T, H5 * W5), **f32)
+        co_pack = decoder.conv_out._pack
+        co_wp = co_pack.fwd(co_w)
+        seq_ok = _conv_out_seq_ok(last.hid, W5)
+        if seq_ok:
+            check(L.rsis_conv_out_seq_fwd(ptr(UP5), ptr(co_wp), ptr(co_b.detach()), ptr(out_masks), T, B, last.hid, H5, W5, stream()),
+                  "rsis_conv_out_seq_fwd")
+        else:
+            tmp = torch.empty((B, 1, H5, W5), **f32)
+            for t in range(T):
+                check(L.rsis_conv2d_fwd(ptr_array([UP5[t]]), int_array([last.hid]), 1, B, H5, W5, ptr(co_wp), 1, 3, 1, 1, ptr(co_b.detach()), None,
+                                        ptr(tmp), H5, W5, ops.FORCE_TILE[0], co_pack.dtype, stream()), "rsis_conv2d_fwd(conv_out)")
+                out_masks[:, t].copy_(tmp.view(B, -1))
+        out_probs = probs_tb.transpose(0, 1).contiguous()            # (B, T, C)   train.py:119
+        out_stops = stop_tb.transpose(0, 1).contiguous()             # (B, T, 1)   train.py:120
+        hidden = []
+        for lv in levels:
+            hidden += [lv.Hs[T - 1], lv.Cs[T - 1]]
+        ctx.set_materialize_grads(False)
+        if need_grad:
+            ctx.decoder, ctx.T, ctx.levels, ctx.seq_ok = decoder, T, levels, seq_ok
+            ctx.UP5, ctx.probs_tb, ctx.feats = UP5, probs_tb, feats
+            ctx.params = params
+        else:
+            for lv in levels:
+                lv.G = lv.ACT = lv.UP = None
+        return (out_masks, out_probs, out_stops) + tuple(hidden)
+
+    @staticmethod
+    def backward(ctx, d_masks, d_probs, d_stops, *d_hidden):
+        L = lib()
+        decoder, T, levels = ctx.decoder, ctx.T, ctx.levels
+        n = len(levels)
+        feats, params = ctx.feats, ctx.params
+        gates_w = [params[2 * i] for i in range(n)]
+        gates_b = [params[2 * i + 1] for i in range(n)]
+        co_w, co_b, Wc, bc, Ws, bs = params[2 * n:2 * n + 6]
+        need = ctx.needs_input_grad            # (decoder, T, keep, feats..., params...)
+        need_feat = [need[3 + i] for i in range(n)]
+        need_par = [need[3 + n + k] for k in range(len(params))]
+        dev = feats[0].device
+        B = feats[0].shape[0]
+        hs = [lv.hid for lv in levels]
+        f32 = dict(dtype=torch.float32, device=dev)
+        last = levels[-1]
+        H5, W5 = 2 * last.H, 2 * last.W
+        UP5 = ctx.UP5
+        grads_par = [None] * len(params)
+
+        def target(k):
+            """(buffer the kernels accumulate parameter k's gradient into, is it the flat gradient buffer)"""
+            p = params[k]
+            t = ops._direct_target(p)
+            if t is not None:
+                return t, True
+            g = torch.zeros_like(p)
+            grads_par[k] = g
+            return g, False
+
+        # ---- conv_out: data gradient of all T steps in one launch, weight + bias gradient in another ----
+        dUP5 = torch.empty_like(UP5)
+        co_pack = decoder.conv_out._pack
+        if d_masks is None:
+            dUP5.zero_()
+        else:
+            d_masks = d_masks if d_masks.is_contiguous() else d_masks.contiguous()
+            co_wd = co_pack.dgrad(co_w)
+            kw, kb = 2 * n, 2 * n + 1
+            dW = db = None
+            if need_par[kw]:
+                dW, _ = target(kw)
+            if need_par[kb]:
+                db, _ = target(kb)
+            if ctx.seq_ok:
+                check(L.rsis_conv_out_seq_dgrad(ptr(d_masks), ptr(co_wd), ptr(dUP5), T, B, last.hid, H5, W5, stream()), "rsis_conv_out_seq_dgrad")
+                if dW is not None:
+                    check(L.rsis_conv_out_seq_wgrad(ptr(d_masks), ptr(UP5), ptr(dW), ptr(db), T, B, last.hid, H5, W5, stream()),
+                          "rsis_conv_out_seq_wgrad")
+                elif db is not None:
+                    db += d_masks.sum()
+            else:
+                for t in range(T):
+                    dy = d_masks[:, t].contiguous().view(B, 1, H5, W5)
+                    check(L.rsis_conv2d_dgrad(ptr(dy), B, 1, H5, W5, ptr(co_wd), co_pack.cin, 3, 1, 1, ptr_array([dUP5[t]]), int_array([last.hid]), 1,
+                                              H5, W5, None, ops.FORCE_TILE[0], co_pack.dtype, stream()), "rsis_conv2d_dgrad(conv_out)")
+                    if dW is not None:
+                        check(L.rsis_conv2d_wgrad(ptr(dy), ptr(UP5[t]), ptr(dW), B, last.hid, H5, W5, 1, H5, W5, 3, 1, 1, last.hid, 0, 0,
+                                                  co_pack.dtype, stream()), "rsis_conv2d_wgrad(conv_out)")
+                    if db is not None:
+                        check(L.rsis_bias_grad(ptr(dy), ptr(db), B, 1, H5 * W5, 0, stream()), "rsis_bias_grad(conv_out)")
+        # ---- heads: per timestep (the parameter gradients accumulate over t) ----
+        tot = sum(hs)
+        DSIDE = torch.empty(T * B * tot, **f32)
+        dsides, off = [], 0
+        for lv in levels:
+            m = T * B * lv.hid
+            dsides.append(DSIDE[off:off + m].view(T, B, lv.hid))
+            off += m
+        if d_probs is None and d_stops is None:
+            DSIDE.zero_()
+        else:
+            dp_tb = d_probs.transpose(0, 1).contiguous() if d_probs is not None else None
+            ds_tb = d_stops.transpose(0, 1).contiguous() if d_stops is not None else None
+            hb = [target(2 * n + 2 + k)[0] if need_par[2 * n + 2 + k] else None for k in range(4)]
+            for t in range(T):
+                check(L.rsis_heads_bwd(ptr_array([lv.SIDE[t] for lv in levels]), int_array(hs), n, B, ptr(Wc.detach()), Wc.shape[0],
+                                       ptr(Ws.detach()), ptr(ctx.probs_tb[t]), ptr(dp_tb[t]) if dp_tb is not None else None,
+                                       ptr(ds_tb[t]) if ds_tb is not None else None, ptr_array([ds[t] for ds in dsides]), ptr(hb[0]), ptr(hb[1]),
+                                       ptr(hb[2]), ptr(hb[3]), stream()), "rsis_heads_bwd")
+        # ---- reverse wavefront ----
+        DA = [torch.empty_like(lv.ACT) for lv in levels]
+        DH = [torch.empty((B, lv.hid, lv.H, lv.W), **f32) for lv in levels]                  # gradient of h[i][t] from above (upsample + pool)
+        DHP = [torch.empty((B, lv.hid, lv.H, lv.W), **f32) for lv in levels]                 # ... through the recurrence, from step t + 1
+        DC = [[torch.empty((B, lv.hid, lv.H, lv.W), **f32) for _ in range(2)] for lv in levels]
+        DUP = [torch.empty((B, lv.c_up, lv.H, lv.W), **f32) if lv.c_up > 0 else None for lv in levels]
+        wds = [lv.dyn.dgrad(gates_w[i]) for i, lv in enumerate(levels)]
+        for d in range(T + n - 2, -1, -1):
+            cells = [(i, d - i) for i in range(n) if 0 <= d - i < T]
+            for i, t in cells:          # gradient reaching h[i][t] through its upsample into the next level (or conv_out) and its side max-pool
+                lv = levels[i]
+                if i + 1 < n:
+                    nx = levels[i + 1]
+                    dy, Ho, Wo = DUP[i + 1], nx.H, nx.W
+                else:
+                    dy, Ho, Wo = dUP5[t], H5, W5
+                if (Ho, Wo) == (lv.H, lv.W):
+                    DH[i].copy_(dy)
+                    check(L.rsis_global_maxpool_bwd_add(ptr(dsides[i][t]), ptr(lv.ARG[t]), ptr(DH[i]), B * lv.hid, lv.H * lv.W, stream()),
+                          "rsis_global_maxpool_bwd_add")
+                else:
+                    check(L.rsis_upsample_maxpool_bwd(ptr(dy), ptr(dsides[i][t]), ptr(lv.ARG[t]), ptr(DH[i]), B * lv.hid, lv.H, lv.W, Ho, Wo,
+                                                      stream()), "rsis_upsample_maxpool_bwd")
+            for i, t in cells:          # clstm.py:47-58 backwards: d(gates), dc_{t-1}
+                lv = levels[i]
+                if t == T - 1:      # gradients a caller put on the returned final state (none in runIter: train.py never reads it)
+                    dh2 = d_hidden[2 * i].contiguous() if d_hidden[2 * i] is not None else None
+                    dcn = d_hidden[2 * i + 1].contiguous() if d_hidden[2 * i + 1] is not None else None
+                else:
+                    dh2, dcn = DHP[i], DC[i][(t + 1) & 1]
+                check(L.rsis_convlstm_bwd_gates(ptr(DH[i]), ptr(dh2), ptr(dcn),
+                                                ptr(lv.ACT[t]), ptr(lv.Cs[t - 1]) if t > 0 else None, ptr(lv.Cs[t]), ptr(DA[i][t]),
+                                                ptr(DC[i][t & 1]) if t > 0 else None, None, B, lv.hid, lv.H * lv.W, stream()),
+                      "rsis_convlstm_bwd_gates")
+            for i, t in cells:          # data gradient of the gate conv: d(up[i][t]) for the level below, dh[i][t-1] through the recurrence
+                lv = levels[i]
+                dxs = ([DUP[i]] if lv.c_up > 0 else []) + ([DHP[i]] if t > 0 else [])
+                if dxs:
+                    check(L.rsis_conv2d_dgrad(ptr(DA[i][t]), B, 4 * lv.hid, lv.H, lv.W, ptr(wds[i]), lv.dyn.cin, 3, 1, 1, ptr_array(dxs),
+                                              int_array([x.shape[1] for x in dxs]), len(dxs), lv.H, lv.W, None, ops.FORCE_TILE[0], lv.dyn.dtype,
+                                              stream()), "rsis_conv2d_dgrad(step)")
+        # ---- per level, once: the time-invariant skip term and the time-batched weight gradients ----
+        dfeats = [None] * n
+        for i, lv in enumerate(levels):
+            kw, kb = 2 * i, 2 * i + 1
+            hid, H, W = lv.hid, lv.H, lv.W
+            if T == 1:
+                dG = DA[i][0]
+            else:
+                dG = torch.empty_like(lv.G)
+                check(L.rsis_sum_leading(ptr(DA[i]), ptr(dG), T, dG.numel(), stream()), "rsis_sum_leading")
+            if need_feat[i]:
+                dfeats[i] = torch.empty_like(feats[i])
+                check(L.rsis_conv2d_dgrad(ptr(dG), B, 4 * hid, H, W, ptr(lv.hoist.dgrad(gates_w[i])), lv.hoist.cin, 3, 1, 1, ptr_array([dfeats[i]]),
+                                          int_array([lv.c_skip]), 1, H, W, None, ops.FORCE_TILE[0], lv.hoist.dtype, stream()), "rsis_conv2d_dgrad(hoist)")
+            if need_par[kb]:
+                db, _ = target(kb)
+                check(L.rsis_bias_grad(ptr(dG), ptr(db), B, 4 * hid, H * W, hid, stream()), "rsis_bias_grad(hoist)")
+            if need_par[kw]:
+                dW, direct = target(kw)
+                Ctot = gates_w[i].shape[1]
+                h_off = lv.c_up + lv.c_skip
+                ops.wgrad_launch(L, dG, feats[i], dW, B, lv.c_skip, H, W, 4 * hid, H, W, 3, 1, 1, Ctot, lv.c_up, hid, lv.hoist.dtype,
+                                 "rsis_conv2d_wgrad(hoist)", direct)
+                dt = lv.dyn.dtype
+                # bf16, rows that are not a multiple of 4 pixels (the 7 / 14-pixel levels of a 224 x 224 input): channel-blocked bf16 copies
+                # of the (small) stacks and the whole-cell loader, see decoder_fused._StepFn.backward
+                as_blk = (dt == ops.DTYPE_BF16 and decoder_fused._BLK_WGRAD[0] and W % 4 != 0 and hid % 8 == 0 and lv.c_up % 8 == 0)
+                if as_blk:
+                    da_b = ops.blk_from_nchw(DA[i].view(T * B, 4 * hid, H, W))
+                    if lv.c_up > 0:
+                        ops.wgrad_launch(L, da_b, ops.blk_from_nchw(lv.UP.view(T * B, lv.c_up, H, W)), dW, T * B, lv.c_up, H, W, 4 * hid, H, W, 3, 1, 1,
+                                         Ctot, 0, hid, ops.DTYPE_BF16_BLK, "rsis_conv2d_wgrad(batched up, blk)", direct)
+                    if T > 1:
+                        ops.wgrad_launch(L, da_b[B:], ops.blk_from_nchw(lv.Hs[:T - 1].reshape((T - 1) * B, hid, H, W)), dW, (T - 1) * B, hid, H, W,
+                                         4 * hid, H, W, 3, 1, 1, Ctot, h_off, hid, ops.DTYPE_BF16_BLK, "rsis_conv2d_wgrad(batched h, blk)", direct)
+                else:
+                    if lv.c_up > 0:
+                        ops.wgrad_launch(L, DA[i], lv.UP, dW, T * B, lv.c_up, H, W, 4 * hid, H, W, 3, 1, 1, Ctot, 0, hid, dt,
+                                         "rsis_conv2d_wgrad(batched up)", direct)
+                    if T > 1:
+                        ops.wgrad_launch(L, DA[i][1], lv.Hs, dW, (T - 1) * B, hid, H, W, 4 * hid, H, W, 3, 1, 1, Ctot, h_off, hid, dt,
+                                         "rsis_conv2d_wgrad(batched h)", direct)
+        for lv in levels:
+            lv.G = lv.Hs = lv.Cs = lv.ACT = lv.UP = None
+        ctx.levels = ctx.UP5 = ctx.feats = ctx.params = ctx.decoder = None
+        return (None, None, None) + tuple(dfeats) + tuple(grads_par)
+
+
+def decoder_sequence_stacked(decoder, skip_feats, T):
+    """(out_masks (B, T, H*W) logits, class_probs (B, T, C), stop logits (B, T, 1), hidden_list, (H, W) of the masks)"""
+    n = len(decoder.clstm_list)
+    params = []
+    for c in decoder.clstm_list:
+        params += [c.Gates.weight, c.Gates.bias]
+    params += [decoder.conv_out.weight, decoder.conv_out.bias, decoder.fc_class.weight, decoder.fc_class.bias, decoder.fc_stop.weight,
+               decoder.fc_stop.bias]
+    keep = torch.is_grad_enabled() and (any(f.requires_grad for f in skip_feats) or any(p.requires_grad for p in params))
+    res = _DecoderSeqFn.apply(decoder, int(T), keep, *skip_feats, *params)
+    out_masks, out_probs, out_stops = res[:3]
+    hidden = [[res[3 + 2 * i], res[4 + 2 * i]] for i in range(n)]
+    size = (2 * skip_feats[-1].shape[2], 2 * skip_feats[-1].shape[3])
+    return out_masks, out_probs, out_stops, hidden, size

@@ -11,7 +11,7 @@ from torch import nn
 
 import os
 
-from .. import decoder_fused, ops
+from .. import decoder_fused, decoder_seq, ops
 from ..utils.utils import get_skip_dims
 from .clstm import ConvLSTMCell
 from .vision import HipBatchNorm2d, HipConv2d, ResNet101
@@ -178,6 +178,12 @@ class RSIS(nn.Module):
         Runs the (level, timestep) wavefront schedule of rsis_amd.decoder_fused.decoder_sequence where it applies, the plain loop
         over forward() otherwise."""
         # (an instance whose forward() has been wrapped -- tests that record per-step intermediates -- sees every step through it)
+        if decoder_seq.supported(self, skip_feats, T):
+            # the whole sequence as one autograd node (explicit BPTT, rsis_amd/decoder_seq.py); the per-step tuples are views of its
+            # stacked outputs (training loops use forward_sequence_stacked and never slice)
+            masks, probs, stops, hidden, (Hm, Wm) = decoder_seq.decoder_sequence_stacked(self, skip_feats, T)
+            B = masks.shape[0]
+            return [(masks[:, t].view(B, 1, Hm, Wm), probs[:, t], stops[:, t]) for t in range(T)], hidden
         if "forward" not in self.__dict__ and decoder_fused.sequence_supported(self, skip_feats, T):
             return decoder_fused.decoder_sequence(self, skip_feats, T)
         hidden, outs = None, []
@@ -185,6 +191,13 @@ class RSIS(nn.Module):
             out_mask, out_class, out_stop, hidden = self.forward(skip_feats, hidden)
             outs.append((out_mask, out_class, out_stop))
         return outs, hidden
+
+    def forward_sequence_stacked(self, skip_feats, T):
+        """forward_sequence with the per-step outputs stacked the way reference train.py:117-120 stacks them: (out_masks (B, T, H*W) logits,
+        class_probs (B, T, C), stop logits (B, T, 1), hidden_list, (H, W) of the masks) -- or None where only the per-step path applies"""
+        if not decoder_seq.supported(self, skip_feats, T):
+            return None
+        return decoder_seq.decoder_sequence_stacked(self, skip_feats, T)
 
     def forward(self, skip_feats, prev_hidden_list):
         if self.fused and self.skip_mode == "concat" and self.dropout == 0 and len(skip_feats) == len(self.clstm_list):

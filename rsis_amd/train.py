@@ -102,16 +102,25 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
         feats = encoder(x)                                           # train.py:77 (once per iteration)
         # train.py:85-94: t_run decoder steps from the zero state -- RSIS.forward_sequence runs them in wavefront order with the
         # gate kernels of a (level, step) diagonal in one launch; same nodes, same results as t_run calls of decoder(feats, hidden)
-        steps, hidden = decoder.forward_sequence(feats, t_run)
-        for out_mask, out_class, out_stop in steps:                  # train.py:85
-            out_mask = ops.upsample_bilinear_ac(out_mask, (x.size(-2), x.size(-1)))         # :96-97
-            out_masks.append(out_mask.reshape(out_mask.size(0), -1))                        # :98
-            out_classes.append(out_class)
-            out_stops.append(out_stop)
-        t = len(out_masks)                                           # :117
-        out_masks = torch.stack(out_masks, 1)                        # (B, t, N)   :118
-        out_classes = torch.stack(out_classes, 1)                    # (B, t, C)   :119
-        out_stops = torch.stack(out_stops, 1)                        # (B, t, 1)   :120
+        stacked = decoder.forward_sequence_stacked(feats, t_run) if hasattr(decoder, "forward_sequence_stacked") else None
+        if stacked is not None:
+            # the whole sequence as ONE autograd node (rsis_amd/decoder_seq.py): outputs already in the (B, t, .) layout of :118-120
+            out_masks, out_classes, out_stops, hidden, (Hm, Wm) = stacked
+            t = out_masks.size(1)
+            if (Hm, Wm) != (x.size(-2), x.size(-1)):                 # :96-97 (identity when the pyramid doubles up to the input size)
+                up = ops.upsample_bilinear_ac(out_masks.view(-1, 1, Hm, Wm), (x.size(-2), x.size(-1)))
+                out_masks = up.view(out_masks.size(0), t, -1)
+        else:
+            steps, hidden = decoder.forward_sequence(feats, t_run)
+            for out_mask, out_class, out_stop in steps:              # train.py:85
+                out_mask = ops.upsample_bilinear_ac(out_mask, (x.size(-2), x.size(-1)))         # :96-97
+                out_masks.append(out_mask.reshape(out_mask.size(0), -1))                        # :98
+                out_classes.append(out_class)
+                out_stops.append(out_stop)
+            t = len(out_masks)                                       # :117
+            out_masks = torch.stack(out_masks, 1)                    # (B, t, N)   :118
+            out_classes = torch.stack(out_classes, 1)                # (B, t, C)   :119
+            out_stops = torch.stack(out_stops, 1)                    # (B, t, 1)   :120
 
     # ---- scores + matching (no grad) : train.py:78,102-110,127-137 ----
     fused_iou = ops.softiou_supported(out_masks, y_mask)    # one pass over logits + GT masks gives every soft-IoU sum

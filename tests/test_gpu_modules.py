@@ -367,8 +367,10 @@ def test_pool_fused_into_gate_kernel_is_bit_identical(shape, dtype):
     torch.manual_seed(1)
     dec = RSIS(a).cuda()
     res = []
-    was, det = decoder_fused.FUSED_POOL[0], ops.is_deterministic()
+    from rsis_amd import decoder_seq
+    was, det, was_seq = decoder_fused.FUSED_POOL[0], ops.is_deterministic(), decoder_seq.ENABLED[0]
     ops.set_deterministic(True)
+    decoder_seq.ENABLED[0] = False      # (both runs on decoder_fused.decoder_sequence: the one-node sequence of decoder_seq always pools in the gate kernels)
     try:
         for fused in (False, True):
             decoder_fused.FUSED_POOL[0] = fused
@@ -384,6 +386,7 @@ def test_pool_fused_into_gate_kernel_is_bit_identical(shape, dtype):
             res.append(([o.detach().clone() for o in outs], [f.grad.clone() for f in feats], {k: p.grad.clone() for k, p in dec.named_parameters()}))
     finally:
         decoder_fused.FUSED_POOL[0] = was
+        decoder_seq.ENABLED[0] = was_seq
         ops.set_deterministic(det)
     for i, (p, q) in enumerate(zip(res[0][0], res[1][0])):
         assert torch.equal(p, q), "out%d differs by %g" % (i, float((p - q).abs().max()))
