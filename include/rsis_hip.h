@@ -350,6 +350,76 @@ int rsis_blk_bn_bwd(const void* dy_blk, const void* x_blk, const void* y_blk, do
 int rsis_blk_subsample2d(const void* x_blk, void* y_blk, int B, int C, int H, int W, int stride, void* stream);
 int rsis_blk_upscatter2d(const void* dy_blk, void* dx_blk, int B, int C, int H, int W, int stride, void* stream);
 
+/* ---- the recurrent decoder on blk tensors (ConvLSTM cells of clstm.py:19-62 inside the loop of model.py:129-165, run over the
+ * (level, timestep) wavefront: the cells of a diagonal are independent, so every entry point below takes SEVERAL independent jobs
+ * and runs them in one grid where it can).  Reference arithmetic with bf16 operands / storage: fp32 accumulation and cell update,
+ * ONE rounding at each blk store; the cell state c stays fp32 NCHW. ---- */
+
+/* One 3x3 / stride 1 / pad 1 conv over the channel concat of nsrc <= 3 blk sources.  Wp: the RSIS_DTYPE_BF16 pack of
+ * rsis_conv_pack_fwd (or _dgrad: the job is then the data gradient, sources = dy) built for the same segments; Cpack = the pack's
+ * row count (Cout of rsis_conv_pack_fwd, Cin_packed of rsis_conv_pack_dgrad; 0 = Cout).
+ *   hid == 0, plain epilogue: out = conv (+ bias[Cout], fp32, packed row order) (+ addend, blk [B][Cout]) split over ndst <= 2 blk
+ *     destinations of Cdst[i] channels (Cdst % 8 == 0, sum = Cout <= Cpack: leading rows of the pack);
+ *   hid > 0, fused ConvLSTM cell (rows gate-interleaved 4 j + gate, Cout = 4 hid, hid % 8 == 0): gates = conv (+ bias) + addend (blk
+ *     [B][4 hid], the time-invariant skip term) -> i, f, o = sigmoid, g = tanh, c = f c_prev + i g, h = o tanh(c).  c_prev (NULL = zero
+ *     state) / c_out: fp32 [B][hid][H][W]; h_out: blk [B][hid]; act_out (may be NULL): blk [B][4 hid], the post-nonlinearity gates;
+ *     side_key (may be NULL): [B][hid] keys of the global max-pool of the STORED h, as rsis_lstm_job.side_key.  nsrc may be 0. */
+typedef struct rsis_blk_conv_job {
+  const void* src[3];
+  int Csrc[3];
+  int nsrc, B, H, W;
+  const void* Wp;
+  int Cout, Cpack;
+  const float* bias;
+  const void* addend;
+  void* dst[2];
+  int Cdst[2];
+  int ndst;
+  int hid;
+  const float* c_prev;
+  float* c_out;
+  void* h_out;
+  void* act_out;
+  unsigned long long* side_key;
+  int tile;              /* 0 = the library picks the MFMA tile; 1 / 4 / 5 force one (tests) */
+} rsis_blk_conv_job;
+int rsis_blk_conv3x3_batch(const rsis_blk_conv_job* jobs, int njobs, void* stream);
+
+/* align-corners bilinear resize (nn.UpsamplingBilinear2d, model.py:149-150,163-164) of blk tensors, x [B][C][Hi][Wi] -> y [B][C][Ho][Wo],
+ * and its transpose dx = resize^T(dy); with dpool / arg (both [B][C], or both NULL) the transpose also adds dpool[b][c] at flat pixel
+ * arg[b][c] of every channel plane: the gradient of the global max-pool side feature (model.py:143) of the same tensor. */
+typedef struct rsis_blk_resize_job {
+  const void* src;       /* forward: x; backward: dy */
+  void* dst;             /* forward: y; backward: dx */
+  const float* dpool;
+  const int* arg;
+  int B, C, Hi, Wi, Ho, Wo;
+} rsis_blk_resize_job;
+int rsis_blk_upsample_fwd_batch(const rsis_blk_resize_job* jobs, int njobs, void* stream);
+int rsis_blk_upsample_bwd_batch(const rsis_blk_resize_job* jobs, int njobs, void* stream);
+
+/* rsis_convlstm_bwd_gates on blk tensors: dh, dh2 (may be NULL) blk [B][hid]; act, da blk [B][4 hid] (rows 4 j + gate); c, c_prev,
+ * dc_next, dc_prev fp32 [B][hid][HW] (c_prev / dc_next / dc_prev may be NULL). */
+typedef struct rsis_blk_lstm_bwd_job {
+  const void* dh;
+  const void* dh2;
+  const float* dc_next;
+  const void* act;
+  const float* c_prev;
+  const float* c;
+  void* da;
+  float* dc_prev;
+  int B, hid, HW;
+} rsis_blk_lstm_bwd_job;
+int rsis_blk_lstm_bwd_batch(const rsis_blk_lstm_bwd_job* jobs, int njobs, void* stream);
+
+/* conv_out (model.py:109,167; Cin == 8: hidden_size / 16 at hidden_size 128) over all T timesteps from the blk hidden state:
+ * x / dx blk [T][B][8][H][W]; y / dy fp32 [B][T][H*W]; Wref = the reference-layout weight [1][8][3][3] (fp32, no pack); bias [1] or
+ * NULL; dW[72] / db[1] (db may be NULL) are ACCUMULATED.  W % 4 == 0. */
+int rsis_blk_conv_out_seq_fwd(const void* x, const float* Wref, const float* bias, float* y, int T, int B, int H, int W, void* stream);
+int rsis_blk_conv_out_seq_dgrad(const float* dy, const float* Wref, void* dx, int T, int B, int H, int W, void* stream);
+int rsis_blk_conv_out_seq_wgrad(const float* dy, const void* x, float* dW, float* db, int T, int B, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,27 @@ class LstmJob(ctypes.Structure):
                 ("side_key", ctypes.c_void_p)]
 
 
+class BlkConvJob(ctypes.Structure):
+    """struct rsis_blk_conv_job of include/rsis_hip.h"""
+    _fields_ = [("src", ctypes.c_void_p * 3), ("Csrc", ctypes.c_int * 3), ("nsrc", ctypes.c_int), ("B", ctypes.c_int), ("H", ctypes.c_int),
+                ("W", ctypes.c_int), ("Wp", ctypes.c_void_p), ("Cout", ctypes.c_int), ("Cpack", ctypes.c_int), ("bias", ctypes.c_void_p),
+                ("addend", ctypes.c_void_p), ("dst", ctypes.c_void_p * 2), ("Cdst", ctypes.c_int * 2), ("ndst", ctypes.c_int),
+                ("hid", ctypes.c_int), ("c_prev", ctypes.c_void_p), ("c_out", ctypes.c_void_p), ("h_out", ctypes.c_void_p),
+                ("act_out", ctypes.c_void_p), ("side_key", ctypes.c_void_p), ("tile", ctypes.c_int)]
+
+
+class BlkResizeJob(ctypes.Structure):
+    """struct rsis_blk_resize_job of include/rsis_hip.h"""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dpool", ctypes.c_void_p), ("arg", ctypes.c_void_p)] + \
+               [(k, ctypes.c_int) for k in ("B", "C", "Hi", "Wi", "Ho", "Wo")]
+
+
+class BlkLstmBwdJob(ctypes.Structure):
+    """struct rsis_blk_lstm_bwd_job of include/rsis_hip.h"""
+    _fields_ = [(k, ctypes.c_void_p) for k in ("dh", "dh2", "dc_next", "act", "c_prev", "c", "da", "dc_prev")] + \
+               [(k, ctypes.c_int) for k in ("B", "hid", "HW")]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/rsis_hip.h
 SIGNATURES = {
     "rsis_version": (_i, []),
@@ -88,6 +109,13 @@ SIGNATURES = {
     "rsis_blk_subsample2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsis_blk_upscatter2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsis_blk_conv2d": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    "rsis_blk_conv3x3_batch": (_i, [ctypes.POINTER(BlkConvJob), _i, _vp]),
+    "rsis_blk_upsample_fwd_batch": (_i, [ctypes.POINTER(BlkResizeJob), _i, _vp]),
+    "rsis_blk_upsample_bwd_batch": (_i, [ctypes.POINTER(BlkResizeJob), _i, _vp]),
+    "rsis_blk_lstm_bwd_batch": (_i, [ctypes.POINTER(BlkLstmBwdJob), _i, _vp]),
+    "rsis_blk_conv_out_seq_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsis_blk_conv_out_seq_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsis_blk_conv_out_seq_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_heads_bwd": (_i, [_vpp, _ip, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vpp, _vp, _vp, _vp, _vp, _vp]),
     "rsis_loss_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rsis_softiou_sums": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _vp]),

@@ -30,6 +30,13 @@ int rsis_l_c1_fwd(const float*, const float*, int, const float*, float*, int, in
 int rsis_l_c1_dgrad(const float*, const float*, int, float*, int, int, int, int, int, hipStream_t);
 int rsis_l_c1_wgrad(const float*, const float*, float*, float*, int, int, int, int, int, hipStream_t);
 int rsis_l_sum_leading(const float*, float*, int, long, hipStream_t);
+int rsis_launch_conv_blk_dec(BlkConvJob*, int, int, const int*, hipStream_t);
+int rsis_l_blk_upsample_fwd(const BlkResizeJob*, int, hipStream_t);
+int rsis_l_blk_upsample_bwd(const BlkResizeJob*, int, hipStream_t);
+int rsis_l_blk_lstm_bwd(const BlkLstmBwdJob*, int, hipStream_t);
+int rsis_l_blk_c1_fwd(const void*, const float*, const float*, float*, int, int, int, int, hipStream_t);
+int rsis_l_blk_c1_dgrad(const float*, const float*, void*, int, int, int, int, hipStream_t);
+int rsis_l_blk_c1_wgrad(const float*, const void*, float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_pack(int, const float*, void*, int, int, int, int, const int*, const int*, int, int, int, hipStream_t);
 
 int rsis_l_lstm_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int,
@@ -727,4 +734,100 @@ int rsis_loss_tail(const float* probs, const long long* y_class, const float* st
   if (!out && !dprobs) return RSIS_ERR_ARG;
   return rsis_l_loss_tail(probs, y_class, stop, siou, sw_mask, sw_class, cls_w, n, C, bw, w_iou, w_cls, w_stop, out, dprobs, dstop, dsiou,
                           gout, (hipStream_t)stream);
+}
+
+
+// ---- the recurrent decoder on blk tensors (conv_blk_dec.hip, blk_dec.hip) ----
+int rsis_blk_conv3x3_batch(const rsis_blk_conv_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs < 1 || njobs > 64) return RSIS_ERR_ARG;
+  BlkConvJob plain[64], lstm[64];
+  int fp[64], fl[64], np = 0, nl = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const rsis_blk_conv_job& q = jobs[j];
+    BlkConvJob a = {};
+    if (q.nsrc < 0 || q.nsrc > RSIS_MAX_SRC || !q.Wp || q.B < 1 || q.H < 1 || q.W < 1 || q.Cout < 8 || (q.Cout & 7)) return RSIS_ERR_ARG;
+    for (int s = 0; s < RSIS_MAX_SRC; ++s) { a.src[s] = q.nsrc > 0 ? q.src[0] : nullptr; a.C[s] = 0; }
+    for (int s = 0; s < q.nsrc; ++s) {
+      if (!q.src[s] || q.Csrc[s] < 8 || (q.Csrc[s] & 7)) return RSIS_ERR_ARG;
+      if ((size_t)(q.Csrc[s] >> 3) * q.H * q.W * 16 >= (1ull << 31)) return RSIS_ERR_UNSUPPORTED;
+      a.src[s] = q.src[s]; a.C[s] = q.Csrc[s];
+    }
+    if ((size_t)(q.Cout >> 3) * q.H * q.W * 16 >= (1ull << 31)) return RSIS_ERR_UNSUPPORTED;
+    a.nsrc = q.nsrc; a.B = q.B; a.H = q.H; a.W = q.W; a.wp = q.Wp; a.Cout = q.Cout;
+    const int cpack = q.Cpack > 0 ? q.Cpack : q.Cout;
+    if (cpack < q.Cout) return RSIS_ERR_ARG;
+    a.ldw = rsis_roundup(cpack, RSIS_LDW_ALIGN);
+    a.bias = q.bias; a.addend = q.addend;
+    if (q.hid > 0) {
+      if ((q.hid & 7) || q.Cout != 4 * q.hid || !q.c_out || !q.h_out || (q.nsrc == 0 && !q.addend)) return RSIS_ERR_ARG;
+      if ((long)q.H * q.W >= 0x7FFFFFFFL / (4L * q.hid)) return RSIS_ERR_UNSUPPORTED;
+      a.hid = q.hid; a.c_prev = q.c_prev; a.c_out = q.c_out; a.h_out = q.h_out; a.act_out = q.act_out; a.side_key = q.side_key;
+      a.dst[0] = a.dst[1] = q.h_out;
+      fl[nl] = q.tile; lstm[nl++] = a;
+    } else {
+      if (q.nsrc < 1 || q.ndst < 1 || q.ndst > 2) return RSIS_ERR_ARG;
+      int tot = 0;
+      for (int d = 0; d < q.ndst; ++d) {
+        if (!q.dst[d] || q.Cdst[d] < 8 || (q.Cdst[d] & 7)) return RSIS_ERR_ARG;
+        a.dst[d] = q.dst[d]; a.Cd[d] = q.Cdst[d]; tot += q.Cdst[d];
+      }
+      if (tot != q.Cout) return RSIS_ERR_ARG;
+      a.ndst = q.ndst;
+      if (q.ndst == 1) { a.dst[1] = a.dst[0]; a.Cd[1] = 0; }
+      fp[np] = q.tile; plain[np++] = a;
+    }
+  }
+  int rc = RSIS_OK;
+  if (nl) rc = rsis_launch_conv_blk_dec(lstm, nl, 1, fl, (hipStream_t)stream);
+  if (rc == RSIS_OK && np) rc = rsis_launch_conv_blk_dec(plain, np, 0, fp, (hipStream_t)stream);
+  return rc;
+}
+static int blk_resize_jobs(const rsis_blk_resize_job* jobs, int njobs, BlkResizeJob* out, bool bwd) {
+  if (!jobs || njobs < 1 || njobs > 64) return RSIS_ERR_ARG;
+  for (int j = 0; j < njobs; ++j) {
+    const rsis_blk_resize_job& q = jobs[j];
+    if (!q.src || !q.dst || q.B < 1 || q.C < 8 || (q.C & 7) || q.Hi < 1 || q.Wi < 1 || q.Ho < 1 || q.Wo < 1) return RSIS_ERR_ARG;
+    if ((!q.dpool) != (!q.arg) || (!bwd && q.dpool)) return RSIS_ERR_ARG;
+    if ((long)q.Hi * q.Wi >= (1L << 27) || (long)q.Ho * q.Wo >= (1L << 27)) return RSIS_ERR_UNSUPPORTED;
+    out[j].src = q.src; out[j].dst = q.dst; out[j].dpool = q.dpool; out[j].arg = q.arg;
+    out[j].planes = q.B * (q.C >> 3); out[j].Hi = q.Hi; out[j].Wi = q.Wi; out[j].Ho = q.Ho; out[j].Wo = q.Wo;
+  }
+  return RSIS_OK;
+}
+int rsis_blk_upsample_fwd_batch(const rsis_blk_resize_job* jobs, int njobs, void* stream) {
+  BlkResizeJob a[64];
+  const int rc = blk_resize_jobs(jobs, njobs, a, false);
+  return rc ? rc : rsis_l_blk_upsample_fwd(a, njobs, (hipStream_t)stream);
+}
+int rsis_blk_upsample_bwd_batch(const rsis_blk_resize_job* jobs, int njobs, void* stream) {
+  BlkResizeJob a[64];
+  const int rc = blk_resize_jobs(jobs, njobs, a, true);
+  return rc ? rc : rsis_l_blk_upsample_bwd(a, njobs, (hipStream_t)stream);
+}
+int rsis_blk_lstm_bwd_batch(const rsis_blk_lstm_bwd_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs < 1 || njobs > 64) return RSIS_ERR_ARG;
+  BlkLstmBwdJob a[64];
+  for (int j = 0; j < njobs; ++j) {
+    const rsis_blk_lstm_bwd_job& q = jobs[j];
+    if (!q.dh || !q.act || !q.c || !q.da || q.B < 1 || q.hid < 8 || (q.hid & 7) || q.HW < 1) return RSIS_ERR_ARG;
+    a[j].dh = q.dh; a[j].dh2 = q.dh2; a[j].dc_next = q.dc_next; a[j].act = q.act; a[j].c_prev = q.c_prev; a[j].c = q.c; a[j].da = q.da;
+    a[j].dc_prev = q.dc_prev; a[j].B = q.B; a[j].hid = q.hid; a[j].HW = q.HW;
+  }
+  return rsis_l_blk_lstm_bwd(a, njobs, (hipStream_t)stream);
+}
+static inline bool blk_c1_ok(int T, int B, int H, int W) { return T >= 1 && B >= 1 && H >= 1 && W >= 4 && W % 4 == 0 && (long)H * W < (1L << 27); }
+int rsis_blk_conv_out_seq_fwd(const void* x, const float* Wref, const float* bias, float* y, int T, int B, int H, int W, void* stream) {
+  if (!x || !Wref || !y) return RSIS_ERR_ARG;
+  if (!blk_c1_ok(T, B, H, W)) return RSIS_ERR_UNSUPPORTED;
+  return rsis_l_blk_c1_fwd(x, Wref, bias, y, T, B, H, W, (hipStream_t)stream);
+}
+int rsis_blk_conv_out_seq_dgrad(const float* dy, const float* Wref, void* dx, int T, int B, int H, int W, void* stream) {
+  if (!dy || !Wref || !dx) return RSIS_ERR_ARG;
+  if (!blk_c1_ok(T, B, H, W)) return RSIS_ERR_UNSUPPORTED;
+  return rsis_l_blk_c1_dgrad(dy, Wref, dx, T, B, H, W, (hipStream_t)stream);
+}
+int rsis_blk_conv_out_seq_wgrad(const float* dy, const void* x, float* dW, float* db, int T, int B, int H, int W, void* stream) {
+  if (!dy || !x || !dW) return RSIS_ERR_ARG;
+  if (!blk_c1_ok(T, B, H, W)) return RSIS_ERR_UNSUPPORTED;
+  return rsis_l_blk_c1_wgrad(dy, x, dW, db, T, B, H, W, (hipStream_t)stream);
 }

@@ -115,3 +115,52 @@ struct WgradArgs {
   int n_co_tiles, n_n_tiles;
   int blk;           // bf16 kernels only: dy and x are channel-blocked bf16 tensors (conv_blk.hip)
 };
+
+// ---- the recurrent decoder on channel-blocked bf16 tensors (conv_blk_dec.hip, blk_dec.hip; include/rsis_hip.h rsis_blk_*_batch) ----
+// One 3x3 / stride 1 / pad 1 conv over the channel concat of <= 3 blk sources ([B][C/8][H][W][8] bf16, C % 8 == 0), bf16 pack of
+// pack.hip (16-channel chunks per source).  Plain epilogue: (+ fp32 bias in packed row order) (+ blk addend) -> <= 2 blk destinations
+// splitting the output channels (Cd % 8 == 0).  LSTM epilogue (hid > 0): rows are gate-interleaved (4 j + gate); addend = the
+// time-invariant gate term (blk, 4 hid channels), c_prev / c_out fp32 NCHW, h_out blk (hid % 8 == 0), act_out blk (4 hid channels).
+struct BlkConvJob {
+  const void* src[RSIS_MAX_SRC];
+  int C[RSIS_MAX_SRC];
+  int nsrc;
+  int B, H, W;
+  const void* wp;
+  int ldw;
+  int Cout;
+  const float* bias;
+  const void* addend;
+  void* dst[2];
+  int Cd[2];
+  int ndst;
+  int hid;
+  const float* c_prev;
+  float* c_out;
+  void* h_out;
+  void* act_out;
+  unsigned long long* side_key;
+  int n_co_tiles, n_px_tiles;
+};
+// align-corners bilinear resize of a blk tensor (planes = B * C / 8 cell planes); backward: dx = resize^T(dy) (+ dpool[b][c] at pixel
+// arg[b][c] of every channel plane: the side max-pool's gradient; both [B][C] arrays, null = none)
+struct BlkResizeJob {
+  const void* src;       // forward: x [planes][Hi][Wi][8]; backward: dy [planes][Ho][Wo][8]
+  void* dst;             // forward: y [planes][Ho][Wo][8]; backward: dx [planes][Hi][Wi][8]
+  const float* dpool;
+  const int* arg;
+  int planes, Hi, Wi, Ho, Wo;
+};
+// ConvLSTM pointwise backward on blk tensors: dh / dh2 [B][hid/8][HW][8] (dh2 may be null), act / da [B][4 hid / 8][HW][8] (rows
+// 4 j + gate), c / c_prev / dc_next / dc_prev fp32 [B][hid][HW] (c_prev, dc_next, dc_prev may be null)
+struct BlkLstmBwdJob {
+  const void* dh;
+  const void* dh2;
+  const float* dc_next;
+  const void* act;
+  const float* c_prev;
+  const float* c;
+  void* da;
+  float* dc_prev;
+  int B, hid, HW;
+};

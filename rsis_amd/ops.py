@@ -969,3 +969,79 @@ def blk_conv_wgrad(dy, x, dW, ks):
     check(lib().rsis_conv2d_wgrad(ptr(dy), ptr(x), ptr(dW), B, Cin, H, W, Cbo * 8, H, W, ks, 1, ks // 2, Cin, 0, 0, DTYPE_BF16_BLK, stream()),
           "rsis_conv2d_wgrad(blk)")
     return dW
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the recurrent decoder on blk tensors (csrc/conv_blk_dec.hip, blk_dec.hip): raw batched ops, no autograd (rsis_amd/decoder_seq.py)
+# ---------------------------------------------------------------------------------------------------------------------------
+def blk_conv_job(srcs, wp, cout, cpack=0, bias=None, addend=None, dsts=None, hid=0, c_prev=None, c_out=None, h_out=None, act_out=None,
+                 side_key=None, tile=0, shape=None):
+    """one job of rsis_blk_conv3x3_batch (include/rsis_hip.h: rsis_blk_conv_job).  srcs: blk tensors [B][C/8][H][W][8]; plain epilogue:
+    dsts = list of <= 2 blk outputs; LSTM epilogue: hid > 0 with c_prev / c_out (fp32 NCHW), h_out / act_out (blk), side_key (int64).
+    shape = (B, H, W) when there is no source (gates = addend only).  Returns (struct, tensors it points to)."""
+    _blk_ok(*srcs)
+    j = _lib.BlkConvJob()
+    j.nsrc = len(srcs)
+    for k, s in enumerate(srcs):
+        j.src[k], j.Csrc[k] = s.data_ptr(), s.shape[1] * 8
+    if srcs:
+        B, _cb, H, W, _ = srcs[0].shape
+    else:
+        B, H, W = shape
+    j.B, j.H, j.W, j.Wp, j.Cout, j.Cpack = B, H, W, wp.data_ptr(), int(cout), int(cpack)
+    j.bias = bias.data_ptr() if bias is not None else None
+    j.addend = addend.data_ptr() if addend is not None else None
+    j.hid, j.tile = int(hid), int(tile)
+    if hid > 0:
+        j.c_prev = c_prev.data_ptr() if c_prev is not None else None
+        j.c_out, j.h_out = c_out.data_ptr(), h_out.data_ptr()
+        j.act_out = act_out.data_ptr() if act_out is not None else None
+        j.side_key = side_key.data_ptr() if side_key is not None else None
+    else:
+        _blk_ok(*dsts)
+        j.ndst = len(dsts)
+        for k, d in enumerate(dsts):
+            j.dst[k], j.Cdst[k] = d.data_ptr(), d.shape[1] * 8
+    return j, (srcs, wp, bias, addend, dsts, c_prev, c_out, h_out, act_out, side_key)
+
+
+def blk_conv3x3_batch(jobs):
+    """jobs: list of blk_conv_job results -- independent convs in grouped launches"""
+    arr = (_lib.BlkConvJob * len(jobs))(*[j for j, _keep in jobs])
+    check(lib().rsis_blk_conv3x3_batch(arr, len(jobs), stream()), "rsis_blk_conv3x3_batch")
+
+
+def blk_resize_job(src, dst, dpool=None, arg=None, backward=False):
+    """forward: src = x [B][C/8][Hi][Wi][8] -> dst = y [B][C/8][Ho][Wo][8]; backward: src = dy (Ho x Wo) -> dst = dx (Hi x Wi), + dpool / arg"""
+    _blk_ok(src, dst)
+    j = _lib.BlkResizeJob()
+    small, big = (dst, src) if backward else (src, dst)
+    j.src, j.dst = src.data_ptr(), dst.data_ptr()
+    j.dpool = dpool.data_ptr() if dpool is not None else None
+    j.arg = arg.data_ptr() if arg is not None else None
+    j.B, j.C, j.Hi, j.Wi, j.Ho, j.Wo = small.shape[0], small.shape[1] * 8, small.shape[2], small.shape[3], big.shape[2], big.shape[3]
+    return j, (src, dst, dpool, arg)
+
+
+def blk_upsample_fwd_batch(jobs):
+    arr = (_lib.BlkResizeJob * len(jobs))(*[j for j, _keep in jobs])
+    check(lib().rsis_blk_upsample_fwd_batch(arr, len(jobs), stream()), "rsis_blk_upsample_fwd_batch")
+
+
+def blk_upsample_bwd_batch(jobs):
+    arr = (_lib.BlkResizeJob * len(jobs))(*[j for j, _keep in jobs])
+    check(lib().rsis_blk_upsample_bwd_batch(arr, len(jobs), stream()), "rsis_blk_upsample_bwd_batch")
+
+
+def blk_lstm_bwd_job(dh, dh2, dc_next, act, c_prev, c, da, dc_prev):
+    _blk_ok(dh, dh2, act, da)
+    j = _lib.BlkLstmBwdJob()
+    for k, t in (("dh", dh), ("dh2", dh2), ("dc_next", dc_next), ("act", act), ("c_prev", c_prev), ("c", c), ("da", da), ("dc_prev", dc_prev)):
+        setattr(j, k, t.data_ptr() if t is not None else None)
+    j.B, j.hid, j.HW = dh.shape[0], dh.shape[1] * 8, dh.shape[2] * dh.shape[3]
+    return j, (dh, dh2, dc_next, act, c_prev, c, da, dc_prev)
+
+
+def blk_lstm_bwd_batch(jobs):
+    arr = (_lib.BlkLstmBwdJob * len(jobs))(*[j for j, _keep in jobs])
+    check(lib().rsis_blk_lstm_bwd_batch(arr, len(jobs), stream()), "rsis_blk_lstm_bwd_batch")
