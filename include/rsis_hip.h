@@ -413,6 +413,12 @@ typedef struct rsis_blk_lstm_bwd_job {
 } rsis_blk_lstm_bwd_job;
 int rsis_blk_lstm_bwd_batch(const rsis_blk_lstm_bwd_job* jobs, int njobs, void* stream);
 
+/* y_blk[cell] = sum_t x_blk[t][cell] over T stacked blk tensors of ncells 16-byte cells each (fp32 accumulation, t ascending, one
+ * rounding): the sum over the timesteps of d(gates), i.e. the gradient of a level's time-invariant gate term */
+int rsis_blk_sum_leading(const void* x_blk, void* y_blk, int T, long ncells, void* stream);
+/* rsis_bias_grad for a blk dy [B][C][HW]: db[C] += sum over (b, pixel); lstm_hid > 0: blk channel 4 j + gate -> db[gate * hid + j] */
+int rsis_blk_bias_grad(const void* dy_blk, float* db, int B, int C, int HW, int lstm_hid, void* stream);
+
 /* conv_out (model.py:109,167; Cin == 8: hidden_size / 16 at hidden_size 128) over all T timesteps from the blk hidden state:
  * x / dx blk [T][B][8][H][W]; y / dy fp32 [B][T][H*W]; Wref = the reference-layout weight [1][8][3][3] (fp32, no pack); bias [1] or
  * NULL; dW[72] / db[1] (db may be NULL) are ACCUMULATED.  W % 4 == 0. */

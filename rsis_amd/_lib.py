@@ -113,6 +113,8 @@ SIGNATURES = {
     "rsis_blk_upsample_fwd_batch": (_i, [ctypes.POINTER(BlkResizeJob), _i, _vp]),
     "rsis_blk_upsample_bwd_batch": (_i, [ctypes.POINTER(BlkResizeJob), _i, _vp]),
     "rsis_blk_lstm_bwd_batch": (_i, [ctypes.POINTER(BlkLstmBwdJob), _i, _vp]),
+    "rsis_blk_sum_leading": (_i, [_vp, _vp, _i, _l, _vp]),
+    "rsis_blk_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_blk_conv_out_seq_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_blk_conv_out_seq_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_blk_conv_out_seq_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -34,6 +34,8 @@ int rsis_launch_conv_blk_dec(BlkConvJob*, int, int, const int*, hipStream_t);
 int rsis_l_blk_upsample_fwd(const BlkResizeJob*, int, hipStream_t);
 int rsis_l_blk_upsample_bwd(const BlkResizeJob*, int, hipStream_t);
 int rsis_l_blk_lstm_bwd(const BlkLstmBwdJob*, int, hipStream_t);
+int rsis_l_blk_sum_leading(const void*, void*, int, long, hipStream_t);
+int rsis_l_blk_channel_sum(const void*, float*, int, int, int, int, hipStream_t);
 int rsis_l_blk_c1_fwd(const void*, const float*, const float*, float*, int, int, int, int, hipStream_t);
 int rsis_l_blk_c1_dgrad(const float*, const float*, void*, int, int, int, int, hipStream_t);
 int rsis_l_blk_c1_wgrad(const float*, const void*, float*, float*, int, int, int, int, hipStream_t);
@@ -830,4 +832,12 @@ int rsis_blk_conv_out_seq_wgrad(const float* dy, const void* x, float* dW, float
   if (!dy || !x || !dW) return RSIS_ERR_ARG;
   if (!blk_c1_ok(T, B, H, W)) return RSIS_ERR_UNSUPPORTED;
   return rsis_l_blk_c1_wgrad(dy, x, dW, db, T, B, H, W, (hipStream_t)stream);
+}
+int rsis_blk_sum_leading(const void* x, void* y, int T, long ncells, void* stream) {
+  if (!x || !y || T < 1 || ncells < 1) return RSIS_ERR_ARG;
+  return rsis_l_blk_sum_leading(x, y, T, ncells, (hipStream_t)stream);
+}
+int rsis_blk_bias_grad(const void* dy, float* db, int B, int C, int HW, int lstm_hid, void* stream) {
+  if (!dy || !db || B < 1 || C < 8 || (C & 7) || HW < 1 || (lstm_hid > 0 && C != 4 * lstm_hid)) return RSIS_ERR_ARG;
+  return rsis_l_blk_channel_sum(dy, db, B, C, HW, lstm_hid, (hipStream_t)stream);
 }

@@ -207,6 +207,71 @@ int rsis_l_blk_lstm_bwd(const BlkLstmBwdJob* jobs, int n, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// y[cell] = sum_t x[t][cell] (t ascending, fp32 accumulation, one rounding): the gradient of a level's time-invariant gate term
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void blk_sum_leading_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int T, long n) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float acc[8], v[8];
+  kd_unpack(x[e], acc);
+  for (int t = 1; t < T; ++t) {
+    kd_unpack(x[(size_t)t * n + e], v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+  }
+  y[e] = kd_pack(acc);
+}
+int rsis_l_blk_sum_leading(const void* x, void* y, int T, long n, hipStream_t st) {
+  if ((n + 255) / 256 > 0x7FFFFFFFL) return RSIS_ERR_ARG;
+  hipLaunchKernelGGL(blk_sum_leading_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32x4*)x, (u32x4*)y, T, n);
+  return rsis_check_launch();
+}
+
+// db[row(c)] += sum over (b, pixel) of dy[b][c][pixel] for a blk dy [B][C/8][HW][8]; hid > 0: blk channel c = 4 j + gate goes to
+// db[gate * hid + j] (the reference row order of a ConvLSTM bias, clstm.py:47).  Block (cb, split) reduces its slice of the
+// B * HW cells of channel block cb and issues 8 atomics (deterministic mode: one split).
+__global__ __launch_bounds__(256) void blk_channel_sum_kernel(const u32x4* __restrict__ dy, float* __restrict__ db, int B, int Cb, int HW, int hid,
+                                                              int splits) {
+  const int cb = blockIdx.x / splits, sp = blockIdx.x % splits;
+  const long n = (long)B * HW;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v[8];
+  for (long i = (long)sp * 256 + threadIdx.x; i < n; i += (long)splits * 256) {
+    const long b = i / HW;
+    kd_unpack(dy[(b * Cb + cb) * HW + (i - b * HW)], v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+  }
+  __shared__ float red[4][8];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float s = acc[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) red[wv][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int c = cb * 8 + threadIdx.x;
+    const int row = hid > 0 ? (c & 3) * hid + (c >> 2) : c;
+    atomicAdd(db + row, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+int rsis_l_blk_channel_sum(const void* dy, float* db, int B, int C, int HW, int hid, hipStream_t st) {
+  const int Cb = C >> 3;
+  const long n = (long)B * HW;
+  int splits = 1;
+  if (!rsis_deterministic()) {
+    splits = (int)((n + 2047) / 2048);
+    const int cap = (1024 + Cb - 1) / Cb;
+    if (splits > cap) splits = cap;
+    if (splits < 1) splits = 1;
+  }
+  hipLaunchKernelGGL(blk_channel_sum_kernel, dim3(Cb * splits), dim3(256), 0, st, (const u32x4*)dy, db, B, Cb, HW, hid, splits);
+  return rsis_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv_out on the blk hidden state of the last level (8 channels = ONE cell per pixel), all T timesteps in one launch.
 // x / dx: [T * B][H][W][8] bf16 (image t * B + b); y / dy: fp32 [B][T][H * W] (image b * T + t, the (B, T, N) layout of train.py:118).
 // w[72] = W[0][c][r][s] (reference layout), fp32.

@@ -53,7 +53,7 @@ def supported(decoder, skip_feats, T):
 
 
 class _Level(object):
-    __slots__ = ("cell", "hid", "c_up", "c_skip", "H", "W", "hoist", "dyn", "G", "Hs", "Cs", "ACT", "UP", "KEY", "SIDE", "ARG")
+    __slots__ = ("cell", "hid", "c_up", "c_skip", "H", "W", "hoist", "dyn", "G", "Hs", "Cs", "ACT", "UP", "KEY", "SIDE", "ARG", "skip")
 
 
 def _conv_out_seq_ok(Cin, W):
@@ -338,7 +338,237 @@ class _DecoderSeqFn(torch.autograd.Function):
         return (None, None, None) + tuple(dfeats) + tuple(grads_par)
 
 
-def decoder_sequence_stacked(decoder, skip_feats, T):
+# RSIS_DECODER_BLK=0: keep fp32 NCHW storage in the decoder under -dtype bf16 (bf16 operands only, the round-3 path)
+BLK_ENABLED = [os.environ.get("RSIS_DECODER_BLK", "1") != "0"]
+
+
+def blk_supported(decoder, skip_feats):
+    """the decoder's storage half of `-dtype bf16`: every tensor of the recurrence as channel-blocked bf16 (csrc/conv_blk_dec.hip,
+    blk_dec.hip) -- needs bf16 cells, whole 8-channel cells at every level and the 8-channel conv_out (hidden_size % 128 == 0)"""
+    if not BLK_ENABLED[0]:
+        return False
+    hs = [c.hidden_size for c in decoder.clstm_list]
+    if not all(getattr(c, "dtype", ops.DTYPE_F32) == ops.DTYPE_BF16 for c in decoder.clstm_list):
+        return False
+    if any(h % 8 for h in hs) or any(f.shape[1] % 8 for f in skip_feats) or hs[-1] != 8:
+        return False
+    return (2 * skip_feats[-1].shape[3]) % 4 == 0
+
+
+class _DecoderSeqBlkFn(torch.autograd.Function):
+    """_DecoderSeqFn with every tensor of the recurrence stored channel-blocked bf16: hidden states, saved gates, up-sampled inputs,
+    the hoisted gate terms and every gradient of them; the cell state and its gradient stay fp32.  Per diagonal ONE grouped launch
+    per kind of work (gate convs, upsamples; backward: upsample transposes, pointwise LSTM backward, data gradients)."""
+
+    @staticmethod
+    def forward(ctx, decoder, T, keep, want_hidden, *tensors):
+        L = lib()
+        n = len(decoder.clstm_list)
+        feats = [t if t.is_contiguous() else t.contiguous() for t in tensors[:n]]
+        params = tensors[n:]
+        gates_w = [params[2 * i] for i in range(n)]
+        gates_b = [params[2 * i + 1] for i in range(n)]
+        co_w, co_b, Wc, bc, Ws, bs = params[2 * n:2 * n + 6]
+        _lib.require_cuda_f32(*feats, *params)
+        need_grad = bool(keep) and any(ctx.needs_input_grad)
+        dev = feats[0].device
+        B = feats[0].shape[0]
+        hs = [c.hidden_size for c in decoder.clstm_list]
+        tot = sum(hs)
+        f32 = dict(dtype=torch.float32, device=dev)
+        b16 = dict(dtype=torch.bfloat16, device=dev)
+        KEY = torch.zeros(T * B * tot, dtype=torch.int64, device=dev)
+        SIDE = torch.empty(T * B * tot, **f32)
+        ARG = torch.empty(T * B * tot, dtype=torch.int32, device=dev)
+        levels, off, hoist_jobs = [], 0, []
+        for i, cell in enumerate(decoder.clstm_list):
+            lv = _Level()
+            lv.cell, lv.hid, lv.c_up, lv.c_skip = cell, hs[i], (0 if i == 0 else hs[i - 1]), feats[i].shape[1]
+            lv.H, lv.W = feats[i].shape[2], feats[i].shape[3]
+            lv.hoist, lv.dyn = decoder_fused._packs(cell, lv.c_up, lv.c_skip)
+            lv.skip = ops.blk_from_nchw(feats[i])
+            lv.G = torch.empty((B, 4 * lv.hid // 8, lv.H, lv.W, 8), **b16)
+            hoist_jobs.append(ops.blk_conv_job([lv.skip], lv.hoist.fwd(gates_w[i], gates_b[i]), 4 * lv.hid, bias=lv.hoist.bias_p, dsts=[lv.G]))
+            lv.Hs = torch.empty((T, B, lv.hid // 8, lv.H, lv.W, 8), **b16)
+            lv.Cs = torch.empty((T, B, lv.hid, lv.H, lv.W), **f32)
+            lv.ACT = torch.empty((T, B, 4 * lv.hid // 8, lv.H, lv.W, 8), **b16) if need_grad else None
+            lv.UP = torch.empty((T, B, lv.c_up // 8, lv.H, lv.W, 8), **b16) if lv.c_up > 0 else None
+            m = T * B * lv.hid
+            lv.KEY, lv.SIDE, lv.ARG = KEY[off:off + m].view(T, B, lv.hid), SIDE[off:off + m].view(T, B, lv.hid), ARG[off:off + m].view(T, B, lv.hid)
+            off += m
+            levels.append(lv)
+        ops.blk_conv3x3_batch(hoist_jobs)          # G_i = W[:, skip channels] * skip_i + b of all five levels: one grouped launch
+        last = levels[-1]
+        H5, W5 = 2 * last.H, 2 * last.W
+        UP5 = torch.empty((T, B, 1, H5, W5, 8), **b16)
+        ncls = Wc.shape[0]
+        probs_tb = torch.empty((T, B, ncls), **f32)
+        stop_tb = torch.empty((T, B, 1), **f32)
+        wps = [lv.dyn.fwd(gates_w[i]) for i, lv in enumerate(levels)]
+        Wc_d, bc_d, Ws_d, bs_d = Wc.detach(), bc.detach(), Ws.detach(), bs.detach()
+        for d in range(T + n - 1):
+            cells = [(i, d - i) for i in range(n) if 0 <= d - i < T]
+            jobs, ups = [], []
+            for i, t in cells:
+                lv = levels[i]
+                srcs = ([lv.UP[t]] if lv.c_up > 0 else []) + ([lv.Hs[t - 1]] if t > 0 else [])
+                jobs.append(ops.blk_conv_job(srcs, wps[i], 4 * lv.hid, addend=lv.G, hid=lv.hid, c_prev=lv.Cs[t - 1] if t > 0 else None, c_out=lv.Cs[t],
+                                             h_out=lv.Hs[t], act_out=lv.ACT[t] if lv.ACT is not None else None, side_key=lv.KEY[t],
+                                             shape=(B, lv.H, lv.W)))
+                ups.append(ops.blk_resize_job(lv.Hs[t], levels[i + 1].UP[t] if i + 1 < n else UP5[t]))
+            ops.blk_conv3x3_batch(jobs)
+            ops.blk_upsample_fwd_batch(ups)
+            if cells[-1][0] == n - 1:
+                t = cells[-1][1]
+                check(L.rsis_heads_fwd_keys(ptr_array([v.KEY[t] for v in levels]), ptr_array([v.SIDE[t] for v in levels]),
+                                            ptr_array([v.ARG[t] for v in levels]), int_array(hs), n, B, ptr(Wc_d), ptr(bc_d), ncls,
+                                            ptr(Ws_d), ptr(bs_d), ptr(probs_tb[t]), ptr(stop_tb[t]), stream()), "rsis_heads_fwd_keys")
+        out_masks = torch.empty((B, T, H5 * W5), **f32)
+        check(L.rsis_blk_conv_out_seq_fwd(ptr(UP5), ptr(co_w.detach()), ptr(co_b.detach()), ptr(out_masks), T, B, H5, W5, stream()),
+              "rsis_blk_conv_out_seq_fwd")
+        out_probs = probs_tb.transpose(0, 1).contiguous()
+        out_stops = stop_tb.transpose(0, 1).contiguous()
+        hidden = []
+        if want_hidden:
+            for lv in levels:
+                hidden += [ops.blk_to_nchw(lv.Hs[T - 1]), lv.Cs[T - 1]]
+        ctx.set_materialize_grads(False)
+        if need_grad:
+            ctx.decoder, ctx.T, ctx.levels = decoder, T, levels
+            ctx.UP5, ctx.probs_tb, ctx.feats, ctx.params = UP5, probs_tb, feats, params
+        else:
+            for lv in levels:
+                lv.G = lv.ACT = lv.UP = lv.skip = None
+        return (out_masks, out_probs, out_stops) + tuple(hidden)
+
+    @staticmethod
+    def backward(ctx, d_masks, d_probs, d_stops, *d_hidden):
+        L = lib()
+        decoder, T, levels = ctx.decoder, ctx.T, ctx.levels
+        n = len(levels)
+        feats, params = ctx.feats, ctx.params
+        gates_w = [params[2 * i] for i in range(n)]
+        co_w, co_b, Wc, bc, Ws, bs = params[2 * n:2 * n + 6]
+        need = ctx.needs_input_grad            # (decoder, T, keep, want_hidden, feats..., params...)
+        need_feat = [need[4 + i] for i in range(n)]
+        need_par = [need[4 + n + k] for k in range(len(params))]
+        dev = feats[0].device
+        B = feats[0].shape[0]
+        hs = [lv.hid for lv in levels]
+        f32 = dict(dtype=torch.float32, device=dev)
+        b16 = dict(dtype=torch.bfloat16, device=dev)
+        last = levels[-1]
+        H5, W5 = 2 * last.H, 2 * last.W
+        UP5 = ctx.UP5
+        grads_par = [None] * len(params)
+
+        def target(k):
+            p = params[k]
+            t = ops._direct_target(p)
+            if t is not None:
+                return t, True
+            g = torch.zeros_like(p)
+            grads_par[k] = g
+            return g, False
+
+        dUP5 = torch.empty_like(UP5)
+        if d_masks is None:
+            dUP5.zero_()
+        else:
+            d_masks = d_masks if d_masks.is_contiguous() else d_masks.contiguous()
+            kw, kb = 2 * n, 2 * n + 1
+            check(L.rsis_blk_conv_out_seq_dgrad(ptr(d_masks), ptr(co_w.detach()), ptr(dUP5), T, B, H5, W5, stream()), "rsis_blk_conv_out_seq_dgrad")
+            if need_par[kw] or need_par[kb]:
+                dW = target(kw)[0] if need_par[kw] else torch.zeros_like(co_w)
+                db = target(kb)[0] if need_par[kb] else None
+                check(L.rsis_blk_conv_out_seq_wgrad(ptr(d_masks), ptr(UP5), ptr(dW), ptr(db), T, B, H5, W5, stream()), "rsis_blk_conv_out_seq_wgrad")
+        tot = sum(hs)
+        DSIDE = torch.empty(T * B * tot, **f32)
+        dsides, off = [], 0
+        for lv in levels:
+            m = T * B * lv.hid
+            dsides.append(DSIDE[off:off + m].view(T, B, lv.hid))
+            off += m
+        if d_probs is None and d_stops is None:
+            DSIDE.zero_()
+        else:
+            dp_tb = d_probs.transpose(0, 1).contiguous() if d_probs is not None else None
+            ds_tb = d_stops.transpose(0, 1).contiguous() if d_stops is not None else None
+            hb = [target(2 * n + 2 + k)[0] if need_par[2 * n + 2 + k] else None for k in range(4)]
+            for t in range(T):
+                check(L.rsis_heads_bwd(ptr_array([lv.SIDE[t] for lv in levels]), int_array(hs), n, B, ptr(Wc.detach()), Wc.shape[0],
+                                       ptr(Ws.detach()), ptr(ctx.probs_tb[t]), ptr(dp_tb[t]) if dp_tb is not None else None,
+                                       ptr(ds_tb[t]) if ds_tb is not None else None, ptr_array([ds[t] for ds in dsides]), ptr(hb[0]), ptr(hb[1]),
+                                       ptr(hb[2]), ptr(hb[3]), stream()), "rsis_heads_bwd")
+        DA = [torch.empty_like(lv.ACT) for lv in levels]
+        DH = [torch.empty((B, lv.hid // 8, lv.H, lv.W, 8), **b16) for lv in levels]
+        DHP = [torch.empty((B, lv.hid // 8, lv.H, lv.W, 8), **b16) for lv in levels]
+        DC = [[torch.empty((B, lv.hid, lv.H, lv.W), **f32) for _ in range(2)] for lv in levels]
+        DUP = [torch.empty((B, lv.c_up // 8, lv.H, lv.W, 8), **b16) if lv.c_up > 0 else None for lv in levels]
+        wds = [lv.dyn.dgrad(gates_w[i]) for i, lv in enumerate(levels)]
+        dhf = [ops.blk_from_nchw(d_hidden[2 * i].contiguous()) if (len(d_hidden) > 2 * i and d_hidden[2 * i] is not None) else None for i in range(n)]
+        dcf = [d_hidden[2 * i + 1].contiguous() if (len(d_hidden) > 2 * i + 1 and d_hidden[2 * i + 1] is not None) else None for i in range(n)]
+        for d in range(T + n - 2, -1, -1):
+            cells = [(i, d - i) for i in range(n) if 0 <= d - i < T]
+            ups, lbs, dgs = [], [], []
+            for i, t in cells:
+                lv = levels[i]
+                dy = DUP[i + 1] if i + 1 < n else dUP5[t]
+                ups.append(ops.blk_resize_job(dy, DH[i], dsides[i][t], lv.ARG[t], backward=True))
+                dh2, dcn = (dhf[i], dcf[i]) if t == T - 1 else (DHP[i], DC[i][(t + 1) & 1])
+                lbs.append(ops.blk_lstm_bwd_job(DH[i], dh2, dcn, lv.ACT[t], lv.Cs[t - 1] if t > 0 else None, lv.Cs[t], DA[i][t],
+                                                DC[i][t & 1] if t > 0 else None))
+                dxs = ([DUP[i]] if lv.c_up > 0 else []) + ([DHP[i]] if t > 0 else [])
+                if dxs:
+                    dgs.append(ops.blk_conv_job([DA[i][t]], wds[i], sum(x.shape[1] for x in dxs) * 8, cpack=lv.dyn.cin, dsts=dxs))
+            ops.blk_upsample_bwd_batch(ups)
+            ops.blk_lstm_bwd_batch(lbs)
+            if dgs:
+                ops.blk_conv3x3_batch(dgs)
+        dfeats = [None] * n
+        dG, dskip_jobs = [], []
+        for i, lv in enumerate(levels):
+            if T == 1:
+                dG.append(DA[i][0])
+            else:
+                g = torch.empty_like(lv.G)
+                check(L.rsis_blk_sum_leading(ptr(DA[i]), ptr(g), T, g.numel() // 8, stream()), "rsis_blk_sum_leading")
+                dG.append(g)
+        dskips = [None] * n
+        for i, lv in enumerate(levels):
+            if need_feat[i]:
+                dskips[i] = torch.empty_like(lv.skip)
+                dskip_jobs.append(ops.blk_conv_job([dG[i]], lv.hoist.dgrad(gates_w[i]), lv.c_skip, cpack=lv.hoist.cin, dsts=[dskips[i]]))
+        if dskip_jobs:
+            ops.blk_conv3x3_batch(dskip_jobs)       # the data gradients of the five skip terms: one grouped launch
+        for i, lv in enumerate(levels):
+            kw, kb = 2 * i, 2 * i + 1
+            hid, H, W = lv.hid, lv.H, lv.W
+            if dskips[i] is not None:
+                dfeats[i] = ops.blk_to_nchw(dskips[i])
+            if need_par[kb]:
+                db, _ = target(kb)
+                check(L.rsis_blk_bias_grad(ptr(dG[i]), ptr(db), B, 4 * hid, H * W, hid, stream()), "rsis_blk_bias_grad")
+            if need_par[kw]:
+                dW, direct = target(kw)
+                Ctot = gates_w[i].shape[1]
+                h_off = lv.c_up + lv.c_skip
+                blk = ops.DTYPE_BF16_BLK
+                ops.wgrad_launch(L, dG[i], lv.skip, dW, B, lv.c_skip, H, W, 4 * hid, H, W, 3, 1, 1, Ctot, lv.c_up, hid, blk, "rsis_conv2d_wgrad(hoist, blk)",
+                                 direct)
+                if lv.c_up > 0:
+                    ops.wgrad_launch(L, DA[i], lv.UP, dW, T * B, lv.c_up, H, W, 4 * hid, H, W, 3, 1, 1, Ctot, 0, hid, blk,
+                                     "rsis_conv2d_wgrad(batched up, blk)", direct)
+                if T > 1:
+                    ops.wgrad_launch(L, DA[i][1], lv.Hs, dW, (T - 1) * B, hid, H, W, 4 * hid, H, W, 3, 1, 1, Ctot, h_off, hid, blk,
+                                     "rsis_conv2d_wgrad(batched h, blk)", direct)
+        for lv in levels:
+            lv.G = lv.Hs = lv.Cs = lv.ACT = lv.UP = lv.skip = None
+        ctx.levels = ctx.UP5 = ctx.feats = ctx.params = ctx.decoder = None
+        return (None, None, None, None) + tuple(dfeats) + tuple(grads_par)
+
+
+def decoder_sequence_stacked(decoder, skip_feats, T, want_hidden=True):
     """(out_masks (B, T, H*W) logits, class_probs (B, T, C), stop logits (B, T, 1), hidden_list, (H, W) of the masks)"""
     n = len(decoder.clstm_list)
     params = []
@@ -347,8 +577,11 @@ def decoder_sequence_stacked(decoder, skip_feats, T):
     params += [decoder.conv_out.weight, decoder.conv_out.bias, decoder.fc_class.weight, decoder.fc_class.bias, decoder.fc_stop.weight,
                decoder.fc_stop.bias]
     keep = torch.is_grad_enabled() and (any(f.requires_grad for f in skip_feats) or any(p.requires_grad for p in params))
-    res = _DecoderSeqFn.apply(decoder, int(T), keep, *skip_feats, *params)
+    if blk_supported(decoder, skip_feats):
+        res = _DecoderSeqBlkFn.apply(decoder, int(T), keep, bool(want_hidden), *skip_feats, *params)
+    else:
+        res = _DecoderSeqFn.apply(decoder, int(T), keep, *skip_feats, *params)
     out_masks, out_probs, out_stops = res[:3]
-    hidden = [[res[3 + 2 * i], res[4 + 2 * i]] for i in range(n)]
+    hidden = [[res[3 + 2 * i], res[4 + 2 * i]] for i in range(n)] if len(res) > 3 else None
     size = (2 * skip_feats[-1].shape[2], 2 * skip_feats[-1].shape[3])
     return out_masks, out_probs, out_stops, hidden, size

@@ -192,12 +192,12 @@ class RSIS(nn.Module):
             outs.append((out_mask, out_class, out_stop))
         return outs, hidden
 
-    def forward_sequence_stacked(self, skip_feats, T):
+    def forward_sequence_stacked(self, skip_feats, T, want_hidden=True):
         """forward_sequence with the per-step outputs stacked the way reference train.py:117-120 stacks them: (out_masks (B, T, H*W) logits,
         class_probs (B, T, C), stop logits (B, T, 1), hidden_list, (H, W) of the masks) -- or None where only the per-step path applies"""
         if not decoder_seq.supported(self, skip_feats, T):
             return None
-        return decoder_seq.decoder_sequence_stacked(self, skip_feats, T)
+        return decoder_seq.decoder_sequence_stacked(self, skip_feats, T, want_hidden)
 
     def forward(self, skip_feats, prev_hidden_list):
         if self.fused and self.skip_mode == "concat" and self.dropout == 0 and len(skip_feats) == len(self.clstm_list):

@@ -102,7 +102,8 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
         feats = encoder(x)                                           # train.py:77 (once per iteration)
         # train.py:85-94: t_run decoder steps from the zero state -- RSIS.forward_sequence runs them in wavefront order with the
         # gate kernels of a (level, step) diagonal in one launch; same nodes, same results as t_run calls of decoder(feats, hidden)
-        stacked = decoder.forward_sequence_stacked(feats, t_run) if hasattr(decoder, "forward_sequence_stacked") else None
+        # (train.py never reads the final recurrent state: it is not materialised)
+        stacked = decoder.forward_sequence_stacked(feats, t_run, want_hidden=False) if hasattr(decoder, "forward_sequence_stacked") else None
         if stacked is not None:
             # the whole sequence as ONE autograd node (rsis_amd/decoder_seq.py): outputs already in the (B, t, .) layout of :118-120
             out_masks, out_classes, out_stops, hidden, (Hm, Wm) = stacked
