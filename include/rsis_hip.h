@@ -363,7 +363,7 @@ int rsis_blk_upscatter2d(const void* dy_blk, void* dx_blk, int B, int C, int H, 
  *   hid > 0, fused ConvLSTM cell (rows gate-interleaved 4 j + gate, Cout = 4 hid, hid % 8 == 0): gates = conv (+ bias) + addend (blk
  *     [B][4 hid], the time-invariant skip term) -> i, f, o = sigmoid, g = tanh, c = f c_prev + i g, h = o tanh(c).  c_prev (NULL = zero
  *     state) / c_out: fp32 [B][hid][H][W]; h_out: blk [B][hid]; act_out (may be NULL): blk [B][4 hid], the post-nonlinearity gates;
- *     side_key (may be NULL): [B][hid] keys of the global max-pool of the STORED h, as rsis_lstm_job.side_key.  nsrc may be 0. */
+ *     side_key (may be NULL): [B][hid] keys of the global max-pool of h (fp32, before the rounding of h_out), as rsis_lstm_job.side_key.  nsrc may be 0. */
 typedef struct rsis_blk_conv_job {
   const void* src[3];
   int Csrc[3];

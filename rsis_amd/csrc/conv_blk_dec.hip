@@ -6,8 +6,10 @@
 //   * the channel concat of up to three blk sources ([up(h) | h_prev], torch.cat of clstm.py:43 folded into the chunk cursor),
 //   * the fused LSTM cell epilogue: gates = acc + G (blk addend, the hoisted skip term) -> sigma / tanh -> c (fp32 NCHW: the cell
 //     state keeps its precision over the T steps), h (blk, rounded ONCE), the saved gates (blk, rows 4 j + gate) and the packed
-//     (value, pixel) keys of the global max-pool side feature (model.py:143) -- computed from the STORED (rounded) h, so that the
-//     pooled feature is exactly the maximum of the tensor every other consumer reads,
+//     (value, pixel) keys of the global max-pool side feature (model.py:143) -- taken from the fp32 h BEFORE it is rounded for
+//     storage: the heads see the unrounded maximum and the arg-max (which routes the pooled gradient) is decided on fp32 values;
+//     deciding it on the rounded tensor makes every pixel within 2^-9 of the maximum a tie for "first", and on the 7 / 14-pixel
+//     levels that moved the gradients of levels 0-1 from 2 % to 5 % of their float64 value (tools/exp/diag_blk_decoder.py),
 //   * a plain epilogue with fp32 bias and up to two blk destinations splitting the output channels (the data gradient's
 //     d(up) | d(h_prev), the inverse of the concat),
 //   * several independent convs in ONE grid: the cells (level i, step d - i) of a diagonal of the decoder's (level, timestep)
@@ -261,7 +263,7 @@ __device__ __forceinline__ void bd_body(const BlkConvJob& p, const int bid, u32x
         const float ao = acc[j][4 * r4 + 2] + bv[4 * r4 + 2] + bd_lo(ga[r4][1]), ag = acc[j][4 * r4 + 3] + bv[4 * r4 + 3] + bd_hi(ga[r4][1]);
         const float gi = rsis_sigmoid(ai), gf = rsis_sigmoid(af), go = rsis_sigmoid(ao), gg = tanhf(ag);
         const float c = gf * cpv[r4] + gi * gg;     // clstm.py:57
-        const float h = bd_round(go * tanhf(c));    // clstm.py:58, as stored
+        const float h = go * tanhf(c);              // clstm.py:58
         hv[r4] = h;
         if (p.side_key && ok) { const unsigned long long k = rsis_side_key(h, osp); best[r4] = k > best[r4] ? k : best[r4]; }
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), r_c, ok ? (unsigned)(jh * HW + osp) * 4u : RSIS_OOB, 0, 0);
