@@ -169,6 +169,62 @@ def gate_kernel_roofline(B, iters, imsize, dtype="fp32", T=10, product_only=Fals
     return out
 
 
+def gate_kernel_roofline_blk(B, iters, imsize, T=10):
+    """bf16 (`-dtype bf16`): the gate kernels as rsis_amd.decoder_seq._DecoderSeqBlkFn launches them -- every tensor of the recurrence
+    channel-blocked bf16 (cell state fp32), the five levels of a wavefront diagonal as ONE rsis_blk_conv3x3_batch call
+    (conv_blk_dec_group_kernel<1>).  Bound: HBM.  Algorithmic bytes per pixel of a level: [up | h_prev] in (2 B per channel), the hoisted
+    gate term G in (4 hid x 2 B), c_prev in / c out (hid x 4 B each), h out (hid x 2 B), saved gates out (4 hid x 2 B)."""
+    from rsis_amd import ops
+    L_rows, jobs, tot_bytes, tot_flops, keep = [], [], 0.0, 0.0, []
+    dt = ops.DTYPE_BF16
+    b16 = dict(dtype=torch.bfloat16, device="cuda")
+    singles_ms = 0.0
+    hoist_ms = 0.0
+    for li, (segs, hid, hw) in enumerate(GATE_LAYERS):
+        H = W = hw * imsize // 256
+        c_skip = segs[-1]
+        c_up = segs[0] if len(segs) > 1 else 0
+        cin = sum(segs) + hid
+        w = torch.randn(4 * hid, cin, 3, 3, device="cuda") * (1.0 / (3.0 * cin ** 0.5))
+        bias = torch.randn(4 * hid, device="cuda") * 0.1
+        hoist = ops.PackedConv(3, [c_skip], lstm_hid=hid, offs=[c_up], dtype=dt)
+        dyn = ops.PackedConv(3, ([c_up] if c_up else []) + [hid], lstm_hid=hid, offs=([0] if c_up else []) + [c_up + c_skip], dtype=dt)
+        wh, wd = hoist.fwd(w, bias), dyn.fwd(w)
+        skip = torch.randn((B, c_skip // 8, H, W, 8), device="cuda").to(torch.bfloat16)
+        G = torch.empty((B, 4 * hid // 8, H, W, 8), **b16)
+        ms_h = _time_launch(lambda: ops.blk_conv3x3_batch([ops.blk_conv_job([skip], wh, 4 * hid, bias=hoist.bias_p, dsts=[G])]), max(2, iters // 4))
+        srcs = ([torch.randn((B, c_up // 8, H, W, 8), device="cuda").to(torch.bfloat16)] if c_up else []) + \
+               [torch.tanh(torch.randn((B, hid // 8, H, W, 8), device="cuda")).to(torch.bfloat16)]
+        c_prev = torch.randn(B, hid, H, W, device="cuda")
+        h, c = torch.empty((B, hid // 8, H, W, 8), **b16), torch.empty_like(c_prev)
+        act = torch.empty((B, 4 * hid // 8, H, W, 8), **b16)
+        job = ops.blk_conv_job(srcs, wd, 4 * hid, addend=G, hid=hid, c_prev=c_prev, c_out=c, h_out=h, act_out=act)
+        ms = _time_launch(lambda: ops.blk_conv3x3_batch([job]), iters)
+        M = B * H * W
+        fl = 2.0 * M * ((c_up + hid) * 9) * (4 * hid)
+        byts = 1.0 * M * (2 * (c_up + hid) + 2 * 4 * hid + 4 * hid + 2 * hid + 4 * hid + 2 * 4 * hid)
+        L_rows.append({"HxW": "%dx%d" % (H, W), "gemm_MKN_product": [M, (c_up + hid) * 9, 4 * hid], "ms_product": round(ms, 4),
+                       "tflops_product": round(fl / ms / 1e9, 2), "gbs_product": round(byts / ms / 1e6, 1), "mbytes": round(byts / 1e6, 1),
+                       "ms_hoist_per_iteration": round(ms_h, 4)})
+        jobs.append(job)
+        keep.append((w, wh, wd, skip, G, srcs, c_prev, h, c, act))
+        tot_bytes += byts
+        tot_flops += fl
+        singles_ms += ms
+        hoist_ms += ms_h
+    ms_diag = _time_launch(lambda: ops.blk_conv3x3_batch(jobs), iters)
+    gbs = tot_bytes / ms_diag / 1e6
+    return {"kernel": "conv_blk_dec_group_kernel<1> (rsis_blk_conv3x3_batch): the ConvLSTM gate kernels of the 5 pyramid levels -- one decoder "
+                      "timestep's worth of work -- as rsis_amd.decoder_seq launches them under -dtype bf16: channel-blocked bf16 operands / "
+                      "hidden state / saved gates, fp32 cell state, the cells of one (level, timestep) wavefront diagonal in ONE grid",
+            "per_scale": L_rows, "ms_per_timestep": round(ms_diag, 4), "ms_per_timestep_as_five_single_launches": round(singles_ms, 4),
+            "executed_gflop_per_timestep": round(tot_flops / 1e9, 3), "hoisted_convs_ms_per_iteration": round(hoist_ms, 4),
+            "achieved_executed": round(tot_flops / ms_diag / 1e9, 2), "achieved_algorithmic": None, "full_k": {"achieved": None, "note": "fp32 only"},
+            "algorithmic_mbytes_per_timestep": round(tot_bytes / 1e6, 1), "traffic": None,
+            "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "note": "bf16 MFMA at 16x the f32 rate: the launch is bound by its activation traffic (2 B per blk element, 4 B per cell-state element)"}
+
+
 # (Cin, Cout, ks, out HxW at 256^2, layers of that shape in ResNet-101 + skip convs) -- SURVEY.md Appendix A
 N_TRUNK_SHAPES = 11      # the first 11 are trunk layers (blocked bf16 activations under -dtype bf16), the last three the skip convs
 TRUNK_SHAPES = [(256, 256, 3, 16, 22), (256, 1024, 1, 16, 23), (1024, 256, 1, 16, 22), (64, 64, 3, 64, 3), (128, 128, 3, 32, 3),
@@ -329,6 +385,8 @@ GATE_KERNEL_RE = re.compile(r"conv3x3_direct_kernel<\d+, \d+, \d+, \d+, 1, \d+, 
 GATE_GROUP_RE = re.compile(r"conv3x3_direct_group_kernel<1>")
 # ... and its bf16 twin, conv_bf16_kernel<KS, BM, TW, TH, EPI, CKB, V4> with KS == 3 and EPI == 1 (five single launches per diagonal)
 GATE_BF16_RE = re.compile(r"conv_bf16_kernel<3, \d+, \d+, \d+, 1, \d+, \w+>")
+# ... and the grouped launch on channel-blocked bf16 tensors (rsis_blk_conv3x3_batch, LSTM epilogue): template argument <EPI>
+GATE_BLK_RE = re.compile(r"conv_blk_dec_group_kernel<1, \d>")
 
 
 def gate_kernel_traffic(batch, imsize, dtype="fp32", timeout=150):
@@ -338,6 +396,12 @@ def gate_kernel_traffic(batch, imsize, dtype="fp32", timeout=150):
     profiles/r02_fetch_calibration.txt).  fp32: ONE launch shape (the grouped kernel); bf16: the five single launches of the
     diagonal, summed.  Returns (bytes, detail) or (None, why)."""
     name_re, n_shapes = (GATE_GROUP_RE, 1) if dtype == "fp32" else (GATE_BF16_RE, 5)
+    blk = False
+    if dtype != "fp32":
+        from rsis_amd import decoder_seq
+        blk = decoder_seq.BLK_ENABLED[0]
+        if blk:        # the roofline leg launches the group kernel six times: five single-job grids and the five-job grid (the largest)
+            name_re, n_shapes = GATE_BLK_RE, 6
     import csv
     import shutil
     import statistics
@@ -368,6 +432,9 @@ def gate_kernel_traffic(batch, imsize, dtype="fp32", timeout=150):
                         vals.setdefault((k, r["Grid_Size"]), []).append(float(r["Counter_Value"]))
             if len(vals) != n_shapes:
                 return None, "expected %d gate-kernel launch shape(s) in the counter file, found %d" % (n_shapes, len(vals))
+            if blk:
+                big = max(vals, key=lambda kg: int(kg[1]))
+                vals = {big: vals[big]}
             per_counter[counter] = sum(statistics.median(v) for v in vals.values()) * 1024.0      # counters are in KiB
     except Exception as e:  # noqa: BLE001  (profiler missing / refused / timed out: the figure stays null)
         return None, "rocprofv3 pass failed: %r" % (e,)
@@ -375,6 +442,15 @@ def gate_kernel_traffic(batch, imsize, dtype="fp32", timeout=150):
         shutil.rmtree(tmp, ignore_errors=True)
     fetch, write = 2.0 * per_counter["FETCH_SIZE"], per_counter["WRITE_SIZE"]
     return fetch + write, {"fetch_bytes_x2": fetch, "write_bytes": write}
+
+
+def _gate_roofline(batch, iters, imsize, dtype, T, product_only=False):
+    """the gate-kernel roofline leg in the form the product launches for this dtype"""
+    if dtype != "fp32":
+        from rsis_amd import decoder_seq
+        if decoder_seq.BLK_ENABLED[0]:
+            return gate_kernel_roofline_blk(batch, iters, imsize, T)
+    return gate_kernel_roofline(batch, iters, imsize, dtype, T, product_only=product_only)
 
 
 def _free_port():
@@ -423,6 +499,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     ap.add_argument("--imsize", type=int, default=256)
+    ap.add_argument("--imsize-w", type=int, default=0, help="image width when it differs from --imsize (the height): 512 x 1024 = --imsize 512 --imsize-w 1024")
     ap.add_argument("--T", type=int, default=10)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="arithmetic of the conv / gate MFMA kernels")
     ap.add_argument("--kernel-iters", type=int, default=20)
@@ -446,7 +523,7 @@ def main():
         return
     if o.roofline_only:
         assert torch.cuda.is_available(), "bench.py needs the GPU (there is no CPU path)"
-        print(json.dumps(gate_kernel_roofline(o.batch, o.kernel_iters, o.imsize, o.dtype, o.T, product_only=o.product_only)))
+        print(json.dumps(_gate_roofline(o.batch, o.kernel_iters, o.imsize, o.dtype, o.T, product_only=o.product_only)))
         return
 
     if o.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -477,7 +554,12 @@ def main():
     force = os.environ.get("RSIS_FORCE_DIST", "") == "1"
     reducer = BucketedAllReduce([dec_opt.group, enc_opt.group], force=force) if (world > 1 or force) else None
     crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
-    batch = synthetic_batch(a.seed + 1000 * rank, o.batch, o.imsize, o.imsize, a.gt_maxseqlen, 12, a.num_classes, "cuda")
+    imw = o.imsize_w or o.imsize
+    if imw != o.imsize:
+        assert o.skip_roofline, "the roofline legs are defined on square inputs: pass --skip-roofline with --imsize-w"
+    # 12 instances per image; with T > 12 every slot is an instance, so that all T steps run (train.py:87-92 stops after the
+    # first step whose slot is empty in every image)
+    batch = synthetic_batch(a.seed + 1000 * rank, o.batch, o.imsize, imw, a.gt_maxseqlen, max(12, min(o.T, a.gt_maxseqlen)), a.num_classes, "cuda")
 
     from rsis_amd.train import steps_to_run
     t_run = steps_to_run(a, batch[3])      # early-stop rule evaluated once for the resident batch (it is all T steps here)
@@ -515,9 +597,9 @@ def main():
 
     roof = roof_kernels = None
     if rank == 0 and not o.skip_roofline:
-        roof = gate_kernel_roofline(o.batch, o.kernel_iters, o.imsize, o.dtype, o.T)
-        note("gate kernel roofline: executed %s, algorithmic %s, full-K %s TFLOP/s" % (roof["achieved_executed"], roof["achieved_algorithmic"],
-                                                                                       roof["full_k"]["achieved"]))
+        roof = _gate_roofline(o.batch, o.kernel_iters, o.imsize, o.dtype, o.T)
+        note("gate kernel roofline: executed %s, algorithmic %s, full-K %s TFLOP/s; %s %s of %s %s" % (
+            roof["achieved_executed"], roof["achieved_algorithmic"], roof["full_k"]["achieved"], roof["bound"], roof["achieved"], roof["peak"], roof["unit"]))
         roof_kernels = trunk_kernel_rooflines(o.batch, max(3, o.kernel_iters // 4), o.imsize, o.dtype)
         note("roofline_kernels: %s" % "; ".join("%s %.1f TF/s" % (r["family"], r["tflops"]) for r in roof_kernels))
         if world == 1 and not o.skip_traffic:
@@ -617,7 +699,7 @@ def main():
             secondary = []
             # (third record: bf16 operands on fp32 NCHW activations, RSIS_BF16_STORAGE=0 -- what the blocked bf16 trunk is measured against)
             for sd, extra, env in (("bf16", [], {}), ("fp32", ["--skip-traffic"], {}),
-                                   ("bf16", ["--skip-traffic", "--skip-roofline"], {"RSIS_BF16_STORAGE": "0"})):
+                                   ("bf16", ["--skip-traffic", "--skip-roofline"], {"RSIS_BF16_STORAGE": "0", "RSIS_DECODER_BLK": "0"})):
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", sd, "--imsize", "224", "--batch", str(o.batch), "--T",
                                         str(o.T), "--steps", str(o.steps), "--warmup", str(o.warmup), "--skip-cpu", "--skip-secondary",
@@ -631,21 +713,33 @@ def main():
             if all(s_.get("value") for s_ in secondary):
                 secondary[0]["speedup_over_fp32_same_geometry"] = round(secondary[0]["value"] / secondary[1]["value"], 3)
                 secondary[0]["speedup_over_bf16_operands_on_fp32_activations"] = round(secondary[0]["value"] / secondary[2]["value"], 3)
+            # BASELINE configs[4]'s per-GPU workload (Cityscapes geometry 512x1024, T=20, batch 8 per GPU, bf16), same harness, graph replay
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", "bf16", "--imsize", "512", "--imsize-w", "1024", "--batch", "8", "--T", "20",
+                                    "--steps", str(max(5, o.steps // 2)), "--warmup", str(o.warmup), "--skip-cpu", "--skip-secondary", "--skip-roofline"],
+                                   capture_output=True, text=True, timeout=600, env=dict(os.environ))
+                sj = json.loads(r.stdout.strip().splitlines()[-1])
+                sj["config"]["workload"] = sj["config"]["workload"].replace("configs[1]", "configs[4] per-GPU workload")
+                secondary.append({k: sj.get(k) for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config")})
+            except Exception as ex:  # noqa: BLE001
+                secondary.append({"dtype": "bf16", "config": "configs[4]", "error": repr(ex)})
             note("secondary (224x224): bf16 %s images/s, fp32 %s images/s" % (secondary[0].get("value"), secondary[1].get("value")))
         value = world * o.batch * o.steps / dt
-        out = {"metric": "training images/sec at %dx%d, T=%d, batch=%d per GPU" % (o.imsize, o.imsize, o.T, o.batch),
+        out = {"metric": "training images/sec at %dx%d, T=%d, batch=%d per GPU" % (o.imsize, imw, o.T, o.batch),
                "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": o.steps, "warmup": o.warmup,
                "ms_per_step": round(1000.0 * dt / o.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if o.dtype == "fp32" else "bf16", "data": "synthetic",
                "config": {"workload": "configs[1]: synthetic %dx%dx3, T=%d, batch=%d/GPU, ResNet-101 encoder + 5-scale ConvLSTM "
-                                      "decoder, %s, fwd+match+3 losses+bwd+Adam (update_encoder on)" % (o.imsize, o.imsize, o.T, o.batch, o.dtype),
+                                      "decoder, %s, fwd+match+3 losses+bwd+Adam (update_encoder on)" % (o.imsize, imw, o.T, o.batch, o.dtype),
                           "global_batch": world * o.batch, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5),
                           "launch": "hipGraph replay of the captured iteration" if (gstep is not None and gstep.graph is not None)
                                     else "eager (one Python launch per kernel)"},
                "roofline": roof, "roofline_kernels": roof_kernels, "cpu_baseline": cpu, "secondary": secondary}
         if o.dtype != "fp32":
             from rsis_amd import blk_trunk
-            out["config"]["activations"] = ("trunk layers 1-4: channel-blocked bf16 (rsis_amd/blk_trunk.py); stem, skip convs, decoder: fp32 NCHW"
+            from rsis_amd import decoder_seq
+            out["config"]["activations"] = ("trunk layers 1-4: channel-blocked bf16 (rsis_amd/blk_trunk.py); decoder: %s; stem, skip convs: fp32 NCHW"
+                                            % ("channel-blocked bf16, fp32 cell state (rsis_amd/decoder_seq.py)" if decoder_seq.BLK_ENABLED[0] else "fp32 NCHW")
                                             if blk_trunk.ENABLED[0] else "fp32 NCHW everywhere (RSIS_BF16_STORAGE=0: bf16 operands only)")
         if seg is not None:
             out["config"]["exchange_ms_per_step"] = {k: round(v, 3) for k, v in seg.items()}

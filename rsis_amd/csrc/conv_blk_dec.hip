@@ -21,6 +21,7 @@
 // gates of hidden channels 2 r4 + hi: the two lanes (l31, hi = 0 / 1) exchange two values each (one wave shuffle pair) to own
 // channels 0-3 / 4-7 of the cell.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((address_space(3))) void* lds_vp_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -47,14 +48,14 @@ __device__ __forceinline__ float bd_round(float v) { return bd_lo(bd_pack2(v, 0.
 
 constexpr int bd_up256(int n) { return (n + 255) / 256 * 256; }
 // 16-byte cells of LDS one block of a tile variant needs: a ring of 3 stages of (activation patch + weight chunk)
-template <int BM, int TW, int TH>
-constexpr int bd_lds_cells() { return 3 * (bd_up256(2 * (TH + 2) * (TW + 2)) + bd_up256(9 * 2 * BM)); }
+template <int BM, int TW, int TH, int NR>
+constexpr int bd_lds_cells() { return NR * (bd_up256(2 * (TH + 2) * (TW + 2)) + bd_up256(9 * 2 * BM)); }
 
 // The block program.  bid: the block's index inside its job.
-template <int BM, int TW, int TH, int EPI>
+template <int BM, int TW, int TH, int EPI, int NR>
 __device__ __forceinline__ void bd_body(const BlkConvJob& p, const int bid, u32x4* const lds) {
 #if __HIP_DEVICE_COMPILE__
-  constexpr int NR = 3, NCB = 2, KK = 9;
+  constexpr int NCB = 2, KK = 9;
   constexpr int BN = TW * TH;
   constexpr int WGM = BM / 32, WGN = 4 / WGM;
   constexpr int TN = BN / WGN / 32;
@@ -64,8 +65,8 @@ __device__ __forceinline__ void bd_body(const BlkConvJob& p, const int bid, u32x
   constexpr int XCP = NXD * 256, WCP = NWD * 256;
   constexpr int C_DMA = NXD + NWD;
   static_assert(TN >= 1 && BN % (WGN * 32) == 0 && WGM * WGN == 4, "tile");
-  static_assert(NR * (XCP + WCP) == bd_lds_cells<BM, TW, TH>(), "LDS size helper out of sync");
-  static_assert((NR - 2) * C_DMA < 64, "vmcnt is 6 bits");
+  static_assert(NR * (XCP + WCP) == bd_lds_cells<BM, TW, TH, NR>(), "LDS size helper out of sync");
+  static_assert(NR >= 2 && NR <= 3 && (NR - 2) * C_DMA < 64, "vmcnt is 6 bits");
 
   u32x4* const xs0 = lds;
   u32x4* const ws0 = lds + NR * XCP;
@@ -301,9 +302,9 @@ constexpr int bd_max(int a, int b) { return a > b ? a : b; }
 
 // tile variants of the group kernel: 1 = 64 rows x 8x8 px (7 / 14-pixel maps: the decoder's coarse levels have >= 128 output rows),
 // 4 = 32 rows x 16x8, 5 = 32 rows x 32x8 (wide maps).  74 KB of LDS at most: two blocks per CU.
-template <int EPI>
+template <int EPI, int NR>
 __global__ __launch_bounds__(256) void conv_blk_dec_group_kernel(const BlkConvGroup g) {
-  constexpr int LMAX = bd_max(bd_lds_cells<64, 8, 8>(), bd_max(bd_lds_cells<32, 16, 8>(), bd_lds_cells<32, 32, 8>()));
+  constexpr int LMAX = bd_max(bd_lds_cells<64, 8, 8, NR>(), bd_max(bd_lds_cells<32, 16, 8, NR>(), bd_lds_cells<32, 32, 8, NR>()));
   __shared__ __attribute__((aligned(16))) u32x4 lds[LMAX];
   const int b = blockIdx.x;
   int j = 0;
@@ -312,9 +313,9 @@ __global__ __launch_bounds__(256) void conv_blk_dec_group_kernel(const BlkConvGr
   const BlkConvJob& p = g.job[j];
   const int local = b - g.begin[j];
   switch (g.variant[j]) {
-    case 1: bd_body<64, 8, 8, EPI>(p, local, lds); break;
-    case 4: bd_body<32, 16, 8, EPI>(p, local, lds); break;
-    default: bd_body<32, 32, 8, EPI>(p, local, lds); break;
+    case 1: bd_body<64, 8, 8, EPI, NR>(p, local, lds); break;
+    case 4: bd_body<32, 16, 8, EPI, NR>(p, local, lds); break;
+    default: bd_body<32, 32, 8, EPI, NR>(p, local, lds); break;
   }
 }
 
@@ -357,8 +358,14 @@ int rsis_launch_conv_blk_dec(BlkConvJob* jobs, int n, int epi, const int* force_
       blocks += a.n_co_tiles * 8 * rsis_cdiv(a.n_px_tiles, 8);
     }
     for (int k = m; k <= RSIS_BD_MAXJ; ++k) g.begin[k] = blocks;
-    if (epi == BEPI_LSTM) hipLaunchKernelGGL((conv_blk_dec_group_kernel<BEPI_LSTM>), dim3(blocks), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((conv_blk_dec_group_kernel<BEPI_PLAIN>), dim3(blocks), dim3(256), 0, st, g);
+    static const int nr = (getenv("RSIS_BLKDEC_NR") && getenv("RSIS_BLKDEC_NR")[0] == '3') ? 3 : 2;     // ring depth (A/B switch)
+    if (epi == BEPI_LSTM) {
+      if (nr == 3) hipLaunchKernelGGL((conv_blk_dec_group_kernel<BEPI_LSTM, 3>), dim3(blocks), dim3(256), 0, st, g);
+      else hipLaunchKernelGGL((conv_blk_dec_group_kernel<BEPI_LSTM, 2>), dim3(blocks), dim3(256), 0, st, g);
+    } else {
+      if (nr == 3) hipLaunchKernelGGL((conv_blk_dec_group_kernel<BEPI_PLAIN, 3>), dim3(blocks), dim3(256), 0, st, g);
+      else hipLaunchKernelGGL((conv_blk_dec_group_kernel<BEPI_PLAIN, 2>), dim3(blocks), dim3(256), 0, st, g);
+    }
     if (rsis_check_launch() != RSIS_OK) return RSIS_ERR_LAUNCH;
   }
   return RSIS_OK;

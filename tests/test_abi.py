@@ -88,3 +88,4 @@ def test_bench_finds_the_gate_kernel_by_name():
     gates = [l for l in names if bench.GATE_KERNEL_RE.search(l)]
     assert len(names) >= 20 and len(gates) >= 5, (len(names), len(gates))
     assert any(bench.GATE_GROUP_RE.search(l) for l in out.splitlines()), "the grouped gate kernel is not in the library under the name bench.py filters on"
+    assert any(bench.GATE_BLK_RE.search(l) for l in out.splitlines()), "the blk grouped gate kernel (bf16) is not in the library under the name bench.py filters on"
