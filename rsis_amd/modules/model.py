@@ -65,13 +65,16 @@ class FeatureExtractor(nn.Module):
     def forward(self, x, semseg=False, raw=False):
         if self.training and x.is_cuda:
             self._arm_bn_arena(x.device)
-        self.base.cut_layer3 = int(self.split_backward) >= 2
+        # (the second cut is armed only on the path that records the first one below: a semseg / raw caller, or one outside a training
+        #  iteration, gets the uncut graph and a plain loss.backward() reaches every layer)
+        self.base.cut_layer3 = int(self.split_backward) >= 2 and not (semseg or raw) and self.training and torch.is_grad_enabled()
+        self.base._cut3 = None
+        self._cut = None
         x5, x4, x3, x2, x1 = self.base(x)            # model.py:57
         if semseg:
             return x5
         if raw:
             return x5, x4, x3, x2, x1
-        self._cut = None
         if self.split_backward and self.training and torch.is_grad_enabled() and x5.requires_grad:
             roots = (x5, x4, x3, x2, x1)
             leaves = tuple(t.detach().requires_grad_(True) for t in roots)

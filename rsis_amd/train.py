@@ -83,11 +83,12 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
     # (RSIS_EXCHANGE=hooks) keeps the hook-driven bucketed exchange of optim.BucketedAllReduce (one flush per completed bucket).
     staged = bool(train and do_update and between is None and reducer is not None and getattr(reducer, "active", False)
                   and getattr(reducer, "staged", False) and hasattr(encoder, "split_backward"))
+    restore = None
     if staged:
+        restore = (encoder.split_backward, reducer.hooks_enabled)      # (not sticky: a later forward + backward outside runIter gets the uncut graph)
         encoder.split_backward, reducer.hooks_enabled = EXCHANGE_CUTS, False
-        plan, pending = exchange_plan(encoder, optims, EXCHANGE_CUTS), []
-        between = lambda stage: pending.extend(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=reducer.pg, async_op=True)   # noqa: E731
-                                               for b in plan[stage])
+        between = exchange = StagedExchange(exchange_plan(encoder, optims, EXCHANGE_CUTS),
+                                            lambda b, a: dist.all_reduce(b, op=dist.ReduceOp.SUM, group=reducer.pg, async_op=a))
     encoder.train(train)                                             # train.py:71-76
     decoder.train(train)
     y_mask = y_mask.float()
@@ -203,10 +204,8 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
             ops.WGRAD_DEFER[0] = prev_defer
             del ops._WGRAD_QUEUE[:]
         if staged:
-            for h in pending:
-                h.wait()
-            for b in plan["rest"]:
-                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=reducer.pg)
+            encoder.split_backward, reducer.hooks_enabled = restore
+            exchange.finish()         # waits; reduces "rest" and the range of any stage whose cut did not materialise
             apply_update(args, optims, 1.0 / reducer.world)
         elif do_update:
             apply_update(args, optims, reducer.finish() if reducer is not None else 1.0)
@@ -276,6 +275,32 @@ def build_optimizers(args, encoder, decoder):
 
 
 EXCHANGE_CUTS = int(os.environ.get("RSIS_EXCHANGE_CUTS", "2"))     # 0 / 1 / 2, see GraphedStep
+
+
+class StagedExchange(object):
+    """The `between` callback of a split backward (runIter) for an eager staged gradient exchange: between(stage) launches the
+    asynchronous SUM all-reduce of the flat-gradient ranges that are final after that stage (exchange_plan).  finish() waits for them
+    and reduces, synchronously, the "rest" range AND every range whose stage never fired -- a cut of the backward only materialises
+    when the tensor it sits on requires grad (frozen stem + layers 1-2, a wrapped encoder, ...); without this the ranges of the
+    missing stages would reach the optimizer un-reduced and the replicas would drift apart silently."""
+
+    def __init__(self, plan, reduce):
+        self.plan, self.reduce, self.fired, self.pending = plan, reduce, [], []
+
+    def __call__(self, stage):
+        self.fired.append(stage)
+        self.pending.extend(self.reduce(b, True) for b in self.plan[stage])
+
+    def finish(self):
+        for h in self.pending:
+            h.wait()
+        self.pending = []
+        for stage in ("dec", "trunk_hi"):
+            if stage not in self.fired:
+                for b in self.plan[stage]:
+                    self.reduce(b, False)
+        for b in self.plan["rest"]:
+            self.reduce(b, False)
 
 
 def exchange_plan(encoder, optims, cuts):
@@ -373,13 +398,9 @@ class GraphedStep(object):
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 if self.split:
-                    plan, pending = self._plan(), []
-                    res = self._run(batch, t_run, do_update=False,
-                                    between=lambda stage: pending.extend(self._reduce(b, True) for b in plan[stage]))
-                    for h in pending:
-                        h.wait()
-                    for b in plan["rest"]:
-                        self._reduce(b)
+                    exchange = StagedExchange(self._plan(), self._reduce)
+                    res = self._run(batch, t_run, do_update=False, between=exchange)
+                    exchange.finish()     # (also covers a backward whose cuts did not materialise: every range is reduced exactly once)
                     apply_update(self.args, self.optims, 1.0 / self.reducer.world)
                 else:
                     res = self._run(batch, t_run)

@@ -239,3 +239,30 @@ def test_exchange_plan_partitions_the_flat_gradient_buffers():
     first3 = next(enc.base.layer3.parameters())
     assert hi.data_ptr() == first3.grad.data_ptr()                       # the range starts at layer3's first parameter
     assert hi.numel() > 0.9 * n_enc                                      # layers 3-4: 41 M of the trunk's 42.5 M optimised parameters
+
+
+def test_staged_exchange_reduces_the_ranges_of_stages_that_never_fired():
+    """train.StagedExchange (the eager staged gradient exchange of runIter / GraphedStep's warm-up steps): a cut of the split backward
+    only materialises when the tensor it sits on requires grad; the ranges of a stage that never called back must still be reduced
+    (exactly once) before the optimizer step -- otherwise decoder / layer 3-4 gradients reach Adam un-summed and the replicas diverge."""
+    from rsis_amd.train import StagedExchange
+
+    class H(object):
+        def __init__(self, log, b):
+            self.log, self.b = log, b
+
+        def wait(self):
+            self.log.append(("wait", self.b))
+
+    for fired in ([], ["dec"], ["dec", "trunk_hi"], ["trunk_hi"]):
+        log = []
+        plan = {"dec": ["d0", "d1"], "trunk_hi": ["hi"], "rest": ["lo"]}
+        ex = StagedExchange(plan, lambda b, a: (log.append(("async" if a else "sync", b)), H(log, b))[1])
+        for st in fired:
+            ex(st)
+        ex.finish()
+        reduced = [b for kind, b in log if kind in ("async", "sync")]
+        assert sorted(reduced) == ["d0", "d1", "hi", "lo"], (fired, log)          # every range exactly once
+        waited = [b for kind, b in log if kind == "wait"]
+        assert sorted(waited) == sorted(b for st in fired for b in plan[st])     # every asynchronous launch was waited for
+        assert [b for kind, b in log if kind == "async"] == [b for st in fired for b in plan[st]]
