@@ -553,6 +553,9 @@ def main():
     enc_opt, dec_opt = build_optimizers(a, encoder, decoder)
     force = os.environ.get("RSIS_FORCE_DIST", "") == "1"
     reducer = BucketedAllReduce([dec_opt.group, enc_opt.group], force=force) if (world > 1 or force) else None
+    if reducer is not None and reducer.active:
+        from rsis_amd.comm import make_direct_reducer
+        reducer.direct = make_direct_reducer(lambda m: print("[bench] rank %d: %s" % (rank, m), file=sys.stderr, flush=True) if rank == 0 else None)
     crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
     imw = o.imsize_w or o.imsize
     if imw != o.imsize:
@@ -647,10 +650,12 @@ def main():
         note("hipGraph: %s" % ("captured, replaying" if gstep.graph is not None else "NOT captured (%s): eager launches" % gstep.failed))
     note("warmup done %.2f s" % (time.time() - tw))
     if dist.is_initialized():
+        direct = gstep is not None and gstep.graph is not None and gstep.split and gstep.direct is not None
         note("gradient exchange: backend %s, communicator size %d (%s)" % (dist.get_backend(), dist.get_world_size(),
+             "RCCL bound directly, ONE graph: the all-reduces of the three gradient ranges are nodes on a forked branch" if direct else
              "%d cuts: graph A | all-reduce(dec) || graph B1 | all-reduce(layers 3-4) || graph B2 | all-reduce(rest) | graph C" % gstep.cuts
              if (gstep is not None and gstep.graph is not None and gstep.split)
-             else "bucketed all-reduce from autograd hooks (eager launches)"))
+             else "staged all-reduce at the cuts of the split backward (eager launches)"))
     if gstep is not None and gstep.graph is not None and gstep.split:
         gstep.timing = True            # HIP events around graph A / graph B (+ overlapped collective) / exposed collective / graph C
     t0 = time.time()
@@ -666,7 +671,9 @@ def main():
     note("host enqueue marks (s): %s | end %.3f" % (" ".join("%.3f" % m for m in marks), dt))
     note("GPU ms per step (events): %s" % " ".join("%.1f" % evs[i].elapsed_time(evs[i + 1]) for i in range(o.steps)))
     seg = gstep.segment_ms() if (gstep is not None and gstep.timing) else None
-    if seg is not None:
+    if seg is not None and "mode" in seg:
+        note("direct in-graph exchange, ms per step over %d replays: %.3f (one graph)" % (seg["replays"], seg["one_graph_fwd_bwd_allreduce_adam_repack"]))
+    elif seg is not None:
         note("split-graph schedule (%d cuts), ms per step over %d replays: %s | EXPOSED all-reduce (wait for the ranges in flight + the "
              "remaining range) %.2f | graph C (Adam + repack) %.2f"
              % (seg["cuts"], seg["replays"], " | ".join("%s %.2f" % (k, v) for k, v in seg.items() if k.startswith(("graph_A", "graph_B"))),
@@ -742,7 +749,7 @@ def main():
                                             % ("channel-blocked bf16, fp32 cell state (rsis_amd/decoder_seq.py)" if decoder_seq.BLK_ENABLED[0] else "fp32 NCHW")
                                             if blk_trunk.ENABLED[0] else "fp32 NCHW everywhere (RSIS_BF16_STORAGE=0: bf16 operands only)")
         if seg is not None:
-            out["config"]["exchange_ms_per_step"] = {k: round(v, 3) for k, v in seg.items()}
+            out["config"]["exchange_ms_per_step"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in seg.items()}
     # RCCL prints a banner (version, library path) through C stdio, which on a pipe is flushed only at exit, i.e. AFTER anything
     # python printed: every rank flushes its C streams before the final barrier, rank 0 prints after it, so that the JSON line
     # is the last line of the job's (merged) stdout

@@ -426,6 +426,22 @@ int rsis_blk_conv_out_seq_fwd(const void* x, const float* Wref, const float* bia
 int rsis_blk_conv_out_seq_dgrad(const float* dy, const float* Wref, void* dx, int T, int B, int H, int W, void* stream);
 int rsis_blk_conv_out_seq_wgrad(const float* dy, const void* x, float* dW, float* db, int T, int B, int H, int W, void* stream);
 
+/* ---- gradient exchange: RCCL bound directly (replaces nn.DataParallel, reference src/train.py:269-274: one process per GPU, the flat
+ * gradient buffers SUM-all-reduced over xGMI once per iteration).  A collective issued here is an ordinary operation of `stream`: it
+ * can be captured into the hipGraph of the training iteration (torch.distributed's ProcessGroupNCCL cannot: its watchdog thread's
+ * event queries abort a concurrent stream capture).  RCCL is resolved at run time (dlopen); RSIS_ERR_UNSUPPORTED if it is not there.
+ *   rsis_comm_unique_id : rank 0 fills id_out[128] (ncclUniqueId); the caller distributes it to the other ranks (any channel);
+ *   rsis_comm_init      : collective over the `world` ranks, each on its own current HIP device; *comm receives the communicator;
+ *   rsis_comm_size      : number of ranks of the communicator (-1 on error);
+ *   rsis_comm_allreduce_sum_f32 : buf[n] <- sum over ranks, in place, enqueued on `stream`;
+ *   rsis_comm_destroy, rsis_comm_last_error (text of the last RCCL failure of this process). ---- */
+int rsis_comm_unique_id(void* id_out);
+int rsis_comm_init(void** comm, int world, int rank, const void* id);
+int rsis_comm_size(void* comm);
+int rsis_comm_allreduce_sum_f32(void* comm, float* buf, long n, void* stream);
+int rsis_comm_destroy(void* comm);
+const char* rsis_comm_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

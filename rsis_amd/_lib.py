@@ -118,6 +118,12 @@ SIGNATURES = {
     "rsis_blk_conv_out_seq_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_blk_conv_out_seq_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsis_blk_conv_out_seq_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsis_comm_unique_id": (_i, [_vp]),
+    "rsis_comm_init": (_i, [_vpp, _i, _i, _vp]),
+    "rsis_comm_size": (_i, [_vp]),
+    "rsis_comm_allreduce_sum_f32": (_i, [_vp, _vp, _l, _vp]),
+    "rsis_comm_destroy": (_i, [_vp]),
+    "rsis_comm_last_error": (ctypes.c_char_p, []),
     "rsis_heads_bwd": (_i, [_vpp, _ip, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vpp, _vp, _vp, _vp, _vp, _vp]),
     "rsis_loss_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rsis_softiou_sums": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _vp]),

@@ -87,8 +87,9 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
     if staged:
         restore = (encoder.split_backward, reducer.hooks_enabled)      # (not sticky: a later forward + backward outside runIter gets the uncut graph)
         encoder.split_backward, reducer.hooks_enabled = EXCHANGE_CUTS, False
-        between = exchange = StagedExchange(exchange_plan(encoder, optims, EXCHANGE_CUTS),
-                                            lambda b, a: dist.all_reduce(b, op=dist.ReduceOp.SUM, group=reducer.pg, async_op=a))
+        direct = getattr(reducer, "direct", None)          # RCCL bound directly (rsis_amd/comm.py) when it could be built
+        between = exchange = StagedExchange(exchange_plan(encoder, optims, EXCHANGE_CUTS), direct if direct is not None else
+                                            (lambda b, a: dist.all_reduce(b, op=dist.ReduceOp.SUM, group=reducer.pg, async_op=a)))
     encoder.train(train)                                             # train.py:71-76
     decoder.train(train)
     y_mask = y_mask.float()
@@ -350,6 +351,9 @@ class GraphedStep(object):
     def __init__(self, args, encoder, decoder, crits, optims, reducer=None, warm=2, pool=None, cuts=None):
         self.args, self.encoder, self.decoder, self.crits, self.optims, self.reducer = args, encoder, decoder, crits, optims, reducer
         self.split = reducer is not None and getattr(reducer, "active", False)
+        # direct: the collectives go through rsis_amd.comm.DirectReducer and live INSIDE one captured graph (forked stream); else the
+        # iteration is cut into graphs with torch.distributed collectives between them
+        self.direct = getattr(reducer, "direct", None) if self.split else None
         self.cuts = max(0, min(2, EXCHANGE_CUTS if cuts is None else int(cuts))) if self.split else 0
         if self.split:
             # this schedule all-reduces the flat gradient buffers itself: the reducer's per-bucket hooks must not fire inside
@@ -385,6 +389,8 @@ class GraphedStep(object):
     def _reduce(self, buf, async_op=False):
         """SUM all-reduce of (a range of) a flat gradient buffer, issued from the current stream (RCCL runs it on its own stream
         after the work already enqueued here; `wait()` -- or the synchronous form -- makes the current stream wait for it)"""
+        if self.direct is not None:
+            return self.direct(buf, async_op)
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.reducer.pg, async_op=async_op)
 
     def _plan(self):
@@ -420,6 +426,15 @@ class GraphedStep(object):
             self._in_src = [(t, t._version) for t in batch]
         if not self.split:
             self.graphs[0].replay()
+        elif self.direct is not None:              # ONE graph: backward, the all-reduces on their forked branch, both Adam steps, repack
+            if self.timing:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ev[0].record()
+                self.graphs[0].replay()
+                ev[1].record()
+                self._events.append(ev)
+            else:
+                self.graphs[0].replay()
         else:
             n = len(self.graphs)
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 3)] if self.timing else None
@@ -455,6 +470,11 @@ class GraphedStep(object):
             return None
         torch.cuda.synchronize()
         n, ng = len(self._events), len(self.graphs)
+        if self.direct is not None:
+            ms = sum(e[0].elapsed_time(e[1]) for e in self._events) / n
+            self._events = []
+            return {"one_graph_fwd_bwd_allreduce_adam_repack": ms, "exposed_allreduce": 0.0, "replays": n, "cuts": 0,
+                    "mode": "RCCL bound directly: the all-reduces are nodes of the iteration's graph (forked branch)"}
         seg = [sum(e[k].elapsed_time(e[k + 1]) for e in self._events) / n for k in range(ng + 2)]
         self._events = []
         names = (["graph_A_fwd_bptt"] + ["graph_B%d_trunk_bwd" % (k + 1) for k in range(ng - 1)])
@@ -490,6 +510,14 @@ class GraphedStep(object):
             if not self.split:
                 with torch.cuda.graph(graphs[0], pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
                     self.result = self._run(self.static, t_run)
+            elif self.direct is not None:
+                # the split backward still tells WHEN a range of the flat gradient buffers is final (between("dec") / ("trunk_hi"));
+                # its all-reduce is captured on the forked stream right there and joined before the optimizer steps
+                with torch.cuda.graph(graphs[0], pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
+                    exchange = StagedExchange(self._plan(), self._reduce)
+                    self.result = self._run(self.static, t_run, do_update=False, between=exchange)
+                    exchange.finish()
+                    apply_update(self.args, self.optims, 1.0 / self.reducer.world)
             else:
                 # one pass of runIter, cut into graphs where its split backward calls back (same thread: the callback runs in
                 # runIter between the backward calls), then graph C; all share one memory pool (they always replay in this
@@ -613,6 +641,9 @@ def trainIters(args):
                   % (", ".join(n for n, ok in (("encoder", ok_e), ("decoder", ok_d)) if ok) or "nothing",
                      ", ".join(n for n, ok in (("encoder", ok_e), ("decoder", ok_d)) if not ok)))
     reducer = BucketedAllReduce([dec_opt.group, enc_opt.group]) if world > 1 else None
+    if reducer is not None and reducer.active:
+        from .comm import make_direct_reducer
+        reducer.direct = make_direct_reducer(lambda m: print("[train] %s" % m, file=sys.stderr, flush=True) if rank == 0 else None)
     if not args.log_term and rank == 0:                                   # train.py:253-256
         print("Training logs will be saved to:", os.path.join(model_dir, "train.log"))
         sys.stdout = open(os.path.join(model_dir, "train.log"), "w")

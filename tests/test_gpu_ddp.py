@@ -292,3 +292,63 @@ def test_graph_capture_with_rccl_collectives_world1():
     assert p.exitcode == 0
     assert captured, "capture refused: %s" % failed
     assert all(v == v for v in ls) and ls[-1] < ls[0], ls
+
+
+def _worker_exchange_mode(q, mode):
+    """world size 1 with the collective path forced on; mode "direct": RCCL bound directly, the all-reduces inside ONE captured graph
+    (rsis_amd/comm.py); mode "cuts": torch.distributed collectives between cut graphs.  Deterministic library mode: the two schedules
+    must produce the same bits."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", RSIS_FORCE_DIST="1",
+                      RSIS_EXCHANGE=mode, RSIS_DETERMINISTIC="1")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import mk_args
+    from rsis_amd.comm import make_direct_reducer
+    from rsis_amd.modules import RSIS, FeatureExtractor
+    from rsis_amd.optim import BucketedAllReduce
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import GraphedStep, build_optimizers, init_distributed, steps_to_run
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    init_distributed()
+    a = mk_args(hidden_size=32, maxseqlen=3, optim="adam", optim_cnn="adam", lr=1e-3, lr_cnn=1e-4, weight_decay=0.0, weight_decay_cnn=0.0)
+    torch.manual_seed(0)
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    opts = list(build_optimizers(a, enc, dec))
+    red = BucketedAllReduce([opts[1].group, opts[0].group], bucket_bytes=8 << 20, force=True)
+    notes = []
+    red.direct = make_direct_reducer(notes.append)
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(0.5)]
+    batch = synthetic_batch(10, 2, 64, 64, 20, 3, 21, "cuda")
+    t_run = steps_to_run(a, batch[3])
+    g = GraphedStep(a, enc, dec, crits, opts, red, warm=1)
+    ls = [float(g(batch, t_run)[0][0]) for _ in range(6)]
+    torch.cuda.synchronize()
+    flat = torch.cat([o.group.flat_p.detach().double().cpu() for o in opts])
+    q.put((g.graph is not None, g.failed, ls, red.direct is not None, len(g.graphs or []), g.graph_update is not None, notes,
+           flat.numpy().tobytes()))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_direct_rccl_exchange_lives_inside_one_graph_and_equals_the_cut_schedule_world1():
+    """train.GraphedStep with the gradient exchange bound directly to RCCL (rsis_comm_*): the iteration is ONE hipGraph whose
+    all-reduces sit on a forked branch -- no cuts, no torch.distributed collective per step -- and, in the deterministic mode, six steps
+    end at bit-identical parameters to the cut-graph schedule over torch.distributed.  (World size 1: the box has one GPU; the
+    communicator, the capture of ncclAllReduce and the fork / join are the real thing.)"""
+    ctx = mp.get_context("spawn")
+    out = {}
+    for mode in ("direct", "cuts"):
+        q = ctx.Queue()
+        p = ctx.Process(target=_worker_exchange_mode, args=(q, mode))
+        p.start()
+        out[mode] = q.get(timeout=300)
+        p.join(120)
+        assert p.exitcode == 0
+    captured, failed, ls, direct, ngraphs, has_update_graph, notes, params = out["direct"]
+    assert direct, "the direct communicator was not built: %s" % (notes,)
+    assert captured and ngraphs == 1 and not has_update_graph, "capture: %s (failed=%s), %d graphs" % (captured, failed, ngraphs)
+    assert all(v == v for v in ls) and ls[-1] < ls[0], ls
+    c2 = out["cuts"]
+    assert c2[0] and not c2[3] and c2[4] == 3 and c2[5], "the cut schedule did not run as three graphs + the update graph: %s" % (c2[:6],)
+    assert ls == c2[2], "losses differ between the two schedules: %s vs %s" % (ls, c2[2])
+    assert params == c2[7], "parameters after six steps differ between the direct and the cut schedule"
