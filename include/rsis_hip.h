@@ -159,6 +159,37 @@ int rsis_convlstm_fwd_batch(const rsis_lstm_job* jobs, int njobs, void* stream);
 int rsis_convlstm_bwd_gates(const float* dh, const float* dh2, const float* dc_next, const float* act, const float* c_prev,
                             const float* c, float* da, float* dc_prev, float* da_sum, int B, int hid, int HW, void* stream);
 
+/* Several INDEPENDENT rsis_convlstm_bwd_gates calls (da_sum == NULL) in one launch, and several independent rsis_conv2d_dgrad calls in
+ * one launch where they run on the exact-f32 direct 3x3 kernel (stride 1, pad 1, no addend; other jobs, and every job in the
+ * deterministic mode, are issued one by one): the cells (level i, timestep d - i) of a diagonal of the decoder's (level, timestep)
+ * wavefront in the BACKWARD pass -- cell (i, t) needs d(up) from cell (i + 1, t) and (dh, dc) from cell (i, t + 1), both one diagonal
+ * later, so the cells of a diagonal are independent (reference: autograd of model.py:129-165 inside train.py:85-94).  Fields as the
+ * arguments of the single calls. */
+typedef struct rsis_lstm_bwd_job {
+  const float* dh;
+  const float* dh2;
+  const float* dc_next;
+  const float* act;
+  const float* c_prev;
+  const float* c;
+  float* da;
+  float* dc_prev;
+  int B, hid, HW;
+} rsis_lstm_bwd_job;
+int rsis_convlstm_bwd_gates_batch(const rsis_lstm_bwd_job* jobs, int njobs, void* stream);
+typedef struct rsis_dgrad_job {
+  const float* dy;
+  int B, Cout, Hy, Wy;
+  const void* Wd;
+  int Cin_packed, ks, stride, pad;
+  float* dx[3];
+  int Cdx[3];
+  int ndst, Hx, Wx;
+  const float* addend;
+  int tile, dtype;
+} rsis_dgrad_job;
+int rsis_conv2d_dgrad_batch(const rsis_dgrad_job* jobs, int njobs, void* stream);
+
 /* ---- nn.UpsamplingBilinear2d(size) = bilinear, align_corners=True (model.py:149,163; train.py:96; test.py:39) ---- */
 int rsis_upsample_bilinear_ac_fwd(const float* x, float* y, long BC, int Hi, int Wi, int Ho, int Wo, void* stream);
 int rsis_upsample_bilinear_ac_bwd(const float* dy, float* dx, long BC, int Hi, int Wi, int Ho, int Wo, void* stream);

@@ -39,6 +39,20 @@ class LstmJob(ctypes.Structure):
                 ("side_key", ctypes.c_void_p)]
 
 
+class LstmBwdJob(ctypes.Structure):
+    """struct rsis_lstm_bwd_job of include/rsis_hip.h"""
+    _fields_ = [(k, ctypes.c_void_p) for k in ("dh", "dh2", "dc_next", "act", "c_prev", "c", "da", "dc_prev")] + \
+               [(k, ctypes.c_int) for k in ("B", "hid", "HW")]
+
+
+class DgradJob(ctypes.Structure):
+    """struct rsis_dgrad_job of include/rsis_hip.h"""
+    _fields_ = [("dy", ctypes.c_void_p), ("B", ctypes.c_int), ("Cout", ctypes.c_int), ("Hy", ctypes.c_int), ("Wy", ctypes.c_int),
+                ("Wd", ctypes.c_void_p), ("Cin_packed", ctypes.c_int), ("ks", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int),
+                ("dx", ctypes.c_void_p * 3), ("Cdx", ctypes.c_int * 3), ("ndst", ctypes.c_int), ("Hx", ctypes.c_int), ("Wx", ctypes.c_int),
+                ("addend", ctypes.c_void_p), ("tile", ctypes.c_int), ("dtype", ctypes.c_int)]
+
+
 class BlkConvJob(ctypes.Structure):
     """struct rsis_blk_conv_job of include/rsis_hip.h"""
     _fields_ = [("src", ctypes.c_void_p * 3), ("Csrc", ctypes.c_int * 3), ("nsrc", ctypes.c_int), ("B", ctypes.c_int), ("H", ctypes.c_int),
@@ -109,6 +123,8 @@ SIGNATURES = {
     "rsis_blk_subsample2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsis_blk_upscatter2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsis_blk_conv2d": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    "rsis_convlstm_bwd_gates_batch": (_i, [ctypes.POINTER(LstmBwdJob), _i, _vp]),
+    "rsis_conv2d_dgrad_batch": (_i, [ctypes.POINTER(DgradJob), _i, _vp]),
     "rsis_blk_conv3x3_batch": (_i, [ctypes.POINTER(BlkConvJob), _i, _vp]),
     "rsis_blk_upsample_fwd_batch": (_i, [ctypes.POINTER(BlkResizeJob), _i, _vp]),
     "rsis_blk_upsample_bwd_batch": (_i, [ctypes.POINTER(BlkResizeJob), _i, _vp]),

@@ -8,6 +8,8 @@ int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_t
 int rsis_launch_conv_wgrad(WgradArgs& a, int ks, hipStream_t st);
 int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st);
 int rsis_launch_convlstm_direct_group(ConvArgs* jobs, int n, const int* force_variant, hipStream_t st);
+int rsis_launch_conv3x3_direct_group_plain(ConvArgs* jobs, int n, const int* force_variant, hipStream_t st);
+int rsis_l_lstm_bwd_group(const void* const*, const int*, int, hipStream_t);
 int rsis_launch_conv_bf16(ConvArgs& a, int ks, int epi, int force_variant, hipStream_t st);
 int rsis_launch_conv_blk(ConvArgs& a, int ks, int variant, hipStream_t st);
 int rsis_l_blk_from_nchw(const float*, void*, int, int, int, hipStream_t);
@@ -840,4 +842,54 @@ int rsis_blk_sum_leading(const void* x, void* y, int T, long ncells, void* strea
 int rsis_blk_bias_grad(const void* dy, float* db, int B, int C, int HW, int lstm_hid, void* stream) {
   if (!dy || !db || B < 1 || C < 8 || (C & 7) || HW < 1 || (lstm_hid > 0 && C != 4 * lstm_hid)) return RSIS_ERR_ARG;
   return rsis_l_blk_channel_sum(dy, db, B, C, HW, lstm_hid, (hipStream_t)stream);
+}
+
+// ---- grouped launches of the fp32 decoder's backward (the cells of a reverse diagonal of the (level, timestep) wavefront) ----
+int rsis_convlstm_bwd_gates_batch(const rsis_lstm_bwd_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs < 1 || njobs > 64) return RSIS_ERR_ARG;
+  const void* ptrs[64 * 8];
+  int dims[64 * 3];
+  for (int j = 0; j < njobs; ++j) {
+    const rsis_lstm_bwd_job& q = jobs[j];
+    if (!q.act || !q.c || !q.da || q.B < 1 || q.hid < 1 || q.HW < 1) return RSIS_ERR_ARG;
+    const void* p8[8] = {q.dh, q.dh2, q.dc_next, q.act, q.c_prev, q.c, q.da, q.dc_prev};
+    for (int k = 0; k < 8; ++k) ptrs[j * 8 + k] = p8[k];
+    dims[j * 3] = q.B; dims[j * 3 + 1] = q.hid; dims[j * 3 + 2] = q.HW;
+  }
+  return rsis_l_lstm_bwd_group(ptrs, dims, njobs, (hipStream_t)stream);
+}
+int rsis_conv2d_dgrad_batch(const rsis_dgrad_job* jobs, int njobs, void* stream) {
+  if (!jobs || njobs < 1 || njobs > 64) return RSIS_ERR_ARG;
+  ConvArgs grp[64];
+  int force[64], ng = 0, rc = RSIS_OK;
+  for (int j = 0; j < njobs && rc == RSIS_OK; ++j) {
+    const rsis_dgrad_job& q = jobs[j];
+    if (!q.dy || !q.Wd || q.ndst < 1 || q.ndst > RSIS_MAX_SRC) return RSIS_ERR_ARG;
+    int ctot = 0;
+    for (int i = 0; i < q.ndst; ++i) { if (!q.dx[i] || q.Cdx[i] < 1) return RSIS_ERR_ARG; ctot += q.Cdx[i]; }
+    // grouped: the exact-f32 direct kernel (3x3 / stride 1 / pad 1, no addend) with 32-bit epilogue addressing; everything else -- and
+    // every job in the deterministic mode, where launches stay as the single-call path issues them -- through rsis_conv2d_dgrad
+    const bool groupable = q.dtype == RSIS_DTYPE_F32 && use_direct(q.ks, q.stride, q.pad) && !q.addend && q.Hx == q.Hy && q.Wx == q.Wy &&
+                           !(q.Cout == 1) && ctot <= q.Cin_packed && (size_t)q.B * (ctot > q.Cout ? ctot : q.Cout) * q.Hy * q.Wy * 4 < (1ull << 31) &&
+                           !rsis_deterministic();
+    if (!groupable) {
+      rc = rsis_conv2d_dgrad(q.dy, q.B, q.Cout, q.Hy, q.Wy, q.Wd, q.Cin_packed, q.ks, q.stride, q.pad, q.dx, q.Cdx, q.ndst, q.Hx, q.Wx, q.addend, q.tile,
+                             q.dtype, stream);
+      continue;
+    }
+    ConvArgs a = {};
+    const float* srcs[1] = {q.dy};
+    const int cs[1] = {q.Cout};
+    rc = fill_sources(a, srcs, cs, 1, 3);
+    if (rc) break;
+    for (int i = 0; i < q.ndst; ++i) { a.dst[i] = q.dx[i]; a.Cd[i] = q.Cdx[i]; }
+    a.ndst = q.ndst;
+    a.B = q.B; a.H = q.Hy; a.W = q.Wy; a.Ho = q.Hx; a.Wo = q.Wx; a.stride = 1; a.pad = 1; a.sshift = 0;
+    a.ostride = 1; a.oH = q.Hx; a.oW = q.Wx; a.ksplit = 1;
+    a.wp = (const float*)q.Wd; a.ldw = rsis_roundup(q.Cin_packed, RSIS_LDW_ALIGN); a.Cout = ctot; a.bias = nullptr; a.addend = nullptr;
+    force[ng] = direct_variant(q.tile); grp[ng++] = a;
+  }
+  if (rc == RSIS_OK && ng == 1) rc = rsis_launch_conv3x3_direct(grp[0], 0, force[0], (hipStream_t)stream);
+  else if (rc == RSIS_OK && ng > 1) rc = rsis_launch_conv3x3_direct_group_plain(grp, ng, force, (hipStream_t)stream);
+  return rc;
 }

@@ -533,7 +533,18 @@ int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStrea
 
 // n independent 3x3 / stride 1 / pad 1 convs with the fused ConvLSTM cell epilogue in one grid (see conv3x3_direct_group_kernel).
 // Jobs are ordered by decreasing work per block (the long blocks start first: longest-processing-time scheduling of the tail).
+template <int EPI>
+static int launch_direct_group(ConvArgs* jobs, int n, const int* force_variant, hipStream_t st);
 int rsis_launch_convlstm_direct_group(ConvArgs* jobs, int n, const int* force_variant, hipStream_t st) {
+  return launch_direct_group<EPI_LSTM>(jobs, n, force_variant, st);
+}
+// ... and with the plain epilogue: the data gradients of the gate convs of one REVERSE diagonal of the wavefront (multi-destination:
+// d(up) | d(h_prev)), rsis_conv2d_dgrad_batch
+int rsis_launch_conv3x3_direct_group_plain(ConvArgs* jobs, int n, const int* force_variant, hipStream_t st) {
+  return launch_direct_group<EPI_PLAIN>(jobs, n, force_variant, st);
+}
+template <int EPI>
+static int launch_direct_group(ConvArgs* jobs, int n, const int* force_variant, hipStream_t st) {
   if (n < 1) return RSIS_OK;
   for (int j0 = 0; j0 < n; j0 += RSIS_DG_MAXJ) {
     const int m = n - j0 < RSIS_DG_MAXJ ? n - j0 : RSIS_DG_MAXJ;
@@ -542,7 +553,7 @@ int rsis_launch_convlstm_direct_group(ConvArgs* jobs, int n, const int* force_va
     for (int j = 0; j < m; ++j) {
       ConvArgs& a = jobs[j0 + j];
       if (a.nsrc < 0 || a.nsrc > RSIS_MAX_SRC) return RSIS_ERR_ARG;
-      int v = pick_direct_variant<EPI_LSTM>(a, force_variant ? force_variant[j0 + j] : 0);
+      int v = pick_direct_variant<EPI>(a, force_variant ? force_variant[j0 + j] : 0);
       // the grouped kernel's variants: 6 (8x8 maps), 4 (16 x 8 tiles), 5 (32 x 8 tiles), all 32 rows x 256 threads
       if (v == 1) v = 6; else if (v == 2 || v == 9) v = 4; else if (v == 3 || v == 7 || v == 8) v = 5;
       var[j] = v;
@@ -570,7 +581,7 @@ int rsis_launch_convlstm_direct_group(ConvArgs* jobs, int n, const int* force_va
       blocks += a.n_co_tiles * 8 * rsis_cdiv(a.n_px_tiles, 8);
     }
     for (int k = m; k <= RSIS_DG_MAXJ; ++k) g.begin[k] = blocks;
-    hipLaunchKernelGGL((conv3x3_direct_group_kernel<EPI_LSTM>), dim3(blocks), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((conv3x3_direct_group_kernel<EPI>), dim3(blocks), dim3(256), 0, st, g);
     if (rsis_check_launch() != RSIS_OK) return RSIS_ERR_LAUNCH;
   }
   return RSIS_OK;

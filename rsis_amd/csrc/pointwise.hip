@@ -36,6 +36,44 @@ __global__ void lstm_bwd_kernel(const float* __restrict__ dh, const float* __res
   }
 }
 
+// several independent cells in ONE grid (the cells of a reverse diagonal of the decoder's (level, timestep) wavefront): thread e of
+// the grid belongs to the job whose [begin, begin + total) range holds it; same arithmetic per element as lstm_bwd_kernel
+#define RSIS_LB_MAXJ 8
+struct LstmBwdJobF {
+  const float* dh; const float* dh2; const float* dc_next; const float* act; const float* c_prev; const float* c;
+  float* da; float* dc_prev;
+  int hid, HW;
+};
+struct LstmBwdGroupF {
+  int n;
+  long begin[RSIS_LB_MAXJ + 1];
+  LstmBwdJobF job[RSIS_LB_MAXJ];
+};
+__global__ __launch_bounds__(256) void lstm_bwd_group_kernel(const LstmBwdGroupF g) {
+  const long e0 = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e0 >= g.begin[g.n]) return;
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < RSIS_LB_MAXJ; ++k) j += (k < g.n && g.begin[k] <= e0) ? 1 : 0;
+  const LstmBwdJobF& p = g.job[j];
+  const long e = e0 - g.begin[j];
+  const int HW = p.HW;
+  const long bj = e / HW;
+  const int sp = (int)(e - bj * HW);
+  const long g0 = bj * 4 * HW + sp;
+  const float gi = p.act[g0], gf = p.act[g0 + HW], go = p.act[g0 + 2L * HW], gg = p.act[g0 + 3L * HW];
+  const float tc = tanhf(p.c[e]);
+  const float dhv = (p.dh ? p.dh[e] : 0.f) + (p.dh2 ? p.dh2[e] : 0.f);
+  float dcv = dhv * go * (1.f - tc * tc);
+  if (p.dc_next) dcv += p.dc_next[e];
+  const float cp = p.c_prev ? p.c_prev[e] : 0.f;
+  p.da[g0] = dcv * gg * gi * (1.f - gi);
+  p.da[g0 + HW] = dcv * cp * gf * (1.f - gf);
+  p.da[g0 + 2L * HW] = dhv * tc * go * (1.f - go);
+  p.da[g0 + 3L * HW] = dcv * gi * (1.f - gg * gg);
+  if (p.dc_prev) p.dc_prev[e] = dcv * gf;
+}
+
 // ------------------------------------------------------------------------------------------------
 // bilinear upsample, align_corners=True  (nn.UpsamplingBilinear2d: model.py:149,163; train.py:96; test.py:39)
 // ------------------------------------------------------------------------------------------------
@@ -936,6 +974,30 @@ int rsis_l_lstm_bwd(const float* dh, const float* dh2, const float* dc_next, con
   hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, dh, dh2, dc_next, act, c_prev, c, da, dc_prev,
                      da_sum, hid, HW, total);
   return rsis_check_launch();
+}
+// jobs[j] = {dh, dh2, dc_next, act, c_prev, c, da, dc_prev} pointers, dims[j] = {B, hid, HW}
+int rsis_l_lstm_bwd_group(const void* const* ptrs, const int* dims, int n, hipStream_t st) {
+  for (int j0 = 0; j0 < n; j0 += RSIS_LB_MAXJ) {
+    const int m = n - j0 < RSIS_LB_MAXJ ? n - j0 : RSIS_LB_MAXJ;
+    LstmBwdGroupF g;
+    g.n = m;
+    long tot = 0;
+    for (int k = 0; k < m; ++k) {
+      const void* const* q = ptrs + (size_t)(j0 + k) * 8;
+      const int* d = dims + (size_t)(j0 + k) * 3;
+      LstmBwdJobF& a = g.job[k];
+      a.dh = (const float*)q[0]; a.dh2 = (const float*)q[1]; a.dc_next = (const float*)q[2]; a.act = (const float*)q[3];
+      a.c_prev = (const float*)q[4]; a.c = (const float*)q[5]; a.da = (float*)q[6]; a.dc_prev = (float*)q[7];
+      a.hid = d[1]; a.HW = d[2];
+      g.begin[k] = tot;
+      tot += (long)d[0] * d[1] * d[2];
+    }
+    for (int k = m; k <= RSIS_LB_MAXJ; ++k) g.begin[k] = tot;
+    if ((tot + 255) / 256 > 0x7FFFFFFFL) return RSIS_ERR_ARG;
+    hipLaunchKernelGGL(lstm_bwd_group_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, g);
+    if (rsis_check_launch() != RSIS_OK) return RSIS_ERR_LAUNCH;
+  }
+  return RSIS_OK;
 }
 int rsis_l_upsample_fwd(const float* x, float* y, long BC, int Hi, int Wi, int Ho, int Wo, hipStream_t st) {
   const long total = BC * Ho * Wo;

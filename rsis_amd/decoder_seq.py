@@ -134,11 +134,12 @@ class _DecoderSeqFn(torch.autograd.Function):
                         check(L.rsis_upsample_bilinear_ac_fwd(ptr(lv.Hs[t]), ptr(nx.UP[t]), B * lv.hid, lv.H, lv.W, nx.H, nx.W, stream()),
                               "rsis_upsample_fwd")
                 else:
-                    check(L.rsis_upsample_bilinear_ac_fwd(ptr(lv.Hs[t]), ptr(UP5[t]), B * lv.hid, lv.H, lv.W, H5, W5, stream()), "rsis_upsample_fwd")
+                    # (the x2 upsample of the last level, model.py:163-164, feeds conv_out only: all T steps in one launch after the loop)
                     # the heads of step t: decode the keys of all five levels (writes SIDE / ARG), two linears + softmax
                     check(L.rsis_heads_fwd_keys(ptr_array([v.KEY[t] for v in levels]), ptr_array([v.SIDE[t] for v in levels]),
                                                 ptr_array([v.ARG[t] for v in levels]), int_array(hs), n, B, ptr(Wc_d), ptr(bc_d), ncls,
                                                 ptr(Ws_d), ptr(bs_d), ptr(probs_tb[t]), ptr(stop_tb[t]), stream()), "rsis_heads_fwd_keys")
+        check(L.rsis_upsample_bilinear_ac_fwd(ptr(last.Hs), ptr(UP5), T * B * last.hid, last.H, last.W, H5, W5, stream()), "rsis_upsample_fwd(all steps)")
         # conv_out (model.py:167) on every timestep at once, logits straight into (B, T, N)
         out_masks = torch.empty((B, T, H5 * W5), **f32)
         co_pack = decoder.conv_out._pack
@@ -256,15 +257,18 @@ class _DecoderSeqFn(torch.autograd.Function):
         DC = [[torch.empty((B, lv.hid, lv.H, lv.W), **f32) for _ in range(2)] for lv in levels]
         DUP = [torch.empty((B, lv.c_up, lv.H, lv.W), **f32) if lv.c_up > 0 else None for lv in levels]
         wds = [lv.dyn.dgrad(gates_w[i]) for i, lv in enumerate(levels)]
+        # the last level's hidden states receive their gradient from conv_out only (no level above): all T steps in one launch
+        DH_last = torch.empty((T, B, last.hid, last.H, last.W), **f32)
+        check(L.rsis_upsample_maxpool_bwd(ptr(dUP5), ptr(dsides[n - 1]), ptr(last.ARG), ptr(DH_last), T * B * last.hid, last.H, last.W, H5, W5,
+                                          stream()), "rsis_upsample_maxpool_bwd(all steps)")
         for d in range(T + n - 2, -1, -1):
             cells = [(i, d - i) for i in range(n) if 0 <= d - i < T]
-            for i, t in cells:          # gradient reaching h[i][t] through its upsample into the next level (or conv_out) and its side max-pool
+            for i, t in cells:          # gradient reaching h[i][t] through its upsample into the next level and its side max-pool
                 lv = levels[i]
-                if i + 1 < n:
-                    nx = levels[i + 1]
-                    dy, Ho, Wo = DUP[i + 1], nx.H, nx.W
-                else:
-                    dy, Ho, Wo = dUP5[t], H5, W5
+                if i + 1 == n:
+                    continue
+                nx = levels[i + 1]
+                dy, Ho, Wo = DUP[i + 1], nx.H, nx.W
                 if (Ho, Wo) == (lv.H, lv.W):
                     DH[i].copy_(dy)
                     check(L.rsis_global_maxpool_bwd_add(ptr(dsides[i][t]), ptr(lv.ARG[t]), ptr(DH[i]), B * lv.hid, lv.H * lv.W, stream()),
@@ -272,24 +276,35 @@ class _DecoderSeqFn(torch.autograd.Function):
                 else:
                     check(L.rsis_upsample_maxpool_bwd(ptr(dy), ptr(dsides[i][t]), ptr(lv.ARG[t]), ptr(DH[i]), B * lv.hid, lv.H, lv.W, Ho, Wo,
                                                       stream()), "rsis_upsample_maxpool_bwd")
-            for i, t in cells:          # clstm.py:47-58 backwards: d(gates), dc_{t-1}
+            # clstm.py:47-58 backwards: d(gates), dc_{t-1} of the diagonal's cells -- ONE grouped launch
+            lb = (_lib.LstmBwdJob * len(cells))()
+            keep = []
+            for j, (i, t) in zip(lb, cells):
                 lv = levels[i]
                 if t == T - 1:      # gradients a caller put on the returned final state (none in runIter: train.py never reads it)
                     dh2 = d_hidden[2 * i].contiguous() if d_hidden[2 * i] is not None else None
                     dcn = d_hidden[2 * i + 1].contiguous() if d_hidden[2 * i + 1] is not None else None
+                    keep += [dh2, dcn]
                 else:
                     dh2, dcn = DHP[i], DC[i][(t + 1) & 1]
-                check(L.rsis_convlstm_bwd_gates(ptr(DH[i]), ptr(dh2), ptr(dcn),
-                                                ptr(lv.ACT[t]), ptr(lv.Cs[t - 1]) if t > 0 else None, ptr(lv.Cs[t]), ptr(DA[i][t]),
-                                                ptr(DC[i][t & 1]) if t > 0 else None, None, B, lv.hid, lv.H * lv.W, stream()),
-                      "rsis_convlstm_bwd_gates")
-            for i, t in cells:          # data gradient of the gate conv: d(up[i][t]) for the level below, dh[i][t-1] through the recurrence
-                lv = levels[i]
-                dxs = ([DUP[i]] if lv.c_up > 0 else []) + ([DHP[i]] if t > 0 else [])
-                if dxs:
-                    check(L.rsis_conv2d_dgrad(ptr(DA[i][t]), B, 4 * lv.hid, lv.H, lv.W, ptr(wds[i]), lv.dyn.cin, 3, 1, 1, ptr_array(dxs),
-                                              int_array([x.shape[1] for x in dxs]), len(dxs), lv.H, lv.W, None, ops.FORCE_TILE[0], lv.dyn.dtype,
-                                              stream()), "rsis_conv2d_dgrad(step)")
+                dh = DH_last[t] if i + 1 == n else DH[i]
+                (j.dh, j.dh2, j.dc_next, j.act, j.c_prev, j.c, j.da, j.dc_prev, j.B, j.hid, j.HW) = (
+                    ptr(dh), ptr(dh2), ptr(dcn), ptr(lv.ACT[t]), ptr(lv.Cs[t - 1]) if t > 0 else None, ptr(lv.Cs[t]), ptr(DA[i][t]),
+                    ptr(DC[i][t & 1]) if t > 0 else None, B, lv.hid, lv.H * lv.W)
+            check(L.rsis_convlstm_bwd_gates_batch(lb, len(cells), stream()), "rsis_convlstm_bwd_gates_batch")
+            # data gradients of the gate convs: d(up[i][t]) for the level below, dh[i][t-1] through the recurrence -- ONE grouped launch
+            dgc = [(i, t) for i, t in cells if levels[i].c_up > 0 or t > 0]
+            if dgc:
+                dg = (_lib.DgradJob * len(dgc))()
+                for j, (i, t) in zip(dg, dgc):
+                    lv = levels[i]
+                    dxs = ([DUP[i]] if lv.c_up > 0 else []) + ([DHP[i]] if t > 0 else [])
+                    (j.dy, j.B, j.Cout, j.Hy, j.Wy, j.Wd, j.Cin_packed, j.ks, j.stride, j.pad, j.ndst, j.Hx, j.Wx, j.addend, j.tile, j.dtype) = (
+                        ptr(DA[i][t]), B, 4 * lv.hid, lv.H, lv.W, ptr(wds[i]), lv.dyn.cin, 3, 1, 1, len(dxs), lv.H, lv.W, None, ops.FORCE_TILE[0],
+                        lv.dyn.dtype)
+                    for k, x in enumerate(dxs):
+                        j.dx[k], j.Cdx[k] = x.data_ptr(), x.shape[1]
+                check(L.rsis_conv2d_dgrad_batch(dg, len(dgc), stream()), "rsis_conv2d_dgrad_batch")
         # ---- per level, once: the time-invariant skip term and the time-batched weight gradients ----
         dfeats = [None] * n
         for i, lv in enumerate(levels):
@@ -415,14 +430,17 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
                 jobs.append(ops.blk_conv_job(srcs, wps[i], 4 * lv.hid, addend=lv.G, hid=lv.hid, c_prev=lv.Cs[t - 1] if t > 0 else None, c_out=lv.Cs[t],
                                              h_out=lv.Hs[t], act_out=lv.ACT[t] if lv.ACT is not None else None, side_key=lv.KEY[t],
                                              shape=(B, lv.H, lv.W)))
-                ups.append(ops.blk_resize_job(lv.Hs[t], levels[i + 1].UP[t] if i + 1 < n else UP5[t]))
+                if i + 1 < n:        # (the last level's x2 upsample feeds conv_out only: all T steps in one launch after the loop)
+                    ups.append(ops.blk_resize_job(lv.Hs[t], levels[i + 1].UP[t]))
             ops.blk_conv3x3_batch(jobs)
-            ops.blk_upsample_fwd_batch(ups)
+            if ups:
+                ops.blk_upsample_fwd_batch(ups)
             if cells[-1][0] == n - 1:
                 t = cells[-1][1]
                 check(L.rsis_heads_fwd_keys(ptr_array([v.KEY[t] for v in levels]), ptr_array([v.SIDE[t] for v in levels]),
                                             ptr_array([v.ARG[t] for v in levels]), int_array(hs), n, B, ptr(Wc_d), ptr(bc_d), ncls,
                                             ptr(Ws_d), ptr(bs_d), ptr(probs_tb[t]), ptr(stop_tb[t]), stream()), "rsis_heads_fwd_keys")
+        ops.blk_upsample_fwd_batch([ops.blk_resize_job(last.Hs.view(T * B, last.hid // 8, last.H, last.W, 8), UP5.view(T * B, 1, H5, W5, 8))])
         out_masks = torch.empty((B, T, H5 * W5), **f32)
         check(L.rsis_blk_conv_out_seq_fwd(ptr(UP5), ptr(co_w.detach()), ptr(co_b.detach()), ptr(out_masks), T, B, H5, W5, stream()),
               "rsis_blk_conv_out_seq_fwd")
@@ -508,20 +526,26 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
         wds = [lv.dyn.dgrad(gates_w[i]) for i, lv in enumerate(levels)]
         dhf = [ops.blk_from_nchw(d_hidden[2 * i].contiguous()) if (len(d_hidden) > 2 * i and d_hidden[2 * i] is not None) else None for i in range(n)]
         dcf = [d_hidden[2 * i + 1].contiguous() if (len(d_hidden) > 2 * i + 1 and d_hidden[2 * i + 1] is not None) else None for i in range(n)]
+        # the last level's hidden states receive their gradient from conv_out only: all T steps in one launch
+        DH_last = torch.empty((T, B, last.hid // 8, last.H, last.W, 8), **b16)
+        ops.blk_upsample_bwd_batch([ops.blk_resize_job(dUP5.view(T * B, 1, H5, W5, 8), DH_last.view(T * B, last.hid // 8, last.H, last.W, 8),
+                                                        dsides[n - 1], last.ARG, backward=True)])
         for d in range(T + n - 2, -1, -1):
             cells = [(i, d - i) for i in range(n) if 0 <= d - i < T]
             ups, lbs, dgs = [], [], []
             for i, t in cells:
                 lv = levels[i]
-                dy = DUP[i + 1] if i + 1 < n else dUP5[t]
-                ups.append(ops.blk_resize_job(dy, DH[i], dsides[i][t], lv.ARG[t], backward=True))
+                if i + 1 < n:
+                    ups.append(ops.blk_resize_job(DUP[i + 1], DH[i], dsides[i][t], lv.ARG[t], backward=True))
+                dh = DH[i] if i + 1 < n else DH_last[t]
                 dh2, dcn = (dhf[i], dcf[i]) if t == T - 1 else (DHP[i], DC[i][(t + 1) & 1])
-                lbs.append(ops.blk_lstm_bwd_job(DH[i], dh2, dcn, lv.ACT[t], lv.Cs[t - 1] if t > 0 else None, lv.Cs[t], DA[i][t],
+                lbs.append(ops.blk_lstm_bwd_job(dh, dh2, dcn, lv.ACT[t], lv.Cs[t - 1] if t > 0 else None, lv.Cs[t], DA[i][t],
                                                 DC[i][t & 1] if t > 0 else None))
                 dxs = ([DUP[i]] if lv.c_up > 0 else []) + ([DHP[i]] if t > 0 else [])
                 if dxs:
                     dgs.append(ops.blk_conv_job([DA[i][t]], wds[i], sum(x.shape[1] for x in dxs) * 8, cpack=lv.dyn.cin, dsts=dxs))
-            ops.blk_upsample_bwd_batch(ups)
+            if ups:
+                ops.blk_upsample_bwd_batch(ups)
             ops.blk_lstm_bwd_batch(lbs)
             if dgs:
                 ops.blk_conv3x3_batch(dgs)
