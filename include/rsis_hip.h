@@ -218,6 +218,13 @@ int rsis_bn_bwd(const float* dy, const float* x, const float* y, const float* sa
                 const float* gamma, double* stats, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C,
                 int HW, int relu, void* stream);
 
+/* eval-mode backward (the module in .eval(): y = relu?(gamma (x - running_mean) / sqrt(running_var + eps) + beta (+ res)), statistics are
+ * constants): g = dy * [y > 0] if relu bit0, dx = gamma / sqrt(running_var + eps) * g, dres = g, dgamma = sum g xhat, dbeta = sum g.
+ * Flags and scratch as rsis_bn_bwd (bit1: stats zeroed by the caller; bit2: accumulate into dgamma / dbeta). */
+int rsis_bn_bwd_eval(const float* dy, const float* x, const float* y, const float* running_mean, const float* running_var,
+                     const float* gamma, double* stats, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C, int HW,
+                     float eps, int relu, void* stream);
+
 /* ---- y[bc][ho][wo] = x[bc][ho * stride][wo * stride], y is [BC][(H-1)/stride+1][(W-1)/stride+1]: the dense input of a
  * 1x1 / stride-s conv (torchvision Bottleneck downsample, layers 2-4; reference vision.py:16-19) -- x[:, :, ::s, ::s].contiguous().
  * The conv then runs as its stride-1 form (rsis_conv2d_fwd on y) and y is what its weight gradient reads. ---- */

@@ -109,6 +109,7 @@ SIGNATURES = {
     "rsis_global_maxpool_bwd_add": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "rsis_bn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp]),
     "rsis_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsis_bn_bwd_eval": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "rsis_subsample2d": (_i, [_vp, _vp, _l, _i, _i, _i, _vp]),
     "rsis_maxpool3x3s2_fwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "rsis_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp]),

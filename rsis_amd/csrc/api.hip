@@ -52,7 +52,7 @@ int rsis_l_gmax_bwd(const float*, const int*, float*, long, int, hipStream_t);
 int rsis_l_bn_fwd(const float*, const float*, float*, double*, const float*, const float*, float*, float*, float*, float*, int,
                   int, int, float, float, int, int, hipStream_t);
 int rsis_l_bn_bwd(const float*, const float*, const float*, const float*, const float*, const float*, double*, float*, float*,
-                  float*, float*, int, int, int, int, hipStream_t);
+                  float*, float*, int, int, int, int, float, hipStream_t);
 int rsis_l_maxpool_fwd(const float*, float*, unsigned char*, long, int, int, int, int, hipStream_t);
 int rsis_l_subsample(const float*, float*, long, int, int, int, int, int, hipStream_t);
 int rsis_l_maxpool_bwd(const float*, const unsigned char*, float*, long, int, int, int, int, int, hipStream_t);
@@ -302,6 +302,7 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
   a.wp = (const float*)Wp; a.ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN); a.Cout = Cout; a.bias = bias; a.addend = addend;
   a.dst[0] = out; a.Cd[0] = Cout; a.ndst = 1;
   a.ostride = 1; a.oH = Ho; a.oW = Wo; a.ksplit = 1;
+  a.precise = allow_splitk ? 0 : 1;       // (tile + 100 marks a training call; everything else is the inference / parity path)
   if (use_bf16(dtype, ks, stride, pad, Cout)) {
     if (stride != 1) return RSIS_ERR_UNSUPPORTED;      // strided 1x1: run the stride-1 form on a sub-sampled input
     if (ks == 1 && nsrc != 1) return RSIS_ERR_UNSUPPORTED;
@@ -508,6 +509,7 @@ static int lstm_fill(ConvArgs& a, int& route, const float* const* src, const int
   a.ostride = 1; a.oH = H; a.oW = W; a.ksplit = 1;
   route = use_bf16(dtype, ks, 1, pad, 4 * hid) ? 0 : (use_direct(ks, 1, pad) ? 1 : 2);
   a.side_key = side_key;
+  a.precise = act_out ? 0 : 1;            // no saved gates: an inference call
   if (side_key && (route == 2 || (long)H * W >= 0x7FFFFFFFL)) return RSIS_ERR_UNSUPPORTED;   // the fused side max-pool lives in the 3x3 epilogues
   return RSIS_OK;
 }
@@ -597,8 +599,15 @@ int rsis_bn_bwd(const float* dy, const float* x, const float* y, const float* sa
                 int HW, int relu, void* stream) {
   if (!dy || !x || !save_mean || !save_rstd || !gamma || !stats || !dx || !dgamma || !dbeta) return RSIS_ERR_ARG;
   if ((relu & 1) && !y) return RSIS_ERR_ARG;
-  return rsis_l_bn_bwd(dy, x, y, save_mean, save_rstd, gamma, stats, dx, dres, dgamma, dbeta, B, C, HW, relu,
+  return rsis_l_bn_bwd(dy, x, y, save_mean, save_rstd, gamma, stats, dx, dres, dgamma, dbeta, B, C, HW, relu, -1.f,
                        (hipStream_t)stream);
+}
+int rsis_bn_bwd_eval(const float* dy, const float* x, const float* y, const float* running_mean, const float* running_var,
+                     const float* gamma, double* stats, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C, int HW,
+                     float eps, int relu, void* stream) {
+  if (!dy || !x || !running_mean || !running_var || !gamma || !stats || !dx || !dgamma || !dbeta || !(eps >= 0.f)) return RSIS_ERR_ARG;
+  if ((relu & 1) && !y) return RSIS_ERR_ARG;
+  return rsis_l_bn_bwd(dy, x, y, running_mean, running_var, gamma, stats, dx, dres, dgamma, dbeta, B, C, HW, relu, eps, (hipStream_t)stream);
 }
 // ---- channel-blocked bf16 activations (conv_blk.hip) ----
 int rsis_blk_conv2d(const void* x, int B, int C, int H, int W, const void* Wp, int Cout, int ks, const void* addend, void* out, int variant,

@@ -75,6 +75,7 @@ struct ConvArgs {
   float* c_out;                    // [B][hid][Ho][Wo]
   float* act_out;                  // [B][4*hid][Ho][Wo] post-nonlinearity gates (interleaved rows) or null
   unsigned long long* side_key;    // [B][hid] or null: global max-pool of h fused into the epilogue (rsis_side_key, zeroed by the caller)
+  int precise;                     // direct 3x3 kernel: sum the reduction in segments whatever its length (inference calls; conv3x3_direct.hip)
 };
 
 // ---- global max-pool of the hidden state (reference model.py:143) fused into the ConvLSTM epilogue ----

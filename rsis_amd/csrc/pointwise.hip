@@ -491,9 +491,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, double* __restrict__ stats,
-                                                            int C, int HW, long N, int relu) {
+                                                            int C, int HW, long N, int relu, float eval_eps) {
   const int c = blockIdx.x;
-  const float m = mean[c], r = rstd[c];
+  // eval_eps >= 0: eval-mode BatchNorm -- `mean` / `rstd` hold the running mean / running VARIANCE
+  const float m = mean[c], r = eval_eps >= 0.f ? 1.f / sqrtf(rstd[c] + eval_eps) : rstd[c];
   double s1 = 0.0, s2 = 0.0;
   if ((HW & 3) == 0) {
     BN_FOREACH(4, {
@@ -524,10 +525,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const double* __restrict__ stats, float* __restrict__ dx,
                                                            float* __restrict__ dres, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int C, int HW, long N, int relu,
-                                                           int accum) {
+                                                           int accum, float eval_eps) {
   const int c = blockIdx.x;
-  const float m = mean[c], r = rstd[c];
-  const float mg = (float)(stats[2 * c] / (double)N), mgx = (float)(stats[2 * c + 1] / (double)N);
+  const bool ev = eval_eps >= 0.f;      // eval mode: the statistics are constants, dx = gamma * rstd * g (no mean terms)
+  const float m = mean[c], r = ev ? 1.f / sqrtf(rstd[c] + eval_eps) : rstd[c];
+  const float mg = ev ? 0.f : (float)(stats[2 * c] / (double)N), mgx = ev ? 0.f : (float)(stats[2 * c + 1] / (double)N);
   const float kk = gamma[c] * r;
   if (blockIdx.y == 0 && threadIdx.x == 0) {
     const float dg = (float)stats[2 * c + 1], db = (float)stats[2 * c];
@@ -1103,11 +1105,11 @@ int rsis_l_bn_fwd(const float* x, const float* res, float* y, double* stats, con
 }
 int rsis_l_bn_bwd(const float* dy, const float* x, const float* y, const float* mean, const float* rstd, const float* gamma,
                   double* stats, float* dx, float* dres, float* dgamma, float* dbeta, int B, int C, int HW, int relu_flags,
-                  hipStream_t st) {
+                  float eval_eps, hipStream_t st) {
   const long N = (long)B * HW;
   const int S = chan_splits(C, N);
   const int relu = relu_flags & 1, accum = (relu_flags >> 2) & 1;
-  if (bn_fused_ok(C, HW, N)) {
+  if (eval_eps < 0.f && bn_fused_ok(C, HW, N)) {
     if (N / 4 <= 256 * 8 && C <= 512)          // (as in the forward)
       hipLaunchKernelGGL((bn_bwd_fused_kernel<512, 4>), dim3(C), dim3(512), 0, st, dy, x, y, mean, rstd, gamma, dx, dres, dgamma, dbeta,
                          C, HW, N, relu, accum);
@@ -1120,9 +1122,9 @@ int rsis_l_bn_bwd(const float* dy, const float* x, const float* y, const float* 
     return rsis_check_launch();
   }
   if (!(relu_flags & 2) && rsis_zero_async(stats, sizeof(double) * 2 * C, st) != RSIS_OK) return RSIS_ERR_LAUNCH;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, mean, rstd, stats, C, HW, N, relu);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, mean, rstd, stats, C, HW, N, relu, eval_eps);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, S), dim3(256), 0, st, dy, x, y, mean, rstd, gamma, stats, dx, dres, dgamma,
-                     dbeta, C, HW, N, relu, accum);
+                     dbeta, C, HW, N, relu, accum, eval_eps);
   return rsis_check_launch();
 }
 int rsis_l_gmax_bwd_add(const float* dy, const int* arg, float* dx, long BC, int HW, hipStream_t st) {

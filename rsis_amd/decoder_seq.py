@@ -91,7 +91,8 @@ class _DecoderSeqFn(torch.autograd.Function):
             wp = lv.hoist.fwd(gates_w[i], gates_b[i])
             lv.G = torch.empty((B, 4 * lv.hid, lv.H, lv.W), **f32)
             check(L.rsis_conv2d_fwd(ptr_array([feats[i]]), int_array([lv.c_skip]), 1, B, lv.H, lv.W, ptr(wp), 4 * lv.hid, 3, 1, 1,
-                                    ptr(lv.hoist.bias_p), None, ptr(lv.G), lv.H, lv.W, ops.FORCE_TILE[0], lv.hoist.dtype, stream()),
+                                    ptr(lv.hoist.bias_p), None, ptr(lv.G), lv.H, lv.W, ops.FORCE_TILE[0] + (100 if need_grad else 0), lv.hoist.dtype,
+                                    stream()),
                   "rsis_conv2d_fwd(hoist)")
             lv.Hs = torch.empty((T, B, lv.hid, lv.H, lv.W), **f32)
             lv.Cs = torch.empty((T, B, lv.hid, lv.H, lv.W), **f32)

@@ -595,12 +595,19 @@ class _BatchNormFn(torch.autograd.Function):
         dy = _contig(dy)
         B, C, H, W = x.shape
         if not ctx.train:
-            # eval-mode BN is an affine map: dx = g * gamma / sqrt(running_var + eps)
-            g = dy * (y > 0).to(dy.dtype) if ctx.relu else dy
-            scale = gamma.detach() / torch.sqrt(rstd + ctx.eps)  # here `rstd` holds running_var
-            dx = g * scale.view(1, C, 1, 1)
-            xh = (x - mean.view(1, C, 1, 1)) / torch.sqrt(rstd + ctx.eps).view(1, C, 1, 1)
-            return dx, (g if ctx.has_res else None), (g * xh).sum((0, 2, 3)), g.sum((0, 2, 3)), None, None, None, None, None, None, None, None
+            # eval-mode BN is an affine map with constant statistics: dx = g * gamma / sqrt(running_var + eps) (rsis_bn_bwd_eval;
+            # here `mean` / `rstd` hold running_mean / running_var)
+            stats = torch.empty(2 * C, dtype=torch.float64, device=dy.device)
+            dx = torch.empty_like(x)
+            need_dres = ctx.has_res and ctx.relu
+            dres = torch.empty_like(x) if need_dres else None
+            dgamma = torch.empty(C, dtype=torch.float32, device=dy.device)
+            dbeta = torch.empty_like(dgamma)
+            check(lib().rsis_bn_bwd_eval(ptr(dy), ptr(x), ptr(y), ptr(mean), ptr(rstd), ptr(gamma.detach()), ptr(stats), ptr(dx), ptr(dres),
+                                         ptr(dgamma), ptr(dbeta), B, C, H * W, float(ctx.eps), int(ctx.relu), stream()), "rsis_bn_bwd_eval")
+            if ctx.has_res and not need_dres:
+                dres = dy
+            return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
         flags = int(ctx.relu)
         if ctx.arena is not None:
             stats, flags = ctx.arena[1], flags | 2

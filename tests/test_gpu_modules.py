@@ -180,11 +180,11 @@ def test_e2e_256_north_star():
     assert_close("e2e.mask_probs", masks[:, :, ::sub, ::sub], g["mask_probs_sub"], 1e-4)
     assert_close("e2e.classes", classes, g["classes"], 1e-4)
     assert_close("e2e.stops", stops, g["stops"], 1e-4)
-    # raw stop logit (the output with the largest fp32 noise of the reference itself on this fixture): fixed bar 1e-4, or -- fixed-k
-    # rule against the float64 truth, k = 3 chosen in advance -- 3 x the reference's own |fp32 - fp64| (4.121e-5,
-    # tools/exp/e2e_fp64_floor.py), whichever is larger
-    REF_FP32_FLOOR = 4.121e-5
-    assert_close("e2e.stop_logits", stop_logits, g["stop_logits"], max(1e-4, 3 * REF_FP32_FLOOR))
+    # raw stop logit, the output with the largest fp32 noise of the reference itself on this fixture (its own |fp32 - fp64| is 4.1e-5,
+    # tools/exp/e2e_fp64_floor.py): the north-star 1e-4 like every other output.  It used to sit at 1.1e-4: the error entered through
+    # the side feature of the coarsest level, whose 18432-deep skip conv this library summed as ONE chain of MFMA accumulations
+    # (tools/exp/stop_logit_diag.py); deep reductions and every inference call are now summed in segments (conv3x3_direct.hip).
+    assert_close("e2e.stop_logits", stop_logits, g["stop_logits"], 1e-4)
     _loaded_native()
 
 
