@@ -28,6 +28,9 @@ from . import _lib, decoder_fused, ops
 from ._lib import check, int_array, lib, ptr, ptr_array, stream
 
 ENABLED = [os.environ.get("RSIS_DECODER_SEQ", "1") != "0"]
+# test hook: RECORD[0] = True keeps a copy of the arg-max pixels of the side max-pools of the last sequence in LAST["arg"] (per level,
+# [T][B][hid] int32) -- what the per-step path's callers can read off the returned hidden states
+RECORD, LAST = [False], {}
 
 
 def supported(decoder, skip_feats, T):
@@ -160,6 +163,8 @@ class _DecoderSeqFn(torch.autograd.Function):
         hidden = []
         for lv in levels:
             hidden += [lv.Hs[T - 1], lv.Cs[T - 1]]
+        if RECORD[0]:
+            LAST["arg"] = [lv.ARG.clone() for lv in levels]
         ctx.set_materialize_grads(False)
         if need_grad:
             ctx.decoder, ctx.T, ctx.levels, ctx.seq_ok = decoder, T, levels, seq_ok
@@ -451,6 +456,8 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
         if want_hidden:
             for lv in levels:
                 hidden += [ops.blk_to_nchw(lv.Hs[T - 1]), lv.Cs[T - 1]]
+        if RECORD[0]:
+            LAST["arg"] = [lv.ARG.clone() for lv in levels]
         ctx.set_materialize_grads(False)
         if need_grad:
             ctx.decoder, ctx.T, ctx.levels = decoder, T, levels

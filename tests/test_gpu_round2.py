@@ -86,8 +86,11 @@ def test_e2e_geometry_bf16(name):
     assert_close(name + ".stops", stops, g["stops"], BF16_TOL["probs"])
 
 
-def _train_step(dtype):
+def _train_step(dtype, path="per_step"):
+    """path "per_step": the decoder through T calls of RSIS.forward (the reference's loop, wrapped to record the arg-max picks);
+    "node": through RSIS.forward_sequence_stacked, the one-node explicit-BPTT sequence runIter uses by default (rsis_amd/decoder_seq.py)"""
     from oracle import filler
+    from rsis_amd import decoder_seq
     from rsis_amd.train import build_optimizers, runIter
     from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
     g = gold("trainstep_160")
@@ -107,9 +110,20 @@ def _train_step(dtype):
         out = orig(feats, hidden)
         picks.append([h.detach().flatten(2).argmax(-1).cpu() for h, _c in out[3]])
         return out
-    dec.forward = fwd
-    losses, outs, perms = runIter(a, enc, dec, x, y_mask, y_class.clone(), sw_mask.double(), sw_class.double(), crits, [enc_opt, dec_opt],
-                                  mode="train", want_outs=False)
+    if path == "per_step":
+        dec.forward = fwd
+    decoder_seq.RECORD[0] = True
+    decoder_seq.LAST.clear()
+    try:
+        losses, outs, perms = runIter(a, enc, dec, x, y_mask, y_class.clone(), sw_mask.double(), sw_class.double(), crits, [enc_opt, dec_opt],
+                                      mode="train", want_outs=False)
+    finally:
+        decoder_seq.RECORD[0] = False
+    if path == "node":
+        assert "arg" in decoder_seq.LAST, "runIter did not go through the sequence node"
+        picks = [[decoder_seq.LAST["arg"][i][t].long().cpu() for i in range(5)] for t in range(T)]
+    else:
+        assert "arg" not in decoder_seq.LAST
     named = [("dec." + k, p) for k, p in dec.named_parameters()] + [("enc." + k, p) for k, p in enc.named_parameters()
                                                                     if not k.startswith("base.fc")]
     # pyramid levels (0 = deepest) at which some plane picked another pixel than the float64 reference run
@@ -129,7 +143,8 @@ def _level_of(k):
     return None
 
 
-def test_trainstep_fp32_losses_outputs_gradients_and_adam_step():
+@pytest.mark.parametrize("path", ["node", "per_step"])
+def test_trainstep_fp32_losses_outputs_gradients_and_adam_step(path):
     """rsis_amd.train.runIter (reference src/train.py:54-197) on (4, 3, 160, 160), T = 4, train-mode encoder and decoder, default
     learning rates: the four loss scalars and the mask outputs within 1e-4 of the reference, the matching permutation identical,
     class probabilities and EVERY gradient tensor by the fp64-truth rule, and the parameters after ONE Adam step of both
@@ -140,7 +155,7 @@ def test_trainstep_fp32_losses_outputs_gradients_and_adam_step():
     largest values for all 3968 plane-timesteps (smallest relative gap: 1.3e-5; the reference's own fp32 run picks another pixel
     than its float64 run in 2 of them).  Where this implementation picks another pixel than the float64 run, the gradients of that
     level, of the deeper levels it feeds and of the trunk are held to 15 % relative L2 instead of the fixed-k rule."""
-    g, losses, outs, perms, named, pre, (B, T, H, W), flipped = _train_step("fp32")
+    g, losses, outs, perms, named, pre, (B, T, H, W), flipped = _train_step("fp32", path)
     for k, v in zip(("loss", "loss_mask_iou", "loss_stop", "loss_class"), losses):
         assert_close(k, v, g[k], 1e-4, 1e-4)       # (1e-4 absolute + 1e-4 relative, as in _check_bench_step below)
     assert (perms[1].cpu().numpy() == g["y_class_perm"]).all()
@@ -174,9 +189,12 @@ def test_trainstep_fp32_losses_outputs_gradients_and_adam_step():
         assert abs(float(flat.double().norm()) - n64) <= K_FLOOR * abs(n32 - n64) + 2e-4 * n64 + 1e-7, "gnorm " + k
     # (visible with -rP / on failure: how many tensors were held to the strict float64-floor rule -- all of them unless an arg-max flipped)
     print("trainstep fp32: %d gradient tensors checked, %d by the strict rule, arg-max flips at levels %s" % (checked, strict, flipped))
-    assert checked > 300 and strict >= 20
+    # every tensor is held to the strict rule except those downstream of a recorded flip: exactly the level tensors at or below the
+    # deepest flipped level and the trunk
+    relaxed = sum(1 for k, _p in named if flipped and (_level_of(k) == -1 or (_level_of(k) is not None and _level_of(k) <= relaxed_upto)))
+    assert checked > 300 and strict == checked - relaxed, "%d checked, %d strict, %d expected relaxed" % (checked, strict, relaxed)
     if not flipped:
-        assert strict == checked, "no arg-max flip, yet %d tensors took the relaxed branch" % (checked - strict)
+        assert strict == checked
     # one Adam step (torch.optim.Adam, lr 1e-3 / 1e-6, weight decay 1e-6): first-step update = -lr * g / (|g| + eps), which is
     # insensitive to the size of g wherever |g| >> eps -- compare where the gradient is well above its own fp32 noise
     n_cmp = 0
@@ -323,6 +341,20 @@ def _bench_config_oracle():
         sd = (copy.deepcopy(oenc.state_dict()), copy.deepcopy(odec.state_dict()))
         _BENCH_ORACLE.update(batch=batch, sd=sd, args=a, modules=(oenc, odec))
         _BENCH_ORACLE.update(_bench_oracle_eval(_BENCH_ORACLE, None))
+        # the same iteration in float64 (the truth the fixed-k gradient rule is stated against), under the fp32 run's assignment so that
+        # the two are the same function; ~1 min of host time, 3 TB of host memory on the GPU box
+        import time
+        t0 = time.time()
+        o64 = dict(_BENCH_ORACLE, modules=(copy.deepcopy(oenc).double(), copy.deepcopy(odec).double()),
+                   batch=tuple(t.double() if t.is_floating_point() else t for t in batch))
+        from oracle import rsis_oracle as O64
+        e64, d64 = o64["modules"]
+        r = O64.run_iter_forward(a, e64, d64, *o64["batch"], mode="train", assignment=_BENCH_ORACLE["assignment"])
+        r["loss"].backward()
+        g64 = {("dec." + k): p.grad.detach().clone() for k, p in d64.named_parameters()}
+        g64.update({("enc." + k): p.grad.detach().clone() for k, p in e64.named_parameters() if not k.startswith("base.")})
+        _BENCH_ORACLE.update(grads64=g64, f64_seconds=time.time() - t0)
+        del o64, e64, d64, r
     return _BENCH_ORACLE
 
 
@@ -336,7 +368,7 @@ def _bench_oracle_eval(o, assignment):
     r["loss"].backward()
     ref = {("dec." + k): p.grad.detach().clone() for k, p in odec.named_parameters()}
     ref.update({("enc." + k): p.grad.detach().clone() for k, p in oenc.named_parameters() if not k.startswith("base.")})
-    return dict(grads=ref, perm=r["y_class_perm"].numpy().copy(), scores=r["scores"].numpy().copy(),
+    return dict(grads=ref, perm=r["y_class_perm"].numpy().copy(), scores=r["scores"].numpy().copy(), assignment=np.asarray(r["assignment"]).copy(),
                 losses={k: float(r[k]) for k in ("loss", "loss_mask_iou", "loss_stop", "loss_class")})
 
 
@@ -345,11 +377,13 @@ def _check_bench_step(o, losses, perms, grads):
     # the matching first: equal to the oracle's, or tied with it inside 1e-5 under the oracle's own costs (every image of this batch has
     # its second-best assignment within ~1e-6 of the optimum: helpers.same_matching) -- then the oracle is evaluated under the
     # product's assignment, so that losses and gradients are compared like with like
+    tied = False
     if not same_matching("bench step", perms[2], perms[1], o["scores"], o["perm"]):
         key = perms[2].cpu().numpy().tobytes()
         if key not in o.setdefault("tied", {}):
             o["tied"][key] = _bench_oracle_eval(o, perms[2].cpu().numpy())
         o = dict(o, **o["tied"][key])
+        tied = True
     # losses: 1e-4 absolute + 1e-4 relative.  The class loss is 4.3 here (random weights, 21 classes): two runs of THIS step already
     # differ by ~5e-5 on it (train-mode split-K sums and BatchNorm statistics end in atomics whose order varies), and 1 run in 4 on
     # fresh boxes landed 1.2e-4 from the oracle's fp32 value -- 2.8e-5 relative, 60 fp32 ulps after ~110 layers.  The bar for O(1)
@@ -358,12 +392,28 @@ def _check_bench_step(o, losses, perms, grads):
         assert_close(k, got, o["losses"][k], 1e-4, 1e-4)
     assert (perms[1].cpu().numpy() == o["perm"]).all()
     errs = []
-    for k, g32 in o["grads"].items():
-        if k.startswith("enc.sk") and k.endswith("bias"):
-            continue                       # (a conv bias in front of a BatchNorm has a mathematically zero gradient: both sides are noise)
-        lvl = _level_of(k)
-        tol = 5e-2 if lvl is not None else 1e-3          # per-level tensors: arg-max-routed gradients; conv_out / heads: tight
-        errs.append((k, _rel_l2(grads[k], g32), tol))
+    if tied or "grads64" not in o:
+        # (the product took an assignment tied with the oracle's: the float64 truth was evaluated under the oracle's own; the flat bars)
+        for k, g32 in o["grads"].items():
+            if k.startswith("enc.sk") and k.endswith("bias"):
+                continue                       # (a conv bias in front of a BatchNorm has a mathematically zero gradient: both sides are noise)
+            lvl = _level_of(k)
+            tol = 5e-2 if lvl is not None else 1e-3          # per-level tensors: arg-max-routed gradients; conv_out / heads: tight
+            errs.append((k, _rel_l2(grads[k], g32), tol))
+    else:
+        # fixed-k rule against the float64 truth, with the k of the 160 x 160 fixture (K_FLOOR = 3): a tensor may be at most three times as
+        # far (relative L2) from the float64 gradient as the reference's own fp32 evaluation of the same iteration is, + 2e-3.  The
+        # per-level tensors collect the arg-max-routed gradients of 7936 hidden-state planes x 10 steps, where the reference's fp32 run
+        # itself picks other pixels than its float64 run: their floor is MEASURED here (0.1-0.9 %) instead of being covered by a flat 5 %.
+        # (First measurement of this rule: every tensor 0.2-1.8 % from float64, the worst ratio to its own floor 2.8 at level 1.)
+        for k, g32 in o["grads"].items():
+            if k.startswith("enc.sk") and k.endswith("bias"):
+                continue
+            f64 = o["grads64"][k]
+            floor = _rel_l2(g32.double(), f64)
+            errs.append((k, _rel_l2(grads[k].double(), f64), K_FLOOR * floor + 2e-3))
+        print("bench step, |hip - f64| / allowed (3 x |ref32 - f64| + 2e-3), worst five: %s  [float64 oracle: %.0f s]"
+              % (sorted(((round(e / t, 3), k, "%.2e" % e) for k, e, t in errs), reverse=True)[:5], o.get("f64_seconds", -1)))
     bad = [e for e in errs if e[1] >= e[2]]
     assert not bad, "gradients outside their bar: %s; all: %s" % (bad, [(k, "%.1e" % e) for k, e, _t in errs])
 
