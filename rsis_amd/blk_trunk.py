@@ -185,6 +185,69 @@ class _LayerFn(torch.autograd.Function):
         return None, dx, None
 
 
+class _SkipsBlkFn(torch.autograd.Function):
+    """The skip branches of reference model.py:59-63 -- x_k_skip = bn_k(sk_k(x_k)), a 3x3 conv with bias and a BatchNorm without ReLU --
+    for the trunk features that are already blk tensors, blk in / blk out: the convs of all given levels in ONE grouped launch
+    (rsis_blk_conv3x3_batch), blk BatchNorm, and in the backward one grouped data-gradient launch, the weight gradients parked for the
+    grouped flush.  No layout converters between the trunk, the skip branches and the decoder."""
+
+    @staticmethod
+    def forward(ctx, mods, *xs):
+        # mods: [(HipConv2d, HipBatchNorm2d)] per level, xs: the blk inputs
+        keep = any(ctx.needs_input_grad)
+        zs, jobs = [], []
+        for (conv, _unused), x in zip(mods, xs):
+            B, _cb, H, W, _ = x.shape
+            z = torch.empty((B, conv.out_channels // 8, H, W, 8), dtype=torch.bfloat16, device=x.device)
+            jobs.append(ops.blk_conv_job([x], conv._pack.fwd(conv.weight), conv.out_channels, bias=conv.bias.detach(), dsts=[z]))
+            zs.append(z)
+        ops.blk_conv3x3_batch(jobs)
+        ys, stats = [], []
+        for (_unused, bn), z in zip(mods, zs):
+            y, st = _bn(bn, z, None, False)
+            ys.append(y)
+            stats.append(st)
+        if keep:
+            ctx.mods, ctx.xs, ctx.zs, ctx.stats = mods, xs, zs, stats
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        mods, xs, zs, stats = ctx.mods, ctx.xs, ctx.zs, ctx.stats
+        ctx.xs = ctx.zs = ctx.stats = None
+        L = lib()
+        dzs, jobs, dxs = [], [], []
+        for (conv, bn), x, z, st, dy in zip(mods, xs, zs, stats, dys):
+            if not bn.training:
+                raise RuntimeError("blk skip branches: the backward exists for train-mode BatchNorm only")
+            dz, _ = _bn_bwd(bn, dy.contiguous(), z, None, st, False, False)
+            dzs.append(dz)
+            _wgrad(conv, dz, x)
+            if conv.bias is not None and conv.bias.requires_grad:
+                tb = ops._direct_target(conv.bias)
+                db = tb if tb is not None else torch.zeros_like(conv.bias)
+                B, _cb, H, W, _ = dz.shape
+                from ._lib import check, ptr, stream
+                check(L.rsis_blk_bias_grad(ptr(dz), ptr(db), B, conv.out_channels, H * W, 0, stream()), "rsis_blk_bias_grad")
+                if tb is None:
+                    _acc(conv.bias, db)
+        for i, ((conv, _unused), x, dz) in enumerate(zip(mods, xs, dzs)):
+            if ctx.needs_input_grad[1 + i]:
+                dx = torch.empty_like(x)
+                jobs.append(ops.blk_conv_job([dz], conv._pack.dgrad(conv.weight), conv.in_channels, cpack=conv._pack.cin, dsts=[dx]))
+                dxs.append(dx)
+            else:
+                dxs.append(None)
+        if jobs:
+            ops.blk_conv3x3_batch(jobs)
+        return (None,) + tuple(dxs)
+
+
+def skips_forward(mods, xs):
+    """[(sk_k, bn_k)] applied to the blk features xs -> the blk skip features (one autograd node)"""
+    return list(_SkipsBlkFn.apply(mods, *xs))
+
+
 def layer_forward(layer, x):
     """x (blk) through one layer.  The anchor keeps the node in the graph when x itself carries no gradient (a frozen stem in front
     of a trainable layer): any parameter of the layer that requires grad."""

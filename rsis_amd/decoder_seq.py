@@ -33,13 +33,24 @@ ENABLED = [os.environ.get("RSIS_DECODER_SEQ", "1") != "0"]
 RECORD, LAST = [False], {}
 
 
+def _is_blk(t):
+    return t.dtype == torch.bfloat16 and t.dim() == 5 and t.shape[-1] == 8
+
+
+def _chan(t):
+    """channels of a skip feature given as fp32 NCHW or as a blk tensor [B][C/8][H][W][8]"""
+    return t.shape[1] * 8 if _is_blk(t) else t.shape[1]
+
+
 def supported(decoder, skip_feats, T):
     """the explicit sequence covers the product configuration: concat skips, 3x3 gates, no dropout, the fused heads kernel"""
     n = len(decoder.clstm_list)
     if not (ENABLED[0] and decoder_fused.WAVEFRONT[0] and decoder_fused.FUSED_POOL[0] and decoder.fused and decoder.skip_mode == "concat" and decoder.dropout == 0 and decoder.dropout_cls == 0 and
             decoder.dropout_stop == 0 and len(skip_feats) == n and T >= 1 and "forward" not in decoder.__dict__):
         return False
-    if not all(f.is_cuda and f.dtype == torch.float32 and f.dim() == 4 for f in skip_feats):
+    if not all(f.is_cuda and ((f.dtype == torch.float32 and f.dim() == 4) or _is_blk(f)) for f in skip_feats):
+        return False
+    if any(_is_blk(f) for f in skip_feats) and not blk_supported(decoder, skip_feats):
         return False
     if not all(c.kernel_size == 3 and c.padding == 1 for c in decoder.clstm_list):
         return False
@@ -50,7 +61,7 @@ def supported(decoder, skip_feats, T):
         return False
     for i, c in enumerate(decoder.clstm_list):      # the channel pyramid of model.py:98-106 (level i consumes up(h[i-1]) | skip[i])
         c_up = 0 if i == 0 else hs[i - 1]
-        if c.input_size != c_up + skip_feats[i].shape[1]:
+        if c.input_size != c_up + _chan(skip_feats[i]):
             return False
     return True
 
@@ -371,7 +382,7 @@ def blk_supported(decoder, skip_feats):
     hs = [c.hidden_size for c in decoder.clstm_list]
     if not all(getattr(c, "dtype", ops.DTYPE_F32) == ops.DTYPE_BF16 for c in decoder.clstm_list):
         return False
-    if any(h % 8 for h in hs) or any(f.shape[1] % 8 for f in skip_feats) or hs[-1] != 8:
+    if any(h % 8 for h in hs) or any(_chan(f) % 8 for f in skip_feats) or hs[-1] != 8:
         return False
     return (2 * skip_feats[-1].shape[3]) % 4 == 0
 
@@ -385,12 +396,12 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
     def forward(ctx, decoder, T, keep, want_hidden, *tensors):
         L = lib()
         n = len(decoder.clstm_list)
-        feats = [t if t.is_contiguous() else t.contiguous() for t in tensors[:n]]
+        feats = [t if t.is_contiguous() else t.contiguous() for t in tensors[:n]]      # fp32 NCHW, or already blk (the encoder's blk skip path)
         params = tensors[n:]
         gates_w = [params[2 * i] for i in range(n)]
         gates_b = [params[2 * i + 1] for i in range(n)]
         co_w, co_b, Wc, bc, Ws, bs = params[2 * n:2 * n + 6]
-        _lib.require_cuda_f32(*feats, *params)
+        _lib.require_cuda_f32(*[f for f in feats if not _is_blk(f)], *params)
         need_grad = bool(keep) and any(ctx.needs_input_grad)
         dev = feats[0].device
         B = feats[0].shape[0]
@@ -404,10 +415,10 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
         levels, off, hoist_jobs = [], 0, []
         for i, cell in enumerate(decoder.clstm_list):
             lv = _Level()
-            lv.cell, lv.hid, lv.c_up, lv.c_skip = cell, hs[i], (0 if i == 0 else hs[i - 1]), feats[i].shape[1]
+            lv.cell, lv.hid, lv.c_up, lv.c_skip = cell, hs[i], (0 if i == 0 else hs[i - 1]), _chan(feats[i])
             lv.H, lv.W = feats[i].shape[2], feats[i].shape[3]
             lv.hoist, lv.dyn = decoder_fused._packs(cell, lv.c_up, lv.c_skip)
-            lv.skip = ops.blk_from_nchw(feats[i])
+            lv.skip = feats[i] if _is_blk(feats[i]) else ops.blk_from_nchw(feats[i])
             lv.G = torch.empty((B, 4 * lv.hid // 8, lv.H, lv.W, 8), **b16)
             hoist_jobs.append(ops.blk_conv_job([lv.skip], lv.hoist.fwd(gates_w[i], gates_b[i]), 4 * lv.hid, bias=lv.hoist.bias_p, dsts=[lv.G]))
             lv.Hs = torch.empty((T, B, lv.hid // 8, lv.H, lv.W, 8), **b16)
@@ -577,7 +588,7 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
             kw, kb = 2 * i, 2 * i + 1
             hid, H, W = lv.hid, lv.H, lv.W
             if dskips[i] is not None:
-                dfeats[i] = ops.blk_to_nchw(dskips[i])
+                dfeats[i] = dskips[i] if _is_blk(feats[i]) else ops.blk_to_nchw(dskips[i])
             if need_par[kb]:
                 db, _ = target(kb)
                 check(L.rsis_blk_bias_grad(ptr(dG[i]), ptr(db), B, 4 * hid, H * W, hid, stream()), "rsis_blk_bias_grad")

@@ -62,7 +62,10 @@ class FeatureExtractor(nn.Module):
             m._arena = (arena[off:off + n], arena[self._bn_total + off:self._bn_total + off + n])
             off += n
 
-    def forward(self, x, semseg=False, raw=False):
+    def forward(self, x, semseg=False, raw=False, blk_skips=False):
+        """blk_skips (internal, used by train.runIter under -dtype bf16): the skip features of the levels whose trunk feature is a
+        channel-blocked bf16 tensor are returned as blk tensors ([B][C/8][H][W][8]; rsis_amd.decoder_seq consumes them as they are) --
+        trunk, skip branches and decoder then exchange no fp32 NCHW copies.  The default returns fp32 NCHW, as the reference does."""
         if self.training and x.is_cuda:
             self._arm_bn_arena(x.device)
         # (the second cut is armed only on the path that records the first one below: a semseg / raw caller, or one outside a training
@@ -70,7 +73,8 @@ class FeatureExtractor(nn.Module):
         self.base.cut_layer3 = int(self.split_backward) >= 2 and not (semseg or raw) and self.training and torch.is_grad_enabled()
         self.base._cut3 = None
         self._cut = None
-        x5, x4, x3, x2, x1 = self.base(x)            # model.py:57
+        blk_skips = bool(blk_skips) and not (semseg or raw) and self.training and self.kernel_size == 3
+        x5, x4, x3, x2, x1 = self.base(x, blk_out=True) if blk_skips else self.base(x)            # model.py:57
         if semseg:
             return x5
         if raw:
@@ -80,6 +84,13 @@ class FeatureExtractor(nn.Module):
             leaves = tuple(t.detach().requires_grad_(True) for t in roots)
             self._cut = (roots, leaves)
             x5, x4, x3, x2, x1 = leaves
+        if blk_skips and x5.dtype == torch.bfloat16:
+            # the four trunk features arrive as blk tensors (blk trunk): their skip branches as one blk autograd node; x1 (the fp32 stem
+            # output) keeps the fp32 branch
+            from .. import blk_trunk
+            s5, s4, s3, s2 = blk_trunk.skips_forward([(self.sk5, self.bn5), (self.sk4, self.bn4), (self.sk3, self.bn3), (self.sk2, self.bn2)],
+                                                     [x5, x4, x3, x2])
+            return s5, s4, s3, s2, self.bn1(self.sk1(x1))
         x5_skip = self.bn5(self.sk5(x5))             # model.py:59-63 (BN, no ReLU)
         x4_skip = self.bn4(self.sk4(x4))
         x3_skip = self.bn3(self.sk3(x3))

@@ -144,12 +144,14 @@ class ResNet101(nn.Module):
             layers.append(Bottleneck(self.inplanes, planes))
         return nn.Sequential(*layers)
 
-    def forward(self, x):
+    def forward(self, x, blk_out=False):
+        """blk_out (internal fast path of FeatureExtractor.forward(blk_skips=True)): under -dtype bf16 return x5..x2 as the blk tensors
+        the trunk computes in, without the converters to fp32 NCHW"""
         x1 = self.bn1(self.conv1(x), relu=True)   # vision.py:12-14 (x1 is the post-ReLU stem)
         hand = self.training and torch.is_grad_enabled() and x1.requires_grad
         x = ops.maxpool3x3s2(x1, grad_slot=self._slot_x1 if hand else None)   # :15
         if blk_trunk.usable(self, x):
-            return self._forward_blk(x, x1, hand)
+            return self._forward_blk(x, x1, hand, blk_out)
         x2 = self.layer1(x)
         x3 = self.layer2(x2)
         self._cut3 = None
@@ -172,7 +174,7 @@ class ResNet101(nn.Module):
             x4 = ops.grad_tap(x4, self.layer4[0]._slot_in)
         return x5, x4, x3, x2, x1
 
-    def _forward_blk(self, x, x1, hand):
+    def _forward_blk(self, x, x1, hand, blk_out=False):
         """layers 1-4 (vision.py:16-19) on channel-blocked bf16 activations: one autograd node per layer, the four feature maps
         converted back to fp32 NCHW where they leave the trunk (autograd adds a tap's gradient to the next layer's)"""
         x2b = blk_trunk.layer_forward(self.layer1, blk_trunk.to_blk(x))
@@ -186,4 +188,6 @@ class ResNet101(nn.Module):
         x5b = blk_trunk.layer_forward(self.layer4, x4b)
         if self.training:
             x1 = ops.grad_tap(x1, self._slot_x1)
+        if blk_out:
+            return x5b, x4b, x3b, x2b, x1
         return blk_trunk.to_nchw(x5b), blk_trunk.to_nchw(x4b), blk_trunk.to_nchw(x3b), blk_trunk.to_nchw(x2b), x1

@@ -33,6 +33,25 @@ from .utils.utils import (base_param_multiplicity, check_parallel, get_base_para
                           save_checkpoint)
 
 
+BLK_SKIPS = [os.environ.get("RSIS_BLK_SKIPS", "1") != "0"]       # A/B switch: blk skip features between encoder and decoder
+
+
+def _blk_skips_ok(encoder, decoder, x):
+    """the decoder will run on blk storage (decoder_seq.blk_supported, decided here from the modules and the input width) and the trunk
+    computes in blk tensors"""
+    from . import blk_trunk, decoder_seq
+    if not (decoder_seq.ENABLED[0] and decoder_seq.BLK_ENABLED[0] and blk_trunk.ENABLED[0] and getattr(encoder.base, "_blk", False)):
+        return False
+    hs = [c.hidden_size for c in decoder.clstm_list]
+    if not all(getattr(c, "dtype", ops.DTYPE_F32) == ops.DTYPE_BF16 and c.kernel_size == 3 for c in decoder.clstm_list):
+        return False
+    skips = [encoder.sk5, encoder.sk4, encoder.sk3, encoder.sk2, encoder.sk1]
+    return (all(h % 8 == 0 for h in hs) and hs[-1] == 8 and all(s.out_channels % 8 == 0 and s.in_channels % 8 == 0 for s in skips) and
+            x.shape[-1] % 4 == 0 and decoder.fused and decoder.skip_mode == "concat" and "forward" not in decoder.__dict__ and
+            decoder.dropout == 0 and decoder.dropout_cls == 0 and decoder.dropout_stop == 0 and 2 <= x.shape[0] <= 64 and
+            sum(hs) == decoder.fc_class.weight.shape[1] and decoder.conv_out.kernel_size == 3)
+
+
 def _masked_mean(costs, sw):
     """mean(masked_select(costs, sw)) for sw in {0,1} without a data-dependent shape (objectives.py:13,23,32)."""
     sw = sw.reshape(costs.shape).to(costs.dtype)
@@ -101,11 +120,17 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
     hidden = None
     out_masks, out_classes, out_stops = [], [], []
     with torch.set_grad_enabled(train):
-        feats = encoder(x)                                           # train.py:77 (once per iteration)
+        # train.py:77 (once per iteration).  Under -dtype bf16 with the blk trunk and the blk decoder the skip features stay
+        # channel-blocked bf16 between them (FeatureExtractor.forward(blk_skips=True)); everywhere else fp32 NCHW as in the reference
+        blk_ok = (train and hasattr(decoder, "forward_sequence_stacked") and isinstance(encoder, FeatureExtractor) and
+                  BLK_SKIPS[0] and _blk_skips_ok(encoder, decoder, x))
+        feats = encoder(x, blk_skips=True) if blk_ok else encoder(x)
         # train.py:85-94: t_run decoder steps from the zero state -- RSIS.forward_sequence runs them in wavefront order with the
         # gate kernels of a (level, step) diagonal in one launch; same nodes, same results as t_run calls of decoder(feats, hidden)
         # (train.py never reads the final recurrent state: it is not materialised)
         stacked = decoder.forward_sequence_stacked(feats, t_run, want_hidden=False) if hasattr(decoder, "forward_sequence_stacked") else None
+        if stacked is None and blk_ok:
+            raise RuntimeError("runIter: blk skip features were produced but the decoder's sequence node does not apply (RSIS_BLK_SKIPS=0 avoids them)")
         if stacked is not None:
             # the whole sequence as ONE autograd node (rsis_amd/decoder_seq.py): outputs already in the (B, t, .) layout of :118-120
             out_masks, out_classes, out_stops, hidden, (Hm, Wm) = stacked

@@ -309,3 +309,45 @@ def test_blk_decoder_sequence_against_the_fp32_storage_decoder_and_float64(geom)
         assert e_store <= 0.06, "%s: blk storage is %.3f relative L2 from the fp32-storage path" % (name, e_store)
         assert e1 <= 1.5 * e0 + 0.01, "%s: %.4f from float64 (fp32 storage: %.4f)" % (name, e1, e0)
     print("largest storage distances:", sorted(worst, reverse=True)[:4])
+
+
+def test_blk_skip_branches_against_the_fp32_storage_branches():
+    """FeatureExtractor.forward(blk_skips=True) -- the skip convs + BatchNorms of model.py:59-63 on the trunk's blk features, blk out
+    (blk_trunk._SkipsBlkFn) -- against the default branches (the same bf16-operand convs on fp32 NCHW copies) on the SAME trunk
+    features: the four blk skip features within half a bf16 ulp of the fp32-storage ones (+ 1 % of the feature scale for the second
+    rounding of the conv output ahead of the BatchNorm), the gradients of the skip convs / BatchNorms within 3 % relative L2, and the
+    gradient handed to the trunk (summed into x_k) within 3 %."""
+    from helpers import mk_args
+    from rsis_amd.modules import FeatureExtractor
+    torch.manual_seed(0)
+    a = mk_args(hidden_size=128, dtype="bf16")
+    enc = FeatureExtractor(a).cuda().train()
+    x = torch.randn(4, 3, 96, 96, device="cuda")
+    res = []
+    gws = None
+    for blk in (False, True):
+        enc.zero_grad()
+        torch.manual_seed(1)
+        feats = enc(x, blk_skips=blk)
+        if blk:
+            assert all(f.dtype == torch.bfloat16 and f.dim() == 5 for f in feats[:4]) and feats[4].dtype == torch.float32
+        dense = [from_blk(f) if f.dim() == 5 else f for f in feats]
+        if gws is None:
+            gws = [torch.randn_like(d) for d in dense]
+        loss = sum((d.float() * g).sum() for d, g in zip(dense, gws))
+        loss.backward()
+        res.append(([d.detach().float() for d in dense],
+                    {k: p.grad.detach().clone() for k, p in enc.named_parameters() if p.grad is not None and not k.startswith("base.fc")}))
+    for i in range(5):
+        ref, got = res[0][0][i], res[1][0][i]
+        assert_close("skip%d" % (5 - i), got, ref, 1e-2 * float(ref.abs().max()), HALF_ULP)
+    bad = []
+    for k, g0 in res[0][1].items():
+        if k.startswith("sk") and k.endswith("bias"):
+            continue                 # (a conv bias in front of a BatchNorm: its gradient is mathematically zero, both sides are noise)
+        g1 = res[1][1][k]
+        e = float((g1 - g0).norm() / g0.norm().clamp_min(1e-30))
+        lim = 0.03 if not k.startswith("base.") else 0.08       # (trunk: the difference is carried back through ~100 train-mode BatchNorms)
+        if e > lim:
+            bad.append((k, e))
+    assert not bad, bad[:8]
