@@ -2,17 +2,17 @@
 # Regenerates the rocprofv3 summaries committed under profiles/ for one round (run on the GPU box: `gpurun -- bash tools/make_profiles.sh r03`).
 # Everything is written under gpurun_out/<tag>/ ; copy the *.txt / *.json you want judged into profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
 STEP="--steps 3 --warmup 3 --skip-cpu --skip-roofline --skip-secondary --no-settle"
-prof() {   # name, then the command
+prof() {   # name, then the command; the command's stdout (bench.py's JSON line) is kept next to the profile: SAME process
   local name=$1; shift
   rm -rf $OUT/raw_$name
-  rocprofv3 --kernel-trace --stats -d $OUT/raw_$name -- "$@" > /dev/null 2> $OUT/${name}.err
+  rocprofv3 --kernel-trace --stats -d $OUT/raw_$name -- "$@" > $OUT/${name}.stdout 2> $OUT/${name}.err
   find $OUT/raw_$name -name "*results.db" | head -1
 }
 # one replayed training step, fp32 256^2 and bf16 224^2
@@ -21,8 +21,21 @@ db=$(prof step_bf16 python bench.py $STEP --dtype bf16 --imsize 224); python too
 # the roofline leg: the launches `roofline.achieved` is computed from, one row per (kernel, grid)
 db=$(prof roof_fp32 python bench.py --roofline-only --product-only)
 python tools/prof_by_grid.py $db conv3x3_direct_group_kernel "conv3x3_direct_kernel<" > $OUT/roofline_leg_fp32.txt
+# (the HIP-event figures of the SAME profiled process, so that the two clocks can be compared line by line)
+python - $OUT/roof_fp32.stdout >> $OUT/roofline_leg_fp32.txt <<'PYEOF'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("# HIP events in the same (profiled) process: grouped launch %.4f ms per timestep; single launches %s; hoisted convs %.4f ms per iteration"
+      % (r["ms_per_timestep"], [(x["HxW"], x["ms_product"]) for x in r["per_scale"]], r["hoisted_convs_ms_per_iteration"]))
+PYEOF
 db=$(prof roof_bf16 python bench.py --roofline-only --product-only --dtype bf16 --imsize 224)
-python tools/prof_by_grid.py $db "conv_bf16_kernel<3" > $OUT/roofline_leg_bf16_224.txt
+python tools/prof_by_grid.py $db "conv_blk_dec_group_kernel" > $OUT/roofline_leg_bf16_224.txt
+python - $OUT/roof_bf16.stdout >> $OUT/roofline_leg_bf16_224.txt <<'PYEOF'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("# HIP events in the same (profiled) process: grouped launch %.4f ms per timestep; single launches %s; hoisted convs %.4f ms per iteration"
+      % (r["ms_per_timestep"], [(x["HxW"], x["ms_product"]) for x in r["per_scale"]], r["hoisted_convs_ms_per_iteration"]))
+PYEOF
 # HBM counters of the gate launches (separate passes per counter: they do not fit one), both dtypes
 for dt in fp32 bf16; do
   sz=256; [ $dt = bf16 ] && sz=224
@@ -32,7 +45,7 @@ for dt in fp32 bf16; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/raw_pmc_${dt}_$c -o pmc -- python bench.py --roofline-only --product-only --kernel-iters 4 --dtype $dt --imsize $sz > /dev/null 2>&1
     csvs="$csvs $(find $OUT/raw_pmc_${dt}_$c -name '*counter_collection.csv' | head -1)"
   done
-  pat="conv3x3_direct_group_kernel"; [ $dt = bf16 ] && pat="conv_bf16_kernel<3"
+  pat="conv3x3_direct_group_kernel"; [ $dt = bf16 ] && pat="conv_blk_dec_group_kernel"
   python tools/pmc_summary.py "$pat" $csvs > $OUT/gate_pmc_$dt.txt
 done
 # per-kernel HBM traffic of one EAGER bf16 224^2 step (blocked bf16 trunk), two PMC passes joined by tools/step_traffic.py
@@ -44,7 +57,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/step_traffic.py $csvs > $OUT/step_traffic_bf16_224.txt
 # blocked bf16 conv against the fp32-storage bf16 conv on the trunk's shapes
-python tools/blk_bench.py --imsize 224 --variants > $OUT/blk_conv_bench_224.txt 2>/dev/null
-python tools/blk_bench.py --imsize 256 > $OUT/blk_conv_bench_256.txt 2>/dev/null
 rm -rf $OUT/raw_*
 ls -la $OUT
