@@ -91,25 +91,58 @@ __global__ __launch_bounds__(256) void blk_upsample_bwd_group_kernel(const KdGro
   if (sw > 0.f) { wo_lo = max(0, (int)floorf((wi - 1) / sw) - 1); wo_hi = min(Wo - 1, (int)ceilf((wi + 1) / sw) + 1); }
   const u32x4* yb = (const u32x4*)p.src + pl * Ho * Wo;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int ho = ho_lo; ho <= ho_hi; ++ho) {
-    int h0, h1; float lh;
-    ac_coord(ho, sh, Hi, h0, h1, lh);
-    const float wh = (h0 == hi ? 1.f - lh : 0.f) + (h1 == hi ? lh : 0.f);
-    if (wh == 0.f) continue;
-    float row[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+  // the interpolation is separable: the column weights of the <= KD_MAXC candidate outputs are computed ONCE (a scan that recomputes
+  // them for every candidate row spends its time in ~60 ac_coord evaluations per cell, 9-16 of which contribute: 30 us per diagonal
+  // for a few MB); wider candidate ranges (upsampling by more than ~4x) take the plain scan
+  constexpr int KD_MAXC = 10;
+  if (wo_hi - wo_lo < KD_MAXC) {
+    float ww[KD_MAXC];
+#pragma unroll
+    for (int k = 0; k < KD_MAXC; ++k) {
+      const int wo = wo_lo + k;
       int w0, w1; float lw;
-      ac_coord(wo, sw, Wi, w0, w1, lw);
-      const float ww = (w0 == wi ? 1.f - lw : 0.f) + (w1 == wi ? lw : 0.f);
-      if (ww != 0.f) {
-        float v[8];
-        kd_unpack(yb[ho * Wo + wo], v);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) row[k] += ww * v[k];
-      }
+      ac_coord(wo <= wo_hi ? wo : wo_hi, sw, Wi, w0, w1, lw);
+      ww[k] = wo <= wo_hi ? (w0 == wi ? 1.f - lw : 0.f) + (w1 == wi ? lw : 0.f) : 0.f;
     }
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      int h0, h1; float lh;
+      ac_coord(ho, sh, Hi, h0, h1, lh);
+      const float wh = (h0 == hi ? 1.f - lh : 0.f) + (h1 == hi ? lh : 0.f);
+      if (wh == 0.f) continue;
+      float row[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] += wh * row[k];
+      for (int k = 0; k < KD_MAXC; ++k) {
+        if (ww[k] != 0.f) {
+          float v[8];
+          kd_unpack(yb[ho * Wo + wo_lo + k], v);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) row[c] += ww[k] * v[c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] += wh * row[c];
+    }
+  } else {
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      int h0, h1; float lh;
+      ac_coord(ho, sh, Hi, h0, h1, lh);
+      const float wh = (h0 == hi ? 1.f - lh : 0.f) + (h1 == hi ? lh : 0.f);
+      if (wh == 0.f) continue;
+      float row[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        int w0, w1; float lw;
+        ac_coord(wo, sw, Wi, w0, w1, lw);
+        const float ww = (w0 == wi ? 1.f - lw : 0.f) + (w1 == wi ? lw : 0.f);
+        if (ww != 0.f) {
+          float v[8];
+          kd_unpack(yb[ho * Wo + wo], v);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) row[k] += ww * v[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += wh * row[k];
+    }
   }
   if (p.dpool) {        // plane pl = (b, channel block): channels 8 pl .. 8 pl + 7 of the [B][C] arrays
     const int sp = hi * Wi + wi;

@@ -74,6 +74,14 @@ def _conv_out_seq_ok(Cin, W):
     return Cin in (4, 8, 16) and W % 4 == 0
 
 
+def _heads_all_steps(L, levels, hs, n, rows, Wc, bc, Ws, bs, ncls, probs_tb, stop_tb):
+    """the class / stop heads (model.py:169-182) of ALL timesteps in one launch: every (t, b) row is independent, the per-level key /
+    feature / arg-max arrays are [T][B][hid] contiguous, i.e. T * B rows; the launch decodes the pooled keys (writes SIDE / ARG)"""
+    check(L.rsis_heads_fwd_keys(ptr_array([v.KEY for v in levels]), ptr_array([v.SIDE for v in levels]), ptr_array([v.ARG for v in levels]),
+                                int_array(hs), n, rows, ptr(Wc), ptr(bc), ncls, ptr(Ws), ptr(bs), ptr(probs_tb), ptr(stop_tb), stream()),
+          "rsis_heads_fwd_keys(all steps)")
+
+
 class _DecoderSeqFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, decoder, T, keep, *tensors):
@@ -148,13 +156,10 @@ class _DecoderSeqFn(torch.autograd.Function):
                     else:
                         check(L.rsis_upsample_bilinear_ac_fwd(ptr(lv.Hs[t]), ptr(nx.UP[t]), B * lv.hid, lv.H, lv.W, nx.H, nx.W, stream()),
                               "rsis_upsample_fwd")
-                else:
-                    # (the x2 upsample of the last level, model.py:163-164, feeds conv_out only: all T steps in one launch after the loop)
-                    # the heads of step t: decode the keys of all five levels (writes SIDE / ARG), two linears + softmax
-                    check(L.rsis_heads_fwd_keys(ptr_array([v.KEY[t] for v in levels]), ptr_array([v.SIDE[t] for v in levels]),
-                                                ptr_array([v.ARG[t] for v in levels]), int_array(hs), n, B, ptr(Wc_d), ptr(bc_d), ncls,
-                                                ptr(Ws_d), ptr(bs_d), ptr(probs_tb[t]), ptr(stop_tb[t]), stream()), "rsis_heads_fwd_keys")
+                # (the x2 upsample of the last level, model.py:163-164, feeds conv_out only, and the heads only the losses: both run once
+                #  over all T steps after the loop)
         check(L.rsis_upsample_bilinear_ac_fwd(ptr(last.Hs), ptr(UP5), T * B * last.hid, last.H, last.W, H5, W5, stream()), "rsis_upsample_fwd(all steps)")
+        _heads_all_steps(L, levels, hs, n, T * B, Wc_d, bc_d, Ws_d, bs_d, ncls, probs_tb, stop_tb)
         # conv_out (model.py:167) on every timestep at once, logits straight into (B, T, N)
         out_masks = torch.empty((B, T, H5 * W5), **f32)
         co_pack = decoder.conv_out._pack
@@ -452,12 +457,8 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
             ops.blk_conv3x3_batch(jobs)
             if ups:
                 ops.blk_upsample_fwd_batch(ups)
-            if cells[-1][0] == n - 1:
-                t = cells[-1][1]
-                check(L.rsis_heads_fwd_keys(ptr_array([v.KEY[t] for v in levels]), ptr_array([v.SIDE[t] for v in levels]),
-                                            ptr_array([v.ARG[t] for v in levels]), int_array(hs), n, B, ptr(Wc_d), ptr(bc_d), ncls,
-                                            ptr(Ws_d), ptr(bs_d), ptr(probs_tb[t]), ptr(stop_tb[t]), stream()), "rsis_heads_fwd_keys")
         ops.blk_upsample_fwd_batch([ops.blk_resize_job(last.Hs.view(T * B, last.hid // 8, last.H, last.W, 8), UP5.view(T * B, 1, H5, W5, 8))])
+        _heads_all_steps(L, levels, hs, n, T * B, Wc_d, bc_d, Ws_d, bs_d, ncls, probs_tb, stop_tb)
         out_masks = torch.empty((B, T, H5 * W5), **f32)
         check(L.rsis_blk_conv_out_seq_fwd(ptr(UP5), ptr(co_w.detach()), ptr(co_b.detach()), ptr(out_masks), T, B, H5, W5, stream()),
               "rsis_blk_conv_out_seq_fwd")
