@@ -327,6 +327,180 @@ __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const i
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3 on blk operands, no staging pass (gfx950: LDS-DMA + ds_read_b64_tr_b16).  The register staging of wgrad3_bf16_body<.., IN = 2>
+// -- 8 x 16-byte loads, an 8 x 8 transposition (~100 VALU) and 8 LDS writes per thread and 64-pixel tile, a full memory round trip
+// per tile behind one stage of prefetch -- bound those launches at ~1.4 us per tile and CU whatever the channel counts (a decoder
+// level with 32 gate rows over 4 M pixels ran 10x over its HBM time).  Here the blk cells go from HBM to LDS as they are, by DMA
+// (1 KB per wave instruction: 16 pixels x the 4 channel blocks of a 32-channel slab, [pixel][cb][8 ch] = 64 bytes per pixel), NR
+// tiles deep, and the MFMA operands -- 8 consecutive pixels of one channel per lane -- are gathered by the transposing LDS read:
+// within a 16-lane group, result element j of lane l is element l % 4 of the 8-byte chunk lane 4 j + l / 4 pointed at
+// (tools/exp/tr16_probe.hip), so lane q of a group points at pixel q / 4, channels 4 (q % 4) .. + 3 of the group's 16 channels: the
+// 32 lanes of a K half read 4 pixels x 64 bytes = 256 consecutive bytes (no bank conflict), a second read 4 pixels on completes
+// the operand, and the 9 taps are 9 immediate offsets ((r PW + s) 64 bytes) off one per-lane base -- no VALU in the loop at all.
+// Tile = TW x TH pixels (TW x TH / 16 K steps, dealt over the 4 / (BM / 32) wave copies of a row group); accumulators, split-K and
+// the epilogue are those of wgrad3_bf16_body.
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
+#define RSIS_VMCNT(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))
+__device__ __forceinline__ bf16x8 tr_operand(const char* a) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a + 256));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int BM, int TW, int TH, int NR>
+__device__ __forceinline__ void wgrad3_tr_body(const WgradBf16Args& p, const int bx, const int by) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int TP = TW * TH, NK = TP / 16;
+  constexpr int WGM = BM / 32, KSPW = 4 / WGM, NGG = NK / KSPW;
+  constexpr int PW = TW + 2, PH = TH + 2, XPX = PH * PW;
+  constexpr int NA = WGM * NK;                       // DMA instructions of the dy tile (slab-major, 16 pixels each)
+  constexpr int NX = (XPX + 15) / 16;                // ... of the input patch (row-major with halo, PW pixels per row)
+  constexpr int C_DMA = (NA + NX + 3) / 4;           // per wave and stage (short waves issue all-OOB fillers: one vmcnt rule)
+  constexpr int ST_BYTES = 4 * C_DMA * 1024, X_OFF = NA * 1024;
+  constexpr int RED_BYTES = 4 * 8 * 288 * 4;
+  constexpr int LDS_BYTES = NR * ST_BYTES > RED_BYTES ? NR * ST_BYTES : RED_BYTES;
+  static_assert(WGM * KSPW == 4 && NK % KSPW == 0 && TW % 8 == 0 && NR >= 2 && NR <= 3, "config");
+  static_assert((NR - 2) * C_DMA < 64 && LDS_BYTES <= 65536, "vmcnt is 6 bits; static LDS");
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WGM, wk = wave / WGM;
+  const int H = p.H, W = p.W, HW = H * W, Cs = p.Cs, Cout = p.Cout;
+  const int co_t = bx % p.n_co_tiles, n_t = bx / p.n_co_tiles;
+  const int co0 = co_t * BM, ci0 = n_t * 32;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int t_begin = by * p.tiles_per_split;
+  const int t_end = min(t_begin + p.tiles_per_split, p.n_sp_tiles);
+  if (t_begin >= t_end) return;
+
+  // ---- loop-invariant part of this lane's share of a stage: instruction d = wave + 4 i moves pixels 16 (d % ..) + lane / 4 ----
+  int d_y[C_DMA], d_x[C_DMA], d_cb[C_DMA];           // tile-local pixel (halo: -1), channel-block offset in cells; d_cb < 0: filler
+  bool d_a[C_DMA];
+#pragma unroll
+  for (int i = 0; i < C_DMA; ++i) {
+    const int d = wave + 4 * i;
+    d_a[i] = d < NA;
+    if (d < NA) {
+      const int pa = 16 * (d % NK) + (lane >> 2);
+      d_y[i] = pa / TW; d_x[i] = pa % TW;
+      d_cb[i] = ((d / NK) * 4 + (lane & 3)) * HW;
+    } else {
+      const int pi = 16 * (d - NA) + (lane >> 2);
+      d_y[i] = pi / PW - 1; d_x[i] = pi % PW - 1;
+      d_cb[i] = (d < NA + NX && pi < XPX) ? (lane & 3) * HW : -1;
+    }
+  }
+  const size_t a_img = (size_t)(Cout >> 3) * HW * 16, x_img = (size_t)(Cs >> 3) * HW * 16;
+  const char* const a_base = (const char*)p.dy + (size_t)(co0 >> 3) * HW * 16;
+  const char* const x_base = (const char*)p.x + (size_t)(ci0 >> 3) * HW * 16;
+  const int a_len = ((Cout - co0) >> 3) * HW * 16, x_len = ((Cs - ci0) >> 3) * HW * 16;
+
+  // scalar tile cursor (of the NEXT tile to fetch)
+  int tb = t_begin / (tiles_x * tiles_y);
+  int trem = t_begin - tb * (tiles_x * tiles_y);
+  int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+#define W3T_ISSUE(SLOT)                                                                                            \
+  {                                                                                                                \
+    const int y0 = ty * TH, x0 = tx * TW;                                                                          \
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)(a_base + tb * a_img), 0, a_len, 0x00020000); \
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(x_base + tb * x_img), 0, x_len, 0x00020000); \
+    char* const sd = lds + (SLOT) * ST_BYTES + wave * 1024;                                                        \
+    _Pragma("unroll") for (int i = 0; i < C_DMA; ++i) {                                                            \
+      const int gy = y0 + d_y[i], gx = x0 + d_x[i];                                                                \
+      const bool ok = d_cb[i] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;                    \
+      const unsigned off = ok ? (unsigned)(d_cb[i] + gy * W + gx) * 16u : RSIS_OOB;                                \
+      if (d_a[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_vp_t)(sd + i * 4096), 16, off, 0, 0, 0);      \
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_vp_t)(sd + i * 4096), 16, off, 0, 0, 0);            \
+    }                                                                                                              \
+    if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++tb; } }                                        \
+  }
+
+  // ---- per-lane operand bases (bytes inside a stage) ----
+  const int q16 = lane & 15, grp = lane >> 4;
+  const int lane_c = (grp & 1) * 32 + (q16 & 3) * 8;               // byte of this lane's 4 channels inside the 64-byte pixel
+  int aoff[NGG], xoff[NGG];
+#pragma unroll
+  for (int gg = 0; gg < NGG; ++gg) {
+    const int pa = 16 * (gg * KSPW + wk) + 8 * hi + (q16 >> 2);
+    aoff[gg] = wm * NK * 1024 + pa * 64 + lane_c;
+    xoff[gg] = X_OFF + ((pa / TW) * PW + pa % TW) * 64 + lane_c;
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int ntl = t_end - t_begin;
+#pragma unroll
+  for (int i = 0; i < NR - 1; ++i)
+    if (i < ntl) W3T_ISSUE(i)
+  for (int t = 0; t < ntl; ++t) {
+    if (NR >= 3 && t + 1 < ntl) { RSIS_VMCNT(C_DMA); } else { RSIS_VMCNT(0); }
+    __builtin_amdgcn_s_barrier();                     // tile t is in LDS (every wave's share); slot (t - 1) % NR is free
+    if (t + NR - 1 < ntl) W3T_ISSUE((t + NR - 1) % NR)
+    const char* const S = lds + (t % NR) * ST_BYTES;
+#pragma unroll
+    for (int gg = 0; gg < NGG; ++gg) {
+      const bf16x8 a = tr_operand(S + aoff[gg]);
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+          const bf16x8 b = tr_operand(S + xoff[gg] + (r * PW + s3) * 64);
+          acc[r * 3 + s3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r * 3 + s3], 0, 0, 0);
+        }
+    }
+  }
+#undef W3T_ISSUE
+  __syncthreads();
+
+  // ---- epilogue (as wgrad3_bf16_body) ----
+  float* red = (float*)lds + wm * (8 * 288);
+  const int nvalid = min(32, Cs - ci0) * 9;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int k = 0; k < KSPW; ++k) {
+      if (wk == k) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* d = red + (r + 4 * hi) * 288 + l31 * 9 + t;
+            if (k == 0) *d = acc[t][4 * q + r];
+            else *d += acc[t][4 * q + r];
+          }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int rr = wk; rr < 8; rr += KSPW) {
+      const int co = co0 + wm * 32 + 8 * q + rr;
+      if (co >= Cout) continue;
+      const int orow = p.interleave_hid > 0 ? (co & 3) * p.interleave_hid + (co >> 2) : co;
+      float* dst = p.dw + (size_t)orow * p.ldo + p.n_off + ci0 * 9;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const int n = c * 64 + lane;
+        if (n < nvalid) atomicAdd(dst + n, red[rr * 288 + n]);
+      }
+    }
+    __syncthreads();
+  }
+#endif
+}
+// tile height / ring depth of the (BM, TW) instantiations: the deepest tile whose ring fits 64 KB of static LDS, two blocks per CU
+constexpr int w3t_th(int bm, int tw) { return tw == 32 ? (bm == 128 ? 2 : 4) : (tw == 16 ? (bm == 128 ? 4 : 8) : 8); }
+constexpr int w3t_nr(int bm, int tw) { return tw == 32 ? 2 : (tw == 16 ? (bm == 32 ? 3 : 2) : (bm == 128 ? 2 : 3)); }
+
+// ------------------------------------------------------------------------------------------------
 // 1x1: D[co][ci] = sum_px dy[co][px] x[ci][px]; block tile BM x BN, waves WGM x WGN, TM x TN MFMA tiles per wave.
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WGM, int WGN, int TW, int IN>
@@ -512,6 +686,10 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
 // conv_wgrad_tiled.hip).  The jobs travel by value in the kernel arguments.
 template <int BM, int TW, int IN>
 __global__ __launch_bounds__(256, 2) void wgrad3_bf16_kernel(const WgradBf16Args p) { wgrad3_bf16_body<BM, TW, IN>(p, blockIdx.x, blockIdx.y); }
+template <int BM, int TW>
+__global__ __launch_bounds__(256, 2) void wgrad3_tr_kernel(const WgradBf16Args p) {
+  wgrad3_tr_body<BM, TW, w3t_th(BM, TW), w3t_nr(BM, TW)>(p, blockIdx.x, blockIdx.y);
+}
 template <int BM, int BN, int WGM, int WGN, int TW, int IN>
 __global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const WgradBf16Args p) {
   wgrad1_bf16_body<BM, BN, WGM, WGN, TW, IN>(p, blockIdx.x, blockIdx.y);
@@ -556,6 +734,12 @@ __global__ __launch_bounds__(256, 2) void wgrad3_bf16_group_kernel(const WgradBf
   if (!wgb_find(g, j, tile, split)) return;
   wgrad3_bf16_body<BM, TW, IN>(g.job[j], tile, split);
 }
+template <int BM, int TW>
+__global__ __launch_bounds__(256, 2) void wgrad3_tr_group_kernel(const WgradBf16Group g) {
+  int j, tile, split;
+  if (!wgb_find(g, j, tile, split)) return;
+  wgrad3_tr_body<BM, TW, w3t_th(BM, TW), w3t_nr(BM, TW)>(g.job[j], tile, split);
+}
 template <int BM, int BN, int WGM, int WGN, int TW, int IN>
 __global__ __launch_bounds__(256) void wgrad1_bf16_group_kernel(const WgradBf16Group g) {
   int j, tile, split;
@@ -563,8 +747,7 @@ __global__ __launch_bounds__(256) void wgrad1_bf16_group_kernel(const WgradBf16G
   wgrad1_bf16_body<BM, BN, WGM, WGN, TW, IN>(g.job[j], tile, split);
 }
 
-static void split_plan(WgradBf16Args& a, int TW, int ntile, int slots) {
-  const int TH = 64 / TW;
+static void split_plan(WgradBf16Args& a, int TW, int TH, int ntile, int slots) {
   a.n_sp_tiles = a.B * rsis_cdiv(a.H, TH) * rsis_cdiv(a.W, TW);
   // Every split adds a dW-sized pass of fp32 atomics, and those run at ~0.3 T atomics/s whatever the layer: measured on the
   // trunk shapes at batch 32 (tools/exp/bf16_shape_sweep.py), one block per CU (256 slots) beats two (512) on every layer --
@@ -581,9 +764,9 @@ static int launch_w3(WgradBf16Args& a, hipStream_t st) {
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
   a.n_n_tiles = rsis_cdiv(a.Cs, 32);
   const int ntile = a.n_co_tiles * a.n_n_tiles;
-  split_plan(a, TW, ntile, 256);
+  split_plan(a, TW, a.blk ? w3t_th(BM, TW) : 64 / TW, ntile, 256);
   const dim3 grid(ntile, rsis_cdiv(a.n_sp_tiles, a.tiles_per_split));
-  if (a.blk) hipLaunchKernelGGL((wgrad3_bf16_kernel<BM, TW, 2>), grid, dim3(256), 0, st, a);
+  if (a.blk) hipLaunchKernelGGL((wgrad3_tr_kernel<BM, TW>), grid, dim3(256), 0, st, a);
   else if (a.W % 4 == 0) hipLaunchKernelGGL((wgrad3_bf16_kernel<BM, TW, 1>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((wgrad3_bf16_kernel<BM, TW, 0>), grid, dim3(256), 0, st, a);
   return rsis_check_launch();
@@ -603,7 +786,7 @@ static int launch_w1(WgradBf16Args& a, hipStream_t st) {
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
   a.n_n_tiles = rsis_cdiv(a.Cs, BN);
   const int ntile = a.n_co_tiles * a.n_n_tiles;
-  split_plan(a, TW, ntile, 256);
+  split_plan(a, TW, 64 / TW, ntile, 256);
   const dim3 grid(ntile, rsis_cdiv(a.n_sp_tiles, a.tiles_per_split));
   if (a.blk) hipLaunchKernelGGL((wgrad1_bf16_kernel<BM, BN, WGM, WGN, TW, 2>), grid, dim3(256), 0, st, a);
   else if (a.W % 4 == 0) hipLaunchKernelGGL((wgrad1_bf16_kernel<BM, BN, WGM, WGN, TW, 1>), grid, dim3(256), 0, st, a);
@@ -646,9 +829,9 @@ int rsis_launch_conv_wgrad_bf16(const WgradArgs& w, int ks, hipStream_t st) {
 }
 
 // ---- grouped launch (host side): jobs bucketed by kernel instantiation, every block of a bucket walks ~L spatial tiles ----
-struct WgbKey { int ks, bm, bn, tw, v4; };
+struct WgbKey { int ks, bm, bn, tw, v4, th; };
 static WgbKey wgb_key(const WgradBf16Args& a, int ks) {      // the rules of launch_w3_tw / launch_w1_tw / rsis_launch_conv_wgrad_bf16
-  WgbKey k = {ks, 0, 0, 0, 0};
+  WgbKey k = {ks, 0, 0, 0, 0, 0};
   if (ks == 3) {
     k.tw = a.W > 16 ? 32 : (a.W > 8 ? 16 : 8);
     k.bm = a.Cout <= 32 ? 32 : ((a.Cout <= 64 || a.Cs <= 512) ? 64 : 128);
@@ -659,13 +842,14 @@ static WgbKey wgb_key(const WgradBf16Args& a, int ks) {      // the rules of lau
     k.bn = a.Cs <= 64 ? 64 : 128;
   }
   k.v4 = a.blk ? 2 : (a.W % 4 == 0 ? 1 : 0);      // the IN template argument
+  k.th = (ks == 3 && a.blk) ? w3t_th(k.bm, k.tw) : 64 / k.tw;      // tile height (blk 3x3: the DMA kernel's tile)
   return k;
 }
 static inline bool wgb_same(const WgbKey& a, const WgbKey& b) { return a.ks == b.ks && a.bm == b.bm && a.bn == b.bn && a.tw == b.tw && a.v4 == b.v4; }
 
 template <typename LaunchFn>
 static int wgb_launch_bucket(WgradBf16Args* jobs, int n, const WgbKey& k, LaunchFn launch) {
-  const int TH = 64 / k.tw;
+  const int TH = k.th;
   long total = 0;
   for (int j = 0; j < n; ++j) {
     WgradBf16Args& a = jobs[j];
@@ -733,7 +917,7 @@ static int wgb_launch_bucket(WgradBf16Args* jobs, int n, const WgbKey& k, Launch
 #define WGB3(BMv, TWv)                                                                                             \
   if (k.bm == BMv && k.tw == TWv) {                                                                                \
     if (k.v4 == 2) return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                 \
-      hipLaunchKernelGGL((wgrad3_bf16_group_kernel<BMv, TWv, 2>), dim3(blocks), dim3(256), 0, st, g); });          \
+      hipLaunchKernelGGL((wgrad3_tr_group_kernel<BMv, TWv>), dim3(blocks), dim3(256), 0, st, g); });               \
     if (k.v4 == 1) return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                 \
       hipLaunchKernelGGL((wgrad3_bf16_group_kernel<BMv, TWv, 1>), dim3(blocks), dim3(256), 0, st, g); });          \
     return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                                \

@@ -161,10 +161,18 @@ def test_blk_subsample_and_its_transpose(hw):
     assert torch.equal(dx, want)
 
 
-@pytest.mark.parametrize("shape", SHAPES + [(32, 256, 256, 14, 14, 3), (32, 64, 64, 56, 56, 1), (4, 32, 64, 28, 28, 3), (4, 24, 40, 17, 9, 3)],
+# every (rows per block, tile width) instantiation of the 3x3 DMA / transposing-read kernel (conv_wgrad_bf16.hip, wgrad3_tr_body):
+# 32 / 64 / 128 rows x 32- / 16- / 8-pixel tiles, ragged maps, channel counts that leave partial slabs, several images per split
+W3T_SHAPES = [(2, 24, 32, 112, 112, 3), (3, 40, 24, 14, 14, 3), (5, 16, 8, 7, 7, 3), (2, 520, 72, 28, 28, 3), (2, 520, 72, 14, 14, 3),
+              (3, 520, 72, 7, 7, 3), (8, 128, 128, 7, 7, 3), (2, 64, 48, 56, 56, 3), (3, 48, 16, 33, 20, 3), (2, 72, 136, 5, 11, 3)]
+
+
+@pytest.mark.parametrize("shape", SHAPES + W3T_SHAPES + [(32, 256, 256, 14, 14, 3), (32, 64, 64, 56, 56, 1), (4, 32, 64, 28, 28, 3),
+                                                         (4, 24, 40, 17, 9, 3)],
                          ids=lambda s: "x".join(str(v) for v in s))
 def test_blk_conv_weight_gradient(shape):
-    """dW of the stride-1 convs from blk dy / x (rsis_conv2d_wgrad, RSIS_DTYPE_BF16_BLK: 8 x 8 register transposition at staging)
+    """dW of the stride-1 convs from blk dy / x (rsis_conv2d_wgrad, RSIS_DTYPE_BF16_BLK: 1x1 -- 8 x 8 register transposition at
+    staging; 3x3 -- cells by DMA into LDS, operands by the transposing LDS read)
     against float64 on the same bf16-valued operands: fp32 accumulation only -- 1e-5 of the gradient scale + 1e-4 relative
     (split-K partial sums meet in fp32 atomics) -- and a second call accumulates."""
     from rsis_amd import ops
