@@ -343,9 +343,16 @@ __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const i
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
 #define RSIS_VMCNT(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))
-__device__ __forceinline__ bf16x8 tr_operand(const char* a) {
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a + 256));
+// The transposing reads are inline asm: behind the intrinsic (__builtin_amdgcn_ds_read_tr16_b64_*) hipcc waits vmcnt(0) before the first
+// read of every tile -- for the DMA of the NEXT tile, issued a few instructions earlier -- and the ring degenerates to load-then-compute
+// (measured: 2.9 us per 128-pixel tile and block whatever NR; plain ds_read_b64 in the same place gets no such wait).  The asm reads are
+// invisible to the waitcnt pass, so their lgkmcnt is counted by hand: LDS returns in order, `s_waitcnt lgkmcnt(N)` = all but the N
+// youngest reads have landed (scalar loads in flight can only make the wait longer).  The waits name the registers they guard as
+// in/out operands so that no consumer is scheduled above them.
+#define TR_READ(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory")
+#define TR_WAIT8(N, a0, a1, b0, b1, b2, b3, b4, b5)                                                                \
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5) : "n"(N))
+__device__ __forceinline__ bf16x8 tr_cat(const s16x4 lo, const s16x4 hi) {
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
@@ -363,9 +370,9 @@ __device__ __forceinline__ void wgrad3_tr_body(const WgradBf16Args& p, const int
   constexpr int ST_BYTES = 4 * C_DMA * 1024, X_OFF = NA * 1024;
   constexpr int RED_BYTES = 4 * 8 * 288 * 4;
   constexpr int LDS_BYTES = NR * ST_BYTES > RED_BYTES ? NR * ST_BYTES : RED_BYTES;
-  static_assert(WGM * KSPW == 4 && NK % KSPW == 0 && TW % 8 == 0 && NR >= 2 && NR <= 3, "config");
-  static_assert((NR - 2) * C_DMA < 64 && LDS_BYTES <= 65536, "vmcnt is 6 bits; static LDS");
-  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+  static_assert(WGM * KSPW == 4 && NK % KSPW == 0 && TW % 8 == 0 && NR >= 2 && NR <= 5, "config");
+  static_assert((NR - 2) * C_DMA < 64 && LDS_BYTES <= 160 * 1024, "vmcnt is 6 bits; LDS of a CU");
+  extern __shared__ __attribute__((aligned(1024))) char lds[];      // w3t_lds_bytes<BM, TW, TH, NR>() at launch
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -437,26 +444,55 @@ __device__ __forceinline__ void wgrad3_tr_body(const WgradBf16Args& p, const int
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
   const int ntl = t_end - t_begin;
 #pragma unroll
   for (int i = 0; i < NR - 1; ++i)
     if (i < ntl) W3T_ISSUE(i)
   for (int t = 0; t < ntl; ++t) {
-    if (NR >= 3 && t + 1 < ntl) { RSIS_VMCNT(C_DMA); } else { RSIS_VMCNT(0); }
+    {   // tile t has landed once at most `ahead` younger tiles of this wave's DMA are still in flight
+      const int ahead = min(NR - 2, ntl - 1 - t);
+      if (NR >= 5 && ahead == 3) { RSIS_VMCNT(3 * C_DMA); }
+      else if (NR >= 4 && ahead == 2) { RSIS_VMCNT(2 * C_DMA); }
+      else if (NR >= 3 && ahead == 1) { RSIS_VMCNT(C_DMA); }
+      else { RSIS_VMCNT(0); }
+    }
     __builtin_amdgcn_s_barrier();                     // tile t is in LDS (every wave's share); slot (t - 1) % NR is free
     if (t + NR - 1 < ntl) W3T_ISSUE((t + NR - 1) % NR)
-    const char* const S = lds + (t % NR) * ST_BYTES;
+    // K steps of this wave, software-pipelined over the LDS queue: the reads of (step, patch row r) are re-issued for the next step
+    // right behind the 3 MFMAs that consumed row r, so that 14 reads (two rows + the next dy operand) are in flight under them
+    const unsigned sb = lds0 + (t % NR) * ST_BYTES;
+    s16x4 A[2][2], X[3][3][2];
+#define W3T_READ_A(GG) { const unsigned aa = sb + aoff[GG]; TR_READ(A[(GG) & 1][0], aa, 0); TR_READ(A[(GG) & 1][1], aa, 256); }
+#define W3T_READ_ROW(GG, R)                                                                                        \
+  {                                                                                                                \
+    const unsigned xa = sb + xoff[GG];                                                                             \
+    TR_READ(X[R][0][0], xa, ((R) * PW + 0) * 64); TR_READ(X[R][0][1], xa, ((R) * PW + 0) * 64 + 256);              \
+    TR_READ(X[R][1][0], xa, ((R) * PW + 1) * 64); TR_READ(X[R][1][1], xa, ((R) * PW + 1) * 64 + 256);              \
+    TR_READ(X[R][2][0], xa, ((R) * PW + 2) * 64); TR_READ(X[R][2][1], xa, ((R) * PW + 2) * 64 + 256);              \
+  }
+#define W3T_ROW(GG, R, N)                                                                                          \
+  {                                                                                                                \
+    TR_WAIT8(N, A[(GG) & 1][0], A[(GG) & 1][1], X[R][0][0], X[R][0][1], X[R][1][0], X[R][1][1], X[R][2][0], X[R][2][1]); \
+    const bf16x8 a = tr_cat(A[(GG) & 1][0], A[(GG) & 1][1]);                                                       \
+    acc[(R) * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, tr_cat(X[R][0][0], X[R][0][1]), acc[(R) * 3 + 0], 0, 0, 0); \
+    acc[(R) * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, tr_cat(X[R][1][0], X[R][1][1]), acc[(R) * 3 + 1], 0, 0, 0); \
+    acc[(R) * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, tr_cat(X[R][2][0], X[R][2][1]), acc[(R) * 3 + 2], 0, 0, 0); \
+  }
+    W3T_READ_A(0) W3T_READ_ROW(0, 0) W3T_READ_ROW(0, 1) W3T_READ_ROW(0, 2)
 #pragma unroll
     for (int gg = 0; gg < NGG; ++gg) {
-      const bf16x8 a = tr_operand(S + aoff[gg]);
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) {
-          const bf16x8 b = tr_operand(S + xoff[gg] + (r * PW + s3) * 64);
-          acc[r * 3 + s3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r * 3 + s3], 0, 0, 0);
-        }
+      if (gg + 1 < NGG) {
+        W3T_ROW(gg, 0, 12) W3T_READ_A(gg + 1) W3T_READ_ROW(gg + 1, 0)
+        W3T_ROW(gg, 1, 14) W3T_READ_ROW(gg + 1, 1)
+        W3T_ROW(gg, 2, 14) W3T_READ_ROW(gg + 1, 2)
+      } else {
+        W3T_ROW(gg, 0, 12) W3T_ROW(gg, 1, 6) W3T_ROW(gg, 2, 0)
+      }
     }
+#undef W3T_READ_A
+#undef W3T_READ_ROW
+#undef W3T_ROW
   }
 #undef W3T_ISSUE
   __syncthreads();
@@ -496,9 +532,30 @@ __device__ __forceinline__ void wgrad3_tr_body(const WgradBf16Args& p, const int
   }
 #endif
 }
+template <int BM, int TW, int TH, int NR>
+constexpr int w3t_lds_bytes() {
+  constexpr int st = 4 * ((BM / 32 * (TW * TH / 16) + ((TH + 2) * (TW + 2) + 15) / 16 + 3) / 4) * 1024;
+  return NR * st > 4 * 8 * 288 * 4 ? NR * st : 4 * 8 * 288 * 4;
+}
 // tile height / ring depth of the (BM, TW) instantiations: the deepest tile whose ring fits 64 KB of static LDS, two blocks per CU
-constexpr int w3t_th(int bm, int tw) { return tw == 32 ? (bm == 128 ? 2 : 4) : (tw == 16 ? (bm == 128 ? 4 : 8) : 8); }
-constexpr int w3t_nr(int bm, int tw) { return tw == 32 ? 2 : (tw == 16 ? (bm == 32 ? 3 : 2) : (bm == 128 ? 2 : 3)); }
+#ifndef W3T_TH_32_32      // (tuning builds override the three configurations that carry the step: -DW3T_TH_32_32=.. -DW3T_NR_32_32=.. ...)
+#define W3T_TH_32_32 4
+#define W3T_NR_32_32 2
+#endif
+#ifndef W3T_TH_64_32
+#define W3T_TH_64_32 4
+#define W3T_NR_64_32 2
+#endif
+#ifndef W3T_TH_64_16
+#define W3T_TH_64_16 8
+#define W3T_NR_64_16 2
+#endif
+constexpr int w3t_th(int bm, int tw) {
+  return tw == 32 ? (bm == 128 ? 2 : (bm == 64 ? W3T_TH_64_32 : W3T_TH_32_32)) : (tw == 16 ? (bm == 128 ? 4 : (bm == 64 ? W3T_TH_64_16 : 8)) : 8);
+}
+constexpr int w3t_nr(int bm, int tw) {
+  return tw == 32 ? (bm == 128 ? 2 : (bm == 64 ? W3T_NR_64_32 : W3T_NR_32_32)) : (tw == 16 ? (bm == 32 ? 3 : (bm == 64 ? W3T_NR_64_16 : 2)) : (bm == 128 ? 2 : 3));
+}
 
 // ------------------------------------------------------------------------------------------------
 // 1x1: D[co][ci] = sum_px dy[co][px] x[ci][px]; block tile BM x BN, waves WGM x WGN, TM x TN MFMA tiles per wave.
@@ -686,9 +743,9 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
 // conv_wgrad_tiled.hip).  The jobs travel by value in the kernel arguments.
 template <int BM, int TW, int IN>
 __global__ __launch_bounds__(256, 2) void wgrad3_bf16_kernel(const WgradBf16Args p) { wgrad3_bf16_body<BM, TW, IN>(p, blockIdx.x, blockIdx.y); }
-template <int BM, int TW>
+template <int BM, int TW, int TH, int NR>
 __global__ __launch_bounds__(256, 2) void wgrad3_tr_kernel(const WgradBf16Args p) {
-  wgrad3_tr_body<BM, TW, w3t_th(BM, TW), w3t_nr(BM, TW)>(p, blockIdx.x, blockIdx.y);
+  wgrad3_tr_body<BM, TW, TH, NR>(p, blockIdx.x, blockIdx.y);
 }
 template <int BM, int BN, int WGM, int WGN, int TW, int IN>
 __global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const WgradBf16Args p) {
@@ -734,12 +791,57 @@ __global__ __launch_bounds__(256, 2) void wgrad3_bf16_group_kernel(const WgradBf
   if (!wgb_find(g, j, tile, split)) return;
   wgrad3_bf16_body<BM, TW, IN>(g.job[j], tile, split);
 }
-template <int BM, int TW>
+template <int BM, int TW, int TH, int NR>
 __global__ __launch_bounds__(256, 2) void wgrad3_tr_group_kernel(const WgradBf16Group g) {
   int j, tile, split;
   if (!wgb_find(g, j, tile, split)) return;
-  wgrad3_tr_body<BM, TW, w3t_th(BM, TW), w3t_nr(BM, TW)>(g.job[j], tile, split);
+  wgrad3_tr_body<BM, TW, TH, NR>(g.job[j], tile, split);
 }
+// the ring is dynamic LDS (up to 80 KB: two blocks per CU); sizes above 64 KB are an opt-in per kernel
+template <int BM, int TW, int TH, int NR>
+static void w3t_launch(const WgradBf16Args& a, dim3 grid, hipStream_t st) {
+  constexpr int lds = w3t_lds_bytes<BM, TW, TH, NR>();
+  static const hipError_t once = hipFuncSetAttribute((const void*)wgrad3_tr_kernel<BM, TW, TH, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)once;
+  hipLaunchKernelGGL((wgrad3_tr_kernel<BM, TW, TH, NR>), grid, dim3(256), lds, st, a);
+}
+template <int BM, int TW, int TH, int NR>
+static void w3t_launch_group(const WgradBf16Group& g, int blocks, hipStream_t st) {
+  constexpr int lds = w3t_lds_bytes<BM, TW, TH, NR>();
+  static const hipError_t once = hipFuncSetAttribute((const void*)wgrad3_tr_group_kernel<BM, TW, TH, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)once;
+  hipLaunchKernelGGL((wgrad3_tr_group_kernel<BM, TW, TH, NR>), dim3(blocks), dim3(256), lds, st, g);
+}
+#ifdef RSIS_W3T_SWEEP      // tuning build: tile height / ring depth of the single launches from the environment (tools/exp/wgrad_blk_bench.py)
+template <int BM, int TW, int TH, int NR>
+static int w3t_try(WgradBf16Args& a, int ntile, hipStream_t st) {
+  constexpr int st_b = w3t_lds_bytes<BM, TW, TH, NR>() / NR;
+  if constexpr (w3t_lds_bytes<BM, TW, TH, NR>() <= 81920 && (NR - 2) * (st_b / 4096) < 64 && (TW * TH / 16) % (4 / (BM / 32)) == 0) {
+    void split_plan(WgradBf16Args&, int, int, int, int);
+    split_plan(a, TW, TH, ntile, 256);
+    w3t_launch<BM, TW, TH, NR>(a, dim3(ntile, rsis_cdiv(a.n_sp_tiles, a.tiles_per_split)), st);
+    return rsis_check_launch();
+  }
+  return RSIS_ERR_UNSUPPORTED;
+}
+template <int BM, int TW, int TH>
+static int w3t_sweep_nr(WgradBf16Args& a, int ntile, int nr, hipStream_t st) {
+  if (nr == 2) return w3t_try<BM, TW, TH, 2>(a, ntile, st);
+  if (nr == 3) return w3t_try<BM, TW, TH, 3>(a, ntile, st);
+  if (nr == 4) return w3t_try<BM, TW, TH, 4>(a, ntile, st);
+  if (nr == 5) return w3t_try<BM, TW, TH, 5>(a, ntile, st);
+  return RSIS_ERR_UNSUPPORTED;
+}
+template <int BM, int TW>
+static int w3t_sweep(WgradBf16Args& a, int ntile, hipStream_t st) {
+  const int th = atoi(getenv("RSIS_W3T_TH")), nr = atoi(getenv("RSIS_W3T_NR"));
+  if (th == 2) return w3t_sweep_nr<BM, TW, 2>(a, ntile, nr, st);
+  if (th == 4) return w3t_sweep_nr<BM, TW, 4>(a, ntile, nr, st);
+  if (th == 8) return w3t_sweep_nr<BM, TW, 8>(a, ntile, nr, st);
+  if (th == 16) return w3t_sweep_nr<BM, TW, 16>(a, ntile, nr, st);
+  return RSIS_ERR_UNSUPPORTED;
+}
+#endif
 template <int BM, int BN, int WGM, int WGN, int TW, int IN>
 __global__ __launch_bounds__(256) void wgrad1_bf16_group_kernel(const WgradBf16Group g) {
   int j, tile, split;
@@ -747,7 +849,7 @@ __global__ __launch_bounds__(256) void wgrad1_bf16_group_kernel(const WgradBf16G
   wgrad1_bf16_body<BM, BN, WGM, WGN, TW, IN>(g.job[j], tile, split);
 }
 
-static void split_plan(WgradBf16Args& a, int TW, int TH, int ntile, int slots) {
+void split_plan(WgradBf16Args& a, int TW, int TH, int ntile, int slots) {
   a.n_sp_tiles = a.B * rsis_cdiv(a.H, TH) * rsis_cdiv(a.W, TW);
   // Every split adds a dW-sized pass of fp32 atomics, and those run at ~0.3 T atomics/s whatever the layer: measured on the
   // trunk shapes at batch 32 (tools/exp/bf16_shape_sweep.py), one block per CU (256 slots) beats two (512) on every layer --
@@ -764,9 +866,12 @@ static int launch_w3(WgradBf16Args& a, hipStream_t st) {
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
   a.n_n_tiles = rsis_cdiv(a.Cs, 32);
   const int ntile = a.n_co_tiles * a.n_n_tiles;
+#ifdef RSIS_W3T_SWEEP
+  if (a.blk && getenv("RSIS_W3T_TH")) return w3t_sweep<BM, TW>(a, ntile, st);
+#endif
   split_plan(a, TW, a.blk ? w3t_th(BM, TW) : 64 / TW, ntile, 256);
   const dim3 grid(ntile, rsis_cdiv(a.n_sp_tiles, a.tiles_per_split));
-  if (a.blk) hipLaunchKernelGGL((wgrad3_tr_kernel<BM, TW>), grid, dim3(256), 0, st, a);
+  if (a.blk) w3t_launch<BM, TW, w3t_th(BM, TW), w3t_nr(BM, TW)>(a, grid, st);
   else if (a.W % 4 == 0) hipLaunchKernelGGL((wgrad3_bf16_kernel<BM, TW, 1>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((wgrad3_bf16_kernel<BM, TW, 0>), grid, dim3(256), 0, st, a);
   return rsis_check_launch();
@@ -917,7 +1022,7 @@ static int wgb_launch_bucket(WgradBf16Args* jobs, int n, const WgbKey& k, Launch
 #define WGB3(BMv, TWv)                                                                                             \
   if (k.bm == BMv && k.tw == TWv) {                                                                                \
     if (k.v4 == 2) return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                 \
-      hipLaunchKernelGGL((wgrad3_tr_group_kernel<BMv, TWv>), dim3(blocks), dim3(256), 0, st, g); });               \
+      w3t_launch_group<BMv, TWv, w3t_th(BMv, TWv), w3t_nr(BMv, TWv)>(g, blocks, st); });                           \
     if (k.v4 == 1) return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                 \
       hipLaunchKernelGGL((wgrad3_bf16_group_kernel<BMv, TWv, 1>), dim3(blocks), dim3(256), 0, st, g); });          \
     return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                                \
