@@ -11,6 +11,7 @@
 // The MFMA loop, the LDS cell layout and the packed bf16 weights (pack.hip modes 5-7) are those of conv_bf16_kernel; the data
 // gradient is the same kernel on the flipped / transposed pack.  Stride 1, "same" padding, one source, C % 8 == 0, Cout % 8 == 0.
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((address_space(3))) void* lds_vp_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -168,26 +169,40 @@ __global__ __launch_bounds__(256) void conv_blk_kernel(const ConvArgs p) {
   const bool has_add = p.addend != nullptr;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(has_add ? (const char*)p.addend + (size_t)b0 * Cbo * HW * 16 : obase), 0, has_add ? Cbo * HW * 16 : 0, 0x00020000);
+  // (the addend cells are fetched for the whole tile BEFORE the first store and outside any per-element condition: with the load
+  //  inside `if (has_add)` hipcc branches around each one and waits vmcnt(0) behind it -- 4 TN dependent L2 round trips per wave,
+  //  each also draining the stores issued so far)
+  auto epilogue = [&](auto with_addend) {
+    constexpr bool ADD = decltype(with_addend)::value;
+    unsigned off[TN][4];
+    u32x2 av[TN][4];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int pp = (wn * TN + j) * 32 + l31;
-    const int ox = x0 + pp % TW, oy = y0 + pp / TW;
-    const bool in = oy < H && ox < W;
-    const int osp = oy * W + ox;
+    for (int j = 0; j < TN; ++j) {
+      const int pp = (wn * TN + j) * 32 + l31;
+      const int ox = x0 + pp % TW, oy = y0 + pp / TW;
+      const bool in = oy < H && ox < W;
+      const int osp = oy * W + ox;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int cbo = (co_base >> 3) + g;
-      const unsigned off = (in && cbo < Cbo) ? (unsigned)(cbo * HW + osp) * 16u + 8u * hi : RSIS_OOB;
-      float o0 = acc[j][4 * g], o1 = acc[j][4 * g + 1], o2 = acc[j][4 * g + 2], o3 = acc[j][4 * g + 3];
-      if (has_add) {
-        const u32x2 av = __builtin_amdgcn_raw_buffer_load_b64(ra, off, 0, 0);
-        o0 += __uint_as_float(av[0] << 16); o1 += __uint_as_float(av[0] & 0xFFFF0000u);
-        o2 += __uint_as_float(av[1] << 16); o3 += __uint_as_float(av[1] & 0xFFFF0000u);
+      for (int g = 0; g < 4; ++g) {
+        const int cbo = (co_base >> 3) + g;
+        off[j][g] = (in && cbo < Cbo) ? (unsigned)(cbo * HW + osp) * 16u + 8u * hi : RSIS_OOB;
+        if constexpr (ADD) av[j][g] = __builtin_amdgcn_raw_buffer_load_b64(ra, off[j][g], 0, 0);
       }
-      const u32x2 v = {blk_pack2(o0, o1), blk_pack2(o2, o3)};
-      __builtin_amdgcn_raw_buffer_store_b64(v, ro, off, 0, 0);
     }
-  }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float o0 = acc[j][4 * g], o1 = acc[j][4 * g + 1], o2 = acc[j][4 * g + 2], o3 = acc[j][4 * g + 3];
+        if constexpr (ADD) {
+          o0 += __uint_as_float(av[j][g][0] << 16); o1 += __uint_as_float(av[j][g][0] & 0xFFFF0000u);
+          o2 += __uint_as_float(av[j][g][1] << 16); o3 += __uint_as_float(av[j][g][1] & 0xFFFF0000u);
+        }
+        const u32x2 v = {blk_pack2(o0, o1), blk_pack2(o2, o3)};
+        __builtin_amdgcn_raw_buffer_store_b64(v, ro, off[j][g], 0, 0);
+      }
+  };
+  if (has_add) epilogue(std::true_type{}); else epilogue(std::false_type{});
 #endif
 }
 

@@ -21,6 +21,7 @@
 // gates of hidden channels 2 r4 + hi: the two lanes (l31, hi = 0 / 1) exchange two values each (one wave shuffle pair) to own
 // channels 0-3 / 4-7 of the cell.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 typedef __attribute__((address_space(3))) void* lds_vp_t;
@@ -195,30 +196,46 @@ __device__ __forceinline__ void bd_body(const BlkConvJob& p, const int bid, u32x
       const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * hi;
       bv[r] = (bias && co < p.Cout) ? bias[co] : 0.f;
     }
+    // (addend cells of the whole tile first, outside any per-element condition: see conv_blk.hip)
+    auto epilogue = [&](auto with_addend) {
+      constexpr bool ADD = decltype(with_addend)::value;
+      u32x2 av[TN][4];
+      if constexpr (ADD) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int pp = (wn * TN + j) * 32 + l31;
-      const int ox = x0 + pp % TW, oy = y0 + pp / TW;
-      const bool in = oy < H && ox < W;
-      const int osp = oy * W + ox;
+        for (int j = 0; j < TN; ++j) {
+          const int pp = (wn * TN + j) * 32 + l31;
+          const int ox = x0 + pp % TW, oy = y0 + pp / TW;
+          const int osp = oy * W + ox;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int cbo = (co_base >> 3) + g;
-        const bool ok = in && cbo < Cbo;
-        float o0 = acc[j][4 * g] + bv[4 * g], o1 = acc[j][4 * g + 1] + bv[4 * g + 1];
-        float o2 = acc[j][4 * g + 2] + bv[4 * g + 2], o3 = acc[j][4 * g + 3] + bv[4 * g + 3];
-        if (has_add) {
-          const u32x2 av = __builtin_amdgcn_raw_buffer_load_b64(ra, ok ? (unsigned)(cbo * HW + osp) * 16u + 8u * hi : RSIS_OOB, 0, 0);
-          o0 += bd_lo(av[0]); o1 += bd_hi(av[0]); o2 += bd_lo(av[1]); o3 += bd_hi(av[1]);
+          for (int g = 0; g < 4; ++g) {
+            const int cbo = (co_base >> 3) + g;
+            av[j][g] = __builtin_amdgcn_raw_buffer_load_b64(ra, (oy < H && ox < W && cbo < Cbo) ? (unsigned)(cbo * HW + osp) * 16u + 8u * hi : RSIS_OOB, 0, 0);
+          }
         }
-        const u32x2 v = {bd_pack2(o0, o1), bd_pack2(o2, o3)};
-        const bool first = cbo < Cbd0;
-        const unsigned off0 = (ok && first) ? (unsigned)(cbo * HW + osp) * 16u + 8u * hi : RSIS_OOB;
-        const unsigned off1 = (ok && !first) ? (unsigned)((cbo - Cbd0) * HW + osp) * 16u + 8u * hi : RSIS_OOB;
-        __builtin_amdgcn_raw_buffer_store_b64(v, ro0, off0, 0, 0);
-        if (Cbd1) __builtin_amdgcn_raw_buffer_store_b64(v, ro1, off1, 0, 0);
       }
-    }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int pp = (wn * TN + j) * 32 + l31;
+        const int ox = x0 + pp % TW, oy = y0 + pp / TW;
+        const bool in = oy < H && ox < W;
+        const int osp = oy * W + ox;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cbo = (co_base >> 3) + g;
+          const bool ok = in && cbo < Cbo;
+          float o0 = acc[j][4 * g] + bv[4 * g], o1 = acc[j][4 * g + 1] + bv[4 * g + 1];
+          float o2 = acc[j][4 * g + 2] + bv[4 * g + 2], o3 = acc[j][4 * g + 3] + bv[4 * g + 3];
+          if constexpr (ADD) { o0 += bd_lo(av[j][g][0]); o1 += bd_hi(av[j][g][0]); o2 += bd_lo(av[j][g][1]); o3 += bd_hi(av[j][g][1]); }
+          const u32x2 v = {bd_pack2(o0, o1), bd_pack2(o2, o3)};
+          const bool first = cbo < Cbd0;
+          const unsigned off0 = (ok && first) ? (unsigned)(cbo * HW + osp) * 16u + 8u * hi : RSIS_OOB;
+          const unsigned off1 = (ok && !first) ? (unsigned)((cbo - Cbd0) * HW + osp) * 16u + 8u * hi : RSIS_OOB;
+          __builtin_amdgcn_raw_buffer_store_b64(v, ro0, off0, 0, 0);
+          if (Cbd1) __builtin_amdgcn_raw_buffer_store_b64(v, ro1, off1, 0, 0);
+        }
+      }
+    };
+    if (has_add) epilogue(std::true_type{}); else epilogue(std::false_type{});
   } else {
     // LSTM cell (clstm.py:47-58).  Rows are gate-interleaved: register 4 r4 + gate of a lane = gate `gate` of hidden channel
     // jl = 2 r4 + hi of the 8 hidden channels this wave's 32 rows cover (hidden cell block cbh = co_base / 32).

@@ -352,6 +352,8 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
 #define TR_READ(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory")
 #define TR_WAIT8(N, a0, a1, b0, b1, b2, b3, b4, b5)                                                                \
   asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5) : "n"(N))
+#define TR_WAITN(N) asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory")
+#define TR_PIN(reg) asm volatile("" : "+v"(reg))        // (orders the consumers of `reg` behind the wait above: volatile asm keeps its order)
 __device__ __forceinline__ bf16x8 tr_cat(const s16x4 lo, const s16x4 hi) {
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -532,6 +534,157 @@ __device__ __forceinline__ void wgrad3_tr_body(const WgradBf16Args& p, const int
   }
 #endif
 }
+// ------------------------------------------------------------------------------------------------
+// 1x1 on blk operands, the same way (DMA ring of raw cells, transposing reads): D[co][ci] over BM x BN with 2 x 2 waves, a stage =
+// TP consecutive pixels of the flattened map for the BM / 32 + BN / 32 channel slabs of the two operands; every wave walks all TP / 16
+// K steps, the reads of step g + 1 in flight under the MFMAs of step g (two register sets, lgkmcnt counted by hand).
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int TP, int NR>
+__device__ __forceinline__ void wgrad1_tr_body(const WgradBf16Args& p, const int bx, const int by) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int WGM = 2, WGN = 2, TM = BM / WGM / 32, TN = BN / WGN / 32, NK = TP / 16;
+  constexpr int SA = BM / 32, SB = BN / 32;            // channel slabs of the dy / x tiles
+  constexpr int ND = (SA + SB) * NK;                   // DMA instructions per stage (16 pixels x 4 channel blocks each)
+  constexpr int C_DMA = (ND + 3) / 4;
+  constexpr int ST_BYTES = 4 * C_DMA * 1024, B_OFF = SA * NK * 1024;
+  constexpr int NRD = 2 * (TM + TN);                   // LDS reads per K step
+  static_assert(TM >= 1 && TN >= 1 && NR >= 2 && NR <= 4 && (NR - 2) * C_DMA < 64 && NRD <= 15 && NR * ST_BYTES <= 160 * 1024, "config");
+  extern __shared__ __attribute__((aligned(1024))) char lds[];      // NR * ST_BYTES at launch
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int HW = p.W, Cs = p.Cs, Cout = p.Cout;        // (1x1: H = 1, W = the flattened map)
+  const int co_t = bx % p.n_co_tiles, n_t = bx / p.n_co_tiles;
+  const int co0 = co_t * BM, n0 = n_t * BN;
+  const int tiles_x = (HW + TP - 1) / TP;
+  const int t_begin = by * p.tiles_per_split;
+  const int t_end = min(t_begin + p.tiles_per_split, p.n_sp_tiles);
+  if (t_begin >= t_end) return;
+
+  int d_px[C_DMA], d_cb[C_DMA];                        // pixel inside the tile; channel-block offset in cells (< 0: filler)
+  bool d_a[C_DMA];
+#pragma unroll
+  for (int i = 0; i < C_DMA; ++i) {
+    const int d = wave + 4 * i;
+    d_a[i] = d < SA * NK;
+    const int slab = d_a[i] ? d / NK : (d - SA * NK) / NK;
+    d_px[i] = 16 * (d % NK) + (lane >> 2);
+    d_cb[i] = d < ND ? (slab * 4 + (lane & 3)) * HW : -1;
+  }
+  const size_t a_img = (size_t)(Cout >> 3) * HW * 16, x_img = (size_t)(Cs >> 3) * HW * 16;
+  const char* const a_base = (const char*)p.dy + (size_t)(co0 >> 3) * HW * 16;
+  const char* const x_base = (const char*)p.x + (size_t)(n0 >> 3) * HW * 16;
+  const int a_len = ((Cout - co0) >> 3) * HW * 16, x_len = ((Cs - n0) >> 3) * HW * 16;
+
+  int tb = t_begin / tiles_x, tx = t_begin - tb * tiles_x;
+#define W1T_ISSUE(SLOT)                                                                                            \
+  {                                                                                                                \
+    const int x0 = tx * TP;                                                                                        \
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)(a_base + tb * a_img), 0, a_len, 0x00020000); \
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(x_base + tb * x_img), 0, x_len, 0x00020000); \
+    char* const sd = lds + (SLOT) * ST_BYTES + wave * 1024;                                                        \
+    _Pragma("unroll") for (int i = 0; i < C_DMA; ++i) {                                                            \
+      const int gx = x0 + d_px[i];                                                                                 \
+      const unsigned off = (d_cb[i] >= 0 && gx < HW) ? (unsigned)(d_cb[i] + gx) * 16u : RSIS_OOB;                  \
+      if (d_a[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_vp_t)(sd + i * 4096), 16, off, 0, 0, 0);      \
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_vp_t)(sd + i * 4096), 16, off, 0, 0, 0);            \
+    }                                                                                                              \
+    if (++tx == tiles_x) { tx = 0; ++tb; }                                                                         \
+  }
+
+  const int q16 = lane & 15, grp = lane >> 4;
+  const unsigned lane_o = (8 * hi + (q16 >> 2)) * 64 + (grp & 1) * 32 + (q16 & 3) * 8;     // K half, pixel in the quad, channel quad
+  const unsigned a_lane = wm * TM * NK * 1024 + lane_o, b_lane = B_OFF + wn * TN * NK * 1024 + lane_o;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  const int ntl = t_end - t_begin;
+#pragma unroll
+  for (int i = 0; i < NR - 1; ++i)
+    if (i < ntl) W1T_ISSUE(i)
+  for (int t = 0; t < ntl; ++t) {
+    {
+      const int ahead = min(NR - 2, ntl - 1 - t);
+      if (NR >= 4 && ahead == 2) { RSIS_VMCNT(2 * C_DMA); }
+      else if (NR >= 3 && ahead == 1) { RSIS_VMCNT(C_DMA); }
+      else { RSIS_VMCNT(0); }
+    }
+    __builtin_amdgcn_s_barrier();
+    if (t + NR - 1 < ntl) W1T_ISSUE((t + NR - 1) % NR)
+    const unsigned sa = lds0 + (t % NR) * ST_BYTES + a_lane, sbb = lds0 + (t % NR) * ST_BYTES + b_lane;
+    s16x4 A[2][TM][2], B[2][TN][2];
+#define W1T_READ(G)                                                                                                \
+  {                                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                               \
+      const unsigned aa = sa + i * NK * 1024;                                                                      \
+      TR_READ(A[(G) & 1][i][0], aa, (G) * 1024); TR_READ(A[(G) & 1][i][1], aa, (G) * 1024 + 256);                  \
+    }                                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                               \
+      const unsigned ba = sbb + j * NK * 1024;                                                                     \
+      TR_READ(B[(G) & 1][j][0], ba, (G) * 1024); TR_READ(B[(G) & 1][j][1], ba, (G) * 1024 + 256);                  \
+    }                                                                                                              \
+  }
+    W1T_READ(0)
+#pragma unroll
+    for (int g = 0; g < NK; ++g) {
+      if (g + 1 < NK) {
+        if (g == 0) W1T_READ(1) else if (g == 1) W1T_READ(2) else if (g == 2) W1T_READ(3) else if (g == 3) W1T_READ(4)
+        else if (g == 4) W1T_READ(5) else if (g == 5) W1T_READ(6) else W1T_READ(7)
+      }
+      // the reads of step g have landed once at most the NRD reads of step g + 1 are outstanding
+      if (g + 1 < NK) { TR_WAITN(NRD); } else { TR_WAITN(0); }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) { TR_PIN(A[g & 1][i][0]); TR_PIN(A[g & 1][i][1]); }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { TR_PIN(B[g & 1][j][0]); TR_PIN(B[g & 1][j][1]); }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_cat(A[g & 1][i][0], A[g & 1][i][1]), tr_cat(B[g & 1][j][0], B[g & 1][j][1]), acc[i][j], 0, 0, 0);
+    }
+#undef W1T_READ
+  }
+#undef W1T_ISSUE
+
+  // (buffer atomics, as wgrad1_bf16_body)
+  const __amdgpu_buffer_rsrc_t rdw = __builtin_amdgcn_make_buffer_rsrc((void*)p.dw, 0, (unsigned)((size_t)Cout * p.ldo * 4), 0x00020000);
+  const int ihid = p.interleave_hid;
+  const unsigned ldb = (unsigned)p.ldo * 4u;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * TN * 32 + j * 32 + l31;
+    if (n >= Cs) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row0 = co0 + wm * TM * 32 + i * 32 + 4 * hi;
+      const int rows_left = Cout - row0;
+      const unsigned vo = (unsigned)((ihid > 0 ? row0 >> 2 : row0) * p.ldo + p.n_off + n) * 4u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2);
+        const unsigned ro = (unsigned)(ihid > 0 ? (r & 3) * ihid + 2 * (r >> 2) : k) * ldb;
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][j][r], rdw, k < rows_left ? vo + ro : 0x7FFFFFF0u, 0, 0);
+      }
+    }
+  }
+#endif
+}
+template <int BM, int BN, int TP, int NR>
+constexpr int w1t_lds_bytes() { return NR * 4 * (((BM / 32 + BN / 32) * (TP / 16) + 3) / 4) * 1024; }
+#ifndef W1T_TP
+#define W1T_TP 64
+#endif
+constexpr int w1t_nr(int bm, int bn) { return (bm + bn) >= 256 ? 2 : 3; }
+
 template <int BM, int TW, int TH, int NR>
 constexpr int w3t_lds_bytes() {
   constexpr int st = 4 * ((BM / 32 * (TW * TH / 16) + ((TH + 2) * (TW + 2) + 15) / 16 + 3) / 4) * 1024;
@@ -812,6 +965,28 @@ static void w3t_launch_group(const WgradBf16Group& g, int blocks, hipStream_t st
   (void)once;
   hipLaunchKernelGGL((wgrad3_tr_group_kernel<BM, TW, TH, NR>), dim3(blocks), dim3(256), lds, st, g);
 }
+template <int BM, int BN, int TP, int NR>
+__global__ __launch_bounds__(256, 2) void wgrad1_tr_kernel(const WgradBf16Args p) { wgrad1_tr_body<BM, BN, TP, NR>(p, blockIdx.x, blockIdx.y); }
+template <int BM, int BN, int TP, int NR>
+__global__ __launch_bounds__(256, 2) void wgrad1_tr_group_kernel(const WgradBf16Group g) {
+  int j, tile, split;
+  if (!wgb_find(g, j, tile, split)) return;
+  wgrad1_tr_body<BM, BN, TP, NR>(g.job[j], tile, split);
+}
+template <int BM, int BN, int TP, int NR>
+static void w1t_launch(const WgradBf16Args& a, dim3 grid, hipStream_t st) {
+  constexpr int lds = w1t_lds_bytes<BM, BN, TP, NR>();
+  static const hipError_t once = hipFuncSetAttribute((const void*)wgrad1_tr_kernel<BM, BN, TP, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)once;
+  hipLaunchKernelGGL((wgrad1_tr_kernel<BM, BN, TP, NR>), grid, dim3(256), lds, st, a);
+}
+template <int BM, int BN, int TP, int NR>
+static void w1t_launch_group(const WgradBf16Group& g, int blocks, hipStream_t st) {
+  constexpr int lds = w1t_lds_bytes<BM, BN, TP, NR>();
+  static const hipError_t once = hipFuncSetAttribute((const void*)wgrad1_tr_group_kernel<BM, BN, TP, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)once;
+  hipLaunchKernelGGL((wgrad1_tr_group_kernel<BM, BN, TP, NR>), dim3(blocks), dim3(256), lds, st, g);
+}
 #ifdef RSIS_W3T_SWEEP      // tuning build: tile height / ring depth of the single launches from the environment (tools/exp/wgrad_blk_bench.py)
 template <int BM, int TW, int TH, int NR>
 static int w3t_try(WgradBf16Args& a, int ntile, hipStream_t st) {
@@ -891,9 +1066,9 @@ static int launch_w1(WgradBf16Args& a, hipStream_t st) {
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
   a.n_n_tiles = rsis_cdiv(a.Cs, BN);
   const int ntile = a.n_co_tiles * a.n_n_tiles;
-  split_plan(a, TW, 64 / TW, ntile, 256);
+  split_plan(a, a.blk ? W1T_TP : TW, a.blk ? 1 : 64 / TW, ntile, 256);
   const dim3 grid(ntile, rsis_cdiv(a.n_sp_tiles, a.tiles_per_split));
-  if (a.blk) hipLaunchKernelGGL((wgrad1_bf16_kernel<BM, BN, WGM, WGN, TW, 2>), grid, dim3(256), 0, st, a);
+  if (a.blk) w1t_launch<BM, BN, W1T_TP, w1t_nr(BM, BN)>(a, grid, st);
   else if (a.W % 4 == 0) hipLaunchKernelGGL((wgrad1_bf16_kernel<BM, BN, WGM, WGN, TW, 1>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((wgrad1_bf16_kernel<BM, BN, WGM, WGN, TW, 0>), grid, dim3(256), 0, st, a);
   return rsis_check_launch();
@@ -942,12 +1117,12 @@ static WgbKey wgb_key(const WgradBf16Args& a, int ks) {      // the rules of lau
     k.bm = a.Cout <= 32 ? 32 : ((a.Cout <= 64 || a.Cs <= 512) ? 64 : 128);
     k.bn = 32;
   } else {
-    k.tw = 64;
+    k.tw = a.blk ? W1T_TP : 64;
     k.bm = a.Cout <= 64 ? 64 : 128;
     k.bn = a.Cs <= 64 ? 64 : 128;
   }
   k.v4 = a.blk ? 2 : (a.W % 4 == 0 ? 1 : 0);      // the IN template argument
-  k.th = (ks == 3 && a.blk) ? w3t_th(k.bm, k.tw) : 64 / k.tw;      // tile height (blk 3x3: the DMA kernel's tile)
+  k.th = ks == 3 ? (a.blk ? w3t_th(k.bm, k.tw) : 64 / k.tw) : (a.blk ? 1 : 64 / k.tw);      // tile height (blk 3x3: the DMA kernel's tile)
   return k;
 }
 static inline bool wgb_same(const WgbKey& a, const WgbKey& b) { return a.ks == b.ks && a.bm == b.bm && a.bn == b.bn && a.tw == b.tw && a.v4 == b.v4; }
@@ -1031,7 +1206,7 @@ static int wgb_launch_bucket(WgradBf16Args* jobs, int n, const WgbKey& k, Launch
 #define WGB1(BMv, BNv)                                                                                             \
   if (k.bm == BMv && k.bn == BNv) {                                                                                \
     if (k.v4 == 2) return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                 \
-      hipLaunchKernelGGL((wgrad1_bf16_group_kernel<BMv, BNv, 2, 2, 64, 2>), dim3(blocks), dim3(256), 0, st, g); });      \
+      w1t_launch_group<BMv, BNv, W1T_TP, w1t_nr(BMv, BNv)>(g, blocks, st); });                                     \
     if (k.v4 == 1) return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                 \
       hipLaunchKernelGGL((wgrad1_bf16_group_kernel<BMv, BNv, 2, 2, 64, 1>), dim3(blocks), dim3(256), 0, st, g); });      \
     return wgb_launch_bucket(jobs, n, k, [&](const WgradBf16Group& g, int blocks) {                                \
