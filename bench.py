@@ -380,9 +380,10 @@ def cpu_baseline(imsize, T, budget_s=25.0):
 # the fused ConvLSTM gate kernel in a profiler's kernel-name column: template arguments <BM, TW, TH, NI, EPI, KSP, NWV>, EPI == 1 is
 # the fused LSTM epilogue (tests/test_abi.py checks the pattern against the symbols of the built library)
 REAL_STDOUT = 1
-GATE_KERNEL_RE = re.compile(r"conv3x3_direct_kernel<\d+, \d+, \d+, \d+, 1, \d+, \d+>")
-# ... and the grouped launch of one wavefront diagonal (rsis_convlstm_fwd_batch): template argument <EPI>
-GATE_GROUP_RE = re.compile(r"conv3x3_direct_group_kernel<1>")
+GATE_KERNEL_RE = re.compile(r"conv3x3_direct_kernel<\d+, \d+, \d+, \d+, 1, \d+, \d+(, (true|false))?>")
+# ... and the grouped launch of one wavefront diagonal (rsis_convlstm_fwd_batch): template arguments <EPI, FLUSH> (FLUSH: the segmented-
+# accumulation instantiation of inference / deep-K calls, not what a training step launches)
+GATE_GROUP_RE = re.compile(r"conv3x3_direct_group_kernel<1(, false)?>")
 # ... and its bf16 twin, conv_bf16_kernel<KS, BM, TW, TH, EPI, CKB, V4> with KS == 3 and EPI == 1 (five single launches per diagonal)
 GATE_BF16_RE = re.compile(r"conv_bf16_kernel<3, \d+, \d+, \d+, 1, \d+, \w+>")
 # ... and the grouped launch on channel-blocked bf16 tensors (rsis_blk_conv3x3_batch, LSTM epilogue): template argument <EPI>

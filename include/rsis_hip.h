@@ -464,6 +464,21 @@ int rsis_blk_conv_out_seq_fwd(const void* x, const float* Wref, const float* bia
 int rsis_blk_conv_out_seq_dgrad(const float* dy, const float* Wref, void* dx, int T, int B, int H, int W, void* stream);
 int rsis_blk_conv_out_seq_wgrad(const float* dy, const void* x, float* dW, float* db, int T, int B, int H, int W, void* stream);
 
+/* The decoder's tail as one op per direction (upconv_out.hip): nn.UpsamplingBilinear2d (align_corners, model.py:163-164) of the last
+ * level's hidden state followed by conv_out (model.py:109,167: Conv2d(8 -> 1, 3x3, pad 1)) over the images of all T timesteps, without
+ * forming the upsampled tensor.  h / dh: fp32 [T][B][8][Hs][Ws] (h_blk = 0) or bf16 blk [T][B][1][Hs][Ws][8] (h_blk = 1); out / dout:
+ * fp32 [B][T][Ho*Wo]; w = the reference-layout weight [1][8][3][3]; bias [1] or NULL.  Backward: dh is WRITTEN (plus, when dside /
+ * arg are given, the gradient dside[T*B][8] of the side max-pool feature at its arg-max pixel arg[T*B][8], model.py:143); dW[72] and
+ * db[1] (either may be NULL) are ACCUMULATED, from per-block sums in `partial` (rsis_upconv_out_bwd_blocks(..) x 80 floats of
+ * scratch) added in a fixed order: reproducible run to run.  rsis_upconv_out_supported: C == 8 and an upsampling factor of ~2
+ * (scale (in-1)/(out-1) in [0.46, 0.52]); otherwise RSIS_ERR_UNSUPPORTED (run rsis_upsample_* + rsis_conv_out_seq_* instead). */
+int rsis_upconv_out_supported(int C, int Hs, int Ws, int Ho, int Wo);
+int rsis_upconv_out_bwd_blocks(int T, int B, int Hs, int Ws);
+int rsis_upconv_out_fwd(const void* h, int h_blk, const float* w, const float* bias, float* out, int T, int B, int C, int Hs, int Ws, int Ho, int Wo,
+                        void* stream);
+int rsis_upconv_out_bwd(const float* dout, const void* h, int h_blk, const float* w, void* dh, float* dW, float* db, const float* dside, const int* arg,
+                        float* partial, int T, int B, int C, int Hs, int Ws, int Ho, int Wo, void* stream);
+
 /* ---- gradient exchange: RCCL bound directly (replaces nn.DataParallel, reference src/train.py:269-274: one process per GPU, the flat
  * gradient buffers SUM-all-reduced over xGMI once per iteration).  A collective issued here is an ordinary operation of `stream`: it
  * can be captured into the hipGraph of the training iteration (torch.distributed's ProcessGroupNCCL cannot: its watchdog thread's

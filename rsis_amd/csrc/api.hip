@@ -902,3 +902,26 @@ int rsis_conv2d_dgrad_batch(const rsis_dgrad_job* jobs, int njobs, void* stream)
   else if (rc == RSIS_OK && ng > 1) rc = rsis_launch_conv3x3_direct_group_plain(grp, ng, force, (hipStream_t)stream);
   return rc;
 }
+
+// ---- upsample x2 (align corners) + conv_out as one op per direction (upconv_out.hip) ----
+bool rsis_upconv_supported(int C, int Hs, int Ws, int Ho, int Wo);
+int rsis_upconv_bwd_blocks(int T, int B, int Hs, int Ws);
+int rsis_l_upconv_fwd(const void* h, int h_blk, const float* w, const float* bias, float* out, int T, int B, int Hs, int Ws, int Ho, int Wo, hipStream_t st);
+int rsis_l_upconv_bwd(const float* dout, const void* h, int h_blk, const float* w, void* dh, float* dW, float* db, const float* dside, const int* arg,
+                      float* partial, int T, int B, int Hs, int Ws, int Ho, int Wo, hipStream_t st);
+extern "C" {
+int rsis_upconv_out_supported(int C, int Hs, int Ws, int Ho, int Wo) { return rsis_upconv_supported(C, Hs, Ws, Ho, Wo) ? 1 : 0; }
+int rsis_upconv_out_bwd_blocks(int T, int B, int Hs, int Ws) { return rsis_upconv_bwd_blocks(T, B, Hs, Ws); }
+int rsis_upconv_out_fwd(const void* h, int h_blk, const float* w, const float* bias, float* out, int T, int B, int C, int Hs, int Ws, int Ho, int Wo,
+                        void* stream) {
+  if (!h || !w || !out || T < 1 || B < 1) return RSIS_ERR_ARG;
+  if (!rsis_upconv_supported(C, Hs, Ws, Ho, Wo)) return RSIS_ERR_UNSUPPORTED;
+  return rsis_l_upconv_fwd(h, h_blk, w, bias, out, T, B, Hs, Ws, Ho, Wo, (hipStream_t)stream);
+}
+int rsis_upconv_out_bwd(const float* dout, const void* h, int h_blk, const float* w, void* dh, float* dW, float* db, const float* dside, const int* arg,
+                        float* partial, int T, int B, int C, int Hs, int Ws, int Ho, int Wo, void* stream) {
+  if (!dout || !h || !w || !dh || !partial || T < 1 || B < 1 || (dside && !arg)) return RSIS_ERR_ARG;
+  if (!rsis_upconv_supported(C, Hs, Ws, Ho, Wo)) return RSIS_ERR_UNSUPPORTED;
+  return rsis_l_upconv_bwd(dout, h, h_blk, w, dh, dW, db, dside, arg, partial, T, B, Hs, Ws, Ho, Wo, (hipStream_t)stream);
+}
+}

@@ -271,12 +271,28 @@ __device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int
   const int co_base = co_t * BM + wm * 32;
   const gcf_t bias = (gcf_t)p.bias, addend = (gcf_t)p.addend;
   unsigned long long best[4] = {0ull, 0ull, 0ull, 0ull};      // EPI_LSTM + side_key: this lane's best (h, pixel) per hidden channel
+  // The bias of this lane's 16 rows, fetched ONCE, before the tiles, through a descriptor (no bias: zero range, loads return 0).
+  // Inside the tile loop and under `if (bias)` hipcc branched around every load and waited vmcnt(0) behind it: 4 dependent
+  // round trips per tile in the LSTM epilogue, each one also draining the stores of the tile before.
+  float bv[16];
+  {
+    const int nrows = EPI == EPI_LSTM ? 4 * p.hid : p.Cout;
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(bias ? (const void*)p.bias : (const void*)p.wp), 0, bias ? nrows * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(co_base + 4 * hi + (r & 3) + 8 * (r >> 2)) * 4u, 0, 0));
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int pp = (wn * TN + j) * 32 + l31;
     const int x = pp % TW, y = (pp / TW) % TH, img = pp / (TW * TH);
     const int ob = b0 + img, oy = y0 + y, ox = x0 + x;
-    if (ob >= B || oy >= H || ox >= W) continue;
+    // (the descriptor paths below run out-of-map lanes through with out-of-range offsets instead of skipping them: without the
+    //  branch the loads of the next tile can be issued under the arithmetic of this one)
+    const bool inb = ob < B && oy < H && ox < W;
+    const bool fast_plain = (EPI == EPI_PLAIN || EPI == EPI_F2) && p.ndst == 1 && ksplit == 1 && (size_t)B * p.Cout * HW * 4 < (1ull << 31);
+    const bool fast_lstm = EPI == EPI_LSTM && (size_t)p.B * 4 * p.hid * HW * 4 < (1ull << 31);
+    if (!inb && !fast_plain && !fast_lstm) continue;
     const int osp = oy * W + ox;
     if (EPI == EPI_S2) {
       const gf_t d0 = (gf_t)p.dst[0];
@@ -295,7 +311,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int
       const gf_t d0 = (gf_t)p.dst[0], d1 = (gf_t)p.dst[1], d2 = (gf_t)p.dst[2];
       const int Cd0 = p.Cd[0], Cd1 = p.Cd[1], Cd2 = p.Cd[2], Cout = p.Cout;
       const int e1 = Cd0, e2 = Cd0 + Cd1;
-      if (p.ndst == 1 && ksplit == 1 && (size_t)B * Cout * HW * 4 < (1ull << 31)) {
+      if (fast_plain) {
         // single destination, no split-K (every trunk / skip / hoisted conv and most data gradients): a row of the tile is ONE
         // buffer store at a per-lane base + row * HW floats; rows >= Cout get an out-of-range offset (dropped by the descriptor).
         // ~3 instructions per stored value instead of ~25 of 64-bit index arithmetic and destination selection: the general
@@ -304,7 +320,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? p.addend : p.dst[0]), 0, (unsigned)((size_t)B * Cout * HW * 4), 0x00020000);
         const unsigned vo = (unsigned)((ob * Cout + co_base + 4 * hi) * HW + osp) * 4u;
         const unsigned rowb = (unsigned)HW * 4u;
-        const int rows_left = Cout - (co_base + 4 * hi);        // rows k of this lane are valid while k < rows_left
+        const int rows_left = inb ? Cout - (co_base + 4 * hi) : 0;        // rows k of this lane are valid while k < rows_left
         float av[16];
         if (addend) {
 #pragma unroll
@@ -316,13 +332,13 @@ __device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int k = (r & 3) + 8 * (r >> 2);
-          float v = acc[j][r];
-          if (bias) v += k < rows_left ? bias[co_base + 4 * hi + k] : 0.f;
+          float v = acc[j][r] + bv[r];
           if (addend) v += av[r];
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, k < rows_left ? vo + k * rowb : 0x7FFFFFF0u, 0, 0);
         }
         continue;
       }
+      if (!inb) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -342,7 +358,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int
       const int hid = p.hid;
       const gcf_t c_prev = (gcf_t)p.c_prev;
       const gf_t c_out = (gf_t)p.c_out, h_out = (gf_t)p.h_out, act_out = (gf_t)p.act_out;
-      if ((size_t)p.B * 4 * hid * HW * 4 < (1ull << 31)) {
+      if (fast_lstm) {
         // the cell update through buffer descriptors: per hidden channel 4 addend loads, c_prev, and the c / h / 4 gate stores are
         // per-lane bases + scalar multiples of HW (no 64-bit index arithmetic per access); channels >= hid get an out-of-range
         // offset (loads return 0, stores are dropped)
@@ -359,7 +375,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int
         float ga[4][4], cpv[4];
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {          // all loads of the tile first
-          const bool ok = jh0 + 2 * r4 < hid;
+          const bool ok = inb && jh0 + 2 * r4 < hid;
 #pragma unroll
           for (int g = 0; g < 4; ++g)
             ga[r4][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_add, ok ? vg + (8 * r4 + g) * rowb : 0x7FFFFFF0u, 0, 0));
@@ -367,11 +383,9 @@ __device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int
         }
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-          const bool ok = jh0 + 2 * r4 < hid;
-          const int cop = 4 * (jh0 + 2 * r4);
-          float ai = acc[j][4 * r4 + 0] + ga[r4][0], af = acc[j][4 * r4 + 1] + ga[r4][1];
-          float ao = acc[j][4 * r4 + 2] + ga[r4][2], ag = acc[j][4 * r4 + 3] + ga[r4][3];
-          if (bias && ok) { ai += bias[cop]; af += bias[cop + 1]; ao += bias[cop + 2]; ag += bias[cop + 3]; }
+          const bool ok = inb && jh0 + 2 * r4 < hid;
+          const float ai = acc[j][4 * r4 + 0] + ga[r4][0] + bv[4 * r4 + 0], af = acc[j][4 * r4 + 1] + ga[r4][1] + bv[4 * r4 + 1];
+          const float ao = acc[j][4 * r4 + 2] + ga[r4][2] + bv[4 * r4 + 2], ag = acc[j][4 * r4 + 3] + ga[r4][3] + bv[4 * r4 + 3];
           const float gi = rsis_sigmoid(ai), gf = rsis_sigmoid(af), go = rsis_sigmoid(ao), gg = tanhf(ag);
           const float c = gf * cpv[r4] + gi * gg;  // clstm.py:57
           const float h = go * tanhf(c);           // clstm.py:58
@@ -386,6 +400,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int
         }
         continue;
       }
+      if (!inb) continue;
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const int jh = (co_base >> 2) + 2 * r4 + hi;   // hidden channel

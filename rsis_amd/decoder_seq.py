@@ -74,6 +74,23 @@ def _conv_out_seq_ok(Cin, W):
     return Cin in (4, 8, 16) and W % 4 == 0
 
 
+UPCONV = [os.environ.get("RSIS_UPCONV", "1") != "0"]       # the last level's upsample + conv_out as one op per direction (upconv_out.hip)
+
+
+def _upconv_ok(L, last, H5, W5):
+    return UPCONV[0] and L.rsis_upconv_out_supported(last.hid, last.H, last.W, H5, W5) == 1
+
+
+def _upconv_bwd(L, d_masks, last, blk, co_w, dW, db, dside, T, B, H5, W5, DH_last):
+    """the backward of the fused tail: DH_last <- the gradient of the last level's hidden states through conv_out and the upsample (plus
+    the side max-pool gradient at its arg-max pixel); dW / db accumulate (fixed-order sums of per-block partials)"""
+    nb = L.rsis_upconv_out_bwd_blocks(T, B, last.H, last.W)
+    partial = torch.empty(nb * 80, dtype=torch.float32, device=d_masks.device)
+    check(L.rsis_upconv_out_bwd(ptr(d_masks), ptr(last.Hs), 1 if blk else 0, ptr(co_w.detach()), ptr(DH_last), ptr(dW) if dW is not None else None,
+                                ptr(db) if db is not None else None, ptr(dside), ptr(last.ARG), ptr(partial), T, B, last.hid, last.H, last.W, H5, W5,
+                                stream()), "rsis_upconv_out_bwd")
+
+
 def _heads_all_steps(L, levels, hs, n, rows, Wc, bc, Ws, bs, ncls, probs_tb, stop_tb):
     """the class / stop heads (model.py:169-182) of ALL timesteps in one launch: every (t, b) row is independent, the per-level key /
     feature / arg-max arrays are [T][B][hid] contiguous, i.e. T * B rows; the launch decodes the pooled keys (writes SIDE / ARG)"""
@@ -126,7 +143,8 @@ class _DecoderSeqFn(torch.autograd.Function):
             levels.append(lv)
         last = levels[-1]
         H5, W5 = 2 * last.H, 2 * last.W
-        UP5 = torch.empty((T, B, last.hid, H5, W5), **f32)            # model.py:163-164, all timesteps
+        upc = _upconv_ok(L, last, H5, W5)
+        UP5 = None if upc else torch.empty((T, B, last.hid, H5, W5), **f32)            # model.py:163-164, all timesteps
         ncls = Wc.shape[0]
         probs_tb = torch.empty((T, B, ncls), **f32)
         stop_tb = torch.empty((T, B, 1), **f32)
@@ -158,14 +176,18 @@ class _DecoderSeqFn(torch.autograd.Function):
                               "rsis_upsample_fwd")
                 # (the x2 upsample of the last level, model.py:163-164, feeds conv_out only, and the heads only the losses: both run once
                 #  over all T steps after the loop)
-        check(L.rsis_upsample_bilinear_ac_fwd(ptr(last.Hs), ptr(UP5), T * B * last.hid, last.H, last.W, H5, W5, stream()), "rsis_upsample_fwd(all steps)")
+        if not upc:
+            check(L.rsis_upsample_bilinear_ac_fwd(ptr(last.Hs), ptr(UP5), T * B * last.hid, last.H, last.W, H5, W5, stream()), "rsis_upsample_fwd(all steps)")
         _heads_all_steps(L, levels, hs, n, T * B, Wc_d, bc_d, Ws_d, bs_d, ncls, probs_tb, stop_tb)
         # conv_out (model.py:167) on every timestep at once, logits straight into (B, T, N)
         out_masks = torch.empty((B, T, H5 * W5), **f32)
         co_pack = decoder.conv_out._pack
-        co_wp = co_pack.fwd(co_w)
+        co_wp = None if upc else co_pack.fwd(co_w)
         seq_ok = _conv_out_seq_ok(last.hid, W5)
-        if seq_ok:
+        if upc:       # upsample + conv_out in one pass, the upsampled tensor never formed
+            check(L.rsis_upconv_out_fwd(ptr(last.Hs), 0, ptr(co_w.detach()), ptr(co_b.detach()), ptr(out_masks), T, B, last.hid, last.H, last.W, H5, W5,
+                                        stream()), "rsis_upconv_out_fwd")
+        elif seq_ok:
             check(L.rsis_conv_out_seq_fwd(ptr(UP5), ptr(co_wp), ptr(co_b.detach()), ptr(out_masks), T, B, last.hid, H5, W5, stream()),
                   "rsis_conv_out_seq_fwd")
         else:
@@ -183,7 +205,7 @@ class _DecoderSeqFn(torch.autograd.Function):
             LAST["arg"] = [lv.ARG.clone() for lv in levels]
         ctx.set_materialize_grads(False)
         if need_grad:
-            ctx.decoder, ctx.T, ctx.levels, ctx.seq_ok = decoder, T, levels, seq_ok
+            ctx.decoder, ctx.T, ctx.levels, ctx.seq_ok, ctx.upc = decoder, T, levels, seq_ok, upc
             ctx.UP5, ctx.probs_tb, ctx.feats = UP5, probs_tb, feats
             ctx.params = params
         else:
@@ -223,9 +245,12 @@ class _DecoderSeqFn(torch.autograd.Function):
             return g, False
 
         # ---- conv_out: data gradient of all T steps in one launch, weight + bias gradient in another ----
-        dUP5 = torch.empty_like(UP5)
+        upc = ctx.upc
+        dUP5 = None if upc else torch.empty_like(UP5)
         co_pack = decoder.conv_out._pack
-        if d_masks is None:
+        if upc:         # (the whole tail runs below, once the side gradients of the heads are known)
+            d_masks = torch.zeros((B, T, H5 * W5), **f32) if d_masks is None else (d_masks if d_masks.is_contiguous() else d_masks.contiguous())
+        elif d_masks is None:
             dUP5.zero_()
         else:
             d_masks = d_masks if d_masks.is_contiguous() else d_masks.contiguous()
@@ -281,8 +306,13 @@ class _DecoderSeqFn(torch.autograd.Function):
         wds = [lv.dyn.dgrad(gates_w[i]) for i, lv in enumerate(levels)]
         # the last level's hidden states receive their gradient from conv_out only (no level above): all T steps in one launch
         DH_last = torch.empty((T, B, last.hid, last.H, last.W), **f32)
-        check(L.rsis_upsample_maxpool_bwd(ptr(dUP5), ptr(dsides[n - 1]), ptr(last.ARG), ptr(DH_last), T * B * last.hid, last.H, last.W, H5, W5,
-                                          stream()), "rsis_upsample_maxpool_bwd(all steps)")
+        if upc:
+            kw, kb = 2 * n, 2 * n + 1
+            _upconv_bwd(L, d_masks, last, False, co_w, target(kw)[0] if need_par[kw] else None, target(kb)[0] if need_par[kb] else None, dsides[n - 1],
+                        T, B, H5, W5, DH_last)
+        else:
+            check(L.rsis_upsample_maxpool_bwd(ptr(dUP5), ptr(dsides[n - 1]), ptr(last.ARG), ptr(DH_last), T * B * last.hid, last.H, last.W, H5, W5,
+                                              stream()), "rsis_upsample_maxpool_bwd(all steps)")
         for d in range(T + n - 2, -1, -1):
             cells = [(i, d - i) for i in range(n) if 0 <= d - i < T]
             for i, t in cells:          # gradient reaching h[i][t] through its upsample into the next level and its side max-pool
@@ -437,7 +467,8 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
         ops.blk_conv3x3_batch(hoist_jobs)          # G_i = W[:, skip channels] * skip_i + b of all five levels: one grouped launch
         last = levels[-1]
         H5, W5 = 2 * last.H, 2 * last.W
-        UP5 = torch.empty((T, B, 1, H5, W5, 8), **b16)
+        upc = _upconv_ok(L, last, H5, W5)
+        UP5 = None if upc else torch.empty((T, B, 1, H5, W5, 8), **b16)
         ncls = Wc.shape[0]
         probs_tb = torch.empty((T, B, ncls), **f32)
         stop_tb = torch.empty((T, B, 1), **f32)
@@ -457,11 +488,15 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
             ops.blk_conv3x3_batch(jobs)
             if ups:
                 ops.blk_upsample_fwd_batch(ups)
-        ops.blk_upsample_fwd_batch([ops.blk_resize_job(last.Hs.view(T * B, last.hid // 8, last.H, last.W, 8), UP5.view(T * B, 1, H5, W5, 8))])
         _heads_all_steps(L, levels, hs, n, T * B, Wc_d, bc_d, Ws_d, bs_d, ncls, probs_tb, stop_tb)
         out_masks = torch.empty((B, T, H5 * W5), **f32)
-        check(L.rsis_blk_conv_out_seq_fwd(ptr(UP5), ptr(co_w.detach()), ptr(co_b.detach()), ptr(out_masks), T, B, H5, W5, stream()),
-              "rsis_blk_conv_out_seq_fwd")
+        if upc:       # upsample + conv_out in one pass, the upsampled tensor never formed (nor rounded to bf16)
+            check(L.rsis_upconv_out_fwd(ptr(last.Hs), 1, ptr(co_w.detach()), ptr(co_b.detach()), ptr(out_masks), T, B, last.hid, last.H, last.W, H5, W5,
+                                        stream()), "rsis_upconv_out_fwd")
+        else:
+            ops.blk_upsample_fwd_batch([ops.blk_resize_job(last.Hs.view(T * B, last.hid // 8, last.H, last.W, 8), UP5.view(T * B, 1, H5, W5, 8))])
+            check(L.rsis_blk_conv_out_seq_fwd(ptr(UP5), ptr(co_w.detach()), ptr(co_b.detach()), ptr(out_masks), T, B, H5, W5, stream()),
+                  "rsis_blk_conv_out_seq_fwd")
         out_probs = probs_tb.transpose(0, 1).contiguous()
         out_stops = stop_tb.transpose(0, 1).contiguous()
         hidden = []
@@ -473,7 +508,7 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         if need_grad:
             ctx.decoder, ctx.T, ctx.levels = decoder, T, levels
-            ctx.UP5, ctx.probs_tb, ctx.feats, ctx.params = UP5, probs_tb, feats, params
+            ctx.UP5, ctx.probs_tb, ctx.feats, ctx.params, ctx.upc = UP5, probs_tb, feats, params, upc
         else:
             for lv in levels:
                 lv.G = lv.ACT = lv.UP = lv.skip = None
@@ -509,12 +544,15 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
             grads_par[k] = g
             return g, False
 
-        dUP5 = torch.empty_like(UP5)
-        if d_masks is None:
+        upc = ctx.upc
+        dUP5 = None if upc else torch.empty_like(UP5)
+        kw, kb = 2 * n, 2 * n + 1
+        if upc:         # (the whole tail runs below, once the side gradients of the heads are known)
+            d_masks = torch.zeros((B, T, H5 * W5), **f32) if d_masks is None else (d_masks if d_masks.is_contiguous() else d_masks.contiguous())
+        elif d_masks is None:
             dUP5.zero_()
         else:
             d_masks = d_masks if d_masks.is_contiguous() else d_masks.contiguous()
-            kw, kb = 2 * n, 2 * n + 1
             check(L.rsis_blk_conv_out_seq_dgrad(ptr(d_masks), ptr(co_w.detach()), ptr(dUP5), T, B, H5, W5, stream()), "rsis_blk_conv_out_seq_dgrad")
             if need_par[kw] or need_par[kb]:
                 dW = target(kw)[0] if need_par[kw] else torch.zeros_like(co_w)
@@ -548,8 +586,12 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
         dcf = [d_hidden[2 * i + 1].contiguous() if (len(d_hidden) > 2 * i + 1 and d_hidden[2 * i + 1] is not None) else None for i in range(n)]
         # the last level's hidden states receive their gradient from conv_out only: all T steps in one launch
         DH_last = torch.empty((T, B, last.hid // 8, last.H, last.W, 8), **b16)
-        ops.blk_upsample_bwd_batch([ops.blk_resize_job(dUP5.view(T * B, 1, H5, W5, 8), DH_last.view(T * B, last.hid // 8, last.H, last.W, 8),
-                                                        dsides[n - 1], last.ARG, backward=True)])
+        if upc:
+            _upconv_bwd(L, d_masks, last, True, co_w, target(kw)[0] if need_par[kw] else None, target(kb)[0] if need_par[kb] else None, dsides[n - 1],
+                        T, B, H5, W5, DH_last)
+        else:
+            ops.blk_upsample_bwd_batch([ops.blk_resize_job(dUP5.view(T * B, 1, H5, W5, 8), DH_last.view(T * B, last.hid // 8, last.H, last.W, 8),
+                                                            dsides[n - 1], last.ARG, backward=True)])
         for d in range(T + n - 2, -1, -1):
             cells = [(i, d - i) for i in range(n) if 0 <= d - i < T]
             ups, lbs, dgs = [], [], []
