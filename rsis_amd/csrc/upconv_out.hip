@@ -11,7 +11,7 @@
 // the forward reads h once and writes the logits once (fp32: 168 + 84 MB instead of 168 + 671 + 671 + 84), and the backward
 //     dq_t = up^T(shift_t^T(dout)),   dh_c = sum_t w[c][t] dq_t,   dW[c][t] = sum h_c dq_t,   db = sum dout
 // reads dout and h once and writes dh once.  U is never formed; nothing is rounded between the two maps (the blk path used to round U
-// to bf16).  Interpolation is separable and done through LDS: columns first (P), then rows.
+// to bf16).  The forward samples the tap maps from LDS; the backward's transpose interpolation is separable: columns (E), then rows.
 //
 // Layouts: h / dh are fp32 planes [T*B][8][Hs][Ws] (HBLK = 0) or bf16 blk cells [T*B][1][Hs][Ws][8] (HBLK = 1), images in [t][b]
 // order; the logits and their gradient are fp32 [B][T][Ho*Wo] (image t * B + b of the former pairs with image b * T + t of the
@@ -68,7 +68,6 @@ __device__ __forceinline__ void load_h8(const void* h, long img, int HsWs, int s
 template <int HBLK>
 __global__ __launch_bounds__(256) void upconv_fwd_kernel(const UpconvArgs a) {
   __shared__ float q[9][UF_MR][UF_MC + 1];
-  __shared__ float P[9][UF_MR][UF_OX];
   __shared__ int ry0[UF_OY + 2], ry1[UF_OY + 2], cx0[UF_OX + 2], cx1[UF_OX + 2];
   __shared__ float rfy[UF_OY + 2], rv[UF_OY + 2], cfx[UF_OX + 2], cv[UF_OX + 2];
   const int tid = threadIdx.x;
@@ -76,60 +75,63 @@ __global__ __launch_bounds__(256) void upconv_fwd_kernel(const UpconvArgs a) {
   const int m = blockIdx.x / per_img, trem = blockIdx.x - m * per_img;
   const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
   const int Y0 = ty * UF_OY, X0 = tx * UF_OX;
-  const int Hs = a.Hs, Ws = a.Ws, Ho = a.Ho, Wo = a.Wo;
+  const int Hs = a.Hs, Ws = a.Ws, Ho = a.Ho, Wo = a.Wo, HsWs = Hs * Ws;
 
-  // ---- source rows / columns of the tile's outputs and of the one-pixel ring around them (the 3x3 taps) ----
+  // ---- the low-resolution footprint of the tile and its one-pixel ring, by every thread for itself: the loads of h go out first ----
+  int rlo, rhi, clo, chi, tmp; float tl;
+  ac_coord(max(Y0 - 1, 0), a.sh, Hs, rlo, tmp, tl);
+  ac_coord(min(Y0 + UF_OY, Ho - 1), a.sh, Hs, tmp, rhi, tl);
+  ac_coord(max(X0 - 1, 0), a.sw, Ws, clo, tmp, tl);
+  ac_coord(min(X0 + UF_OX, Wo - 1), a.sw, Ws, tmp, chi, tl);
+  const int nr = rhi - rlo + 1, nc = chi - clo + 1, npx = nr * nc;       // (nr <= UF_MR, nc <= UF_MC: the launcher checks the scale)
+  constexpr int NPT = (UF_MR * UF_MC + 255) / 256;
+  float hv[NPT][8];
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int e = min(tid + i * 256, npx - 1);        // (clamped, not skipped: a load under a per-lane branch is waited for at once)
+    const int lr = e / nc, lc = e - lr * nc;
+    load_h8<HBLK>(a.h, m, HsWs, (rlo + lr) * Ws + clo + lc, hv[i]);
+  }
+  // ---- source rows / columns of the outputs and of the ring around them (the 3x3 taps) ----
   if (tid < UF_OY + 2) {
     const int Y = Y0 - 1 + tid;
     const bool ok = Y >= 0 && Y < Ho;
     int i0, i1; float l;
     ac_coord(ok ? Y : (Y < 0 ? 0 : Ho - 1), a.sh, Hs, i0, i1, l);
-    ry0[tid] = i0; ry1[tid] = i1; rfy[tid] = l; rv[tid] = ok ? 1.f : 0.f;
+    ry0[tid] = i0 - rlo; ry1[tid] = i1 - rlo; rfy[tid] = l; rv[tid] = ok ? 1.f : 0.f;
   } else if (tid >= 128 && tid < 128 + UF_OX + 2) {
     const int j = tid - 128, X = X0 - 1 + j;
     const bool ok = X >= 0 && X < Wo;
     int i0, i1; float l;
     ac_coord(ok ? X : (X < 0 ? 0 : Wo - 1), a.sw, Ws, i0, i1, l);
-    cx0[j] = i0; cx1[j] = i1; cfx[j] = l; cv[j] = ok ? 1.f : 0.f;
+    cx0[j] = i0 - clo; cx1[j] = i1 - clo; cfx[j] = l; cv[j] = ok ? 1.f : 0.f;
   }
-  __syncthreads();
-  // (clamped entries repeat the nearest valid one: first / last entries bound the footprint)
-  const int rlo = ry0[0], nr = ry1[UF_OY + 1] - rlo + 1;
-  const int clo = cx0[0], nc = cx1[UF_OX + 1] - clo + 1;
-
-  // ---- the 9 tap maps on the low-resolution footprint ----
+  // ---- the 9 tap maps on the footprint ----
   float wv[72];
 #pragma unroll
   for (int i = 0; i < 72; ++i) wv[i] = a.w[i];
-  const int HsWs = Hs * Ws;
-  for (int e = tid; e < nr * nc; e += 256) {
-    const int lr = e / nc, lc = e - lr * nc;
-    float hv[8];
-    load_h8<HBLK>(a.h, m, HsWs, (rlo + lr) * Ws + clo + lc, hv);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      float s = 0.f;
+  for (int i = 0; i < NPT; ++i) {
+    const int e = tid + i * 256;
+    if (e < npx) {
+      const int lr = e / nc, lc = e - lr * nc;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) s += wv[c * 9 + t] * hv[c];
-      q[t][lr][lc] = s;
+      for (int t = 0; t < 9; ++t) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) s += wv[c * 9 + t] * hv[i][c];
+        q[t][lr][lc] = s;
+      }
     }
   }
   __syncthreads();
-  // ---- columns: P[t][row][x] = up_x(q_t[row]) at output column X0 + x + s - 1 (0 outside the map) ----
-  {
-    const int x = tid & 63;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int j = x + t % 3;
-      const int l0 = cx0[j] - clo, l1 = cx1[j] - clo;
-      const float f = cfx[j], ok = cv[j];
-      for (int lr = tid >> 6; lr < nr; lr += 4) P[t][lr][x] = ok * ((1.f - f) * q[t][lr][l0] + f * q[t][lr][l1]);
-    }
-  }
-  __syncthreads();
-  // ---- rows, the sum over the taps, the bias ----
+  // ---- out(Y, X) = b + sum over the taps of the bilinear sample of q_t at (Y + r - 1, X + s - 1) (0 outside the upsampled map) ----
   {
     const int x = tid & 63, X = X0 + x;
+    int l0s[3], l1s[3];
+    float fxs[3], oks[3];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) { l0s[s3] = cx0[x + s3]; l1s[s3] = cx1[x + s3]; fxs[s3] = cfx[x + s3]; oks[s3] = cv[x + s3]; }
     const float b = a.bias ? a.bias[0] : 0.f;
     const int bimg = m % a.Bn, timg = m / a.Bn;
     float* const o = a.out + ((long)bimg * a.T + timg) * Ho * Wo;
@@ -140,12 +142,17 @@ __global__ __launch_bounds__(256) void upconv_fwd_kernel(const UpconvArgs a) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const int i = y + r;
-        const int l0 = ry0[i] - rlo, l1 = ry1[i] - rlo;
+        const int l0 = ry0[i], l1 = ry1[i];
         const float f = rfy[i], ok = rv[i];
-        float s = 0.f;
+        float sr = 0.f;
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) s += (1.f - f) * P[r * 3 + s3][l0][x] + f * P[r * 3 + s3][l1][x];
-        acc += ok * s;
+        for (int s3 = 0; s3 < 3; ++s3) {
+          const float (*qt)[UF_MC + 1] = q[r * 3 + s3];
+          const float a0 = (1.f - fxs[s3]) * qt[l0][l0s[s3]] + fxs[s3] * qt[l0][l1s[s3]];
+          const float a1 = (1.f - fxs[s3]) * qt[l1][l0s[s3]] + fxs[s3] * qt[l1][l1s[s3]];
+          sr += oks[s3] * ((1.f - f) * a0 + f * a1);
+        }
+        acc += ok * sr;
       }
       if (Y < Ho && X < Wo) o[Y * Wo + X] = acc;
     }
@@ -158,16 +165,14 @@ __global__ __launch_bounds__(256) void upconv_fwd_kernel(const UpconvArgs a) {
 #define UB_RY 16
 #define UB_RX 32
 #define UB_UK 6           // candidate outputs per input index and axis (scale >= 0.46: the launcher checks)
-#define UB_FY 44          // dout footprint of a tile: candidates + the taps' ring
-#define UB_FX 76
+#define UB_FY 46          // dout footprint of a tile: (conservative) candidate range + the taps' ring
+#define UB_FX 80
 template <int HBLK>
-__global__ __launch_bounds__(256) void upconv_bwd_kernel(const UpconvArgs a) {
+__global__ __launch_bounds__(256, 2) void upconv_bwd_kernel(const UpconvArgs a) {
   __shared__ float D[UB_FY][UB_FX + 1];
   __shared__ float E[3][UB_FY][UB_RX + 1];
   __shared__ float wy[UB_RY][UB_UK], wx[UB_RX][UB_UK];
   __shared__ int sty[UB_RY], stx[UB_RX];
-  __shared__ float owny[UB_FY], ownx[UB_FX];
-  __shared__ int org[2], ext[2];
   const int tid = threadIdx.x;
   const int Hs = a.Hs, Ws = a.Ws, Ho = a.Ho, Wo = a.Wo, HsWs = Hs * Ws;
   const int per_img = a.tiles_x * a.tiles_y;
@@ -182,8 +187,50 @@ __global__ __launch_bounds__(256) void upconv_bwd_kernel(const UpconvArgs a) {
     const int m = tile / per_img, trem = tile - m * per_img;
     const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
     const int R0 = ty * UB_RY, C0 = tx * UB_RX;
-    // ---- per-axis tables: first candidate output of every input index of the tile and its UB_UK transpose weights ----
-    if (tid < UB_RY || (tid >= 64 && tid < 64 + UB_RX)) {
+    // ---- phase 0, nothing depends on anything: the hidden state of this thread's two pixels, the footprint of dout (its extent by a
+    //      conservative closed form: an output o touches input i only if i - 1 < scale * o < i + 1), the per-axis tables ----
+    float hv[2][8];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int px = tid + 256 * half;
+      const int ys = min(R0 + (px >> 5), Hs - 1), xs = min(C0 + (px & 31), Ws - 1);      // (clamped, not skipped: no branch around a load)
+      load_h8<HBLK>(a.h, m, HsWs, ys * Ws + xs, hv[half]);
+    }
+    const int oy = max(0, (int)floorf((R0 - 1) / a.sh) - 1) - 1, ox = max(0, (int)floorf((C0 - 1) / a.sw) - 1) - 1;
+    const int ey = min((int)floorf(min(R0 + UB_RY, Hs) / a.sh) + 1 - oy + 1, UB_FY);
+    const int ex = min((int)floorf(min(C0 + UB_RX, Ws) / a.sw) + 1 - ox + 1, UB_FX);
+    {
+      const int bimg = m % a.Bn, timg = m / a.Bn;
+      const float* const d = a.dout + ((long)bimg * a.T + timg) * Ho * Wo;
+      // element e = tid + 256 i of the MAXIMAL footprint (a constant divisor), 8 loads in flight at a time: every load of a chunk goes
+      // out before the first use, at clamped addresses (no branch around a load)
+      constexpr int NIT = (UB_FY * UB_FX + 255) / 256, CH = 8;
+#pragma unroll
+      for (int i0 = 0; i0 < NIT; i0 += CH) {
+        float dv_[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int e = tid + 256 * (i0 + i);
+          const int fr = e / UB_FX, fc = e - fr * UB_FX;
+          const int Y = min(max(oy + fr, 0), Ho - 1), X = min(max(ox + fc, 0), Wo - 1);
+          if (i0 + i < NIT) dv_[i] = d[Y * Wo + X];
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          if (i0 + i >= NIT) continue;
+          const int e = tid + 256 * (i0 + i);
+          const int fr = e / UB_FX, fc = e - fr * UB_FX;
+          const int Y = oy + fr, X = ox + fc;
+          const bool in = fr < ey && fc < ex && Y >= 0 && Y < Ho && X >= 0 && X < Wo;
+          const float v = in ? dv_[i] : 0.f;
+          if (fr < UB_FY) D[fr][fc] = v;
+          // (bias gradient: an output belongs to the tile that holds its (i0, i0) source corner -- every output has exactly one)
+          const int iy = min((int)(a.sh * Y), Hs - 1), ix = min((int)(a.sw * X), Ws - 1);
+          accb += (in && iy >= R0 && iy < R0 + UB_RY && ix >= C0 && ix < C0 + UB_RX) ? v : 0.f;
+        }
+      }
+    }
+    if (tid < UB_RY || (tid >= 64 && tid < 64 + UB_RX)) {      // first candidate output of every input index and its UB_UK transpose weights
       const int axis = tid >= 64, li = axis ? tid - 64 : tid;
       const int in = axis ? Ws : Hs, out = axis ? Wo : Ho;
       const float sc = axis ? a.sw : a.sh;
@@ -202,52 +249,16 @@ __global__ __launch_bounds__(256) void upconv_bwd_kernel(const UpconvArgs a) {
           if (first >= 0 && o - first < UB_UK) w[o - first] = wo;
         }
       }
-      if (first < 0) first = min(l, out - 1);
+      if (first < 0) first = l;                  // (no candidate: all weights 0; any in-footprint start will do)
 #pragma unroll
       for (int k = 0; k < UB_UK; ++k) { if (axis) wx[li][k] = w[k]; else wy[li][k] = w[k]; }
       if (axis) stx[li] = first; else sty[li] = first;
     }
     __syncthreads();
-    if (tid < 2) {
-      const int n = tid ? UB_RX : UB_RY;
-      const int* st = tid ? stx : sty;
-      int lo = st[0], hi = 0;
-      for (int li = 0; li < n; ++li) { lo = min(lo, st[li]); hi = max(hi, st[li] + UB_UK - 1); }
-      org[tid] = lo - 1;                                        // (the taps reach one output further on either side)
-      ext[tid] = min(hi + 1 - (lo - 1) + 1, tid ? UB_FX : UB_FY);
-    }
-    __syncthreads();
-    const int oy = org[0], ox = org[1], ey = ext[0], ex = ext[1];
-    // (ownership for the bias gradient: an output belongs to the tile that holds its (i0, i0) source corner)
-    if (tid < ey) {
-      const int Y = oy + tid;
-      int i0 = -1, i1; float l1;
-      if (Y >= 0 && Y < Ho) ac_coord(Y, a.sh, Hs, i0, i1, l1);
-      owny[tid] = (i0 >= R0 && i0 < R0 + UB_RY) ? 1.f : 0.f;
-    } else if (tid >= 128 && tid < 128 + ex) {
-      const int X = ox + tid - 128;
-      int i0 = -1, i1; float l1;
-      if (X >= 0 && X < Wo) ac_coord(X, a.sw, Ws, i0, i1, l1);
-      ownx[tid - 128] = (i0 >= C0 && i0 < C0 + UB_RX) ? 1.f : 0.f;
-    }
-    __syncthreads();
-    // ---- the footprint of dout (zero outside the map: the conv's padding) ----
-    {
-      const int bimg = m % a.Bn, timg = m / a.Bn;
-      const float* const d = a.dout + ((long)bimg * a.T + timg) * Ho * Wo;
-      for (int e = tid; e < ey * ex; e += 256) {
-        const int fr = e / ex, fc = e - fr * ex;
-        const int Y = oy + fr, X = ox + fc;
-        const float v = (Y >= 0 && Y < Ho && X >= 0 && X < Wo) ? d[Y * Wo + X] : 0.f;
-        D[fr][fc] = v;
-        accb += v * owny[fr] * ownx[fc];
-      }
-    }
-    __syncthreads();
     // ---- columns: E[s][row][xs] = sum_k wx[xs][k] dout[row][stx[xs] + k - (s - 1)] ----
     {
       const int xs = tid & 31;
-      const int c0 = stx[xs] - ox;
+      const int c0 = stx[xs] - ox;               // >= 1
       float wk[UB_UK];
 #pragma unroll
       for (int k = 0; k < UB_UK; ++k) wk[k] = wx[xs][k];
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(256) void upconv_bwd_kernel(const UpconvArgs a) {
         float dq[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) dq[t] = 0.f;
-        const int r0 = sty[lys] - oy;
+        const int r0 = sty[lys] - oy;            // >= 1
         float ev[3][UB_UK + 2];
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3)
@@ -297,14 +308,13 @@ __global__ __launch_bounds__(256) void upconv_bwd_kernel(const UpconvArgs a) {
 #pragma unroll
             for (int s3 = 0; s3 < 3; ++s3) dq[r * 3 + s3] += wk * ev[s3][k + 2 - r];      // row sty + k - (r - 1)
         }
-        float hv[8], dv[8];
+        float dv[8];
         const int sp = ys * Ws + xs;
-        load_h8<HBLK>(a.h, m, HsWs, sp, hv);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           float s = 0.f;
 #pragma unroll
-          for (int t = 0; t < 9; ++t) { s += wv[c * 9 + t] * dq[t]; accw[c * 9 + t] += hv[c] * dq[t]; }
+          for (int t = 0; t < 9; ++t) { s += wv[c * 9 + t] * dq[t]; accw[c * 9 + t] += hv[half][c] * dq[t]; }
           s += argv[c] == sp ? sidev[c] : 0.f;
           dv[c] = s;
         }
@@ -335,19 +345,22 @@ __global__ __launch_bounds__(256) void upconv_bwd_kernel(const UpconvArgs a) {
   if (tid < 73) a.partial[(long)blockIdx.x * 80 + tid] = red[tid] + red[80 + tid] + red[160 + tid] + red[240 + tid];
 }
 
-__global__ __launch_bounds__(128) void upconv_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dW, float* __restrict__ db) {
-  const int i = threadIdx.x;
-  if (i >= 73) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 4 <= nblk; b += 4) {
-    s0 += partial[(long)b * 80 + i]; s1 += partial[(long)(b + 1) * 80 + i];
-    s2 += partial[(long)(b + 2) * 80 + i]; s3 += partial[(long)(b + 3) * 80 + i];
+// dW / db += the blocks' rows, in a fixed order: 12 row groups x 80 columns sum their strided rows, then the groups in order
+__global__ __launch_bounds__(960) void upconv_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float red[12][80];
+  const int i = threadIdx.x % 80, g = threadIdx.x / 80;
+  float s = 0.f;
+  if (i < 73)
+    for (int b = g; b < nblk; b += 12) s += partial[(long)b * 80 + i];
+  red[g][i] = s;
+  __syncthreads();
+  if (g == 0 && i < 73) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) t += red[k][i];
+    if (i < 72) { if (dW) dW[i] += t; }
+    else if (db) db[0] += t;
   }
-  for (; b < nblk; ++b) s0 += partial[(long)b * 80 + i];
-  const float s = (s0 + s1) + (s2 + s3);
-  if (i < 72) { if (dW) dW[i] += s; }
-  else if (db) db[0] += s;
 }
 
 // ---- host side ----
@@ -356,12 +369,12 @@ bool rsis_upconv_supported(int C, int Hs, int Ws, int Ho, int Wo) {
   const float sh = ac_scale(Hs, Ho), sw = ac_scale(Ws, Wo);
   if (sh < 0.46f || sw < 0.46f) return false;                                   // backward: UB_UK candidates per index
   if ((UF_OY + 1) * sh + 3.f > UF_MR || (UF_OX + 1) * sw + 3.f > UF_MC) return false;     // forward: the q footprint
-  if ((UB_RY - 1) / sh + UB_UK + 4.f > UB_FY || (UB_RX - 1) / sw + UB_UK + 4.f > UB_FX) return false;
+  if ((UB_RY + 1) / sh + 7.f > UB_FY || (UB_RX + 1) / sw + 7.f > UB_FX) return false;           // backward: the dout footprint
   return (long)Ho * Wo < (1L << 30) && (long)Hs * Ws * 8 < (1L << 30);
 }
 int rsis_upconv_bwd_blocks(int T, int B, int Hs, int Ws) {
   const long ntiles = (long)T * B * rsis_cdiv(Hs, UB_RY) * rsis_cdiv(Ws, UB_RX);
-  return (int)(ntiles < 768 ? ntiles : 768);
+  return (int)(ntiles < 512 ? ntiles : 512);          // two blocks per CU are resident (registers): one round of persistent blocks
 }
 
 int rsis_l_upconv_fwd(const void* h, int h_blk, const float* w, const float* bias, float* out, int T, int B, int Hs, int Ws, int Ho, int Wo,
@@ -391,7 +404,7 @@ int rsis_l_upconv_bwd(const float* dout, const void* h, int h_blk, const float* 
   else hipLaunchKernelGGL(upconv_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, a);
   if (rsis_check_launch() != RSIS_OK) return RSIS_ERR_LAUNCH;
   if (dW || db) {
-    hipLaunchKernelGGL(upconv_finalize_kernel, dim3(1), dim3(128), 0, st, (const float*)partial, grid, dW, db);
+    hipLaunchKernelGGL(upconv_finalize_kernel, dim3(1), dim3(960), 0, st, (const float*)partial, grid, dW, db);
     return rsis_check_launch();
   }
   return RSIS_OK;
