@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void blk_lstm_bwd_group_kernel(const KdGroup<B
     for (int h2 = 0; h2 < 2; ++h2) {
       const int k = 2 * q + h2;
       const float gi = a[4 * h2], gf = a[4 * h2 + 1], go = a[4 * h2 + 2], gg = a[4 * h2 + 3];
-      const float tc = tanhf(cv[k]);
+      const float tc = rsis_tanh_fast(cv[k]);
       const float dcv = dh[k] * go * (1.f - tc * tc) + dcn[k];
       da[4 * h2] = dcv * gg * gi * (1.f - gi);
       da[4 * h2 + 1] = dcv * cp[k] * gf * (1.f - gf);

@@ -35,6 +35,13 @@ static inline int rsis_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int rsis_roundup(int a, int b) { return ((a + b - 1) / b) * b; }
 
 __device__ __forceinline__ float rsis_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// The same two functions on the hardware's transcendental units (v_exp_f32, v_rcp_f32: ~1 ulp each), for the bf16 (blk) decoder
+// kernels: 4 / 5 instructions instead of ~25 (expf + an IEEE division) / ~35 (tanhf).  The ConvLSTM cell of the 112 x 112 level has
+// 216 MACs per gate row and 5 of these per hidden channel and pixel: with the library functions the gate launch was bound by its
+// epilogue's VALU (rocprofv3: 1600 VALU instructions per wave, 47 % of the wave's lifetime issuing), not by HBM.  Absolute error
+// ~2e-7, far below the bf16 rounding of everything these values feed except the fp32 cell state (where it is the fp32 noise floor).
+__device__ __forceinline__ float rsis_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float rsis_tanh_fast(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f; }
 
 // align_corners=True bilinear source coordinate (nn.UpsamplingBilinear2d: model.py:149,163): output index o reads inputs i0, i1
 // with weights (1 - l1, l1).  One definition for every kernel that must agree bit for bit on which inputs an output touches.

@@ -279,9 +279,9 @@ __device__ __forceinline__ void bd_body(const BlkConvJob& p, const int bid, u32x
         const bool ok = in && jh < hid;
         const float ai = acc[j][4 * r4 + 0] + bv[4 * r4 + 0] + bd_lo(ga[r4][0]), af = acc[j][4 * r4 + 1] + bv[4 * r4 + 1] + bd_hi(ga[r4][0]);
         const float ao = acc[j][4 * r4 + 2] + bv[4 * r4 + 2] + bd_lo(ga[r4][1]), ag = acc[j][4 * r4 + 3] + bv[4 * r4 + 3] + bd_hi(ga[r4][1]);
-        const float gi = rsis_sigmoid(ai), gf = rsis_sigmoid(af), go = rsis_sigmoid(ao), gg = tanhf(ag);
+        const float gi = rsis_sigmoid_fast(ai), gf = rsis_sigmoid_fast(af), go = rsis_sigmoid_fast(ao), gg = rsis_tanh_fast(ag);
         const float c = gf * cpv[r4] + gi * gg;     // clstm.py:57
-        const float h = go * tanhf(c);              // clstm.py:58
+        const float h = go * rsis_tanh_fast(c);      // clstm.py:58
         hv[r4] = h;
         if (p.side_key && ok) { const unsigned long long k = rsis_side_key(h, osp); best[r4] = k > best[r4] ? k : best[r4]; }
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), r_c, ok ? (unsigned)(jh * HW + osp) * 4u : RSIS_OOB, 0, 0);

@@ -3,10 +3,9 @@
 //     dW[co][ci][r][s] += sum_{b,y,x} dy[b][co][y][x] * x[b][ci][y+r-pad][x+s-pad]
 // (autograd of nn.Conv2d in reference src/modules/clstm.py:17,44 -- the ConvLSTM gates, time-batched over T*B images --
 //  model.py:43-47 and the 1x1 / 3x3 convs of the torchvision bottlenecks).  dy, x and dW are fp32 (NCHW / reference layout);
-//  the operands are rounded to bf16 while they are staged into LDS.  IN = 2: dy and x are channel-blocked bf16 tensors
-//  (conv_blk.hip: cells of 8 channels x 1 pixel) -- a staging task then fetches the 8 cells of 8 consecutive pixels (whole 16-byte
-//  loads whatever the map width: no ragged-row slow path), transposes the 8 x 8 block in registers and writes the 8 pixel-major
-//  cells [channel][8 px] the MFMA operands are read from.
+//  the operands are rounded to bf16 while they are staged into LDS (IN = 1 / 0: rows of whole / ragged float4s).  Channel-blocked bf16
+//  operands (conv_blk.hip: cells of 8 channels x 1 pixel) take the DMA / transposing-read kernels further down (wgrad3_tr_body,
+//  wgrad1_tr_body): no staging pass at all.
 //
 // The PIXELS are the reduction axis, and NCHW has them contiguous: a lane's 8 K values are 8 consecutive pixels of one row,
 // i.e. one 16-byte LDS cell, for dy (A operand, rows = co) and for x (B operand) alike.
@@ -35,7 +34,7 @@ struct WgradBf16Args {
   int B, Cs, H, W, Cout;
   int ldo, n_off;
   short interleave_hid;
-  short blk;         // dy and x are channel-blocked bf16 tensors (IN = 2)
+  short blk;         // dy and x are channel-blocked bf16 tensors (wgrad3_tr_body / wgrad1_tr_body)
   int n_co_tiles, n_n_tiles, n_sp_tiles, tiles_per_split;
 };
 
@@ -71,38 +70,6 @@ struct Task8 {
     return c;
   }
 };
-
-// IN = 2 staging: the 8 x 8 (pixel x channel) block held as 8 cells `in[px]` -> the pixel-major cell of channel c
-__device__ __forceinline__ u32x4 blk_tr_cell(const u32x4* in, const int c) {
-  u32x4 o;
-  const int k = c >> 1;
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-    o[m] = (c & 1) ? ((in[2 * m][k] >> 16) | (in[2 * m + 1][k] & 0xFFFF0000u)) : ((in[2 * m][k] & 0xFFFFu) | (in[2 * m + 1][k] << 16));
-  return o;
-}
-// One blk staging task: 8 channels (one channel block) x 8 consecutive pixels of a row.
-struct BlkTask {
-  int off;        // cell offset of pixel 0 inside the descriptor at tile (0, 0) (negative for halo cells), or BLK_NEVER
-  int y, x;       // position inside the tile (may be negative: halo)
-  int lds;        // byte offset of channel 0's cell inside a stage
-};
-#define BLK_NEVER 0x40000000
-// PS: pixel stride between the task's 8 cells.  1 = 8 consecutive pixels (3x3: the taps need neighbours in a lane).  8 (1x1, where the
-// reduction over pixels has no spatial structure and ANY assignment of pixels to K slots works as long as dy and x use the same):
-// task G takes pixels G, G + 8, ..., G + 56 of the 64-pixel tile, so that load j of the 8 tasks of a channel block -- 8 neighbouring
-// lanes -- reads 8 ADJACENT cells = one 128-byte line per instruction instead of 16 bytes out of each of 8 lines (measured with one
-// block per dW tile, tools/exp/wgrad_step_latency.py: the consecutive form took 1.46 us per tile, the fp32 loader 1.21).
-template <int PS>
-__device__ __forceinline__ void blk_task_load(u32x4* rc, const BlkTask& t, const __amdgpu_buffer_rsrc_t r, const int tsc, const int y0, const int x0,
-                                              const int H, const int W) {
-  const bool row_ok = t.off < 0x20000000 && (unsigned)(y0 + t.y) < (unsigned)H;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const bool ok = row_ok && (unsigned)(x0 + t.x + j * PS) < (unsigned)W;
-    rc[j] = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? (unsigned)(t.off + tsc + j * PS) * 16u : RSIS_OOB, 0, 0);
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // 3x3: block = BM dy rows x 32 input channels x 9 taps; wave = 32 rows x 32 channels x 9 taps, the 4 / (BM / 32) wave copies of a
@@ -156,58 +123,6 @@ __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const i
     x_lds[i] = cl * CHSB + (py * PWP + xg * 8) * 2;
   }
 
-  // ---- IN = 2: super tasks (channel block, 8-pixel group): dy first (padded to whole waves), then the patch ----
-  constexpr int NSA = BM / 8 * NG, NSAP = (NSA + 63) / 64 * 64, NSX = 4 * PH * XG, NTS = (NSAP + NSX + 255) / 256;
-  BlkTask bt[IN == 2 ? NTS : 1];
-  bool bt_a[IN == 2 ? NTS : 1];
-  if constexpr (IN == 2) {
-#pragma unroll
-    for (int i = 0; i < NTS; ++i) {
-      const int e = tid + i * 256;
-      bt_a[i] = __builtin_amdgcn_readfirstlane(e) < NSAP;       // (NSAP % 64 == 0: a wave's tasks are all dy or all patch)
-      if (bt_a[i]) {
-        const int cbl = e / NG, G = e % NG;
-        bt[i].y = G / GPR; bt[i].x = (G % GPR) * 8;
-        bt[i].off = (e < NSA && co0 + cbl * 8 < Cout) ? cbl * HW + bt[i].y * W + bt[i].x : BLK_NEVER;
-        bt[i].lds = cbl * 8 * ARS + G * 16;
-      } else {
-        const int idx = e - NSAP;
-        const int cbl = idx / (PH * XG), rem = idx - cbl * (PH * XG);
-        const int py = rem / XG, xg = rem - py * XG;
-        bt[i].y = py - 1; bt[i].x = (xg - 1) * 8;
-        bt[i].off = (idx < NSX && ci0 + cbl * 8 < Cs) ? cbl * HW + bt[i].y * W + bt[i].x : BLK_NEVER;
-        bt[i].lds = A_BYTES + cbl * 8 * CHSB + (py * PWP + xg * 8) * 2;
-      }
-    }
-  }
-  u32x4 rc[IN == 2 ? NTS : 1][8];
-#define W3B_LOAD()                                                                                                 \
-  {                                                                                                                \
-    const int y0 = ty * TH, x0 = tx * TW;                                                                          \
-    const int tsc = y0 * W + x0;                                                                                   \
-    const char* ab = (const char*)p.dy + ((size_t)tb * (Cout >> 3) + (co0 >> 3)) * HW * 16;                        \
-    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, ((Cout - co0) >> 3) * HW * 16, 0x00020000); \
-    const char* xb = (const char*)p.x + ((size_t)tb * (Cs >> 3) + (ci0 >> 3)) * HW * 16;                            \
-    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, ((Cs - ci0) >> 3) * HW * 16, 0x00020000); \
-    _Pragma("unroll") for (int i = 0; i < NTS; ++i) {                                                              \
-      if (bt_a[i]) blk_task_load<1>(rc[i], bt[i], ra_, tsc, y0, x0, H, W);                                         \
-      else blk_task_load<1>(rc[i], bt[i], rx_, tsc, y0, x0, H, W);                                                 \
-    }                                                                                                              \
-    if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++tb; } }                                        \
-  }
-#define W3B_STORE(BUF)                                                                                             \
-  {                                                                                                                \
-    char* st = lds + (BUF) * ST_BYTES;                                                                             \
-    _Pragma("unroll") for (int i = 0; i < NTS; ++i) {                                                              \
-      if ((NSAP + NSX) % 256 == 0 || tid + i * 256 < NSAP + NSX) {                                                 \
-        const int rs = bt_a[i] ? ARS : CHSB;                                                                       \
-        if (!bt_a[i] || tid + i * 256 < NSA) {                                                                     \
-          _Pragma("unroll") for (int c = 0; c < 8; ++c) *(u32x4*)(st + bt[i].lds + c * rs) = blk_tr_cell(rc[i], c); \
-        }                                                                                                          \
-      }                                                                                                            \
-    }                                                                                                              \
-  }
-
   // ---- per-lane LDS read bases (bytes) ----
   const int a_base = (wm * 32 + l31) * ARS + hi * 16;
   // step g covers groups 2g (lanes 0-31) and 2g+1 (lanes 32-63): pixel (y, x8*8) of the tile, patch column 8 + x8*8
@@ -229,7 +144,7 @@ __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const i
   int trem = t_begin - tb * (tiles_x * tiles_y);
   int ty = trem / tiles_x, tx = trem - ty * tiles_x;
 
-  Task8<IN == 1> ra[IN == 2 ? 1 : NTA], rxp[IN == 2 ? 1 : NTX];
+  Task8<IN == 1> ra[NTA], rxp[NTX];
 #define W3_LOAD()                                                                                                  \
   {                                                                                                                \
     const int y0 = ty * TH, x0 = tx * TW;                                                                          \
@@ -252,12 +167,12 @@ __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const i
       if (XT % 256 == 0 || tid + i * 256 < XT) *(u32x4*)(st + A_BYTES + x_lds[i]) = rxp[i].cell();                 \
   }
 
-  if constexpr (IN == 2) { W3B_LOAD() W3B_STORE(0) } else { W3_LOAD() W3_STORE(0) }
+  W3_LOAD() W3_STORE(0)
   __syncthreads();
   const int ntl = t_end - t_begin;
   for (int t = 0; t < ntl; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntl) { if constexpr (IN == 2) W3B_LOAD() else W3_LOAD() }
+    if (t + 1 < ntl) W3_LOAD()
     {
       const char* As = lds + cur * ST_BYTES + a_base;
       const char* Xs = lds + cur * ST_BYTES + A_BYTES;
@@ -280,13 +195,11 @@ __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const i
         }
       }
     }
-    if (t + 1 < ntl) { if constexpr (IN == 2) W3B_STORE(cur ^ 1) else W3_STORE(cur ^ 1) }
+    if (t + 1 < ntl) W3_STORE(cur ^ 1)
     __syncthreads();
   }
 #undef W3_LOAD
 #undef W3_STORE
-#undef W3B_LOAD
-#undef W3B_STORE
 
   // ---- epilogue: the KSPW wave copies of a row group first sum their partial tiles in LDS (fewer same-address atomics: they are
   // serialised by the L2), 8 rows x 288 columns at a time; the rows are then split over the copies and added to dW with the lanes
@@ -327,9 +240,9 @@ __device__ __forceinline__ void wgrad3_bf16_body(const WgradBf16Args& p, const i
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3x3 on blk operands, no staging pass (gfx950: LDS-DMA + ds_read_b64_tr_b16).  The register staging of wgrad3_bf16_body<.., IN = 2>
-// -- 8 x 16-byte loads, an 8 x 8 transposition (~100 VALU) and 8 LDS writes per thread and 64-pixel tile, a full memory round trip
-// per tile behind one stage of prefetch -- bound those launches at ~1.4 us per tile and CU whatever the channel counts (a decoder
+// 3x3 on blk operands, no staging pass (gfx950: LDS-DMA + ds_read_b64_tr_b16).  The register-staged version of round 3 -- per thread
+// and 64-pixel tile 8 x 16-byte loads, an 8 x 8 transposition (~100 VALU) and 8 LDS writes, a full memory round trip per tile behind
+// one stage of prefetch -- bound those launches at ~1.4 us per tile and CU whatever the channel counts (a decoder
 // level with 32 gate rows over 4 M pixels ran 10x over its HBM time).  Here the blk cells go from HBM to LDS as they are, by DMA
 // (1 KB per wave instruction: 16 pixels x the 4 channel blocks of a 32-channel slab, [pixel][cb][8 ch] = 64 bytes per pixel), NR
 // tiles deep, and the MFMA operands -- 8 consecutive pixels of one channel per lane -- are gathered by the transposing LDS read:
@@ -753,49 +666,6 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
     b_off[i] = n0 + row < Cs ? row * HW + b_y[i] * W + b_x[i] : -1;
     b_lds[i] = row * ARS + G * 16;
   }
-  // ---- IN = 2: super tasks (channel block, 8-pixel group): the dy tile, then the x tile ----
-  constexpr int NSA = BM / 8 * NG, NSB = BN / 8 * NG, NTS = (NSA + NSB + 255) / 256;
-  static_assert(NSA % 64 == 0, "a wave's tasks are all dy or all x");
-  BlkTask bt[IN == 2 ? NTS : 1];
-  bool bt_a[IN == 2 ? NTS : 1];
-  if constexpr (IN == 2) {
-#pragma unroll
-    for (int i = 0; i < NTS; ++i) {
-      const int e = tid + i * 256;
-      bt_a[i] = __builtin_amdgcn_readfirstlane(e) < NSA;
-      const int idx = bt_a[i] ? e : e - NSA;
-      const int cbl = idx / NG, G = idx % NG;
-      static_assert(IN != 2 || (TW == 64 && NG == 8), "blk 1x1: the flattened map, 64-pixel tiles, task G = pixels G + 8 j");
-      bt[i].y = 0; bt[i].x = G;
-      const bool ok = bt_a[i] ? (co0 + cbl * 8 < Cout) : (idx < NSB && n0 + cbl * 8 < Cs);
-      bt[i].off = ok ? cbl * HW + bt[i].y * W + bt[i].x : BLK_NEVER;
-      bt[i].lds = (bt_a[i] ? 0 : A_BYTES) + cbl * 8 * ARS + G * 16;
-    }
-  }
-  u32x4 rc[IN == 2 ? NTS : 1][8];
-#define W1B_LOAD()                                                                                                 \
-  {                                                                                                                \
-    const int y0 = ty * TH, x0 = tx * TW;                                                                          \
-    const int tsc = y0 * W + x0;                                                                                   \
-    const char* ab = (const char*)p.dy + ((size_t)tb * (Cout >> 3) + (co0 >> 3)) * HW * 16;                        \
-    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, ((Cout - co0) >> 3) * HW * 16, 0x00020000); \
-    const char* xb = (const char*)p.x + ((size_t)tb * (Cs >> 3) + (n0 >> 3)) * HW * 16;                             \
-    const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, ((Cs - n0) >> 3) * HW * 16, 0x00020000); \
-    _Pragma("unroll") for (int i = 0; i < NTS; ++i) {                                                              \
-      if (bt_a[i]) blk_task_load<8>(rc[i], bt[i], ra_, tsc, y0, x0, H, W);                                         \
-      else blk_task_load<8>(rc[i], bt[i], rb_, tsc, y0, x0, H, W);                                                 \
-    }                                                                                                              \
-    if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++tb; } }                                        \
-  }
-#define W1B_STORE(BUF)                                                                                             \
-  {                                                                                                                \
-    char* st = lds + (BUF) * ST_BYTES;                                                                             \
-    _Pragma("unroll") for (int i = 0; i < NTS; ++i) {                                                              \
-      if ((NSA + NSB) % 256 == 0 || tid + i * 256 < NSA + NSB) {                                                   \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c) *(u32x4*)(st + bt[i].lds + c * ARS) = blk_tr_cell(rc[i], c); \
-      }                                                                                                            \
-    }                                                                                                              \
-  }
   const int a_base = (wm * TM * 32 + l31) * ARS + hi * 16;
   const int b_base = (wn * TN * 32 + l31) * ARS + hi * 16;
 
@@ -811,7 +681,7 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
   int trem = t_begin - tb * (tiles_x * tiles_y);
   int ty = trem / tiles_x, tx = trem - ty * tiles_x;
 
-  Task8<IN == 1> ra[IN == 2 ? 1 : NTA], rb[IN == 2 ? 1 : NTB];
+  Task8<IN == 1> ra[NTA], rb[NTB];
 #define W1_LOAD()                                                                                                  \
   {                                                                                                                \
     const int y0 = ty * TH, x0 = tx * TW;                                                                          \
@@ -833,12 +703,12 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
     _Pragma("unroll") for (int i = 0; i < NTB; ++i) *(u32x4*)(st + A_BYTES + b_lds[i]) = rb[i].cell();             \
   }
 
-  if constexpr (IN == 2) { W1B_LOAD() W1B_STORE(0) } else { W1_LOAD() W1_STORE(0) }
+  W1_LOAD() W1_STORE(0)
   __syncthreads();
   const int ntl = t_end - t_begin;
   for (int t = 0; t < ntl; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntl) { if constexpr (IN == 2) W1B_LOAD() else W1_LOAD() }
+    if (t + 1 < ntl) W1_LOAD()
     {
       const char* As = lds + cur * ST_BYTES + a_base;
       const char* Bs = lds + cur * ST_BYTES + A_BYTES + b_base;
@@ -855,13 +725,11 @@ __device__ __forceinline__ void wgrad1_bf16_body(const WgradBf16Args& p, const i
           for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (t + 1 < ntl) { if constexpr (IN == 2) W1B_STORE(cur ^ 1) else W1_STORE(cur ^ 1) }
+    if (t + 1 < ntl) W1_STORE(cur ^ 1)
     __syncthreads();
   }
 #undef W1_LOAD
 #undef W1_STORE
-#undef W1B_LOAD
-#undef W1B_STORE
 
   // (buffer atomics, as in conv_wgrad_tiled.hip)
   const __amdgpu_buffer_rsrc_t rdw = __builtin_amdgcn_make_buffer_rsrc((void*)p.dw, 0, (unsigned)((size_t)Cout * p.ldo * 4), 0x00020000);
@@ -1121,7 +989,7 @@ static WgbKey wgb_key(const WgradBf16Args& a, int ks) {      // the rules of lau
     k.bm = a.Cout <= 64 ? 64 : 128;
     k.bn = a.Cs <= 64 ? 64 : 128;
   }
-  k.v4 = a.blk ? 2 : (a.W % 4 == 0 ? 1 : 0);      // the IN template argument
+  k.v4 = a.blk ? 2 : (a.W % 4 == 0 ? 1 : 0);      // the IN template argument (2: blk operands -> the DMA kernels)
   k.th = ks == 3 ? (a.blk ? w3t_th(k.bm, k.tw) : 64 / k.tw) : (a.blk ? 1 : 64 / k.tw);      // tile height (blk 3x3: the DMA kernel's tile)
   return k;
 }
