@@ -320,8 +320,12 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
             "conv3x3 fwd+dgrad": ("conv3x3_direct_kernel<..., EPI_PLAIN>",
                                   "conv_blk_kernel<3, ...> (trunk, blocked bf16) + conv_bf16_kernel<3, ..., EPI_PLAIN> (skip convs, fp32 activations)"
                                   if blk_on else "conv_bf16_kernel<3, ..., EPI_PLAIN>"),
-            "conv1x1 wgrad": ("conv_wgrad_tiled_group_kernel<..., 1, ...> (rsis_conv2d_wgrad_batch)", "wgrad1_bf16_group_kernel (rsis_conv2d_wgrad_batch)"),
-            "conv3x3 wgrad": ("conv_wgrad_tiled_group_kernel<..., 3, ...> (rsis_conv2d_wgrad_batch)", "wgrad3_bf16_group_kernel (rsis_conv2d_wgrad_batch)")}
+            "conv1x1 wgrad": ("conv_wgrad_tiled_group_kernel<..., 1, ...> (rsis_conv2d_wgrad_batch)",
+                              "wgrad1_tr_group_kernel (rsis_conv2d_wgrad_batch: blk operands by LDS-DMA, MFMA operands by ds_read_b64_tr_b16)" if blk_on
+                              else "wgrad1_bf16_group_kernel (rsis_conv2d_wgrad_batch)"),
+            "conv3x3 wgrad": ("conv_wgrad_tiled_group_kernel<..., 3, ...> (rsis_conv2d_wgrad_batch)",
+                              "wgrad3_tr_group_kernel (trunk, blk operands: LDS-DMA + ds_read_b64_tr_b16) + wgrad3_bf16_group_kernel (skip convs, fp32 operands)"
+                              if blk_on else "wgrad3_bf16_group_kernel (rsis_conv2d_wgrad_batch)")}
     out = []
     for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
         tf = f["flops"] / f["ms"] / 1e9
