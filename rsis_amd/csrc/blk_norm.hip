@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void blk_bn_stats_kernel(const u32x4* __restri
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long nn = n + u * 256;
-      c[u] = nn < n1 ? x[cell_index(nn, cb, Cb, HW)] : u32x4{0u, 0u, 0u, 0u};
+      const u32x4 cv = x[cell_index(nn < n1 ? nn : n0, cb, Cb, HW)];        // (clamped address + select: no branch around the load)
+      c[u] = nn < n1 ? cv : u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -212,14 +213,19 @@ __global__ __launch_bounds__(256) void blk_bn_apply_kernel(const u32x4* __restri
   const int cb = blockIdx.y;
   // the block's cells are requested BEFORE the per-channel prologue (a chain of dependent loads and double arithmetic on 8 threads):
   // their latency hides behind it
+  // (no load sits under a condition: `res ? res[idx] : 0` compiles to a branch around each load and a vmcnt(0) behind every second one --
+  //  two dependent round trips where one will do.  Without a residual the second stream re-reads x: the same lines, L1 hits.)
   u32x4 xc[U], rc[U];
+  const u32x4* const rp = res ? res : x;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const long n = ((long)blockIdx.x * U + u) * 256 + threadIdx.x;
     const size_t idx = cell_index(n < N ? n : 0, cb, Cb, HW);
     xc[u] = x[idx];
-    rc[u] = res ? res[idx] : u32x4{0u, 0u, 0u, 0u};
+    rc[u] = rp[idx];
   }
+  float gam_c = 0.f, bet_c = 0.f;            // (the affine parameters of this thread's channel: requested before the partial sums)
+  if (threadIdx.x < 8) { gam_c = gamma[cb * 8 + threadIdx.x]; bet_c = beta[cb * 8 + threadIdx.x]; }
   if (train) partial_sums16(part, S, cb, Cb, ptot);
   if (threadIdx.x < 8) {
     const int k = threadIdx.x, c = cb * 8 + k;
@@ -244,9 +250,9 @@ __global__ __launch_bounds__(256) void blk_bn_apply_kernel(const u32x4* __restri
       mean = run_mean[c];
       rstd = rsqrtf(run_var[c] + eps);
     }
-    const float g = gamma[c] * rstd;
+    const float g = gam_c * rstd;
     sc[k] = g;
-    sh[k] = beta[c] - mean * g;
+    sh[k] = bet_c - mean * g;
   }
   __syncthreads();
   float scv[8], shv[8];
@@ -305,6 +311,7 @@ __global__ __launch_bounds__(256) void blk_bn_bwd_reduce_kernel(const u32x4* __r
 #pragma unroll
   for (int k = 0; k < 16; ++k) a[k] = 0.f;
   const bool has_y = y != nullptr;
+  const u32x4* const yp = has_y ? y : x;       // (every load unconditional: see blk_bn_apply_kernel)
   constexpr int RB = 4;        // cells requested per thread before the first use (a split is 2048+ cells: 8+ per thread)
   for (long n = n0 + threadIdx.x; n < n1; n += 256 * RB) {
     u32x4 dc[RB], xc[RB], yc[RB];
@@ -313,10 +320,11 @@ __global__ __launch_bounds__(256) void blk_bn_bwd_reduce_kernel(const u32x4* __r
     for (int u = 0; u < RB; ++u) {
       const long nn = n + u * 256;
       ok[u] = nn < n1;
-      const size_t idx = ok[u] ? cell_index(nn, cb, Cb, HW) : 0;
-      dc[u] = ok[u] ? dy[idx] : u32x4{0u, 0u, 0u, 0u};
+      const size_t idx = cell_index(ok[u] ? nn : n0, cb, Cb, HW);
+      const u32x4 dv = dy[idx];
+      dc[u] = ok[u] ? dv : u32x4{0u, 0u, 0u, 0u};
       xc[u] = x[idx];
-      yc[u] = has_y ? y[idx] : u32x4{0u, 0u, 0u, 0u};
+      yc[u] = yp[idx];
     }
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
@@ -341,15 +349,18 @@ __global__ __launch_bounds__(256) void blk_bn_bwd_apply_kernel(const u32x4* __re
   __shared__ double ptot[16];
   const int cb = blockIdx.y;
   const bool has_y = y != nullptr;
-  u32x4 dcv[U], xcv[U], ycv[U];       // requested before the prologue, as in blk_bn_apply_kernel
+  const u32x4* const yp = has_y ? y : x;
+  u32x4 dcv[U], xcv[U], ycv[U];       // requested before the prologue, as in blk_bn_apply_kernel (and none under a condition)
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const long n = ((long)blockIdx.x * U + u) * 256 + threadIdx.x;
     const size_t idx = cell_index(n < N ? n : 0, cb, Cb, HW);
     dcv[u] = dy[idx];
     xcv[u] = x[idx];
-    ycv[u] = has_y ? y[idx] : u32x4{0u, 0u, 0u, 0u};
+    ycv[u] = yp[idx];
   }
+  float pm = 0.f, pr = 0.f, pg = 0.f, pb = 0.f;      // (this thread's channel parameters: requested before the partial sums)
+  if (threadIdx.x < 8) { const int c = cb * 8 + threadIdx.x; pm = save_mean[c]; pr = save_rstd[c]; pg = gamma[c]; pb = beta[c]; }
   partial_sums16(part, S, cb, Cb, ptot);
   if (threadIdx.x < 8) {
     const int k = threadIdx.x, c = cb * 8 + k;
@@ -358,7 +369,7 @@ __global__ __launch_bounds__(256) void blk_bn_bwd_apply_kernel(const u32x4* __re
       if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
       if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
     }
-    sm[0][k] = save_mean[c]; sm[1][k] = save_rstd[c]; sm[2][k] = gamma[c]; sm[3][k] = beta[c];
+    sm[0][k] = pm; sm[1][k] = pr; sm[2][k] = pg; sm[3][k] = pb;
     sm[4][k] = (float)(s / (double)N); sm[5][k] = (float)(q / (double)N);
   }
   __syncthreads();
