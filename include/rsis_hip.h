@@ -310,7 +310,7 @@ int rsis_softiou_bwd(const float* logits, const float* y, const long long* perm,
  * side[i][B][Cside[i]] (the global max-pools of the hidden states); class_probs[B][ncls] = softmax(Wc side + bc) with
  * Wc[ncls][K], K = sum Cside; stop[B] = Ws . side + bs (a logit).  rsis_heads_bwd: dside[i][B][Cside[i]] (any pointer may be
  * null) from dprobs[B][ncls] / dstop[B] (either may be null = zero), and dWc, dbc, dWs, dbs are ACCUMULATED into (null = skip).
- * K <= 2048, ncls <= 64; rsis_heads_bwd: B <= 64 (the parameter gradients are reduced over the batch in-kernel, no atomics). ---- */
+ * K <= 2048, ncls <= 64; rsis_heads_bwd: 2 B (ncls + 1) + B ceil(K / B) floats of LDS <= 64 KB -- B = 320 rows at 21 classes (the parameter gradients are reduced over the rows in-kernel, no atomics; decoder_seq passes the T * B rows of all timesteps in one call). ---- */
 int rsis_heads_fwd(const float* const* side, const int* Cside, int nside, int B, const float* Wc, const float* bc, int ncls,
                    const float* Ws, const float* bs, float* class_probs, float* stop, void* stream);
 /* rsis_heads_fwd with the pooled side features given as the keys of rsis_lstm_job.side_key (one [B][Cside[i]] key array per level):
@@ -365,7 +365,8 @@ int rsis_blk_to_nchw(const void* x_blk, float* y, int B, int C, int H, int W, vo
 /* out_blk[B][Cout] = conv(x_blk[B][C], W), ks in {1, 3}, stride 1, "same" padding, no bias (torchvision's trunk convs have none);
  * Wp: the bf16 pack rsis_conv_pack_fwd (forward) or rsis_conv_pack_dgrad (data gradient: x = dy, out = dx) produce for dtype
  * RSIS_DTYPE_BF16.  addend_blk (optional, the output's shape; may alias out_blk) is added in fp32 before the ONE rounding to bf16 at
- * the store.  variant: 0 = pick a tile, > 0 force (tests). */
+ * the store.  variant: 0 = pick a tile, > 0 force (tests).  C and Cout need only be multiples of 8: the ring stages hold 16 (3x3) or 32
+ * (1x1) input channels, and a ragged last stage reads zero cells (descriptor range) against the pack's zero-padded rows. */
 int rsis_blk_conv2d(const void* x_blk, int B, int C, int H, int W, const void* Wp, int Cout, int ks, const void* addend_blk,
                     void* out_blk, int variant, void* stream);
 

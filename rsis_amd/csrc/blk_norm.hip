@@ -293,7 +293,10 @@ __device__ __forceinline__ void bn_bwd_g(const u32x4 dyc, const u32x4 xc, const 
   for (int k = 0; k < 8; ++k) {
     xh[k] = (xv[k] - mean[k]) * rstd[k];
     bool on = true;
-    if (relu) on = has_y ? (yv[k] > 0.f) : (xh[k] * gam[k] + bet[k] > 0.f);
+    // (without y the mask is recomputed in the forward's own fused form x * sc + sh, sc = gamma * rstd, sh = beta - mean * sc: the
+    //  same roundings, so the mask is the one of the output the forward stored)
+    const float sc = gam[k] * rstd[k], sh = bet[k] - mean[k] * sc;
+    if (relu) on = has_y ? (yv[k] > 0.f) : (xv[k] * sc + sh > 0.f);
     g[k] = on ? dv[k] : 0.f;
   }
 }

@@ -170,22 +170,25 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadSides s, int K, cons
 // K / gridDim.x feature columns, which it reduces over the batch and adds to the gradient buffers with plain read-modify-writes.
 // Everything a thread loops over is first staged in LDS with independent parallel loads, and the remaining global loads are
 // issued 8 at a time: the first version (one dependent global load per loop iteration) took 37 us for ~0.5 MFLOP.
-#define HEADS_MAXB 64
-#define HEADS_SLAB (HEADS_MAXK + HEADS_MAXB)     // >= B * ceil(K / B)
+// (B = the rows of one launch: the batch, or -- decoder_seq -- the T * B rows of all timesteps at once; dl / gp / svs are carved
+//  from dynamic LDS, 2 * B * (ncls + 1) + B * ceil(K / B) floats: the launcher refuses what does not fit 64 KB)
 __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadSides s, int K, int B, const float* __restrict__ Wc, int ncls,
                                                         const float* __restrict__ Ws, const float* __restrict__ probs,
                                                         const float* __restrict__ dprobs, const float* __restrict__ dstop,
                                                         float* __restrict__ dWc, float* __restrict__ dbc, float* __restrict__ dWs,
                                                         float* __restrict__ dbs) {
-  __shared__ float dl[HEADS_MAXB][HEADS_MAXC + 1];     // probs, then d logits of fc_class | d stop, of every image
-  __shared__ float gp[HEADS_MAXB][HEADS_MAXC + 1];     // dprobs
-  __shared__ float svs[HEADS_SLAB];                    // side features of every image, this block's columns
+  extern __shared__ __attribute__((aligned(16))) float heads_lds[];
   const int b = blockIdx.x, R = ncls + 1;
+  float* const dl = heads_lds;                         // [B][R]: probs, then d logits of fc_class | d stop, of every row
+  float* const gp = dl + (size_t)B * R;                // [B][R]: dprobs
+  float* const svs = gp + (size_t)B * R;               // side features of every row, this block's columns
+#define DL(i, c) dl[(i) * R + (c)]
+#define GP(i, c) gp[(i) * R + (c)]
   const int slab = (K + gridDim.x - 1) / gridDim.x, k0 = min(K, b * slab), k1 = min(K, k0 + slab), nk = k1 - k0;
   for (int e = threadIdx.x; e < B * ncls; e += blockDim.x) {
     const int i = e / ncls, c = e - i * ncls;
-    dl[i][c] = probs[e];
-    gp[i][c] = dprobs ? dprobs[e] : 0.f;
+    DL(i, c) = probs[e];
+    GP(i, c) = dprobs ? dprobs[e] : 0.f;
   }
   for (int e = threadIdx.x; e < B * nk; e += blockDim.x) {
     const int i = e / nk, k = k0 + e - i * nk;
@@ -196,9 +199,9 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadSides s, int K, int 
   __syncthreads();
   for (int i = threadIdx.x; i < B; i += blockDim.x) {   // softmax backward: p * (g - sum g p)
     float dot = 0.f;
-    for (int c = 0; c < ncls; ++c) dot += gp[i][c] * dl[i][c];
-    for (int c = 0; c < ncls; ++c) dl[i][c] = dl[i][c] * (gp[i][c] - dot);
-    dl[i][ncls] = dstop ? dstop[i] : 0.f;
+    for (int c = 0; c < ncls; ++c) dot += GP(i, c) * DL(i, c);
+    for (int c = 0; c < ncls; ++c) DL(i, c) = DL(i, c) * (GP(i, c) - dot);
+    DL(i, ncls) = dstop ? dstop[i] : 0.f;
   }
   __syncthreads();
   // d side[k] = sum_c dl[c] * Wc[c][k] + dstop * Ws[k]   (coalesced along k)
@@ -206,13 +209,13 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadSides s, int K, int 
   for (int i = 0; i < s.n; ++i) {
     for (int k = threadIdx.x; k < s.C[i]; k += blockDim.x) {
       const int kk = base + k;
-      float acc = dl[b][ncls] * Ws[kk];
+      float acc = DL(b, ncls) * Ws[kk];
       for (int c0 = 0; c0 < ncls; c0 += 8) {
         float wv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) wv[j] = c0 + j < ncls ? Wc[(size_t)(c0 + j) * K + kk] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc = fmaf(c0 + j < ncls ? dl[b][c0 + j] : 0.f, wv[j], acc);
+        for (int j = 0; j < 8; ++j) acc = fmaf(c0 + j < ncls ? DL(b, c0 + j) : 0.f, wv[j], acc);
       }
       if (s.d[i]) s.d[i][(size_t)b * s.C[i] + k] = acc;
     }
@@ -223,17 +226,19 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadSides s, int K, int 
     const int r = e / nk, kl = e - r * nk;
     if (r < ncls ? !dWc : !dWs) continue;
     float g = 0.f;
-    for (int i = 0; i < B; ++i) g = fmaf(dl[i][r], svs[i * nk + kl], g);
+    for (int i = 0; i < B; ++i) g = fmaf(DL(i, r), svs[i * nk + kl], g);
     if (r < ncls) dWc[(size_t)r * K + k0 + kl] += g;
     else dWs[k0 + kl] += g;
   }
   if (b == 0 && threadIdx.x < R) {
     float g = 0.f;
-    for (int i = 0; i < B; ++i) g += dl[i][threadIdx.x];
+    for (int i = 0; i < B; ++i) g += DL(i, threadIdx.x);
     if (threadIdx.x < ncls) { if (dbc) dbc[threadIdx.x] += g; }
     else if (dbs) dbs[0] += g;
   }
 }
+#undef DL
+#undef GP
 
 static int heads_sides(HeadSides& s, const float* const* side, float* const* dside, const int* C, int n) {
   if (n < 1 || n > 5) return -1;
@@ -263,8 +268,10 @@ int rsis_l_heads_bwd(const float* const* side, const int* C, int n, int B, const
                      float* dWs, float* dbs, hipStream_t st) {
   HeadSides s;
   const int K = heads_sides(s, side, dside, C, n);
-  if (K < 1 || K > HEADS_MAXK || ncls < 1 || ncls > HEADS_MAXC || B < 1 || B > HEADS_MAXB) return RSIS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(heads_bwd_kernel, dim3(B), dim3(256), 0, st, s, K, B, Wc, ncls, Ws, probs, dprobs, dstop, dWc, dbc, dWs, dbs);
+  if (K < 1 || K > HEADS_MAXK || ncls < 1 || ncls > HEADS_MAXC || B < 1) return RSIS_ERR_UNSUPPORTED;
+  const size_t lds = ((size_t)2 * B * (ncls + 1) + (size_t)B * ((K + B - 1) / B)) * sizeof(float);
+  if (lds > 64 * 1024) return RSIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(heads_bwd_kernel, dim3(B), dim3(256), lds, st, s, K, B, Wc, ncls, Ws, probs, dprobs, dstop, dWc, dbc, dWs, dbs);
   return rsis_check_launch();
 }
 

@@ -91,6 +91,21 @@ def _upconv_bwd(L, d_masks, last, blk, co_w, dW, db, dside, T, B, H5, W5, DH_las
                                 stream()), "rsis_upconv_out_bwd")
 
 
+def _heads_bwd_all_steps(L, levels, hs, n, T, B, Wc, Ws, probs_tb, dp_tb, ds_tb, dsides, hb):
+    """backward of the class / stop heads: the T * B rows of all timesteps in ONE launch (every row is independent; the parameter
+    gradients are sums over rows, which the kernel reduces itself) -- per timestep when the rows do not fit the kernel's LDS"""
+    def call(rows, sl):
+        return L.rsis_heads_bwd(ptr_array([lv.SIDE[sl] for lv in levels]), int_array(hs), n, rows, ptr(Wc.detach()), Wc.shape[0], ptr(Ws.detach()),
+                                ptr(probs_tb[sl]), ptr(dp_tb[sl]) if dp_tb is not None else None, ptr(ds_tb[sl]) if ds_tb is not None else None,
+                                ptr_array([ds[sl] for ds in dsides]), ptr(hb[0]), ptr(hb[1]), ptr(hb[2]), ptr(hb[3]), stream())
+    rc = call(T * B, slice(None))
+    if rc == 3:          # RSIS_ERR_UNSUPPORTED: more rows than the kernel's LDS holds
+        for t in range(T):
+            check(call(B, t), "rsis_heads_bwd")
+    else:
+        check(rc, "rsis_heads_bwd(all steps)")
+
+
 def _heads_all_steps(L, levels, hs, n, rows, Wc, bc, Ws, bs, ncls, probs_tb, stop_tb):
     """the class / stop heads (model.py:169-182) of ALL timesteps in one launch: every (t, b) row is independent, the per-level key /
     feature / arg-max arrays are [T][B][hid] contiguous, i.e. T * B rows; the launch decodes the pooled keys (writes SIDE / ARG)"""
@@ -292,11 +307,7 @@ class _DecoderSeqFn(torch.autograd.Function):
             dp_tb = d_probs.transpose(0, 1).contiguous() if d_probs is not None else None
             ds_tb = d_stops.transpose(0, 1).contiguous() if d_stops is not None else None
             hb = [target(2 * n + 2 + k)[0] if need_par[2 * n + 2 + k] else None for k in range(4)]
-            for t in range(T):
-                check(L.rsis_heads_bwd(ptr_array([lv.SIDE[t] for lv in levels]), int_array(hs), n, B, ptr(Wc.detach()), Wc.shape[0],
-                                       ptr(Ws.detach()), ptr(ctx.probs_tb[t]), ptr(dp_tb[t]) if dp_tb is not None else None,
-                                       ptr(ds_tb[t]) if ds_tb is not None else None, ptr_array([ds[t] for ds in dsides]), ptr(hb[0]), ptr(hb[1]),
-                                       ptr(hb[2]), ptr(hb[3]), stream()), "rsis_heads_bwd")
+            _heads_bwd_all_steps(L, levels, hs, n, T, B, Wc, Ws, ctx.probs_tb, dp_tb, ds_tb, dsides, hb)
         # ---- reverse wavefront ----
         DA = [torch.empty_like(lv.ACT) for lv in levels]
         DH = [torch.empty((B, lv.hid, lv.H, lv.W), **f32) for lv in levels]                  # gradient of h[i][t] from above (upsample + pool)
@@ -571,11 +582,7 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
             dp_tb = d_probs.transpose(0, 1).contiguous() if d_probs is not None else None
             ds_tb = d_stops.transpose(0, 1).contiguous() if d_stops is not None else None
             hb = [target(2 * n + 2 + k)[0] if need_par[2 * n + 2 + k] else None for k in range(4)]
-            for t in range(T):
-                check(L.rsis_heads_bwd(ptr_array([lv.SIDE[t] for lv in levels]), int_array(hs), n, B, ptr(Wc.detach()), Wc.shape[0],
-                                       ptr(Ws.detach()), ptr(ctx.probs_tb[t]), ptr(dp_tb[t]) if dp_tb is not None else None,
-                                       ptr(ds_tb[t]) if ds_tb is not None else None, ptr_array([ds[t] for ds in dsides]), ptr(hb[0]), ptr(hb[1]),
-                                       ptr(hb[2]), ptr(hb[3]), stream()), "rsis_heads_bwd")
+            _heads_bwd_all_steps(L, levels, hs, n, T, B, Wc, Ws, ctx.probs_tb, dp_tb, ds_tb, dsides, hb)
         DA = [torch.empty_like(lv.ACT) for lv in levels]
         DH = [torch.empty((B, lv.hid // 8, lv.H, lv.W, 8), **b16) for lv in levels]
         DHP = [torch.empty((B, lv.hid // 8, lv.H, lv.W, 8), **b16) for lv in levels]

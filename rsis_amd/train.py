@@ -733,11 +733,20 @@ def trainIters(args):
                         #  captures instead of re-capturing on every change; a resident synthetic batch only ever has one)
                         cache = graphs.setdefault("cache", {})
                         if key not in cache:
-                            while len(cache) >= 4:
+                            while len(cache) >= 4:                 # evict the least recently USED capture (dicts keep insertion order)
                                 cache.pop(next(iter(cache))).release()
-                            cache[key] = GraphedStep(args, encoder, decoder, crits, optims, reducer)
+                            # the captures never replay concurrently and their results are cloned at once: ONE graph memory pool for all
+                            # of them (a private pool each held a full step's activations per key)
+                            if "pool" not in graphs:
+                                graphs["pool"] = torch.cuda.graph_pool_handle()
+                            cache[key] = GraphedStep(args, encoder, decoder, crits, optims, reducer, pool=graphs["pool"])
+                        else:
+                            cache[key] = cache.pop(key)            # most recently used goes last
                         graphs["key"], graphs["step"] = key, cache[key]
                     losses, _outs, _perm = graphs["step"]((x, y_mask, y_class, sw_mask, sw_class), t_run)
+                    if graphs["step"].failed is not None and not graphs.get("warned") and rank == 0:
+                        print("[train] hipGraph capture failed (%s): this configuration runs eagerly" % graphs["step"].failed)
+                        graphs["warned"] = True
                     losses = [v.clone() for v in losses]      # (static tensors of the graph: keep this step's values)
                 else:
                     losses, _outs, _perm = runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits, optims,

@@ -356,7 +356,8 @@ def test_repack_all_equals_lazy_packs():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,Cs,ncls", [(2, [32, 16, 8, 4, 2], 7), (32, [128, 64, 32, 16, 8], 21), (3, [5], 2), (4, [100, 3, 9], 64)])
+@pytest.mark.parametrize("B,Cs,ncls", [(2, [32, 16, 8, 4, 2], 7), (32, [128, 64, 32, 16, 8], 21), (3, [5], 2), (4, [100, 3, 9], 64),
+                                       (320, [128, 64, 32, 16, 8], 21), (97, [16, 8], 33)])      # (320: the T * B rows of the sequence node)
 def test_heads_fwd_bwd(B, Cs, ncls):
     """fused class / stop heads (rsis_heads_fwd / _bwd) against model.py:169-182 in plain torch"""
     from rsis_amd import ops
