@@ -9,6 +9,7 @@
 // threads x S adds) -- so the result does not depend on the order blocks run in: bit-reproducible without atomics.
 // The arithmetic is fp32 on the exact bf16 inputs, with ONE rounding to bf16 at each store.
 #include "common.h"
+#include <type_traits>
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -213,16 +214,22 @@ __global__ __launch_bounds__(256) void blk_bn_apply_kernel(const u32x4* __restri
   const int cb = blockIdx.y;
   // the block's cells are requested BEFORE the per-channel prologue (a chain of dependent loads and double arithmetic on 8 threads):
   // their latency hides behind it
-  // (no load sits under a condition: `res ? res[idx] : 0` compiles to a branch around each load and a vmcnt(0) behind every second one --
-  //  two dependent round trips where one will do.  Without a residual the second stream re-reads x: the same lines, L1 hits.)
+  // (ONE uniform branch, then no load under a condition: `res ? res[idx] : 0` per cell compiles to a branch around each load and a
+  //  vmcnt(0) behind every second one -- two dependent round trips where one will do)
   u32x4 xc[U], rc[U];
-  const u32x4* const rp = res ? res : x;
+  if (res) {
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const long n = ((long)blockIdx.x * U + u) * 256 + threadIdx.x;
-    const size_t idx = cell_index(n < N ? n : 0, cb, Cb, HW);
-    xc[u] = x[idx];
-    rc[u] = rp[idx];
+    for (int u = 0; u < U; ++u) {
+      const long n = ((long)blockIdx.x * U + u) * 256 + threadIdx.x;
+      const size_t idx = cell_index(n < N ? n : 0, cb, Cb, HW);
+      xc[u] = x[idx]; rc[u] = res[idx];
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long n = ((long)blockIdx.x * U + u) * 256 + threadIdx.x;
+      xc[u] = x[cell_index(n < N ? n : 0, cb, Cb, HW)]; rc[u] = u32x4{0u, 0u, 0u, 0u};
+    }
   }
   float gam_c = 0.f, bet_c = 0.f;            // (the affine parameters of this thread's channel: requested before the partial sums)
   if (threadIdx.x < 8) { gam_c = gamma[cb * 8 + threadIdx.x]; bet_c = beta[cb * 8 + threadIdx.x]; }
@@ -283,8 +290,9 @@ __global__ __launch_bounds__(256) void blk_bn_apply_kernel(const u32x4* __restri
 
 // ---- backward.  g = dy * [y > 0] (relu; y = the forward output.  Without y the mask is recomputed from x: no residual then);
 //      part[s][cb][0..7] = sum g, [8..15] = sum g * xhat ----
+// (scm / shm: the forward's fused scale / shift per channel, sc = gamma * rstd, sh = beta - mean * sc, computed once per thread)
 __device__ __forceinline__ void bn_bwd_g(const u32x4 dyc, const u32x4 xc, const bool has_y, const u32x4 yc, const float* mean, const float* rstd,
-                                         const float* gam, const float* bet, const int relu, float* g, float* xh) {
+                                         const float* scm, const float* shm, const int relu, float* g, float* xh) {
   float dv[8], xv[8], yv[8];
   cell_unpack(dyc, dv);
   cell_unpack(xc, xv);
@@ -293,10 +301,9 @@ __device__ __forceinline__ void bn_bwd_g(const u32x4 dyc, const u32x4 xc, const 
   for (int k = 0; k < 8; ++k) {
     xh[k] = (xv[k] - mean[k]) * rstd[k];
     bool on = true;
-    // (without y the mask is recomputed in the forward's own fused form x * sc + sh, sc = gamma * rstd, sh = beta - mean * sc: the
-    //  same roundings, so the mask is the one of the output the forward stored)
-    const float sc = gam[k] * rstd[k], sh = bet[k] - mean[k] * sc;
-    if (relu) on = has_y ? (yv[k] > 0.f) : (xv[k] * sc + sh > 0.f);
+    // (without y the mask is recomputed in the forward's own fused form x * sc + sh: the same roundings, so the mask is the one of
+    //  the output the forward stored)
+    if (relu) on = has_y ? (yv[k] > 0.f) : (xv[k] * scm[k] + shm[k] > 0.f);
     g[k] = on ? dv[k] : 0.f;
   }
 }
@@ -310,12 +317,16 @@ __global__ __launch_bounds__(256) void blk_bn_bwd_reduce_kernel(const u32x4* __r
   float mean[8], rstd[8], gam[8], bet[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { mean[k] = save_mean[cb * 8 + k]; rstd[k] = save_rstd[cb * 8 + k]; gam[k] = gamma[cb * 8 + k]; bet[k] = beta[cb * 8 + k]; }
+  float scm[8], shm[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { scm[k] = gam[k] * rstd[k]; shm[k] = bet[k] - mean[k] * scm[k]; }
   float a[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) a[k] = 0.f;
   const bool has_y = y != nullptr;
-  const u32x4* const yp = has_y ? y : x;       // (every load unconditional: see blk_bn_apply_kernel)
   constexpr int RB = 4;        // cells requested per thread before the first use (a split is 2048+ cells: 8+ per thread)
+  // (measured both ways: this loop with its loads under their conditions -- 9.0 us per launch -- beats the branch-free forms,
+  //  9.9-10.6 us: a split is a few cells per thread and 66 of the 97 layers have no y stream to skip)
   for (long n = n0 + threadIdx.x; n < n1; n += 256 * RB) {
     u32x4 dc[RB], xc[RB], yc[RB];
     bool ok[RB];
@@ -323,16 +334,15 @@ __global__ __launch_bounds__(256) void blk_bn_bwd_reduce_kernel(const u32x4* __r
     for (int u = 0; u < RB; ++u) {
       const long nn = n + u * 256;
       ok[u] = nn < n1;
-      const size_t idx = cell_index(ok[u] ? nn : n0, cb, Cb, HW);
-      const u32x4 dv = dy[idx];
-      dc[u] = ok[u] ? dv : u32x4{0u, 0u, 0u, 0u};
+      const size_t idx = ok[u] ? cell_index(nn, cb, Cb, HW) : 0;
+      dc[u] = ok[u] ? dy[idx] : u32x4{0u, 0u, 0u, 0u};
       xc[u] = x[idx];
-      yc[u] = yp[idx];
+      yc[u] = has_y ? y[idx] : u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
       float g[8], xh[8];
-      bn_bwd_g(dc[u], xc[u], has_y, yc[u], mean, rstd, gam, bet, relu, g, xh);
+      bn_bwd_g(dc[u], xc[u], has_y, yc[u], mean, rstd, scm, shm, relu, g, xh);
 #pragma unroll
       for (int k = 0; k < 8; ++k) { a[k] += g[k]; a[8 + k] += g[k] * xh[k]; }
     }
@@ -352,15 +362,21 @@ __global__ __launch_bounds__(256) void blk_bn_bwd_apply_kernel(const u32x4* __re
   __shared__ double ptot[16];
   const int cb = blockIdx.y;
   const bool has_y = y != nullptr;
-  const u32x4* const yp = has_y ? y : x;
-  u32x4 dcv[U], xcv[U], ycv[U];       // requested before the prologue, as in blk_bn_apply_kernel (and none under a condition)
+  u32x4 dcv[U], xcv[U], ycv[U];       // requested before the prologue, as in blk_bn_apply_kernel (one uniform branch, no load under a condition)
+  if (has_y) {
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const long n = ((long)blockIdx.x * U + u) * 256 + threadIdx.x;
-    const size_t idx = cell_index(n < N ? n : 0, cb, Cb, HW);
-    dcv[u] = dy[idx];
-    xcv[u] = x[idx];
-    ycv[u] = yp[idx];
+    for (int u = 0; u < U; ++u) {
+      const long n = ((long)blockIdx.x * U + u) * 256 + threadIdx.x;
+      const size_t idx = cell_index(n < N ? n : 0, cb, Cb, HW);
+      dcv[u] = dy[idx]; xcv[u] = x[idx]; ycv[u] = y[idx];
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long n = ((long)blockIdx.x * U + u) * 256 + threadIdx.x;
+      const size_t idx = cell_index(n < N ? n : 0, cb, Cb, HW);
+      dcv[u] = dy[idx]; xcv[u] = x[idx]; ycv[u] = u32x4{0u, 0u, 0u, 0u};
+    }
   }
   float pm = 0.f, pr = 0.f, pg = 0.f, pb = 0.f;      // (this thread's channel parameters: requested before the partial sums)
   if (threadIdx.x < 8) { const int c = cb * 8 + threadIdx.x; pm = save_mean[c]; pr = save_rstd[c]; pg = gamma[c]; pb = beta[c]; }
@@ -379,13 +395,16 @@ __global__ __launch_bounds__(256) void blk_bn_bwd_apply_kernel(const u32x4* __re
   float mean[8], rstd[8], gam[8], bet[8], c1[8], c2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { mean[k] = sm[0][k]; rstd[k] = sm[1][k]; gam[k] = sm[2][k]; bet[k] = sm[3][k]; c1[k] = sm[4][k]; c2[k] = sm[5][k]; }
+  float scm[8], shm[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { scm[k] = gam[k] * rstd[k]; shm[k] = bet[k] - mean[k] * scm[k]; }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const long n = ((long)blockIdx.x * U + u) * 256 + threadIdx.x;
     if (n >= N) continue;
     const size_t idx = cell_index(n, cb, Cb, HW);
     float g[8], xh[8], o[8];
-    bn_bwd_g(dcv[u], xcv[u], has_y, ycv[u], mean, rstd, gam, bet, relu, g, xh);
+    bn_bwd_g(dcv[u], xcv[u], has_y, ycv[u], mean, rstd, scm, shm, relu, g, xh);
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = gam[k] * rstd[k] * (g[k] - c1[k] - xh[k] * c2[k]);
     dx[idx] = cell_pack(o);
@@ -416,13 +435,16 @@ __global__ __launch_bounds__(512) void blk_bn_bwd_block_kernel(const u32x4* __re
   float mean[8], rstd[8], gam[8], bet[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { mean[k] = save_mean[cb * 8 + k]; rstd[k] = save_rstd[cb * 8 + k]; gam[k] = gamma[cb * 8 + k]; bet[k] = beta[cb * 8 + k]; }
+  float scm[8], shm[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { scm[k] = gam[k] * rstd[k]; shm[k] = bet[k] - mean[k] * scm[k]; }
   float a[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) a[k] = 0.f;
 #pragma unroll
   for (int u = 0; u < NPT; ++u) {
     float g[8], xh[8];
-    bn_bwd_g(dc[u], xc[u], has_y, yc[HAS_Y ? u : 0], mean, rstd, gam, bet, relu, g, xh);
+    bn_bwd_g(dc[u], xc[u], has_y, yc[HAS_Y ? u : 0], mean, rstd, scm, shm, relu, g, xh);
 #pragma unroll
     for (int k = 0; k < 8; ++k) { a[k] += g[k]; a[8 + k] += g[k] * xh[k]; }
   }
@@ -439,7 +461,7 @@ __global__ __launch_bounds__(512) void blk_bn_bwd_block_kernel(const u32x4* __re
   for (int u = 0; u < NPT; ++u) {
     if (threadIdx.x + u * 512 >= N) continue;
     float g[8], xh[8], o[8];
-    bn_bwd_g(dc[u], xc[u], has_y, yc[HAS_Y ? u : 0], mean, rstd, gam, bet, relu, g, xh);
+    bn_bwd_g(dc[u], xc[u], has_y, yc[HAS_Y ? u : 0], mean, rstd, scm, shm, relu, g, xh);
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = gam[k] * rstd[k] * (g[k] - c1[k] - xh[k] * c2[k]);
     const size_t id = cell_index(threadIdx.x + u * 512, cb, Cb, HW);
