@@ -125,11 +125,18 @@ def make_direct_reducer(log=None):
     if dist.get_backend() != "nccl":
         say("direct RCCL exchange off (backend %s)" % dist.get_backend())
         return None
+    red, why = None, None
     try:
         red = DirectReducer(DirectComm())
         red.self_test()
-        say("direct RCCL exchange: communicator of %d rank(s), captured all-reduce self-test passed" % red.world)
-        return red
     except Exception as e:  # noqa: BLE001  (the cut-graph schedule over torch.distributed remains)
-        say("direct RCCL exchange not available: %r" % (e,))
+        red, why = None, repr(e)
+    # every rank must take the same schedule: one rank on the direct exchange and another on the cut graphs would wait for each
+    # other's collectives forever.  Agree over the (working) torch.distributed group: direct only if it came up everywhere.
+    ok = torch.tensor([1 if red is not None else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        say("direct RCCL exchange not available%s" % (": " + why if why else " on another rank"))
         return None
+    say("direct RCCL exchange: communicator of %d rank(s), captured all-reduce self-test passed" % red.world)
+    return red
