@@ -39,7 +39,11 @@ struct WgradTiledArgs {
 
 // KSP = 2: the block's four waves form a WGM x WGN grid TWICE; the two copies take alternate halves of every stage's reduction
 // depth and both add their partial tile with the (already atomic) epilogue -- lets a 32-row tile be only 64 columns wide.
-template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1>
+// RAG: maps that no tile shape divides (the 7 / 14 / 28-pixel pyramid of 224 x 224 inputs).  The dy tile (and the x tile of a 1x1) then
+// goes dword by dword -- four DMA instructions where the aligned map needs one dwordx4 -- so that every element carries its own
+// "beyond the map" test: an element of the last tile column / row whose pixel lies outside gets an out-of-range offset and lands as
+// 0.  The MFMA loop is unchanged (zeros add nothing); the tile grid rounds up.
+template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1, bool RAG = false>
 __device__ __forceinline__ void wgrad_tiled_body(const WgradTiledArgs& p, const int bx, const int by) {
 #if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; the buffer-resource builtins do not exist there)
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -69,7 +73,8 @@ __device__ __forceinline__ void wgrad_tiled_body(const WgradTiledArgs& p, const 
   const int co0 = co_t * BM, n0 = n_t * BN;
   const int ci0 = n0 / KK;                     // first input channel of this block's patch / x tile
   const int Nn = Cs * KK;
-  const int tiles_x = W / TW, tiles_y = H / TH;
+  const int tiles_x = RAG ? (W + TW - 1) / TW : W / TW, tiles_y = RAG ? (H + TH - 1) / TH : H / TH;
+  const int rx = W - (tiles_x - 1) * TW, ry = H - (tiles_y - 1) * TH;      // valid columns / rows of the last tile column / row
   const int t_begin = by * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.n_sp_tiles);
   if (t_begin >= t_end) return;
@@ -83,6 +88,30 @@ __device__ __forceinline__ void wgrad_tiled_body(const WgradTiledArgs& p, const 
     const int G = (sl & ~7) | ((sl & 7) ^ (row & 7));     // group held by this slot
     const int y = G / GPR, x4 = G % GPR;
     voa[i] = co0 + row < Cout ? (unsigned)((co0 + row) * HW + y * W + x4 * 4) * 4u : RSIS_OOB;
+  }
+  // RAG: dword DMA k of the dy tile moves LDS floats k * 256 + tid = element e of the dwordx4 slot (k * 256 + tid) / 4; bits 0 / 1 of
+  // the offset (a multiple of 4) flag "column >= rx" / "row >= ry": outside the map in the last tile column / row
+  unsigned voa1[RAG ? 4 * NA : 1];
+  unsigned vob1r[RAG && NB4 ? 4 * NB4 : 1];
+  if constexpr (RAG) {
+#pragma unroll
+    for (int k = 0; k < 4 * NA; ++k) {
+      const int P = k * 256 + tid, idx = P >> 2, e = P & 3;
+      const int row = idx / NG, sl = idx % NG;
+      const int G = (sl & ~7) | ((sl & 7) ^ (row & 7));
+      const int y = G / GPR, x = (G % GPR) * 4 + e;
+      voa1[k] = co0 + row < Cout ? ((unsigned)((co0 + row) * HW + y * W + x) * 4u) | (x >= rx ? 1u : 0u) | (y >= ry ? 2u : 0u) : RSIS_OOB;
+    }
+    if constexpr (KS == 1) {
+#pragma unroll
+      for (int k = 0; k < 4 * NB4; ++k) {
+        const int P = k * 256 + tid, idx = P >> 2, e = P & 3;
+        const int row = idx / NG, sl = idx % NG;
+        const int G = (sl & ~7) | ((sl & 7) ^ (row & 7));
+        const int y = G / GPR, x = (G % GPR) * 4 + e;
+        vob1r[k] = n0 + row < Cs ? ((unsigned)((n0 + row) * HW + y * W + x) * 4u) | (x >= rx ? 1u : 0u) | (y >= ry ? 2u : 0u) : RSIS_OOB;
+      }
+    }
   }
   unsigned vob4[NB4 ? NB4 : 1];
   unsigned vob1[NB1 ? NB1 : 1];
@@ -105,7 +134,7 @@ __device__ __forceinline__ void wgrad_tiled_body(const WgradTiledArgs& p, const 
       const bool ok = cl < CI_P && ci0 + cl < Cs;
       // relative to the element one row above / one column left of the tile origin in channel ci0 (+ (W+1)*4 so that it is >= 0)
       vob1[i] = ok ? (unsigned)(cl * HW + py * W + pxx) * 4u : RSIS_OOB;
-      cls1[i] = (py == 0 ? 1u : 0u) | (py == PH - 1 ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx == PW - 1 ? 8u : 0u);
+      cls1[i] = (py == 0 ? 1u : 0u) | (py - 1 >= ry ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx - 1 >= rx ? 8u : 0u);      // (aligned maps: ry = TH, rx = TW -- the halo ring)
     }
   }
 
@@ -153,19 +182,32 @@ __device__ __forceinline__ void wgrad_tiled_body(const WgradTiledArgs& p, const 
     const int y0 = ty * TH, x0 = tx * TW;                                                                      \
     const float* ab = p.dy + ((size_t)tb * Cout * HW + y0 * W + x0);                                           \
     const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, 0x7FFFFFF0, 0x00020000); \
-    float* As = As0 + (BUF) * AS + wave * 256;                                                                 \
-    _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                             \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_vp_t)(As + i * 1024), 16, voa[i], 0, 0, 0);           \
+    const unsigned lastm = (tx == tiles_x - 1 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u);                      \
+    if constexpr (RAG) {                                                                                       \
+      float* As = As0 + (BUF) * AS + wave * 64;                                                                \
+      _Pragma("unroll") for (int k = 0; k < 4 * NA; ++k)                                                       \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_vp_t)(As + k * 256), 4, (voa1[k] & lastm) ? RSIS_OOB : (voa1[k] & ~3u), 0, 0, 0); \
+    } else {                                                                                                   \
+      float* As = As0 + (BUF) * AS + wave * 256;                                                               \
+      _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_vp_t)(As + i * 1024), 16, voa[i], 0, 0, 0);         \
+    }                                                                                                          \
     if constexpr (KS == 1) {                                                                                   \
       const float* bb = p.x + ((size_t)tb * Cs * HW + y0 * W + x0);                                            \
       const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)bb, 0, 0x7FFFFFF0, 0x00020000); \
-      float* Xs = Xs0 + (BUF) * XS + wave * 256;                                                               \
-      _Pragma("unroll") for (int i = 0; i < NB4; ++i)                                                          \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_vp_t)(Xs + i * 1024), 16, vob4[i], 0, 0, 0);        \
+      if constexpr (RAG) {                                                                                     \
+        float* Xs = Xs0 + (BUF) * XS + wave * 64;                                                              \
+        _Pragma("unroll") for (int k = 0; k < 4 * NB4; ++k)                                                    \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_vp_t)(Xs + k * 256), 4, (vob1r[k] & lastm) ? RSIS_OOB : (vob1r[k] & ~3u), 0, 0, 0); \
+      } else {                                                                                                 \
+        float* Xs = Xs0 + (BUF) * XS + wave * 256;                                                             \
+        _Pragma("unroll") for (int i = 0; i < NB4; ++i)                                                        \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_vp_t)(Xs + i * 1024), 16, vob4[i], 0, 0, 0);      \
+      }                                                                                                        \
     } else {                                                                                                   \
       const float* bb = p.x + (((size_t)tb * Cs + ci0) * HW + (y0 - 1) * W + (x0 - 1));                        \
       const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)bb, 0, 0x7FFFFFF0, 0x00020000); \
-      const unsigned edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + TW == W ? 8u : 0u); \
+      const unsigned edge = (y0 == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (tx == tiles_x - 1 ? 8u : 0u); \
       float* Xs = Xs0 + (BUF) * XS + wave * 64;                                                                \
       _Pragma("unroll") for (int i = 0; i < NB1; ++i) {                                                        \
         const unsigned vo = (cls1[i] & edge) ? RSIS_OOB : vob1[i];                                             \
@@ -266,7 +308,7 @@ struct WgradTiledGroup {
 };
 static_assert(sizeof(WgradTiledGroup) <= 4000, "kernel arguments are limited to 4 KB");
 
-template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1>
+template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1, bool RAG = false>
 __global__ __launch_bounds__(256) void conv_wgrad_tiled_group_kernel(const WgradTiledGroup g) {
   const int b = blockIdx.x;
   int lo = 0, hi = g.n - 1;
@@ -277,7 +319,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiled_group_kernel(const Wgrad
   const WgradTiledArgs& p = g.job[lo];
   const int local = b - g.begin[lo];
   const int ntile = p.n_co_tiles * p.n_n_tiles;
-  wgrad_tiled_body<BM, BN, WGM, WGN, KS, TW, KSP>(p, local % ntile, local / ntile);
+  wgrad_tiled_body<BM, BN, WGM, WGN, KS, TW, KSP, RAG>(p, local % ntile, local / ntile);
 }
 
 template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1>
@@ -329,6 +371,11 @@ static int tiled_tw(int H, int W, int ks) {
     if (W % tw == 0 && H % (tp / tw) == 0) return tw;
   return 0;
 }
+// ragged maps (RAG instantiations): the narrowest tile that is at least as wide as the map, or the widest one
+static int tiled_tw_ragged(int W, int ks) {
+  const int wide = ks == 1 ? 32 : 16;
+  return W > 16 ? wide : (W > 8 ? 16 : 8);
+}
 
 // ---- grouped launch (host side) ----
 // tile configuration of a job, the same rule as launch_tiled_tw: 0 = 32x64 (KSP 2), 1 = 32x128, 2 = 64x64, 3 = 64x128, 4 = 128x64, 5 = 128x128
@@ -341,7 +388,7 @@ static int tiled_cfg_code(const WgradTiledArgs& a, int ks) {
   return narrow ? 4 : 5;
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1>
+template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1, bool RAG = false>
 static int launch_group_cfg(WgradTiledArgs* jobs, int n, hipStream_t st) {
   constexpr int TH = (KS == 1 ? 32 : 64) / TW;
   long total_iters = 0;
@@ -349,7 +396,7 @@ static int launch_group_cfg(WgradTiledArgs* jobs, int n, hipStream_t st) {
     WgradTiledArgs& a = jobs[j];
     a.n_co_tiles = rsis_cdiv(a.Cout, BM);
     a.n_n_tiles = rsis_cdiv((long)a.Cs * KS * KS, BN);
-    a.n_sp_tiles = a.B * (a.H / TH) * (a.W / TW);
+    a.n_sp_tiles = RAG ? a.B * rsis_cdiv(a.H, TH) * rsis_cdiv(a.W, TW) : a.B * (a.H / TH) * (a.W / TW);
     total_iters += (long)a.n_co_tiles * a.n_n_tiles * a.n_sp_tiles;
   }
   // equal work per block: every block walks ~L spatial tiles of its job; ~8 blocks per CU over the whole group keeps the tail short,
@@ -374,21 +421,21 @@ static int launch_group_cfg(WgradTiledArgs* jobs, int n, hipStream_t st) {
       blocks += a.n_co_tiles * a.n_n_tiles * nsplit;
     }
     g.begin[g.n] = blocks;
-    hipLaunchKernelGGL((conv_wgrad_tiled_group_kernel<BM, BN, WGM, WGN, KS, TW, KSP>), dim3(blocks), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((conv_wgrad_tiled_group_kernel<BM, BN, WGM, WGN, KS, TW, KSP, RAG>), dim3(blocks), dim3(256), 0, st, g);
     if (rsis_check_launch() != RSIS_OK) return RSIS_ERR_LAUNCH;
   }
   return RSIS_OK;
 }
 
-template <int KS, int TW>
+template <int KS, int TW, bool RAG = false>
 static int launch_group_tw(int code, WgradTiledArgs* jobs, int n, hipStream_t st) {
   switch (code) {
-    case 0: return launch_group_cfg<32, 64, 1, 2, KS, TW, 2>(jobs, n, st);
-    case 1: return launch_group_cfg<32, 128, 1, 4, KS, TW>(jobs, n, st);
-    case 2: return launch_group_cfg<64, 64, 2, 2, KS, TW>(jobs, n, st);
-    case 3: return launch_group_cfg<64, 128, 2, 2, KS, TW>(jobs, n, st);
-    case 4: return launch_group_cfg<128, 64, 2, 2, KS, TW>(jobs, n, st);
-    default: return launch_group_cfg<128, 128, 2, 2, KS, TW>(jobs, n, st);
+    case 0: return launch_group_cfg<32, 64, 1, 2, KS, TW, 2, RAG>(jobs, n, st);
+    case 1: return launch_group_cfg<32, 128, 1, 4, KS, TW, 1, RAG>(jobs, n, st);
+    case 2: return launch_group_cfg<64, 64, 2, 2, KS, TW, 1, RAG>(jobs, n, st);
+    case 3: return launch_group_cfg<64, 128, 2, 2, KS, TW, 1, RAG>(jobs, n, st);
+    case 4: return launch_group_cfg<128, 64, 2, 2, KS, TW, 1, RAG>(jobs, n, st);
+    default: return launch_group_cfg<128, 128, 2, 2, KS, TW, 1, RAG>(jobs, n, st);
   }
 }
 
@@ -405,7 +452,8 @@ int rsis_launch_conv_wgrad_tiled_group(const WgradArgs* w, int n, int ks, hipStr
     a.dy = w[j].dy; a.x = w[j].x; a.dw = w[j].dw; a.B = w[j].B; a.Cs = w[j].Cs; a.H = w[j].H; a.W = w[j].W; a.Cout = w[j].Cout;
     a.ldo = w[j].ldo; a.n_off = w[j].n_off; a.interleave_hid = w[j].interleave_hid;
     all[j] = a;
-    key[j] = tiled_tw(a.H, a.W, ks) * 8 + tiled_cfg_code(a, ks);
+    const int twa = tiled_tw(a.H, a.W, ks);
+    key[j] = twa ? twa * 8 + tiled_cfg_code(a, ks) : 1024 + tiled_tw_ragged(a.W, ks) * 8 + tiled_cfg_code(a, ks);      // (1024: ragged map)
   }
   int rc = RSIS_OK;
   for (int j = 0; j < n && rc == RSIS_OK; ++j) {
@@ -414,8 +462,12 @@ int rsis_launch_conv_wgrad_tiled_group(const WgradArgs* w, int n, int ks, hipStr
     int m = 0;
     for (int i = j; i < n; ++i)
       if (key[i] == k) { bucket[m++] = all[i]; key[i] = -1; }
-    const int tw = k / 8, code = k % 8;
-    if (ks == 1) rc = tw == 32 ? launch_group_tw<1, 32>(code, bucket, m, st) : (tw == 16 ? launch_group_tw<1, 16>(code, bucket, m, st) : launch_group_tw<1, 8>(code, bucket, m, st));
+    const bool rag = k >= 1024;
+    const int tw = (k & 1023) / 8, code = k % 8;
+    if (rag) {
+      if (ks == 1) rc = tw == 32 ? launch_group_tw<1, 32, true>(code, bucket, m, st) : (tw == 16 ? launch_group_tw<1, 16, true>(code, bucket, m, st) : launch_group_tw<1, 8, true>(code, bucket, m, st));
+      else rc = tw == 16 ? launch_group_tw<3, 16, true>(code, bucket, m, st) : launch_group_tw<3, 8, true>(code, bucket, m, st);
+    } else if (ks == 1) rc = tw == 32 ? launch_group_tw<1, 32>(code, bucket, m, st) : (tw == 16 ? launch_group_tw<1, 16>(code, bucket, m, st) : launch_group_tw<1, 8>(code, bucket, m, st));
     else rc = tw == 16 ? launch_group_tw<3, 16>(code, bucket, m, st) : launch_group_tw<3, 8>(code, bucket, m, st);
   }
   free(all); free(key);
@@ -425,7 +477,8 @@ int rsis_launch_conv_wgrad_tiled_group(const WgradArgs* w, int n, int ks, hipStr
 // true when the LDS-DMA tiled kernel covers this weight gradient (stride 1, "same" padding, tile-aligned map, 32-bit offsets)
 bool rsis_wgrad_tiled_supported(const WgradArgs& w, int ks) {
   if (!(ks == 1 || ks == 3) || w.stride != 1 || w.pad != ks / 2 || w.H != w.Ho || w.W != w.Wo) return false;
-  if (tiled_tw(w.H, w.W, ks) == 0) return false;
+  static const bool ragged_on = !(getenv("RSIS_WGRAD_RAGGED") && getenv("RSIS_WGRAD_RAGGED")[0] == '0');
+  if (tiled_tw(w.H, w.W, ks) == 0 && !ragged_on) return false;      // (ragged maps: the RAG instantiations, grouped launch)
   const long img = (long)w.H * w.W * 4;
   return (long)w.Cout * img < (1L << 30) && (long)w.Cs * img < (1L << 30);
 }
@@ -435,6 +488,7 @@ int rsis_launch_conv_wgrad_tiled(const WgradArgs& w, int ks, hipStream_t st) {
   a.dy = w.dy; a.x = w.x; a.dw = w.dw; a.B = w.B; a.Cs = w.Cs; a.H = w.H; a.W = w.W; a.Cout = w.Cout;
   a.ldo = w.ldo; a.n_off = w.n_off; a.interleave_hid = w.interleave_hid;
   const int tw = tiled_tw(w.H, w.W, ks);
+  if (tw == 0) return rsis_launch_conv_wgrad_tiled_group(&w, 1, ks, st);       // ragged map: the grouped kernel with one job
   if (ks == 1) {
     if (tw == 32) return launch_tiled_tw<1, 32>(a, st);
     if (tw == 16) return launch_tiled_tw<1, 16>(a, st);

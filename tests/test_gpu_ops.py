@@ -497,6 +497,57 @@ def test_maxpool3x3s2_accumulates_into_parked_gradient(shape):
     assert_close("dx", got, want, 1e-6)
 
 
+# fp32 weight gradients on maps no tile shape divides (the RAG instantiations of conv_wgrad_tiled.hip: dword DMA with a per-element
+# "beyond the map" test): the 7 / 14 / 28-pixel pyramid of 224 x 224 inputs, odd sizes, every tile configuration (Cout 16..200, narrow
+# and wide N), 1x1 and 3x3, two sources into one dW, a gate-interleaved ConvLSTM weight -- single launches and one grouped call
+RAGGED_WGRAD_CASES = [(3, [64], 14, 14, 64, 3, 0), (2, [128], 28, 28, 128, 3, 0), (4, [64], 7, 7, 256, 3, 0), (2, [256], 14, 14, 1024, 1, 0),
+                      (2, [1024], 14, 14, 256, 1, 0), (3, [96], 7, 7, 48, 1, 0), (2, [8], 9, 11, 16, 3, 0), (2, [20, 12], 17, 23, 40, 3, 0),
+                      (2, [72], 5, 13, 200, 3, 0), (3, [40], 12, 18, 24, 1, 0), (2, [24, 8], 14, 14, 32, 3, 8), (1, [16], 30, 27, 96, 1, 0),
+                      (2, [16], 28, 28, 32, 3, 0), (2, [200], 7, 7, 72, 3, 0)]
+
+
+@pytest.mark.parametrize("grouped", [False, True], ids=["single", "grouped"])
+def test_conv2d_wgrad_fp32_on_ragged_maps(grouped):
+    from rsis_amd import ops
+    from rsis_amd._lib import WgradJob, check, lib, ptr, stream
+    L = lib()
+    jobs, keep, want = [], [], []
+    for k, (B, segs, H, W, Cout, ks, hid) in enumerate(RAGGED_WGRAD_CASES):
+        Ctot, pad = sum(segs), ks // 2
+        xs = [_rng_t(700 + 10 * k + i, (B, c, H, W)) for i, c in enumerate(segs)]
+        w = _rng_t(800 + k, (Cout, Ctot, ks, ks)).requires_grad_()
+        gy = _rng_t(900 + k, (B, Cout, H, W))
+        F.conv2d(torch.cat(xs, 1).double(), w.double(), None, padding=pad).backward(gy.double()) if False else None
+        wd = w.detach().double().requires_grad_()
+        F.conv2d(torch.cat(xs, 1).double(), wd, None, padding=pad).backward(gy.double())
+        ref = wd.grad.clone()
+        if hid > 0:
+            gy = gy.reshape(B, 4, hid, H, W).transpose(1, 2).reshape(B, Cout, H, W).contiguous()
+        prev = _rng_t(1000 + k, (Cout, Ctot, ks, ks))
+        dW, dy = _dev(prev.clone()), _dev(gy)
+        c_off = 0
+        for x in xs:
+            xd = _dev(x)
+            if grouped:
+                j = WgradJob()
+                (j.dy, j.x, j.dW, j.B, j.Cs, j.H, j.W, j.Cout, j.Ho, j.Wo, j.ks, j.stride, j.pad, j.Ctot, j.c_off, j.lstm_hid, j.dtype) = (
+                    dy.data_ptr(), xd.data_ptr(), dW.data_ptr(), B, x.shape[1], H, W, Cout, H, W, ks, 1, pad, Ctot, c_off, hid, ops.DTYPE_F32)
+                jobs.append(j)
+            else:
+                check(L.rsis_conv2d_wgrad(ptr(dy), ptr(xd), ptr(dW), B, x.shape[1], H, W, Cout, H, W, ks, 1, pad, Ctot, c_off, hid, ops.DTYPE_F32,
+                                          stream()), "rsis_conv2d_wgrad")
+            keep.append(xd)
+            c_off += x.shape[1]
+        keep.append(dy)
+        want.append((dW, prev.double() + ref))
+    if grouped:
+        arr = (WgradJob * len(jobs))(*jobs)
+        check(L.rsis_conv2d_wgrad_batch(arr, len(jobs), stream()), "rsis_conv2d_wgrad_batch")
+    torch.cuda.synchronize()
+    for k, (got, ref) in enumerate(want):
+        assert_close("dW of case %d %r" % (k, RAGGED_WGRAD_CASES[k]), got, ref, 2e-5 * max(1.0, float(ref.abs().max())), 1e-5)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_conv2d_wgrad_batch(dtype):
     """rsis_conv2d_wgrad_batch: a mixed bag of weight gradients (tiled 3x3 / 1x1 in several tile configurations, two sources of one
