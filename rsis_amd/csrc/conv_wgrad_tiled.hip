@@ -42,8 +42,10 @@ struct WgradTiledArgs {
 // RAG: maps that no tile shape divides (the 7 / 14 / 28-pixel pyramid of 224 x 224 inputs).  The dy tile (and the x tile of a 1x1) then
 // goes dword by dword -- four DMA instructions where the aligned map needs one dwordx4 -- so that every element carries its own
 // "beyond the map" test: an element of the last tile column / row whose pixel lies outside gets an out-of-range offset and lands as
-// 0.  The MFMA loop is unchanged (zeros add nothing); the tile grid rounds up.
-template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1, bool RAG = false>
+// 0.  The MFMA loop is unchanged (zeros add nothing); the tile grid rounds up.  RAG = 2: the map width is a multiple of 4 (28-pixel maps;
+// every 1x1 whose H * W is, since a 1x1 may walk the FLATTENED map): a dwordx4 group is inside or outside as a whole, so the one
+// DMA per group stays and only carries the two flag bits.
+template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1, int RAG = 0>
 __device__ __forceinline__ void wgrad_tiled_body(const WgradTiledArgs& p, const int bx, const int by) {
 #if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; the buffer-resource builtins do not exist there)
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -87,13 +89,13 @@ __device__ __forceinline__ void wgrad_tiled_body(const WgradTiledArgs& p, const 
     const int row = idx / NG, sl = idx % NG;
     const int G = (sl & ~7) | ((sl & 7) ^ (row & 7));     // group held by this slot
     const int y = G / GPR, x4 = G % GPR;
-    voa[i] = co0 + row < Cout ? (unsigned)((co0 + row) * HW + y * W + x4 * 4) * 4u : RSIS_OOB;
+    voa[i] = co0 + row < Cout ? ((unsigned)((co0 + row) * HW + y * W + x4 * 4) * 4u) | (RAG == 2 && x4 * 4 >= rx ? 1u : 0u) | (RAG == 2 && y >= ry ? 2u : 0u) : RSIS_OOB;
   }
   // RAG: dword DMA k of the dy tile moves LDS floats k * 256 + tid = element e of the dwordx4 slot (k * 256 + tid) / 4; bits 0 / 1 of
   // the offset (a multiple of 4) flag "column >= rx" / "row >= ry": outside the map in the last tile column / row
-  unsigned voa1[RAG ? 4 * NA : 1];
-  unsigned vob1r[RAG && NB4 ? 4 * NB4 : 1];
-  if constexpr (RAG) {
+  unsigned voa1[RAG == 1 ? 4 * NA : 1];
+  unsigned vob1r[RAG == 1 && NB4 ? 4 * NB4 : 1];
+  if constexpr (RAG == 1) {
 #pragma unroll
     for (int k = 0; k < 4 * NA; ++k) {
       const int P = k * 256 + tid, idx = P >> 2, e = P & 3;
@@ -123,7 +125,7 @@ __device__ __forceinline__ void wgrad_tiled_body(const WgradTiledArgs& p, const 
       const int row = idx / NG, sl = idx % NG;
       const int G = (sl & ~7) | ((sl & 7) ^ (row & 7));
       const int y = G / GPR, x4 = G % GPR;
-      vob4[i] = n0 + row < Cs ? (unsigned)((n0 + row) * HW + y * W + x4 * 4) * 4u : RSIS_OOB;
+      vob4[i] = n0 + row < Cs ? ((unsigned)((n0 + row) * HW + y * W + x4 * 4) * 4u) | (RAG == 2 && x4 * 4 >= rx ? 1u : 0u) | (RAG == 2 && y >= ry ? 2u : 0u) : RSIS_OOB;
     }
   } else {
 #pragma unroll
@@ -183,26 +185,28 @@ __device__ __forceinline__ void wgrad_tiled_body(const WgradTiledArgs& p, const 
     const float* ab = p.dy + ((size_t)tb * Cout * HW + y0 * W + x0);                                           \
     const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, 0x7FFFFFF0, 0x00020000); \
     const unsigned lastm = (tx == tiles_x - 1 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u);                      \
-    if constexpr (RAG) {                                                                                       \
+    if constexpr (RAG == 1) {                                                                                  \
       float* As = As0 + (BUF) * AS + wave * 64;                                                                \
       _Pragma("unroll") for (int k = 0; k < 4 * NA; ++k)                                                       \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_vp_t)(As + k * 256), 4, (voa1[k] & lastm) ? RSIS_OOB : (voa1[k] & ~3u), 0, 0, 0); \
     } else {                                                                                                   \
       float* As = As0 + (BUF) * AS + wave * 256;                                                               \
       _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_vp_t)(As + i * 1024), 16, voa[i], 0, 0, 0);         \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_vp_t)(As + i * 1024), 16,                           \
+                                                 RAG == 2 ? ((voa[i] & lastm) ? RSIS_OOB : (voa[i] & ~3u)) : voa[i], 0, 0, 0); \
     }                                                                                                          \
     if constexpr (KS == 1) {                                                                                   \
       const float* bb = p.x + ((size_t)tb * Cs * HW + y0 * W + x0);                                            \
       const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)bb, 0, 0x7FFFFFF0, 0x00020000); \
-      if constexpr (RAG) {                                                                                     \
+      if constexpr (RAG == 1) {                                                                                \
         float* Xs = Xs0 + (BUF) * XS + wave * 64;                                                              \
         _Pragma("unroll") for (int k = 0; k < 4 * NB4; ++k)                                                    \
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_vp_t)(Xs + k * 256), 4, (vob1r[k] & lastm) ? RSIS_OOB : (vob1r[k] & ~3u), 0, 0, 0); \
       } else {                                                                                                 \
         float* Xs = Xs0 + (BUF) * XS + wave * 256;                                                             \
         _Pragma("unroll") for (int i = 0; i < NB4; ++i)                                                        \
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_vp_t)(Xs + i * 1024), 16, vob4[i], 0, 0, 0);      \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_vp_t)(Xs + i * 1024), 16,                         \
+                                                   RAG == 2 ? ((vob4[i] & lastm) ? RSIS_OOB : (vob4[i] & ~3u)) : vob4[i], 0, 0, 0); \
       }                                                                                                        \
     } else {                                                                                                   \
       const float* bb = p.x + (((size_t)tb * Cs + ci0) * HW + (y0 - 1) * W + (x0 - 1));                        \
@@ -308,7 +312,7 @@ struct WgradTiledGroup {
 };
 static_assert(sizeof(WgradTiledGroup) <= 4000, "kernel arguments are limited to 4 KB");
 
-template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1, bool RAG = false>
+template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1, int RAG = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_tiled_group_kernel(const WgradTiledGroup g) {
   const int b = blockIdx.x;
   int lo = 0, hi = g.n - 1;
@@ -388,7 +392,7 @@ static int tiled_cfg_code(const WgradTiledArgs& a, int ks) {
   return narrow ? 4 : 5;
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1, bool RAG = false>
+template <int BM, int BN, int WGM, int WGN, int KS, int TW, int KSP = 1, int RAG = 0>
 static int launch_group_cfg(WgradTiledArgs* jobs, int n, hipStream_t st) {
   constexpr int TH = (KS == 1 ? 32 : 64) / TW;
   long total_iters = 0;
@@ -427,7 +431,7 @@ static int launch_group_cfg(WgradTiledArgs* jobs, int n, hipStream_t st) {
   return RSIS_OK;
 }
 
-template <int KS, int TW, bool RAG = false>
+template <int KS, int TW, int RAG = 0>
 static int launch_group_tw(int code, WgradTiledArgs* jobs, int n, hipStream_t st) {
   switch (code) {
     case 0: return launch_group_cfg<32, 64, 1, 2, KS, TW, 2, RAG>(jobs, n, st);
@@ -453,7 +457,11 @@ int rsis_launch_conv_wgrad_tiled_group(const WgradArgs* w, int n, int ks, hipStr
     a.ldo = w[j].ldo; a.n_off = w[j].n_off; a.interleave_hid = w[j].interleave_hid;
     all[j] = a;
     const int twa = tiled_tw(a.H, a.W, ks);
-    key[j] = twa ? twa * 8 + tiled_cfg_code(a, ks) : 1024 + tiled_tw_ragged(a.W, ks) * 8 + tiled_cfg_code(a, ks);      // (1024: ragged map)
+    if (twa) key[j] = twa * 8 + tiled_cfg_code(a, ks);
+    else {                      // ragged map: 1024 = dword DMA (RAG 1), 2048 = whole dwordx4 groups (RAG 2)
+      if (ks == 1 && (a.H * a.W) % 4 == 0) { all[j].W = a.W = a.H * a.W; all[j].H = a.H = 1; }      // a 1x1 walks the flattened map
+      key[j] = (a.W % 4 == 0 ? 2048 : 1024) + tiled_tw_ragged(a.W, ks) * 8 + tiled_cfg_code(a, ks);
+    }
   }
   int rc = RSIS_OK;
   for (int j = 0; j < n && rc == RSIS_OK; ++j) {
@@ -462,11 +470,14 @@ int rsis_launch_conv_wgrad_tiled_group(const WgradArgs* w, int n, int ks, hipStr
     int m = 0;
     for (int i = j; i < n; ++i)
       if (key[i] == k) { bucket[m++] = all[i]; key[i] = -1; }
-    const bool rag = k >= 1024;
+    const int rag = k >> 10;
     const int tw = (k & 1023) / 8, code = k % 8;
-    if (rag) {
-      if (ks == 1) rc = tw == 32 ? launch_group_tw<1, 32, true>(code, bucket, m, st) : (tw == 16 ? launch_group_tw<1, 16, true>(code, bucket, m, st) : launch_group_tw<1, 8, true>(code, bucket, m, st));
-      else rc = tw == 16 ? launch_group_tw<3, 16, true>(code, bucket, m, st) : launch_group_tw<3, 8, true>(code, bucket, m, st);
+    if (rag == 1) {
+      if (ks == 1) rc = tw == 32 ? launch_group_tw<1, 32, 1>(code, bucket, m, st) : (tw == 16 ? launch_group_tw<1, 16, 1>(code, bucket, m, st) : launch_group_tw<1, 8, 1>(code, bucket, m, st));
+      else rc = tw == 16 ? launch_group_tw<3, 16, 1>(code, bucket, m, st) : launch_group_tw<3, 8, 1>(code, bucket, m, st);
+    } else if (rag == 2) {
+      if (ks == 1) rc = tw == 32 ? launch_group_tw<1, 32, 2>(code, bucket, m, st) : (tw == 16 ? launch_group_tw<1, 16, 2>(code, bucket, m, st) : launch_group_tw<1, 8, 2>(code, bucket, m, st));
+      else rc = tw == 16 ? launch_group_tw<3, 16, 2>(code, bucket, m, st) : launch_group_tw<3, 8, 2>(code, bucket, m, st);
     } else if (ks == 1) rc = tw == 32 ? launch_group_tw<1, 32>(code, bucket, m, st) : (tw == 16 ? launch_group_tw<1, 16>(code, bucket, m, st) : launch_group_tw<1, 8>(code, bucket, m, st));
     else rc = tw == 16 ? launch_group_tw<3, 16>(code, bucket, m, st) : launch_group_tw<3, 8>(code, bucket, m, st);
   }
