@@ -263,6 +263,7 @@ class _DecoderSeqFn(torch.autograd.Function):
         upc = ctx.upc
         dUP5 = None if upc else torch.empty_like(UP5)
         co_pack = decoder.conv_out._pack
+        have_masks = d_masks is not None       # (no gradient on the logits: conv_out's parameters get none either, as on the unfused path)
         if upc:         # (the whole tail runs below, once the side gradients of the heads are known)
             d_masks = torch.zeros((B, T, H5 * W5), **f32) if d_masks is None else (d_masks if d_masks.is_contiguous() else d_masks.contiguous())
         elif d_masks is None:
@@ -319,7 +320,8 @@ class _DecoderSeqFn(torch.autograd.Function):
         DH_last = torch.empty((T, B, last.hid, last.H, last.W), **f32)
         if upc:
             kw, kb = 2 * n, 2 * n + 1
-            _upconv_bwd(L, d_masks, last, False, co_w, target(kw)[0] if need_par[kw] else None, target(kb)[0] if need_par[kb] else None, dsides[n - 1],
+            _upconv_bwd(L, d_masks, last, False, co_w, target(kw)[0] if need_par[kw] and have_masks else None,
+                        target(kb)[0] if need_par[kb] and have_masks else None, dsides[n - 1],
                         T, B, H5, W5, DH_last)
         else:
             check(L.rsis_upsample_maxpool_bwd(ptr(dUP5), ptr(dsides[n - 1]), ptr(last.ARG), ptr(DH_last), T * B * last.hid, last.H, last.W, H5, W5,
@@ -558,6 +560,7 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
         upc = ctx.upc
         dUP5 = None if upc else torch.empty_like(UP5)
         kw, kb = 2 * n, 2 * n + 1
+        have_masks = d_masks is not None       # (no gradient on the logits: conv_out's parameters get none either, as on the unfused path)
         if upc:         # (the whole tail runs below, once the side gradients of the heads are known)
             d_masks = torch.zeros((B, T, H5 * W5), **f32) if d_masks is None else (d_masks if d_masks.is_contiguous() else d_masks.contiguous())
         elif d_masks is None:
@@ -594,7 +597,8 @@ class _DecoderSeqBlkFn(torch.autograd.Function):
         # the last level's hidden states receive their gradient from conv_out only: all T steps in one launch
         DH_last = torch.empty((T, B, last.hid // 8, last.H, last.W, 8), **b16)
         if upc:
-            _upconv_bwd(L, d_masks, last, True, co_w, target(kw)[0] if need_par[kw] else None, target(kb)[0] if need_par[kb] else None, dsides[n - 1],
+            _upconv_bwd(L, d_masks, last, True, co_w, target(kw)[0] if need_par[kw] and have_masks else None,
+                        target(kb)[0] if need_par[kb] and have_masks else None, dsides[n - 1],
                         T, B, H5, W5, DH_last)
         else:
             ops.blk_upsample_bwd_batch([ops.blk_resize_job(dUP5.view(T * B, 1, H5, W5, 8), DH_last.view(T * B, last.hid // 8, last.H, last.W, 8),
