@@ -49,6 +49,7 @@ def bench_args(batch, imsize, T, dtype="fp32"):
 
 
 PEAK_HBM_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.3 TB/s achievable)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), no sparsity
 
 
 def _time_launch(launch, iters):
@@ -336,8 +337,15 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
         if dtype == "fp32":
             r.update({"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)})
         else:
+            # bf16: the family is priced against the roof its arithmetic intensity (algorithmic FLOP per activation byte) puts it under --
+            # the 3x3 convs of the trunk sit right of the ridge (2500 TFLOP/s / 8 TB/s = 312 FLOP/B), the 1x1 ones left of it
             gbs = f["bytes"] / f["ms"] / 1e6
-            r.update({"bound": "hbm", "gbs": round(gbs, 1), "peak": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4)})
+            ai = f["flops"] / f["bytes"]
+            r.update({"gbs": round(gbs, 1), "flop_per_byte": round(ai, 1)})
+            if ai > PEAK_BF16_MFMA_TFLOPS * 1e3 / PEAK_HBM_GBS:
+                r.update({"bound": "mfma", "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(tf / PEAK_BF16_MFMA_TFLOPS, 4)})
+            else:
+                r.update({"bound": "hbm", "peak": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4)})
         out.append(r)
     return out
 
