@@ -369,6 +369,12 @@ int rsis_blk_to_nchw(const void* x_blk, float* y, int B, int C, int H, int W, vo
  * (1x1) input channels, and a ragged last stage reads zero cells (descriptor range) against the pack's zero-padded rows. */
 int rsis_blk_conv2d(const void* x_blk, int B, int C, int H, int W, const void* Wp, int Cout, int ks, const void* addend_blk,
                     void* out_blk, int variant, void* stream);
+/* ... with a per-output-channel affine map and an optional ReLU in the epilogue: out = relu?(conv * scale[co] + shift[co] (+ addend)),
+ * all in fp32 before the one rounding.  Inference (test(), reference src/test.py:35-38): the eval-mode BatchNorm behind every trunk conv
+ * -- scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale -- (+ the bottleneck's residual) (+ its ReLU)
+ * without a BatchNorm launch.  scale / shift: fp32 [Cout], both or neither. */
+int rsis_blk_conv2d_affine(const void* x_blk, int B, int C, int H, int W, const void* Wp, int Cout, int ks, const void* addend_blk,
+                           const float* scale, const float* shift, int relu, void* out_blk, int variant, void* stream);
 
 /* BatchNorm2d (+ residual add) (+ ReLU) on blk tensors: y = relu?((x - mean) * rstd * gamma + beta (+ res)).  train != 0: batch
  * statistics (saved to save_mean / save_rstd for the backward; run_mean / run_var, if given, updated with `momentum` and the unbiased

@@ -115,7 +115,46 @@ def _wgrad(conv, dy, x):
         _acc(w, dW)
 
 
+EVAL_FOLD = [os.environ.get("RSIS_BLK_EVAL_FOLD", "1") != "0"]      # inference: eval-mode BatchNorm (+ residual) (+ ReLU) in the conv's epilogue
+
+
+def _bn_affine(bn):
+    """(scale, shift) of an eval-mode BatchNorm as fp32 [C] tensors -- gamma / sqrt(running_var + eps), beta - running_mean * scale -- cached on
+    the module until one of its four tensors changes"""
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.data_ptr(), bn.running_var.data_ptr())
+    c = getattr(bn, "_blk_affine", None)
+    if c is None or c[0] != key:
+        with torch.no_grad():
+            sc = (bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)).contiguous()
+            sh = (bn.bias.float() - bn.running_mean.float() * sc).contiguous()
+        c = bn._blk_affine = (key, sc, sh)
+    return c[1], c[2]
+
+
+def _conv_bn(conv, bn, x, res, relu):
+    sc, sh = _bn_affine(bn)
+    return ops.blk_conv2d(x, _pack(conv).fwd(conv.weight), conv.out_channels, conv.kernel_size, addend=res, scale=sc, shift=sh, relu=relu)
+
+
+def _block_forward_eval(blk, x):
+    """the bottleneck for inference: three (four) convs, every eval-mode BatchNorm, the residual add and the ReLUs in their epilogues --
+    no BatchNorm launch.  (A stride-s conv is the stride-1 conv followed by the sub-sampling; the pointwise epilogue commutes with it.)"""
+    s = blk.stride
+    y1 = _conv_bn(blk.conv1, blk.bn1, x, None, True)
+    y2 = _conv_bn(blk.conv2, blk.bn2, y1, None, True)
+    if s != 1:
+        y2 = ops.blk_subsample(y2, s)
+    if blk.downsample is None:
+        res = x
+    else:
+        xs = x if s == 1 else ops.blk_subsample(x, s)
+        res = _conv_bn(blk.downsample[0], blk.downsample[1], xs, None, False)
+    return _conv_bn(blk.conv3, blk.bn3, y2, res, True)
+
+
 def _block_forward(blk, x, keep):
+    if not keep and EVAL_FOLD[0] and not blk.bn1.training:
+        return _block_forward_eval(blk, x), None
     s = blk.stride
     a1 = _conv(blk.conv1, x)
     y1, m1 = _bn(blk.bn1, a1, None, True)

@@ -69,6 +69,9 @@ struct ConvArgs {
   int Cout;                        // real number of output rows
   const float* bias;               // [Cout] (packed row order) or null
   const float* addend;             // optional, same layout as dst[0] (single destination only)
+  const float* ep_scale;           // conv_blk.hip only: per-output-channel affine map + optional ReLU applied to the fp32 product before the
+  const float* ep_shift;           //   addend and the one rounding (inference: an eval-mode BatchNorm folded into its conv's epilogue); null = none
+  int ep_relu;
   float* dst[RSIS_MAX_SRC];        // output tensors, rows split by Cd[]; each [B][Cd[i]][Ho][Wo]
   int Cd[RSIS_MAX_SRC];
   int ndst;

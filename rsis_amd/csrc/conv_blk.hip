@@ -172,8 +172,22 @@ __global__ __launch_bounds__(256) void conv_blk_kernel(const ConvArgs p) {
   // (the addend cells are fetched for the whole tile BEFORE the first store and outside any per-element condition: with the load
   //  inside `if (has_add)` hipcc branches around each one and waits vmcnt(0) behind it -- 4 TN dependent L2 round trips per wave,
   //  each also draining the stores issued so far)
-  auto epilogue = [&](auto with_addend) {
-    constexpr bool ADD = decltype(with_addend)::value;
+  auto epilogue = [&](auto with_addend, auto with_affine) {
+    constexpr bool ADD = decltype(with_addend)::value, AFF = decltype(with_affine)::value;
+    // AFF (inference): y = relu?(acc * scale[c] + shift[c] (+ addend)) -- an eval-mode BatchNorm (+ residual) (+ ReLU) in the epilogue of
+    // the conv that feeds it; this lane's 16 channels are co_base + 8 g + 4 hi + i
+    float sc[16], sh[16];
+    if constexpr (AFF) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.ep_scale, 0, p.Cout * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)p.ep_shift, 0, p.Cout * 4, 0x00020000);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned o = (unsigned)(co_base + 8 * (r >> 2) + 4 * hi + (r & 3)) * 4u;
+        sc[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0));
+        sh[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, o, 0, 0));
+      }
+    }
+    const bool relu = p.ep_relu != 0;
     unsigned off[TN][4];
     u32x2 av[TN][4];
 #pragma unroll
@@ -194,15 +208,25 @@ __global__ __launch_bounds__(256) void conv_blk_kernel(const ConvArgs p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float o0 = acc[j][4 * g], o1 = acc[j][4 * g + 1], o2 = acc[j][4 * g + 2], o3 = acc[j][4 * g + 3];
+        if constexpr (AFF) {
+          o0 = o0 * sc[4 * g] + sh[4 * g]; o1 = o1 * sc[4 * g + 1] + sh[4 * g + 1];
+          o2 = o2 * sc[4 * g + 2] + sh[4 * g + 2]; o3 = o3 * sc[4 * g + 3] + sh[4 * g + 3];
+        }
         if constexpr (ADD) {
           o0 += __uint_as_float(av[j][g][0] << 16); o1 += __uint_as_float(av[j][g][0] & 0xFFFF0000u);
           o2 += __uint_as_float(av[j][g][1] << 16); o3 += __uint_as_float(av[j][g][1] & 0xFFFF0000u);
+        }
+        if constexpr (AFF) {
+          if (relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f); }
         }
         const u32x2 v = {blk_pack2(o0, o1), blk_pack2(o2, o3)};
         __builtin_amdgcn_raw_buffer_store_b64(v, ro, off[j][g], 0, 0);
       }
   };
-  if (has_add) epilogue(std::true_type{}); else epilogue(std::false_type{});
+  if (p.ep_scale) {
+    if (has_add) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{});
+  } else if (has_add) epilogue(std::true_type{}, std::false_type{});
+  else epilogue(std::false_type{}, std::false_type{});
 #endif
 }
 

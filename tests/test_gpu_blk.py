@@ -284,3 +284,61 @@ def test_blk_trunk_eval_forward_against_fp32_storage():
     for i, (a, b) in enumerate(zip(outs[1], outs[0])):
         assert float(b.abs().max()) > 1e-3 and torch.isfinite(b).all()
         assert _rel_l2(a, b) < 3e-2, "x%d: rel L2 %.3g" % (5 - i, _rel_l2(a, b))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 256, 14, 14, 1), (2, 64, 64, 17, 9, 3), (3, 128, 40, 7, 7, 3), (2, 256, 128, 28, 28, 1)],
+                         ids=lambda s: "x".join(str(v) for v in s))
+@pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
+def test_blk_conv_affine_epilogue(shape, res, relu):
+    """rsis_blk_conv2d_affine: out = relu?(conv * scale + shift (+ addend)) in fp32 with ONE rounding -- against float64 on the same
+    bf16-valued operands: half a bf16 ulp of the exact value + 1e-5 of the output's scale"""
+    from rsis_amd import ops
+    B, Cin, Cout, H, W, ks = shape
+    torch.manual_seed(sum(shape) + int(res) + 2 * int(relu))
+    x = _bf16(torch.randn(B, Cin, H, W, device="cuda"))
+    w = torch.randn(Cout, Cin, ks, ks, device="cuda") / (ks * Cin ** 0.5)
+    pack = ops.PackedConv(ks, [Cin], stride=1, pad=ks // 2, dtype=ops.DTYPE_BF16)
+    wp = pack.fwd(w)
+    sc = torch.rand(Cout, device="cuda") + 0.5
+    sh = torch.randn(Cout, device="cuda")
+    r = _bf16(torch.randn(B, Cout, H, W, device="cuda")) if res else None
+    y = ops.blk_conv2d(to_blk(x), wp, Cout, ks, addend=to_blk(r) if res else None, scale=sc, shift=sh, relu=relu)
+    ref = torch.nn.functional.conv2d(x.double(), _bf16(w).double(), padding=ks // 2) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    if res:
+        ref = ref + r.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    assert_close("y", from_blk(y), ref, 1e-5 * float(ref.abs().max()), HALF_ULP)
+
+
+def test_blk_trunk_eval_with_folded_batchnorm():
+    """inference: the blk trunk with every eval-mode BatchNorm (+ residual) (+ ReLU) folded into its conv's epilogue
+    (blk_trunk._block_forward_eval) against the conv -> BatchNorm launches: the folded path rounds once where the other rounds twice --
+    the five feature maps within 1 % relative L2 of each other, and no farther from the fp32-storage kernels than the unfolded path + 1 %"""
+    from rsis_amd import blk_trunk, ops
+    from rsis_amd.modules.vision import HipBatchNorm2d, ResNet101
+    torch.manual_seed(0)
+    net = ResNet101().cuda()
+    for m in net.modules():
+        if isinstance(m, HipBatchNorm2d):
+            m.running_var.fill_(0.4)
+            m.running_mean.normal_(0, 0.05)
+            m.weight.data.fill_(0.5)
+            m.bias.data.normal_(0, 0.05)
+    net.eval()
+    ops.set_dtype(net, "bf16")
+    x = torch.randn(2, 3, 160, 96, device="cuda")
+    outs = {}
+    was, wasf = blk_trunk.ENABLED[0], blk_trunk.EVAL_FOLD[0]
+    try:
+        for name, on, fold in (("fp32 storage", False, False), ("unfolded", True, False), ("folded", True, True)):
+            blk_trunk.ENABLED[0], blk_trunk.EVAL_FOLD[0] = on, fold
+            with torch.no_grad():
+                outs[name] = [o.clone() for o in net(x)]
+    finally:
+        blk_trunk.ENABLED[0], blk_trunk.EVAL_FOLD[0] = was, wasf
+    for i in range(5):
+        a, b, c = outs["folded"][i], outs["unfolded"][i], outs["fp32 storage"][i]
+        assert torch.isfinite(a).all() and float(c.abs().max()) > 1e-3
+        assert _rel_l2(a, b) < 1e-2, "x%d: folded vs unfolded rel L2 %.3g" % (5 - i, _rel_l2(a, b))
+        assert _rel_l2(a, c) < _rel_l2(b, c) + 1e-2, "x%d: %.3g vs %.3g" % (5 - i, _rel_l2(a, c), _rel_l2(b, c))
