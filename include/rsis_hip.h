@@ -369,12 +369,13 @@ int rsis_blk_to_nchw(const void* x_blk, float* y, int B, int C, int H, int W, vo
  * (1x1) input channels, and a ragged last stage reads zero cells (descriptor range) against the pack's zero-padded rows. */
 int rsis_blk_conv2d(const void* x_blk, int B, int C, int H, int W, const void* Wp, int Cout, int ks, const void* addend_blk,
                     void* out_blk, int variant, void* stream);
-/* ... with a per-output-channel affine map and an optional ReLU in the epilogue: out = relu?(conv * scale[co] + shift[co] (+ addend)),
- * all in fp32 before the one rounding.  Inference (test(), reference src/test.py:35-38): the eval-mode BatchNorm behind every trunk conv
- * -- scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale -- (+ the bottleneck's residual) (+ its ReLU)
- * without a BatchNorm launch.  scale / shift: fp32 [Cout], both or neither. */
-int rsis_blk_conv2d_affine(const void* x_blk, int B, int C, int H, int W, const void* Wp, int Cout, int ks, const void* addend_blk,
-                           const float* scale, const float* shift, int relu, void* out_blk, int variant, void* stream);
+/* ... followed by the eval-mode BatchNorm of its output IN THE EPILOGUE (inference: test(), reference src/test.py:35-38; every trunk
+ * conv is followed by one): out = relu?(v * sc + sh (+ addend)), sc = gamma * rsqrt(running_var + eps), sh = beta - running_mean * sc, where
+ * v is the product rounded to bf16 (single_rounding = 0: bit for bit what rsis_blk_conv2d + rsis_blk_bn_fwd (eval) compute, without the
+ * BatchNorm launch) or kept in fp32 (single_rounding = 1: closer to the fp32 result).  gamma .. running_var: fp32 [Cout]. */
+int rsis_blk_conv2d_bn_eval(const void* x_blk, int B, int C, int H, int W, const void* Wp, int Cout, int ks, const void* addend_blk,
+                            const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int relu,
+                            int single_rounding, void* out_blk, int variant, void* stream);
 
 /* BatchNorm2d (+ residual add) (+ ReLU) on blk tensors: y = relu?((x - mean) * rstd * gamma + beta (+ res)).  train != 0: batch
  * statistics (saved to save_mean / save_rstd for the backward; run_mean / run_var, if given, updated with `momentum` and the unbiased

@@ -124,7 +124,7 @@ SIGNATURES = {
     "rsis_blk_subsample2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsis_blk_upscatter2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsis_blk_conv2d": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
-    "rsis_blk_conv2d_affine": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "rsis_blk_conv2d_bn_eval": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i, _i, _vp, _i, _vp]),
     "rsis_convlstm_bwd_gates_batch": (_i, [ctypes.POINTER(LstmBwdJob), _i, _vp]),
     "rsis_conv2d_dgrad_batch": (_i, [ctypes.POINTER(DgradJob), _i, _vp]),
     "rsis_blk_conv3x3_batch": (_i, [ctypes.POINTER(BlkConvJob), _i, _vp]),

@@ -115,25 +115,17 @@ def _wgrad(conv, dy, x):
         _acc(w, dW)
 
 
-EVAL_FOLD = [os.environ.get("RSIS_BLK_EVAL_FOLD", "1") != "0"]      # inference: eval-mode BatchNorm (+ residual) (+ ReLU) in the conv's epilogue
-
-
-def _bn_affine(bn):
-    """(scale, shift) of an eval-mode BatchNorm as fp32 [C] tensors -- gamma / sqrt(running_var + eps), beta - running_mean * scale -- cached on
-    the module until one of its four tensors changes"""
-    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.data_ptr(), bn.running_var.data_ptr())
-    c = getattr(bn, "_blk_affine", None)
-    if c is None or c[0] != key:
-        with torch.no_grad():
-            sc = (bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)).contiguous()
-            sh = (bn.bias.float() - bn.running_mean.float() * sc).contiguous()
-        c = bn._blk_affine = (key, sc, sh)
-    return c[1], c[2]
+# inference: the eval-mode BatchNorm (+ residual) (+ ReLU) behind every trunk conv in the conv's epilogue.  "1" (default): in the
+# arithmetic of the separate launches (the product rounded to bf16, then the BatchNorm: the same bits, minus 103 launches per forward);
+# "2": the product kept in fp32 (one rounding per layer: closer to the fp32 features, but not the bits the parity tests were pinned on);
+# "0": separate BatchNorm launches
+EVAL_FOLD = [int(os.environ.get("RSIS_BLK_EVAL_FOLD", "1"))]
 
 
 def _conv_bn(conv, bn, x, res, relu):
-    sc, sh = _bn_affine(bn)
-    return ops.blk_conv2d(x, _pack(conv).fwd(conv.weight), conv.out_channels, conv.kernel_size, addend=res, scale=sc, shift=sh, relu=relu)
+    return ops.blk_conv2d(x, _pack(conv).fwd(conv.weight), conv.out_channels, conv.kernel_size, addend=res,
+                          bn=(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps), relu=relu,
+                          single_rounding=EVAL_FOLD[0] == 2)
 
 
 def _block_forward_eval(blk, x):

@@ -612,17 +612,20 @@ int rsis_bn_bwd_eval(const float* dy, const float* x, const float* y, const floa
 // ---- channel-blocked bf16 activations (conv_blk.hip) ----
 int rsis_blk_conv2d(const void* x, int B, int C, int H, int W, const void* Wp, int Cout, int ks, const void* addend, void* out, int variant,
                     void* stream) {
-  return rsis_blk_conv2d_affine(x, B, C, H, W, Wp, Cout, ks, addend, nullptr, nullptr, 0, out, variant, stream);
+  return rsis_blk_conv2d_bn_eval(x, B, C, H, W, Wp, Cout, ks, addend, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0, out, variant, stream);
 }
-int rsis_blk_conv2d_affine(const void* x, int B, int C, int H, int W, const void* Wp, int Cout, int ks, const void* addend, const float* scale,
-                           const float* shift, int relu, void* out, int variant, void* stream) {
-  if (!x || !Wp || !out || x == out || B < 1 || C < 8 || H < 1 || W < 1 || Cout < 8 || (!scale != !shift)) return RSIS_ERR_ARG;
+int rsis_blk_conv2d_bn_eval(const void* x, int B, int C, int H, int W, const void* Wp, int Cout, int ks, const void* addend, const float* gamma,
+                            const float* beta, const float* running_mean, const float* running_var, float eps, int relu, int single_rounding,
+                            void* out, int variant, void* stream) {
+  if (!x || !Wp || !out || x == out || B < 1 || C < 8 || H < 1 || W < 1 || Cout < 8) return RSIS_ERR_ARG;
+  if (gamma && !(beta && running_mean && running_var)) return RSIS_ERR_ARG;
   if (ks != 1 && ks != 3) return RSIS_ERR_UNSUPPORTED;
   ConvArgs a = {};
   a.nsrc = 1; a.src[0] = a.src[1] = a.src[2] = (const float*)x; a.C[0] = C; a.K = C * ks * ks;
   a.B = B; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.stride = 1; a.pad = ks / 2;
   a.wp = (const float*)Wp; a.ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN); a.Cout = Cout; a.addend = (const float*)addend;
-  a.ep_scale = scale; a.ep_shift = shift; a.ep_relu = scale ? relu : 0;
+  a.ep_gamma = gamma; a.ep_beta = beta; a.ep_mean = running_mean; a.ep_var = running_var; a.ep_eps = eps;
+  a.ep_relu = gamma ? relu : 0; a.ep_round = single_rounding ? 0 : 1;
   a.dst[0] = (float*)out; a.Cd[0] = Cout; a.ndst = 1; a.ostride = 1; a.oH = H; a.oW = W; a.ksplit = 1;
   return rsis_launch_conv_blk(a, ks, variant, (hipStream_t)stream);
 }

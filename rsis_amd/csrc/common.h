@@ -69,9 +69,12 @@ struct ConvArgs {
   int Cout;                        // real number of output rows
   const float* bias;               // [Cout] (packed row order) or null
   const float* addend;             // optional, same layout as dst[0] (single destination only)
-  const float* ep_scale;           // conv_blk.hip only: per-output-channel affine map + optional ReLU applied to the fp32 product before the
-  const float* ep_shift;           //   addend and the one rounding (inference: an eval-mode BatchNorm folded into its conv's epilogue); null = none
-  int ep_relu;
+  // conv_blk.hip only (inference): the eval-mode BatchNorm behind the conv in its epilogue -- y = relu?(v * sc + sh (+ addend)) with
+  // sc = gamma * rsqrtf(var + eps), sh = beta - mean * sc, v = the product rounded to bf16 first (ep_round: the bits of the separate
+  // BatchNorm launch) or kept in fp32 (one rounding in all).  ep_gamma == null: none.
+  const float* ep_gamma; const float* ep_beta; const float* ep_mean; const float* ep_var;
+  float ep_eps;
+  int ep_relu, ep_round;
   float* dst[RSIS_MAX_SRC];        // output tensors, rows split by Cd[]; each [B][Cd[i]][Ho][Wo]
   int Cd[RSIS_MAX_SRC];
   int ndst;

@@ -174,19 +174,32 @@ __global__ __launch_bounds__(256) void conv_blk_kernel(const ConvArgs p) {
   //  each also draining the stores issued so far)
   auto epilogue = [&](auto with_addend, auto with_affine) {
     constexpr bool ADD = decltype(with_addend)::value, AFF = decltype(with_affine)::value;
-    // AFF (inference): y = relu?(acc * scale[c] + shift[c] (+ addend)) -- an eval-mode BatchNorm (+ residual) (+ ReLU) in the epilogue of
-    // the conv that feeds it; this lane's 16 channels are co_base + 8 g + 4 hi + i
+    // AFF (inference): the eval-mode BatchNorm (+ residual) (+ ReLU) of blk_bn_apply_kernel in the epilogue of the conv that feeds it,
+    // in that kernel's own arithmetic (rstd = rsqrtf(var + eps), g = gamma * rstd, y = x * g + (beta - mean * g), then the residual, then
+    // the ReLU); this lane's 16 channels are co_base + 8 g + 4 hi + i
     float sc[16], sh[16];
     if constexpr (AFF) {
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.ep_scale, 0, p.Cout * 4, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)p.ep_shift, 0, p.Cout * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.ep_gamma, 0, p.Cout * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.ep_beta, 0, p.Cout * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)p.ep_mean, 0, p.Cout * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)p.ep_var, 0, p.Cout * 4, 0x00020000);
+      float gv[16], bv[16], mv[16], vv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const unsigned o = (unsigned)(co_base + 8 * (r >> 2) + 4 * hi + (r & 3)) * 4u;
-        sc[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0));
-        sh[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, o, 0, 0));
+        gv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, o, 0, 0));
+        bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, o, 0, 0));
+        mv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, o, 0, 0));
+        vv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, o, 0, 0));
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float rstd = rsqrtf(vv[r] + p.ep_eps);
+        sc[r] = gv[r] * rstd;
+        sh[r] = bv[r] - mv[r] * sc[r];
       }
     }
+    const bool pre_round = p.ep_round != 0;
     const bool relu = p.ep_relu != 0;
     unsigned off[TN][4];
     u32x2 av[TN][4];
@@ -209,6 +222,10 @@ __global__ __launch_bounds__(256) void conv_blk_kernel(const ConvArgs p) {
       for (int g = 0; g < 4; ++g) {
         float o0 = acc[j][4 * g], o1 = acc[j][4 * g + 1], o2 = acc[j][4 * g + 2], o3 = acc[j][4 * g + 3];
         if constexpr (AFF) {
+          if (pre_round) {        // (the conv's own bf16 store of the unfused path, then its BatchNorm)
+            const unsigned q0 = blk_pack2(o0, o1), q1 = blk_pack2(o2, o3);
+            o0 = __uint_as_float(q0 << 16); o1 = __uint_as_float(q0 & 0xFFFF0000u); o2 = __uint_as_float(q1 << 16); o3 = __uint_as_float(q1 & 0xFFFF0000u);
+          }
           o0 = o0 * sc[4 * g] + sh[4 * g]; o1 = o1 * sc[4 * g + 1] + sh[4 * g + 1];
           o2 = o2 * sc[4 * g + 2] + sh[4 * g + 2]; o3 = o3 * sc[4 * g + 3] + sh[4 * g + 3];
         }
@@ -223,7 +240,7 @@ __global__ __launch_bounds__(256) void conv_blk_kernel(const ConvArgs p) {
         __builtin_amdgcn_raw_buffer_store_b64(v, ro, off[j][g], 0, 0);
       }
   };
-  if (p.ep_scale) {
+  if (p.ep_gamma) {
     if (has_add) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{});
   } else if (has_add) epilogue(std::true_type{}, std::false_type{});
   else epilogue(std::false_type{}, std::false_type{});

@@ -73,7 +73,7 @@ class FeatureExtractor(nn.Module):
         self.base.cut_layer3 = int(self.split_backward) >= 2 and not (semseg or raw) and self.training and torch.is_grad_enabled()
         self.base._cut3 = None
         self._cut = None
-        blk_skips = bool(blk_skips) and not (semseg or raw) and self.training and self.kernel_size == 3
+        blk_skips = bool(blk_skips) and not (semseg or raw) and (self.training or not torch.is_grad_enabled()) and self.kernel_size == 3
         x5, x4, x3, x2, x1 = self.base(x, blk_out=True) if blk_skips else self.base(x)            # model.py:57
         if semseg:
             return x5

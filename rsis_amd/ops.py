@@ -887,20 +887,22 @@ def blk_to_nchw(x):
     return y
 
 
-def blk_conv2d(x, wp, cout, ks, variant=0, addend=None, scale=None, shift=None, relu=False):
+def blk_conv2d(x, wp, cout, ks, variant=0, addend=None, bn=None, relu=False, single_rounding=False):
     """conv (stride 1, same padding, no bias) of a blk tensor with a bf16 pack (PackedConv(dtype=DTYPE_BF16).fwd / .dgrad);
-    addend: a blk tensor of the output's shape, added before the rounding; scale / shift (fp32 [cout]) + relu: the affine epilogue of
-    rsis_blk_conv2d_affine (an eval-mode BatchNorm folded into the conv: inference)"""
+    addend: a blk tensor of the output's shape, added before the rounding; bn = (gamma, beta, running_mean, running_var, eps) (+ relu): the
+    eval-mode BatchNorm of the output in the conv's epilogue (rsis_blk_conv2d_bn_eval: inference)"""
     assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 5 and x.shape[-1] == 8 and cout % 8 == 0
     B, Cb, H, W, _ = x.shape
     y = torch.empty((B, cout // 8, H, W, 8), dtype=torch.bfloat16, device=x.device)
     assert addend is None or (addend.dtype == torch.bfloat16 and addend.is_contiguous() and tuple(addend.shape) == tuple(y.shape))
-    if scale is None:
+    if bn is None:
         check(lib().rsis_blk_conv2d(ptr(x), B, Cb * 8, H, W, ptr(wp), cout, ks, ptr(addend), ptr(y), int(variant), stream()), "rsis_blk_conv2d")
     else:
-        assert scale.dtype == torch.float32 and shift.dtype == torch.float32 and scale.numel() == cout and shift.numel() == cout
-        check(lib().rsis_blk_conv2d_affine(ptr(x), B, Cb * 8, H, W, ptr(wp), cout, ks, ptr(addend), ptr(scale), ptr(shift), 1 if relu else 0, ptr(y),
-                                           int(variant), stream()), "rsis_blk_conv2d_affine")
+        g, b, m, v, eps = bn
+        for t in (g, b, m, v):
+            assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous() and t.numel() == cout
+        check(lib().rsis_blk_conv2d_bn_eval(ptr(x), B, Cb * 8, H, W, ptr(wp), cout, ks, ptr(addend), ptr(g), ptr(b), ptr(m), ptr(v), float(eps),
+                                            1 if relu else 0, 1 if single_rounding else 0, ptr(y), int(variant), stream()), "rsis_blk_conv2d_bn_eval")
     return y
 
 

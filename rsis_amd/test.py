@@ -16,7 +16,12 @@ def test(args, encoder, decoder, x, return_logits=False):
     out_masks, out_classes, out_stops = [], [], []
     encoder.eval()
     decoder.eval()
-    feats = encoder(x)                                                  # test.py:35
+    # (under -dtype bf16 with the decoder on blk storage the encoder hands its skip features over as blk tensors, as in runIter: no fp32
+    #  NCHW copies between trunk, skip branches and decoder)
+    from . import train as _train
+    blk_ok = (x.is_cuda and _train.BLK_SKIPS[0] and hasattr(encoder, "sk5") and hasattr(decoder, "clstm_list") and
+              "forward" not in encoder.__dict__ and _train._blk_skips_ok(encoder, decoder, x))
+    feats = encoder(x, blk_skips=True) if blk_ok else encoder(x)        # test.py:35
     steps, hidden = decoder.forward_sequence(feats, T)                  # test.py:37-38 (the T decoder steps, wavefront order)
     for out_mask, out_class, out_stop in steps:
         out_mask = ops.upsample_bilinear_ac(out_mask, (x.size()[-2], x.size()[-1]))   # test.py:39-40
