@@ -28,45 +28,54 @@ __device__ __forceinline__ int seg_channel(const SegMap& m, int cg) {   // conca
 __device__ __forceinline__ int ref_row(int cop, int hid) { return hid > 0 ? (cop & 3) * hid + (cop >> 2) : cop; }
 
 // ---- one element of each packed layout (shared by the per-conv kernels and the batched repack) ----
+// (the element functions return the INDEX into the reference weight, or -1 for a zero of the padding: the batched repack fetches a
+//  handful of elements per thread at clamped indices before it uses any of them -- `cond ? W[i] : 0` element by element compiles to
+//  a branch around every load and a wait behind it, one memory round trip per element)
 template <int KKC = 0>    // KKC: compile-time ks*ks (0 = use the run-time value) -- makes the row / KK divisions cheap
-__device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ W, int row, int col, int Cout, int Ctot, int KKr,
-                                           const SegMap& m, int hid) {
+__device__ __forceinline__ int pack_elem_idx(int mode, int row, int col, int Cout, int Ctot, int KKr, const SegMap& m, int hid) {
   const int KK = KKC ? KKC : KKr;
   if (mode == 0) {                 // igemm fwd: Wp[cg*KK + rs][co_p]
-    if (col >= Cout) return 0.f;
+    if (col >= Cout) return -1;
     const int cg = row / KK, rs = row - cg * KK;
     const int ci = seg_channel(m, cg);
-    return ci >= 0 ? W[(ref_row(col, hid) * Ctot + ci) * KK + rs] : 0.f;
+    return ci >= 0 ? (ref_row(col, hid) * Ctot + ci) * KK + rs : -1;
   }
   if (mode == 1) {                 // igemm dgrad: Wd[co_p*KK + rs][cg]
     const int cop = row / KK, rs = row - cop * KK;
     const int ci = seg_channel(m, col);
-    return (cop < Cout && ci >= 0) ? W[(ref_row(cop, hid) * Ctot + ci) * KK + rs] : 0.f;
+    return (cop < Cout && ci >= 0) ? (ref_row(cop, hid) * Ctot + ci) * KK + rs : -1;
   }
   const int qg = row / (RSIS_CK * 9), kin = row - qg * (RSIS_CK * 9);
   const int pair = kin >> 1, h = kin & 1;
   const int cc = pair / 9, rs = pair - cc * 9;
   if (mode == 2) {                 // direct fwd: 8-channel chunks per segment, columns = co_p
-    if (col >= Cout) return 0.f;
-    int qs = 0;
+    if (col >= Cout) return -1;
+    int qs = 0, r = -1;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       if (s < m.n) {
         const int nq = (m.C[s] + RSIS_CK - 1) / RSIS_CK;
         if (qg >= qs && qg < qs + nq) {
           const int c = (qg - qs) * RSIS_CK + 2 * cc + h;
-          return c < m.C[s] ? W[(ref_row(col, hid) * Ctot + m.off[s] + c) * 9 + rs] : 0.f;
+          if (c < m.C[s]) r = (ref_row(col, hid) * Ctot + m.off[s] + c) * 9 + rs;
         }
         qs += nq;
       }
     }
-    return 0.f;
+    return r;
   }
   // direct dgrad: rows = chunks of co_p, columns = cg.  mode 3 (stride 1) reads tap 8-rs (the transposed conv); mode 4 (stride 2,
   // EPI_S2 of conv3x3_direct.hip) keeps the original tap order (each tap is routed to its parity class by the kernel)
   const int c = qg * RSIS_CK + 2 * cc + h;      // channel of dy (packed row order for ConvLSTM)
   const int ci = seg_channel(m, col);
-  return (c < Cout && ci >= 0) ? W[(ref_row(c, hid) * Ctot + ci) * 9 + (mode == 3 ? 8 - rs : rs)] : 0.f;
+  return (c < Cout && ci >= 0) ? (ref_row(c, hid) * Ctot + ci) * 9 + (mode == 3 ? 8 - rs : rs) : -1;
+}
+template <int KKC = 0>
+__device__ __forceinline__ float pack_elem(int mode, const float* __restrict__ W, int row, int col, int Cout, int Ctot, int KKr,
+                                           const SegMap& m, int hid) {
+  const int i = pack_elem_idx<KKC>(mode, row, col, Cout, Ctot, KKr, m, hid);
+  const float v = W[i < 0 ? 0 : i];
+  return i < 0 ? 0.f : v;
 }
 
 __global__ void pack_kernel(int mode, const float* __restrict__ W, float* __restrict__ out, int Cout, int Ctot, int KK, SegMap m, int ldw,
@@ -92,31 +101,36 @@ __device__ __forceinline__ unsigned short to_bf16(float v) {
 }
 __host__ __device__ __forceinline__ int bf16_ckb(int KK) { return KK == 1 ? RSIS_CKB1 : RSIS_CKB3; }
 
-__device__ __forceinline__ float pack_bf16_src(int mode, const float* __restrict__ W, int kb, int col, int e, int Cout, int Ctot, int KK,
-                                               const SegMap& m, int hid) {
+__device__ __forceinline__ int pack_bf16_idx(int mode, int kb, int col, int e, int Cout, int Ctot, int KK, const SegMap& m, int hid) {
   const int CKB = bf16_ckb(KK), NCB = CKB / 8;
   const int q = kb / (KK * NCB), rem = kb - q * (KK * NCB);
   const int rs = rem / NCB, cb = rem - rs * NCB;
   const int cl = cb * 8 + e;                         // channel inside the chunk
   if (mode == 5) {
-    if (col >= Cout) return 0.f;
-    int qs = 0;
+    if (col >= Cout) return -1;
+    int qs = 0, r = -1;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       if (s < m.n) {
         const int nq = (m.C[s] + CKB - 1) / CKB;
         if (q >= qs && q < qs + nq) {
           const int c = (q - qs) * CKB + cl;
-          return c < m.C[s] ? W[(ref_row(col, hid) * Ctot + m.off[s] + c) * KK + rs] : 0.f;
+          if (c < m.C[s]) r = (ref_row(col, hid) * Ctot + m.off[s] + c) * KK + rs;
         }
         qs += nq;
       }
     }
-    return 0.f;
+    return r;
   }
   const int c = q * CKB + cl;                        // dy channel (packed row order for ConvLSTM)
   const int ci = seg_channel(m, col);
-  return (c < Cout && ci >= 0) ? W[(ref_row(c, hid) * Ctot + ci) * KK + (KK == 9 ? 8 - rs : rs)] : 0.f;
+  return (c < Cout && ci >= 0) ? (ref_row(c, hid) * Ctot + ci) * KK + (KK == 9 ? 8 - rs : rs) : -1;
+}
+__device__ __forceinline__ float pack_bf16_src(int mode, const float* __restrict__ W, int kb, int col, int e, int Cout, int Ctot, int KK,
+                                               const SegMap& m, int hid) {
+  const int i = pack_bf16_idx(mode, kb, col, e, Cout, Ctot, KK, m, hid);
+  const float v = W[i < 0 ? 0 : i];
+  return i < 0 ? 0.f : v;
 }
 
 __global__ void pack_bf16_kernel(int mode, const float* __restrict__ W, unsigned short* __restrict__ out, int Cout, int Ctot, int KK,
@@ -147,11 +161,23 @@ __device__ __forceinline__ void pack_tile_bf16(const rsis_pack_job& j, int tb, u
     const int R = KK * NCB;                          // cell rows of one chunk (18 or 8)
     const int q = tb / nct;
     const int run = KK * CKB;                        // source floats per column
-    for (int i = threadIdx.x; i < 64 * run; i += 256) {
-      const int cl = i / run, idx = i - cl * run;    // column, position in the run = (channel in chunk, tap)
-      const int ch = idx / KK, rs = idx - ch * KK;
-      const int kb = q * R + rs * NCB + (ch >> 3);
-      lds16[((rs * NCB + (ch >> 3)) * 64 + cl) * 8 + (ch & 7)] = to_bf16(pack_bf16_src(5, j.W, kb, c0 + cl, ch & 7, j.Cout, j.Ctot, KK, m, j.lstm_hid));
+    for (int i0 = threadIdx.x; i0 < 64 * run; i0 += 256 * 4) {      // four elements per thread in flight
+      int src[4], dst[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 256 * u;
+        const int cl = i / run, idx = i - cl * run;    // column, position in the run = (channel in chunk, tap)
+        const int ch = idx / KK, rs = idx - ch * KK;
+        const int kb = q * R + rs * NCB + (ch >> 3);
+        dst[u] = i < 64 * run ? ((rs * NCB + (ch >> 3)) * 64 + cl) * 8 + (ch & 7) : -1;
+        src[u] = i < 64 * run ? pack_bf16_idx(5, kb, c0 + cl, ch & 7, j.Cout, j.Ctot, KK, m, j.lstm_hid) : -1;
+      }
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = j.W[src[u] < 0 ? 0 : src[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (dst[u] >= 0) lds16[dst[u]] = to_bf16(src[u] < 0 ? 0.f : v[u]);
     }
     __syncthreads();
     const pk_u32x4* src = (const pk_u32x4*)lds16;
@@ -164,11 +190,16 @@ __device__ __forceinline__ void pack_tile_bf16(const rsis_pack_job& j, int tb, u
     for (int i = threadIdx.x; i < 16 * 64; i += 256) {
       const int rr = i >> 6, cl = i & 63;
       if (r0 + rr >= j.krows) continue;
+      int src[8];
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) src[e] = pack_bf16_idx(6, r0 + rr, c0 + cl, e, j.Cout, j.Ctot, KK, m, j.lstm_hid);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = j.W[src[e] < 0 ? 0 : src[e]];
       unsigned v[4];
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
-        const unsigned lo = to_bf16(pack_bf16_src(6, j.W, r0 + rr, c0 + cl, 2 * e2, j.Cout, j.Ctot, KK, m, j.lstm_hid));
-        const unsigned hi = to_bf16(pack_bf16_src(6, j.W, r0 + rr, c0 + cl, 2 * e2 + 1, j.Cout, j.Ctot, KK, m, j.lstm_hid));
+        const unsigned lo = to_bf16(src[2 * e2] < 0 ? 0.f : f[2 * e2]), hi = to_bf16(src[2 * e2 + 1] < 0 ? 0.f : f[2 * e2 + 1]);
         v[e2] = lo | (hi << 16);
       }
       const pk_u32x4 cell = {v[0], v[1], v[2], v[3]};
@@ -200,27 +231,54 @@ __device__ __forceinline__ void pack_tile(const rsis_pack_job& j, int tb, float 
     constexpr int R = RSIS_CK * 9;
     r0 = (tb / nct) * R;
     nrow = R;
-    for (int c = 0; c < RSIS_CK; ++c) {
-      for (int i = threadIdx.x; i < PACK_TC * 9; i += 256) {
+    constexpr int PER = (PACK_TC * 9 + 255) / 256;                     // elements per thread and dy channel (3)
+    for (int c = 0; c < RSIS_CK; c += 2) {                             // two dy channels = 2 * PER loads in flight per thread
+      int src[2 * PER], kin_[2 * PER], cl_[2 * PER];
+#pragma unroll
+      for (int u = 0; u < 2 * PER; ++u) {
+        const int cu = c + u / PER, i = threadIdx.x + 256 * (u % PER);
         const int cl = i / 9, tap = i - cl * 9;                      // tap of the reference weight
         const int rs = j.imode == 3 ? 8 - tap : tap;                 // its packed position
-        const int kin = ((c >> 1) * 9 + rs) * 2 + (c & 1);
-        tile[kin][cl] = pack_elem<KKC>(j.imode, j.W, r0 + kin, c0 + cl, j.Cout, j.Ctot, KK, m, j.lstm_hid);
+        const int kin = ((cu >> 1) * 9 + rs) * 2 + (cu & 1);
+        const bool ok = i < PACK_TC * 9;
+        kin_[u] = ok ? kin : -1; cl_[u] = cl;
+        src[u] = ok ? pack_elem_idx<KKC>(j.imode, r0 + kin, c0 + cl, j.Cout, j.Ctot, KK, m, j.lstm_hid) : -1;
       }
+      float v[2 * PER];
+#pragma unroll
+      for (int u = 0; u < 2 * PER; ++u) v[u] = j.W[src[u] < 0 ? 0 : src[u]];
+#pragma unroll
+      for (int u = 0; u < 2 * PER; ++u)
+        if (kin_[u] >= 0) tile[kin_[u]][cl_[u]] = src[u] < 0 ? 0.f : v[u];
     }
   } else {
     r0 = (tb / nct) * PACK_T;
     nrow = min(PACK_T, j.krows - r0);
     if (j.imode == 1) {          // igemm dgrad: columns already run along the reference weight's input channels
-      for (int rr = q; rr < nrow; rr += 4) {
+      static_assert(PACK_TC == 64, "one column per lane");
+      for (int rr0 = q; rr0 < nrow; rr0 += 16) {            // four rows per thread in flight
+        int src[4];
 #pragma unroll
-        for (int cc = l; cc < PACK_TC; cc += 64) tile[rr][cc] = pack_elem<KKC>(1, j.W, r0 + rr, c0 + cc, j.Cout, j.Ctot, KK, m, j.lstm_hid);
+        for (int u = 0; u < 4; ++u) src[u] = rr0 + 4 * u < nrow ? pack_elem_idx<KKC>(1, r0 + rr0 + 4 * u, c0 + l, j.Cout, j.Ctot, KK, m, j.lstm_hid) : -1;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = j.W[src[u] < 0 ? 0 : src[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (rr0 + 4 * u < nrow) tile[rr0 + 4 * u][l] = src[u] < 0 ? 0.f : v[u];
       }
-    } else if (l < nrow) {       // forward layouts: lanes run down the rows
-#pragma unroll 4
-      for (int k = 0; k < PACK_TC / 4; ++k) {
-        const int cc = k * 4 + q;
-        tile[l][cc] = pack_elem<KKC>(j.imode, j.W, r0 + l, c0 + cc, j.Cout, j.Ctot, KK, m, j.lstm_hid);
+    } else {                     // forward layouts: lanes run down the rows
+      const int lr = l < nrow ? l : 0;
+      for (int k0 = 0; k0 < PACK_TC / 4; k0 += 4) {        // four columns per thread in flight
+        int src[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) src[u] = l < nrow ? pack_elem_idx<KKC>(j.imode, r0 + lr, c0 + (k0 + u) * 4 + q, j.Cout, j.Ctot, KK, m, j.lstm_hid) : -1;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = j.W[src[u] < 0 ? 0 : src[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (l < nrow) tile[l][(k0 + u) * 4 + q] = src[u] < 0 ? 0.f : v[u];
       }
     }
   }
