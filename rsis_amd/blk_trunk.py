@@ -223,8 +223,8 @@ class _SkipsBlkFn(torch.autograd.Function):
     grouped flush.  No layout converters between the trunk, the skip branches and the decoder."""
 
     @staticmethod
-    def forward(ctx, mods, *xs):
-        # mods: [(HipConv2d, HipBatchNorm2d)] per level, xs: the blk inputs
+    def forward(ctx, mods, _anchor, *xs):
+        # mods: [(HipConv2d, HipBatchNorm2d)] per level, xs: the blk inputs; _anchor: see skips_forward
         keep = any(ctx.needs_input_grad)
         zs, jobs = [], []
         for (conv, _unused), x in zip(mods, xs):
@@ -263,7 +263,7 @@ class _SkipsBlkFn(torch.autograd.Function):
                 if tb is None:
                     _acc(conv.bias, db)
         for i, ((conv, _unused), x, dz) in enumerate(zip(mods, xs, dzs)):
-            if ctx.needs_input_grad[1 + i]:
+            if ctx.needs_input_grad[2 + i]:
                 dx = torch.empty_like(x)
                 jobs.append(ops.blk_conv_job([dz], conv._pack.dgrad(conv.weight), conv.in_channels, cpack=conv._pack.cin, dsts=[dx]))
                 dxs.append(dx)
@@ -271,12 +271,24 @@ class _SkipsBlkFn(torch.autograd.Function):
                 dxs.append(None)
         if jobs:
             ops.blk_conv3x3_batch(jobs)
-        return (None,) + tuple(dxs)
+        return (None, None) + tuple(dxs)
 
 
 def skips_forward(mods, xs):
-    """[(sk_k, bn_k)] applied to the blk features xs -> the blk skip features (one autograd node)"""
-    return list(_SkipsBlkFn.apply(mods, *xs))
+    """[(sk_k, bn_k)] applied to the blk features xs -> the blk skip features (one autograd node).  As in layer_forward, an anchor
+    (any skip parameter that requires grad) keeps the node in the graph when none of the features carries a gradient -- a frozen
+    trunk in front of trainable skip branches (the reference's update_encoder=False phase still trains nothing of the encoder, but
+    a caller freezing only `base` must not silently lose sk / bn gradients)."""
+    anchor = None
+    if torch.is_grad_enabled() and not any(x.requires_grad for x in xs):
+        for conv, bn in mods:
+            for p in list(conv.parameters()) + list(bn.parameters()):
+                if p.requires_grad:
+                    anchor = p
+                    break
+            if anchor is not None:
+                break
+    return list(_SkipsBlkFn.apply(mods, anchor, *xs))
 
 
 def layer_forward(layer, x):

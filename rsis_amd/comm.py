@@ -31,13 +31,25 @@ class DirectComm(object):
             raise RsisHipError("DirectComm needs torch.distributed for the rendezvous")
         L = lib()
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.handle = None
+        # Agreement BEFORE anything that blocks inside RCCL: every rank resolves librccl and draws an id of its own (the
+        # call that loads the library; only rank 0's id is used), the outcome is MIN-reduced over the working torch.distributed
+        # group, and only a unanimous "loaded" goes on.  A rank that cannot load RCCL therefore fails everyone here, with the same
+        # sequence of torch.distributed collectives on every rank, instead of leaving the others inside ncclCommInitRank.
         buf = ctypes.create_string_buffer(128)
-        if self.rank == 0:
-            _check(L.rsis_comm_unique_id(buf), "rsis_comm_unique_id")
-        box = [bytes(buf.raw)]
+        rc = L.rsis_comm_unique_id(buf)
+        why = "" if rc == 0 else (L.rsis_comm_last_error() or b"").decode()
         if self.world > 1:
-            dist.broadcast_object_list(box, src=0)
-        self._id = ctypes.create_string_buffer(box[0], 128)
+            ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                raise RsisHipError("RCCL did not load on every rank" + (": " + why if why else ""))
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=0)          # reached by every rank or by none
+            buf = ctypes.create_string_buffer(box[0], 128)
+        elif rc != 0:
+            _check(rc, "rsis_comm_unique_id")
+        self._id = buf
         handle = ctypes.c_void_p()
         _check(L.rsis_comm_init(ctypes.byref(handle), self.world, self.rank, self._id), "rsis_comm_init")
         self.handle = handle
@@ -111,20 +123,95 @@ class DirectReducer(object):
         return True
 
 
+PROBE_TIMEOUT = float(os.environ.get("RSIS_COMM_PROBE_TIMEOUT", "120"))
+
+
+def _probe_child():
+    """`python -m rsis_amd.comm --probe` (one child per rank, spawned by probe_direct): its own small rendezvous (gloo over a port the
+    parents agreed on), a communicator, the eager and the captured-on-a-forked-stream all-reduce.  Exit code 0 = both returned the right
+    sums.  It runs in a process of its own so that a collective that never returns can be killed from outside."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["RSIS_COMM_PROBE_PORT"], rank=rank, world_size=world)
+    red = DirectReducer(DirectComm())
+    x = torch.full((1 << 20,), float(rank + 1), device="cuda")
+    red(x)
+    torch.cuda.synchronize()
+    if float(x[0]) != world * (world + 1) / 2 or float(x[-1]) != float(x[0]):
+        raise SystemExit(3)
+    red.self_test()
+    red.comm.close()
+    dist.destroy_process_group()
+
+
+def probe_direct(say=None, timeout=None):
+    """True iff a direct communicator over THESE ranks and devices came up, reduced correctly eagerly and inside a captured graph --
+    established in child processes (one per rank, same devices) under a deadline, because the failure mode that cannot be handled in
+    process is a collective that hangs: a hung child is killed by PID and the parents go on with the cut schedule.  Every parent
+    rank returns the same answer (MIN over torch.distributed).  Asked for by the round-4 advice: the captured forked-stream
+    all-reduce had only ever run at world size 1, so at world > 1 it has to prove itself on the node before it is used."""
+    import socket
+    import subprocess
+    import sys
+    say = say or (lambda _m: None)
+    timeout = PROBE_TIMEOUT if timeout is None else timeout
+    box = [None]
+    if dist.get_rank() == 0:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            box[0] = so.getsockname()[1]
+    dist.broadcast_object_list(box, src=0)
+    env = dict(os.environ, RSIS_COMM_PROBE_PORT=str(box[0]), RANK=str(dist.get_rank()), WORLD_SIZE=str(dist.get_world_size()),
+               LOCAL_RANK=str(torch.cuda.current_device()))
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    child = subprocess.Popen([sys.executable, "-m", "rsis_amd.comm", "--probe"], env=env, cwd=root, stdout=subprocess.DEVNULL,
+                             stderr=subprocess.PIPE)
+    try:
+        _, err = child.communicate(timeout=timeout)
+        rc = child.returncode
+    except subprocess.TimeoutExpired:
+        child.kill()                                   # the exact PID this rank started
+        _, err = child.communicate()
+        rc = -9
+    ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rc != 0:
+        say("direct RCCL probe failed on rank %d (%s): %s" % (dist.get_rank(), "timeout after %.0f s" % timeout if rc == -9 else "exit %d" % rc,
+                                                          (err or b"").decode(errors="replace").strip().splitlines()[-1:] or ""))
+    return int(ok.item()) == 1
+
+
+LAST_STATUS = {"mode": "none", "world": 1, "self_test": None, "probe": None, "why": None}
+
+
 def make_direct_reducer(log=None):
     """DirectReducer over the default process group, or None (with the reason logged) when the direct exchange does not apply:
-    RSIS_EXCHANGE=cuts / hooks, a backend other than nccl (RCCL needs one GPU per rank: the shared-GPU gloo tests), or any failure
-    to build / self-test the communicator."""
+    RSIS_EXCHANGE=cuts / hooks, a backend other than nccl (RCCL needs one GPU per rank: the shared-GPU gloo tests), a failed
+    out-of-process probe at world > 1 (probe_direct), or any failure to build / self-test the communicator.  What was decided and
+    why is kept in LAST_STATUS (bench.py prints it in its JSON line)."""
     say = log or (lambda _m: None)
     mode = os.environ.get("RSIS_EXCHANGE", "direct")
+    st = LAST_STATUS
+    st.update(mode="cuts", world=dist.get_world_size() if dist.is_initialized() else 1, self_test=None, probe=None, why=None)
     if mode in ("cuts", "hooks", "staged"):
+        st.update(mode="hooks" if mode == "hooks" else "cuts", why="RSIS_EXCHANGE=%s" % mode)
         say("direct RCCL exchange off (RSIS_EXCHANGE=%s)" % mode)
         return None
     if not (dist.is_initialized() and torch.cuda.is_available()):
+        st.update(why="no process group")
         return None
     if dist.get_backend() != "nccl":
+        st.update(why="backend %s" % dist.get_backend())
         say("direct RCCL exchange off (backend %s)" % dist.get_backend())
         return None
+    if dist.get_world_size() > 1 and os.environ.get("RSIS_COMM_PROBE", "1") != "0":
+        st["probe"] = probe_direct(say)
+        if not st["probe"]:
+            st.update(why="out-of-process probe failed")
+            say("direct RCCL exchange not available (probe failed): cut schedule over torch.distributed")
+            return None
     red, why = None, None
     try:
         red = DirectReducer(DirectComm())
@@ -136,7 +223,15 @@ def make_direct_reducer(log=None):
     ok = torch.tensor([1 if red is not None else 0], dtype=torch.int32, device="cuda")
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok.item()) == 0:
+        st.update(self_test=False, why=why or "failed on another rank")
         say("direct RCCL exchange not available%s" % (": " + why if why else " on another rank"))
         return None
+    st.update(mode="direct", self_test=True)
     say("direct RCCL exchange: communicator of %d rank(s), captured all-reduce self-test passed" % red.world)
     return red
+
+
+if __name__ == "__main__":
+    import sys
+    if "--probe" in sys.argv:
+        _probe_child()

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_group_kernel(const LstmBwdGroupF
 }
 
 // The same, four consecutive pixels per thread (every job's HW % 4 == 0 and 16-byte aligned tensors: the launcher checks) and NO load
-// under a condition: an absent operand (dh, dh2, dc_next, c_prev) reads `c` instead and is multiplied by 0.  The scalar kernel's
+// under a condition: an absent operand (dh, dh2, dc_next, c_prev) reads `c` instead and is selected away.  The scalar kernel's
 // `p.dh ? p.dh[e] : 0` chain compiles to four branch + load + vmcnt(0) groups -- five dependent round trips per thread, one
 // float each in flight: 3.9 TB/s on 4.2 GB per fp32 step.
 __global__ __launch_bounds__(256) void lstm_bwd_group_v4_kernel(const LstmBwdGroupF g) {
@@ -95,14 +95,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_group_v4_kernel(const LstmBwdGro
   const f32x4 cv = *(const f32x4*)(p.c + e);
   const f32x4 d1 = *(const f32x4*)((p.dh ? p.dh : p.c) + e), d2 = *(const f32x4*)((p.dh2 ? p.dh2 : p.c) + e);
   const f32x4 dn = *(const f32x4*)((p.dc_next ? p.dc_next : p.c) + e), cpv = *(const f32x4*)((p.c_prev ? p.c_prev : p.c) + e);
-  const float m1 = p.dh ? 1.f : 0.f, m2 = p.dh2 ? 1.f : 0.f, mn = p.dc_next ? 1.f : 0.f, mp = p.c_prev ? 1.f : 0.f;
+  // absent operands are SELECTED away (not multiplied by 0: 0 * Inf of a diverged cell state would poison terms the scalar kernel keeps
+  // finite); the loads above stay unconditional
+  const bool m1 = p.dh != nullptr, m2 = p.dh2 != nullptr, mn = p.dc_next != nullptr, mp = p.c_prev != nullptr;
   f32x4 dai, daf, dao, dag, dcp;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float tc = tanhf(cv[i]);
-    const float dhv = m1 * d1[i] + m2 * d2[i];
-    const float dcv = dhv * go[i] * (1.f - tc * tc) + mn * dn[i];
-    const float cp = mp * cpv[i];
+    const float dhv = (m1 ? d1[i] : 0.f) + (m2 ? d2[i] : 0.f);
+    const float dcv = dhv * go[i] * (1.f - tc * tc) + (mn ? dn[i] : 0.f);
+    const float cp = mp ? cpv[i] : 0.f;
     dai[i] = dcv * gg[i] * gi[i] * (1.f - gi[i]);
     daf[i] = dcv * cp * gf[i] * (1.f - gf[i]);
     dao[i] = dhv * tc * go[i] * (1.f - go[i]);

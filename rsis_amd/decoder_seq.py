@@ -66,6 +66,34 @@ def supported(decoder, skip_feats, T):
     return True
 
 
+class ShapeProbe(object):
+    """stands in for a skip feature (blk: [B][C/8][H][W][8] bf16, else fp32 NCHW) where only its shape / dtype are consulted: lets the
+    callers ask supported() BEFORE the encoder has run (train._blk_skips_ok)"""
+
+    def __init__(self, B, C, H, W, blk):
+        self.is_cuda = True
+        self.dtype = torch.bfloat16 if blk else torch.float32
+        self.shape = (B, C // 8, H, W, 8) if blk else (B, C, H, W)
+
+    def dim(self):
+        return len(self.shape)
+
+
+def supported_for_input(decoder, skip_channels, B, H, W, T):
+    """supported() for the skip features a (B, 3, H, W) input will produce when the encoder hands sk5..sk2 over as blk tensors and sk1
+    as fp32 NCHW: THE decision whether runIter / test() ask the encoder for blk skip features -- the same predicate the sequence node
+    applies afterwards, so the two cannot disagree."""
+    sizes, h, w = [], H, W
+    for _ in range(5):                      # stem / max-pool / strided 3x3 convs: every halving is ceil(n / 2)
+        h, w = (h + 1) // 2, (w + 1) // 2
+        sizes.append((h, w))
+    sizes = sizes[::-1]                     # x5 .. x1
+    if any(c % 8 for c in skip_channels[:4]):
+        return False
+    probes = [ShapeProbe(B, c, hh, ww, i < 4) for i, (c, (hh, ww)) in enumerate(zip(skip_channels, sizes))]
+    return supported(decoder, probes, T) and blk_supported(decoder, probes)
+
+
 class _Level(object):
     __slots__ = ("cell", "hid", "c_up", "c_skip", "H", "W", "hoist", "dyn", "G", "Hs", "Cs", "ACT", "UP", "KEY", "SIDE", "ARG", "skip")
 

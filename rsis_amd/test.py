@@ -20,8 +20,12 @@ def test(args, encoder, decoder, x, return_logits=False):
     #  NCHW copies between trunk, skip branches and decoder)
     from . import train as _train
     blk_ok = (x.is_cuda and _train.BLK_SKIPS[0] and hasattr(encoder, "sk5") and hasattr(decoder, "clstm_list") and
-              "forward" not in encoder.__dict__ and _train._blk_skips_ok(encoder, decoder, x))
+              "forward" not in encoder.__dict__ and hasattr(decoder, "forward_sequence") and _train._blk_skips_ok(encoder, decoder, x, T))
     feats = encoder(x, blk_skips=True) if blk_ok else encoder(x)        # test.py:35
+    if any(f.dim() == 5 for f in feats):
+        from . import blk_trunk, decoder_seq
+        if not decoder_seq.supported(decoder, feats, T):                # (same predicate as blk_ok asked: a conversion, never a crash)
+            feats = [blk_trunk.to_nchw(f) if f.dim() == 5 else f for f in feats]
     steps, hidden = decoder.forward_sequence(feats, T)                  # test.py:37-38 (the T decoder steps, wavefront order)
     for out_mask, out_class, out_stop in steps:
         out_mask = ops.upsample_bilinear_ac(out_mask, (x.size()[-2], x.size()[-1]))   # test.py:39-40

@@ -36,20 +36,28 @@ from .utils.utils import (base_param_multiplicity, check_parallel, get_base_para
 BLK_SKIPS = [os.environ.get("RSIS_BLK_SKIPS", "1") != "0"]       # A/B switch: blk skip features between encoder and decoder
 
 
-def _blk_skips_ok(encoder, decoder, x):
-    """the decoder will run on blk storage (decoder_seq.blk_supported, decided here from the modules and the input width) and the trunk
-    computes in blk tensors"""
+def _blk_skips_ok(encoder, decoder, x, T=1):
+    """the trunk computes in blk tensors and the decoder's sequence node will take blk skip features for this input -- asked of
+    decoder_seq.supported itself (through shape probes), not re-derived here"""
     from . import blk_trunk, decoder_seq
-    if not (decoder_seq.ENABLED[0] and decoder_seq.BLK_ENABLED[0] and blk_trunk.ENABLED[0] and getattr(encoder.base, "_blk", False)):
-        return False
-    hs = [c.hidden_size for c in decoder.clstm_list]
-    if not all(getattr(c, "dtype", ops.DTYPE_F32) == ops.DTYPE_BF16 and c.kernel_size == 3 for c in decoder.clstm_list):
+    if not (blk_trunk.ENABLED[0] and getattr(encoder.base, "_blk", False) and x.dim() == 4 and getattr(encoder, "kernel_size", 3) == 3):
         return False
     skips = [encoder.sk5, encoder.sk4, encoder.sk3, encoder.sk2, encoder.sk1]
-    return (all(h % 8 == 0 for h in hs) and hs[-1] == 8 and all(s.out_channels % 8 == 0 and s.in_channels % 8 == 0 for s in skips) and
-            x.shape[-1] % 4 == 0 and decoder.fused and decoder.skip_mode == "concat" and "forward" not in decoder.__dict__ and
-            decoder.dropout == 0 and decoder.dropout_cls == 0 and decoder.dropout_stop == 0 and 2 <= x.shape[0] <= 64 and
-            sum(hs) == decoder.fc_class.weight.shape[1] and decoder.conv_out.kernel_size == 3)
+    if any(s.in_channels % 8 for s in skips[:4]):
+        return False
+    return decoder_seq.supported_for_input(decoder, [s.out_channels for s in skips], x.shape[0], x.shape[-2], x.shape[-1], max(1, int(T)))
+
+
+_LOGGED = set()
+
+
+def log_once(key, msg):
+    """one line on stderr (rank 0) the first time a slower fallback is taken -- the step silently costing more is how perf cliffs hide"""
+    if key in _LOGGED:
+        return
+    _LOGGED.add(key)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[rsis_amd] fallback: %s" % msg, file=sys.stderr, flush=True)
 
 
 def _masked_mean(costs, sw):
@@ -123,14 +131,19 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
         # train.py:77 (once per iteration).  Under -dtype bf16 with the blk trunk and the blk decoder the skip features stay
         # channel-blocked bf16 between them (FeatureExtractor.forward(blk_skips=True)); everywhere else fp32 NCHW as in the reference
         blk_ok = (train and hasattr(decoder, "forward_sequence_stacked") and isinstance(encoder, FeatureExtractor) and
-                  BLK_SKIPS[0] and _blk_skips_ok(encoder, decoder, x))
+                  BLK_SKIPS[0] and _blk_skips_ok(encoder, decoder, x, t_run))
         feats = encoder(x, blk_skips=True) if blk_ok else encoder(x)
         # train.py:85-94: t_run decoder steps from the zero state -- RSIS.forward_sequence runs them in wavefront order with the
         # gate kernels of a (level, step) diagonal in one launch; same nodes, same results as t_run calls of decoder(feats, hidden)
         # (train.py never reads the final recurrent state: it is not materialised)
         stacked = decoder.forward_sequence_stacked(feats, t_run, want_hidden=False) if hasattr(decoder, "forward_sequence_stacked") else None
-        if stacked is None and blk_ok:
-            raise RuntimeError("runIter: blk skip features were produced but the decoder's sequence node does not apply (RSIS_BLK_SKIPS=0 avoids them)")
+        if stacked is None and any(f.dim() == 5 for f in feats):
+            # (cannot happen while _blk_skips_ok asks decoder_seq.supported itself; kept as a conversion instead of an error)
+            from . import blk_trunk
+            log_once("blk-feats-to-nchw", "blk skip features converted to fp32 NCHW: the decoder's sequence node does not apply")
+            feats = [blk_trunk.to_nchw(f) if f.dim() == 5 else f for f in feats]
+        if stacked is None:
+            log_once("per-step-decoder", "decoder runs per step (decoder_seq.supported is False for this model / input)")
         if stacked is not None:
             # the whole sequence as ONE autograd node (rsis_amd/decoder_seq.py): outputs already in the (B, t, .) layout of :118-120
             out_masks, out_classes, out_stops, hidden, (Hm, Wm) = stacked
@@ -158,12 +171,14 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
             iou_sums = ops.softiou_sums(out_masks, y_mask)
             scores[:, :, :t] = args.iou_weight * ops.softiou_cost_matrix(iou_sums)
         else:
+            log_once("softiou-bmm", "soft-IoU scores through torch.bmm (ops.softiou_supported is False for these shapes / dtypes)")
             scores[:, :, :t] = args.iou_weight * softIoU_matrix(y_mask, out_masks)
         valid = (sw_mask.unsqueeze(-1) * sw_mask[:, 0:args.maxseqlen].unsqueeze(1) > 0).float()   # :127-130
         scores = scores * valid + (1 - valid) * 10                                                 # :131
         if scores.is_cuda and scores.size(1) <= 64 and scores.size(1) >= scores.size(2):
             perm = ops.assign_min_cost(scores)                                                     # :137 on the device: no sync
         else:
+            log_once("host-assignment", "assignment on the host (scipy, one D2H sync per step): %d GT slots x %d steps" % (scores.size(1), scores.size(2)))
             perm = torch.from_numpy(match_indices(scores)).to(x.device)                           # more than 64 GT slots: host assignment (scipy), as the reference does
         idx = perm[:, 0:t]
         # :140 -- the permuted GT masks are a RETURN value here (the matched loss below reads y_mask through `perm`): 84 MB of
@@ -229,8 +244,9 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
             ops.DIRECT_GRAD[0] = prev
             ops.WGRAD_DEFER[0] = prev_defer
             del ops._WGRAD_QUEUE[:]
+            if staged:                # (restored on the error path too: a later hook-driven step must not find its hooks off)
+                encoder.split_backward, reducer.hooks_enabled = restore
         if staged:
-            encoder.split_backward, reducer.hooks_enabled = restore
             exchange.finish()         # waits; reduces "rest" and the range of any stage whose cut did not materialise
             apply_update(args, optims, 1.0 / reducer.world)
         elif do_update:

@@ -351,3 +351,33 @@ def test_blk_skip_branches_against_the_fp32_storage_branches():
         if e > lim:
             bad.append((k, e))
     assert not bad, bad[:8]
+
+
+def test_blk_skip_branches_train_behind_a_frozen_trunk():
+    """with `base` frozen the blk features carry no gradient; the skip node must stay in the graph (anchor parameter) so that
+    sk5..sk2 / bn5..bn2 receive the same gradients as with a trainable trunk."""
+    from helpers import mk_args
+    from rsis_amd.modules import FeatureExtractor
+    torch.manual_seed(0)
+    a = mk_args(hidden_size=128, dtype="bf16")
+    enc = FeatureExtractor(a).cuda().train()
+    x = torch.randn(4, 3, 96, 96, device="cuda")
+    grads = []
+    gws = None
+    for frozen in (False, True):
+        for p in enc.base.parameters():
+            p.requires_grad_(not frozen)
+        enc.zero_grad()
+        feats = enc(x, blk_skips=True)
+        dense = [from_blk(f) if f.dim() == 5 else f for f in feats]
+        if gws is None:
+            gws = [torch.randn_like(d) for d in dense]
+        sum((d.float() * g).sum() for d, g in zip(dense, gws)).backward()
+        grads.append({k: p.grad.detach().clone() for k, p in enc.named_parameters() if p.grad is not None and not k.startswith("base.")})
+    want = sorted(k for k in grads[0])
+    assert sorted(grads[1]) == want and any(k.startswith("sk5") for k in want) and any(k.startswith("bn2") for k in want), sorted(grads[1])
+    for k in want:
+        if k.startswith("sk") and k.endswith("bias"):
+            continue
+        e = float((grads[1][k] - grads[0][k]).norm() / grads[0][k].norm().clamp_min(1e-30))
+        assert e <= 0.02, (k, e)        # (not bit-equal: train-mode BatchNorm running statistics moved between the two passes; atomics order)

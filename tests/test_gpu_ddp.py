@@ -352,3 +352,31 @@ def test_direct_rccl_exchange_lives_inside_one_graph_and_equals_the_cut_schedule
     assert c2[0] and not c2[3] and c2[4] == 3 and c2[5], "the cut schedule did not run as three graphs + the update graph: %s" % (c2[:6],)
     assert ls == c2[2], "losses differ between the two schedules: %s vs %s" % (ls, c2[2])
     assert params == c2[7], "parameters after six steps differ between the direct and the cut schedule"
+
+
+def _worker_probe(q, timeout):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", RSIS_FORCE_DIST="1")
+    from rsis_amd import comm
+    from rsis_amd.train import init_distributed
+    init_distributed()
+    notes = []
+    q.put((comm.probe_direct(notes.append, timeout=timeout), notes))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("timeout,want", [(240.0, True), (0.05, False)])
+def test_out_of_process_probe_of_the_direct_exchange(timeout, want):
+    """comm.probe_direct: the communicator + eager + captured all-reduce are proven in a child process per rank under a
+    deadline before the training process commits to the direct schedule at world > 1; a child that does not finish in time is
+    killed and the answer is False on every rank (here: a deadline no child can meet)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_probe, args=(q, timeout))
+    p.start()
+    ok, notes = q.get(timeout=400)
+    p.join(120)
+    assert p.exitcode == 0
+    assert ok is want, notes
+    if not want:
+        assert notes and "timeout" in notes[0], notes
