@@ -140,13 +140,21 @@ def _plain(v):
 
 
 def load_checkpoint(model_name, use_gpu=True, root="../models"):
-    """reference utils/utils.py:97-111 (python-2 pickles of the reference load with encoding='latin1').  The four .pt files are
-    plain tensor dictionaries in both the reference's and this build's format: they are read with weights_only=True; args.pkl
-    goes through an allow-listed unpickler."""
+    """reference utils/utils.py:97-111.  The four .pt files are tensor dictionaries: files in torch's current zip format (this build's
+    own checkpoints, anything saved by torch >= 1.6) are read with weights_only=True; files in the pre-zip container the REFERENCE's
+    torch 0.2 wrote (python-2 protocol-2 pickles, `torch.cuda.FloatTensor` objects) go through rsis_amd.utils.legacy_pt, a closed-list
+    reader that needs neither the GPU they were saved from nor code execution.  Tensors come back on the CPU (`load_state_dict`
+    copies them to wherever the modules live; `use_gpu` is accepted for signature compatibility).  args.pkl (python 2 wrote it with
+    protocol 0) goes through an allow-listed unpickler, `latin1` for its str payloads."""
+    from . import legacy_pt
     d = os.path.join(root, model_name)
-    ml = None if use_gpu else (lambda storage, location: storage)
-    dicts = [torch.load(os.path.join(d, f), map_location=ml, weights_only=True)
-             for f in ("encoder.pt", "decoder.pt", "enc_opt.pt", "dec_opt.pt")]
+    dicts = []
+    for f in ("encoder.pt", "decoder.pt", "enc_opt.pt", "dec_opt.pt"):
+        path = os.path.join(d, f)
+        if legacy_pt.is_legacy_file(path):
+            dicts.append(legacy_pt.load(path))
+        else:
+            dicts.append(torch.load(path, map_location=(lambda storage, location: storage), weights_only=True))
     with open(os.path.join(d, "args.pkl"), "rb") as f:
         try:
             args = _ArgsUnpickler(f).load()

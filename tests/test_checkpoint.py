@@ -139,3 +139,105 @@ def test_args_pickle_numpy_scalars_and_refusals(tmp_path):
         except pickle.UnpicklingError:
             continue
         raise AssertionError("the args unpickler accepted %r" % (bad,))
+
+
+def _py2_opcodes(raw):
+    import pickletools
+    return [op.name for op, _arg, _pos in pickletools.genops(raw)]
+
+
+def test_python2_torch02_byte_streams_load(tmp_path):
+    """N4 against the reference environment's actual byte streams (oracle/legacy_ckpt.py emits them opcode by opcode: python 2.7
+    cPickle protocol 2 inside torch 0.2's pre-zip container for the four .pt files, python 2 protocol 0 for args.pkl).  Checked:
+    the streams hold python-2 opcodes only (py2 `str` = SHORT_BINSTRING, never BINUNICODE; NEWOBJ + BUILD tensors; BINPERSID storages),
+    stock torch's own legacy reader accepts the container (CPU-typed variant), and the product path -- load_checkpoint ->
+    check_parallel -> load_state_dict -- restores every tensor bit for bit from the `torch.cuda.FloatTensor` variant on a host
+    without that device, with the optimizer dictionaries and the args namespace intact."""
+    import io
+    from oracle import legacy_ckpt as G
+    from rsis_amd.utils import legacy_pt
+    a = _args(tmp_path, "py2")
+    enc, dec = FeatureExtractor(a), RSIS(a)
+    _fill(enc, 5)
+    _fill(dec, 6)
+    ns = {k: v for k, v in vars(a).items() if isinstance(v, (bool, int, float, str, type(None)))}
+    ns.update(epoch_resume=7, best_val_loss=np.float64(0.625), use_gpu=True)
+    dec_keys = list(dec.state_dict())
+    dec_opt = {"state": {94001 + i: {"step": 11, "exp_avg": np.full(tuple(dec.state_dict()[k].shape), 0.5, np.float32),
+                                     "exp_avg_sq": np.full(tuple(dec.state_dict()[k].shape), 0.25, np.float32)} for i, k in enumerate(dec_keys)},
+               "param_groups": [{"lr": 1e-3, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "params": [94001 + i for i in range(len(dec_keys))]}]}
+    d = G.write_reference_checkpoint(str(tmp_path), "py2", enc.state_dict(), dec.state_dict(), ns, parallel=True, cuda=True, dec_opt=dec_opt)
+    # --- the streams are python 2's
+    with open(os.path.join(d, "decoder.pt"), "rb") as f:
+        raw = f.read()
+    assert legacy_pt.is_legacy_file(os.path.join(d, "decoder.pt")) and raw[:2] == b"\x80\x02"
+    head = io.BytesIO(raw)
+    for _ in range(3):                       # magic number, protocol version, sys_info
+        pickle.load(head)
+    ops = _py2_opcodes(raw[head.tell():])
+    assert "SHORT_BINSTRING" in ops and "NEWOBJ" in ops and "BUILD" in ops and "BINPERSID" in ops and "BINPUT" in ops, sorted(set(ops))
+    assert not {"BINUNICODE", "SHORT_BINUNICODE", "BINBYTES", "SHORT_BINBYTES", "FRAME", "MEMOIZE"} & set(ops), sorted(set(ops))
+    assert b"ctorch.cuda\nFloatTensor" in raw and b"U\x14module.conv_out.bias" in raw
+    with open(os.path.join(d, "args.pkl"), "rb") as f:
+        araw = f.read()
+    # (pickletools cannot disassemble it: its STRING decoder insists on ASCII and the float64 payload is an escaped byte string)
+    assert araw.startswith(b"ccopy_reg\n_reconstructor\n") and b"sS'hidden_size'\n" in araw and b"\x80" not in araw[:2] and b"I01\n" in araw
+    assert b"cnumpy.core.multiarray\nscalar\n" in araw
+    # --- product path
+    e_sd, d_sd, e_opt, d_opt, largs = load_checkpoint("py2", use_gpu=True, root=str(tmp_path))
+    assert largs.epoch_resume == 7 and largs.hidden_size == 32 and largs.use_gpu is True and largs.model_name == "py2"
+    assert type(largs.best_val_loss) is float and largs.best_val_loss == 0.625
+    assert all(k.startswith("module.") and isinstance(k, str) for k in list(e_sd) + list(d_sd))
+    assert not any("num_batches_tracked" in k for k in e_sd)
+    e_sd, d_sd = check_parallel(e_sd, d_sd)
+    enc2, dec2 = FeatureExtractor(largs), RSIS(largs)
+    enc2.load_state_dict(e_sd)
+    dec2.load_state_dict(d_sd)
+    for m, m2 in ((enc, enc2), (dec, dec2)):
+        for k, v in m.state_dict().items():
+            if "num_batches_tracked" not in k:
+                assert torch.equal(v, m2.state_dict()[k]), k
+    assert e_opt == {"state": {}, "param_groups": []}
+    from rsis_amd.optim import FlatAdam
+    opt = FlatAdam(list(dec2.parameters()), lr=1e-3, name="dec")
+    assert opt.load_state_dict(d_opt) is not False and opt.group.step_count == 11
+    assert float(opt.group.exp_avg.min()) == 0.5 and float(opt.group.exp_avg_sq.max()) == 0.25
+    # --- stock torch reads the same container (CPU-typed tensors: this host has no GPU to put torch.cuda.FloatTensor on)
+    d2 = G.write_reference_checkpoint(str(tmp_path), "py2cpu", enc.state_dict(), dec.state_dict(), ns, parallel=False, cuda=False)
+    stock = torch.load(os.path.join(d2, "decoder.pt"), weights_only=False)
+    ours = legacy_pt.load(os.path.join(d2, "decoder.pt"))
+    assert list(stock) == list(ours) == dec_keys and all(torch.equal(stock[k], ours[k]) and torch.equal(ours[k], dec.state_dict()[k]) for k in stock)
+
+
+def test_legacy_reader_refuses_code_and_truncation(tmp_path):
+    from oracle import legacy_ckpt as G
+    from rsis_amd.utils import legacy_pt
+    p = os.path.join(str(tmp_path), "t.pt")
+    G.torch02_save(OrderedDict([("w", np.arange(12, dtype=np.float32).reshape(3, 4))]), p)
+    assert torch.equal(legacy_pt.load(p)["w"], torch.arange(12.0).reshape(3, 4))
+    with open(p, "rb") as f:
+        raw = f.read()
+    with open(p, "wb") as f:
+        f.write(raw[:-8])                                    # storage cut short
+    try:
+        legacy_pt.load(p)
+        raise AssertionError("truncated storage accepted")
+    except pickle.UnpicklingError:
+        pass
+    evil = raw.replace(b"ccollections\nOrderedDict\n", b"cos\nsystem\n", 1)
+    with open(p, "wb") as f:
+        f.write(evil)
+    try:
+        legacy_pt.load(p)
+        raise AssertionError("foreign global resolved")
+    except pickle.UnpicklingError as e:
+        assert "os.system" in str(e)
+    big = raw.replace(b"K\x03K\x04\x86", b"K\x09K\x04\x86", 1)   # size (3, 4) -> (9, 4): reaches outside its 12-element storage
+    assert big != raw
+    with open(p, "wb") as f:
+        f.write(big)
+    try:
+        legacy_pt.load(p)
+        raise AssertionError("out-of-storage tensor accepted")
+    except pickle.UnpicklingError:
+        pass

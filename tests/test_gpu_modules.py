@@ -188,6 +188,43 @@ def test_e2e_256_north_star():
     _loaded_native()
 
 
+def test_reference_era_checkpoint_runs_the_north_star_case(tmp_path):
+    """N4 end to end (reference utils/utils.py:12-32,89-111 + README.md:90-99): a checkpoint directory in the byte format of
+    the reference's environment (python 2.7 / torch 0.2: oracle/legacy_ckpt.py -- `module.`-prefixed DataParallel keys,
+    torch.cuda.FloatTensor objects, no num_batches_tracked, protocol-0 args.pkl) holding the e2e_256 weights is loaded through
+    load_checkpoint -> check_parallel -> load_state_dict exactly as reference eval.py:43-66 does, the modules are built from the
+    LOADED args namespace, and the HIP test() reproduces the reference's own outputs for those weights at the north-star 1e-4."""
+    from oracle import filler, legacy_ckpt
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.test import test as hip_test
+    from rsis_amd.utils.utils import check_parallel, load_checkpoint
+    g = gold("e2e_256")
+    a = mk_args(maxseqlen=int(g["T"]))
+    oenc = filler.fill_module(O.FeatureExtractor(a), seed=44)
+    odec = filler.fill_module(O.RSIS(a), seed=45)
+    ns = {k: v for k, v in vars(a).items() if isinstance(v, (bool, int, float, str, type(None)))}
+    ns.update(model_name="published", epoch_resume=12, best_val_loss=np.float64(0.731))
+    legacy_ckpt.write_reference_checkpoint(str(tmp_path), "published", oenc.state_dict(), odec.state_dict(), ns, parallel=True, cuda=True)
+    del oenc, odec
+    e_sd, d_sd, _eo, _do, largs = load_checkpoint("published", use_gpu=True, root=str(tmp_path))
+    assert next(iter(e_sd)).startswith("module.") and largs.hidden_size == 128 and largs.maxseqlen == int(g["T"])
+    e_sd, d_sd = check_parallel(e_sd, d_sd)
+    enc, dec = FeatureExtractor(largs).cuda(), RSIS(largs).cuda()
+    enc.load_state_dict(e_sd)
+    dec.load_state_dict(d_sd)
+    x = filler.tensor(44, "e2e_256.x", tuple(int(v) for v in g["shape"])).cuda()
+    sub = int(g["sub"])
+    masks, classes, stops = hip_test(largs, enc, dec, x)
+    logits, _, stop_logits = hip_test(largs, enc, dec, x, return_logits=True)
+    assert_close("ckpt.mask_logits", logits[:, :, ::sub, ::sub], g["mask_logits_sub"], 1e-4)
+    assert_close("ckpt.mask_probs", masks[:, :, ::sub, ::sub], g["mask_probs_sub"], 1e-4)
+    assert_close("ckpt.classes", classes, g["classes"], 1e-4)
+    assert_close("ckpt.stops", stops, g["stops"], 1e-4)
+    assert_close("ckpt.stop_logits", stop_logits, g["stop_logits"], 1e-4)
+    _loaded_native()
+
+
 def test_e2e_odd_size():
     from oracle import filler
     from oracle import rsis_oracle as O
