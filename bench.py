@@ -64,6 +64,11 @@ def _time_launch(launch, iters):
     return e0.elapsed_time(e1) / iters
 
 
+def _hw(imsize):
+    """(H, W) of the input image: `imsize` is an int (square) or a pair"""
+    return (imsize, imsize) if isinstance(imsize, int) else (int(imsize[0]), int(imsize[1]))
+
+
 def gate_kernel_roofline(B, iters, imsize, dtype="fp32", T=10, product_only=False):
     """The fused ConvLSTM gate kernel (rsis_convlstm_fwd) of the 5 pyramid scales of one decoder timestep, timed with HIP events
     on the launch stream, in the TWO forms SURVEY.md 8(d) asks for:
@@ -80,7 +85,7 @@ def gate_kernel_roofline(B, iters, imsize, dtype="fp32", T=10, product_only=Fals
     rows, tot = [], {"full_flops": 0.0, "full_ms": 0.0, "dyn_flops": 0.0, "dyn_ms": 0.0, "hoist_ms": 0.0, "bytes": 0.0}
     diag = []        # the five product launches as jobs of ONE rsis_convlstm_fwd_batch call (a steady-state wavefront diagonal)
     for li, (segs, hid, hw) in enumerate(GATE_LAYERS):
-        H = W = hw * imsize // 256
+        H, W = hw * _hw(imsize)[0] // 256, hw * _hw(imsize)[1] // 256
         c_skip = segs[-1]
         c_up = segs[0] if len(segs) > 1 else 0
         cin = sum(segs) + hid
@@ -118,6 +123,8 @@ def gate_kernel_roofline(B, iters, imsize, dtype="fp32", T=10, product_only=Fals
         f_dyn = 2.0 * M * ((c_up + hid) * 9) * (4 * hid)
         # minimum HBM bytes of the product launch: inputs [up | h_prev], G, c_prev in; h, c, saved gates out (fp32)
         byts = 4.0 * M * ((c_up + hid) + 4 * hid + hid + hid + hid + 4 * hid)
+        # SURVEY 8(d)'s minimal bytes of the FULLY fused reference cell (no saved gates, no hoisted term): x, h_prev, c_prev in; h, c out; weights
+        tot["min_bytes"] = tot.get("min_bytes", 0.0) + 4.0 * (M * (cin + 3 * hid) + 4 * hid * cin * 9)
         rows.append({"HxW": "%dx%d" % (H, W), "gemm_MKN_full": [M, cin * 9, 4 * hid], "gemm_MKN_product": [M, (c_up + hid) * 9, 4 * hid],
                      "ms_full": round(ms_full, 4), "tflops_full": round(f_full / ms_full / 1e9, 2),
                      "ms_product": round(ms_dyn, 4), "tflops_product": round(f_dyn / ms_dyn / 1e9, 2),
@@ -159,6 +166,10 @@ def gate_kernel_roofline(B, iters, imsize, dtype="fp32", T=10, product_only=Fals
                       "note": "the reference's un-hoisted launch (what round 1 reported as roofline.achieved)"},
            "traffic": None}
     out["algorithmic_mbytes_per_timestep"] = round(tot["bytes"] / 1e6, 1)
+    out["algorithmic_mbytes_note"] = ("bytes of the launch AS BUILT (inputs [up | h_prev], hoisted term G, c_prev in; h, c, saved gates out) -- the "
+                                      "denominator of traffic_vs_algorithmic; SURVEY 8(d)'s minimal bytes of a fully fused inference cell (no saved "
+                                      "gates, no G) are in survey_minimal_mbytes_per_timestep, the ratio to them in traffic_vs_survey_minimal")
+    out["survey_minimal_mbytes_per_timestep"] = round(tot["min_bytes"] / 1e6, 1)
     if dtype == "fp32":
         out.update({"bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4), "frac_algorithmic": round(algorithmic / PEAK_F32_MFMA_TFLOPS, 4),
@@ -177,12 +188,13 @@ def gate_kernel_roofline_blk(B, iters, imsize, T=10):
     gate term G in (4 hid x 2 B), c_prev in / c out (hid x 4 B each), h out (hid x 2 B), saved gates out (4 hid x 2 B)."""
     from rsis_amd import ops
     L_rows, jobs, tot_bytes, tot_flops, keep = [], [], 0.0, 0.0, []
+    min_bytes = 0.0
     dt = ops.DTYPE_BF16
     b16 = dict(dtype=torch.bfloat16, device="cuda")
     singles_ms = 0.0
     hoist_ms = 0.0
     for li, (segs, hid, hw) in enumerate(GATE_LAYERS):
-        H = W = hw * imsize // 256
+        H, W = hw * _hw(imsize)[0] // 256, hw * _hw(imsize)[1] // 256
         c_skip = segs[-1]
         c_up = segs[0] if len(segs) > 1 else 0
         cin = sum(segs) + hid
@@ -204,6 +216,7 @@ def gate_kernel_roofline_blk(B, iters, imsize, T=10):
         M = B * H * W
         fl = 2.0 * M * ((c_up + hid) * 9) * (4 * hid)
         byts = 1.0 * M * (2 * (c_up + hid) + 2 * 4 * hid + 4 * hid + 2 * hid + 4 * hid + 2 * 4 * hid)
+        min_bytes = min_bytes + 1.0 * M * (2 * cin + 4 * hid + 2 * hid + 4 * hid) + 2.0 * 4 * hid * cin * 9      # SURVEY 8(d) form, bf16 x / h, fp32 c
         L_rows.append({"HxW": "%dx%d" % (H, W), "gemm_MKN_product": [M, (c_up + hid) * 9, 4 * hid], "ms_product": round(ms, 4),
                        "tflops_product": round(fl / ms / 1e9, 2), "gbs_product": round(byts / ms / 1e6, 1), "mbytes": round(byts / 1e6, 1),
                        "ms_hoist_per_iteration": round(ms_h, 4)})
@@ -222,6 +235,9 @@ def gate_kernel_roofline_blk(B, iters, imsize, T=10):
             "executed_gflop_per_timestep": round(tot_flops / 1e9, 3), "hoisted_convs_ms_per_iteration": round(hoist_ms, 4),
             "achieved_executed": round(tot_flops / ms_diag / 1e9, 2), "achieved_algorithmic": None, "full_k": {"achieved": None, "note": "fp32 only"},
             "algorithmic_mbytes_per_timestep": round(tot_bytes / 1e6, 1), "traffic": None,
+            "algorithmic_mbytes_note": "bytes of the launch AS BUILT (see the docstring); SURVEY 8(d)'s minimal bytes of a fully fused inference cell "
+                                       "(no saved gates, no hoisted term) are in survey_minimal_mbytes_per_timestep",
+            "survey_minimal_mbytes_per_timestep": round(min_bytes / 1e6, 1),
             "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
             "note": "bf16 MFMA at 16x the f32 rate: the launch is bound by its activation traffic (2 B per blk element, 4 B per cell-state element)"}
 
@@ -245,21 +261,21 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
     blk_on = dtype != "fp32" and blk_trunk.ENABLED[0]      # the trunk's layers then run on channel-blocked bf16 tensors (conv_blk.hip)
     fam = {}
     for si, (cin, cout, ks, hw, count) in enumerate(TRUNK_SHAPES):
-        hw = hw * imsize // 256
+        hh, ww = hw * _hw(imsize)[0] // 256, hw * _hw(imsize)[1] // 256
         pad = ks // 2
         if blk_on and si < N_TRUNK_SHAPES:
-            xb = ops.blk_from_nchw(torch.randn(B, cin, hw, hw, device="cuda"))
-            yb = ops.blk_from_nchw(torch.randn(B, cout, hw, hw, device="cuda"))
+            xb = ops.blk_from_nchw(torch.randn(B, cin, hh, ww, device="cuda"))
+            yb = ops.blk_from_nchw(torch.randn(B, cout, hh, ww, device="cuda"))
             w = torch.randn(cout, cin, ks, ks, device="cuda") / (ks * cin ** 0.5)
             pack = ops.PackedConv(ks, [cin], stride=1, pad=pad, dtype=dt)
             wp, wd = pack.fwd(w), pack.dgrad(w)
             ob, dxb, dW = torch.empty_like(yb), torch.empty_like(xb), torch.zeros_like(w)
-            fl = 2.0 * B * hw * hw * cin * ks * ks * cout
-            ms_f = _time_launch(lambda: check(L.rsis_blk_conv2d(ptr(xb), B, cin, hw, hw, ptr(wp), cout, ks, None, ptr(ob), 0, stream()), "blk fwd"), iters)
-            ms_d = _time_launch(lambda: check(L.rsis_blk_conv2d(ptr(yb), B, cout, hw, hw, ptr(wd), cin, ks, None, ptr(dxb), 0, stream()), "blk dgrad"), iters)
-            ms_w = _time_launch(lambda: check(L.rsis_conv2d_wgrad(ptr(yb), ptr(xb), ptr(dW), B, cin, hw, hw, cout, hw, hw, ks, 1, pad, cin, 0, 0,
+            fl = 2.0 * B * hh * ww * cin * ks * ks * cout
+            ms_f = _time_launch(lambda: check(L.rsis_blk_conv2d(ptr(xb), B, cin, hh, ww, ptr(wp), cout, ks, None, ptr(ob), 0, stream()), "blk fwd"), iters)
+            ms_d = _time_launch(lambda: check(L.rsis_blk_conv2d(ptr(yb), B, cout, hh, ww, ptr(wd), cin, ks, None, ptr(dxb), 0, stream()), "blk dgrad"), iters)
+            ms_w = _time_launch(lambda: check(L.rsis_conv2d_wgrad(ptr(yb), ptr(xb), ptr(dW), B, cin, hh, ww, cout, hh, ww, ks, 1, pad, cin, 0, 0,
                                                                   ops.DTYPE_BF16_BLK, stream()), "blk wgrad"), iters)
-            act_bytes = 2.0 * B * hw * hw * (cin + cout)
+            act_bytes = 2.0 * B * hh * ww * (cin + cout)
             for name, ms, n in (("conv%dx%d fwd+dgrad" % (ks, ks), ms_f + ms_d, 2), ("conv%dx%d wgrad" % (ks, ks), ms_w, 1)):
                 f = fam.setdefault(name, {"flops": 0.0, "ms": 0.0, "bytes": 0.0, "launches": 0})
                 f["flops"] += n * fl * count
@@ -267,21 +283,21 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
                 f["bytes"] += n * act_bytes * count
                 f["launches"] += n * count
             continue
-        x = torch.randn(B, cin, hw, hw, device="cuda")
+        x = torch.randn(B, cin, hh, ww, device="cuda")
         w = torch.randn(cout, cin, ks, ks, device="cuda") / (ks * cin ** 0.5)
         pack = ops.PackedConv(ks, [cin], stride=1, pad=pad, dtype=dt)
         wp, wd = pack.fwd(w), pack.dgrad(w)
-        y = torch.empty(B, cout, hw, hw, device="cuda")
+        y = torch.empty(B, cout, hh, ww, device="cuda")
         dx, dW = torch.empty_like(x), torch.zeros_like(w)
         pa, ia, pd = ptr_array([x]), int_array([cin]), ptr_array([dx])
-        fl = 2.0 * B * hw * hw * cin * ks * ks * cout
-        ms_f = _time_launch(lambda: check(L.rsis_conv2d_fwd(pa, ia, 1, B, hw, hw, ptr(wp), cout, ks, 1, pad, None, None, ptr(y), hw, hw, 0, dt,
+        fl = 2.0 * B * hh * ww * cin * ks * ks * cout
+        ms_f = _time_launch(lambda: check(L.rsis_conv2d_fwd(pa, ia, 1, B, hh, ww, ptr(wp), cout, ks, 1, pad, None, None, ptr(y), hh, ww, 0, dt,
                                                             stream()), "fwd"), iters)
-        ms_d = _time_launch(lambda: check(L.rsis_conv2d_dgrad(ptr(y), B, cout, hw, hw, ptr(wd), cin, ks, 1, pad, pd, ia, 1, hw, hw, None, 0, dt,
+        ms_d = _time_launch(lambda: check(L.rsis_conv2d_dgrad(ptr(y), B, cout, hh, ww, ptr(wd), cin, ks, 1, pad, pd, ia, 1, hh, ww, None, 0, dt,
                                                               stream()), "dgrad"), iters)
-        ms_w = _time_launch(lambda: check(L.rsis_conv2d_wgrad(ptr(y), ptr(x), ptr(dW), B, cin, hw, hw, cout, hw, hw, ks, 1, pad, cin, 0, 0, dt,
+        ms_w = _time_launch(lambda: check(L.rsis_conv2d_wgrad(ptr(y), ptr(x), ptr(dW), B, cin, hh, ww, cout, hh, ww, ks, 1, pad, cin, 0, 0, dt,
                                                               stream()), "wgrad"), iters)
-        act_bytes = 4.0 * B * hw * hw * (cin + cout)
+        act_bytes = 4.0 * B * hh * ww * (cin + cout)
         for name, ms, n in (("conv%dx%d fwd+dgrad" % (ks, ks), ms_f + ms_d, 2), ("conv%dx%d wgrad" % (ks, ks), ms_w, 1)):
             f = fam.setdefault(name, {"flops": 0.0, "ms": 0.0, "bytes": 0.0, "launches": 0})
             f["flops"] += n * fl * count
@@ -296,9 +312,9 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
         for si, (cin, cout, ks, hw, count) in enumerate(TRUNK_SHAPES):
             if ks != ksz:
                 continue
-            hw = hw * imsize // 256
-            x = torch.randn(B, cin, hw, hw, device="cuda")
-            y = torch.randn(B, cout, hw, hw, device="cuda")
+            hh, ww = hw * _hw(imsize)[0] // 256, hw * _hw(imsize)[1] // 256
+            x = torch.randn(B, cin, hh, ww, device="cuda")
+            y = torch.randn(B, cout, hh, ww, device="cuda")
             jdt, ebytes = dt, 4.0
             if blk_on and si < N_TRUNK_SHAPES:
                 x, y, jdt, ebytes = ops.blk_from_nchw(x), ops.blk_from_nchw(y), ops.DTYPE_BF16_BLK, 2.0
@@ -308,10 +324,10 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
                 keep.append(dW)
                 j = WgradJob()
                 (j.dy, j.x, j.dW, j.B, j.Cs, j.H, j.W, j.Cout, j.Ho, j.Wo, j.ks, j.stride, j.pad, j.Ctot, j.c_off, j.lstm_hid, j.dtype) = (
-                    y.data_ptr(), x.data_ptr(), dW.data_ptr(), B, cin, hw, hw, cout, hw, hw, ks, 1, ks // 2, cin, 0, 0, jdt)
+                    y.data_ptr(), x.data_ptr(), dW.data_ptr(), B, cin, hh, ww, cout, hh, ww, ks, 1, ks // 2, cin, 0, 0, jdt)
                 jobs.append(j)
-                fl += 2.0 * B * hw * hw * cin * ks * ks * cout
-                by += ebytes * B * hw * hw * (cin + cout)
+                fl += 2.0 * B * hh * ww * cin * ks * ks * cout
+                by += ebytes * B * hh * ww * (cin + cout)
         arr = (WgradJob * len(jobs))(*jobs)
         ms = _time_launch(lambda: check(L.rsis_conv2d_wgrad_batch(arr, len(jobs), stream()), "wgrad_batch"), max(2, iters // 2))
         f = fam["conv%dx%d wgrad" % (ksz, ksz)]
@@ -428,7 +444,7 @@ def gate_kernel_traffic(batch, imsize, dtype="fp32", timeout=150):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", counter.lower(), "--",
                    sys.executable, os.path.abspath(__file__), "--roofline-only", "--product-only", "--kernel-iters", "4", "--batch", str(batch),
-                   "--imsize", str(imsize), "--dtype", dtype]
+                   "--imsize", str(_hw(imsize)[0]), "--imsize-w", str(_hw(imsize)[1]), "--dtype", dtype]
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
             path = None
             for root, _d, files in os.walk(tmp):
@@ -505,6 +521,79 @@ def self_launch(gpus):
     os.execve(sys.executable, cmd, env)
 
 
+def exchange_report(a, encoder, decoder, crits, optims, reducer, gstep, seg, batch, t_run, rank_ms, o, fence, note):
+    """What the gradient exchange of this run was and what it cost -- in the JSON line, so that a scaling curve explains itself
+    (VERDICT r4 item 7).  Runs on EVERY rank after the timed region (it issues collectives): (1) which schedule ran (direct RCCL inside
+    the iteration's graph / cut graphs over torch.distributed / eager staged) and why, (2) the bytes of the three gradient ranges, (3)
+    the collectives ALONE -- the three ranges all-reduced back to back with nothing to overlap: the un-hidden cost of the exchange,
+    (4) the same iteration WITHOUT any exchange (a second captured graph, reducer off; after the timed region the replicas may
+    drift): step - this = the EXPOSED part of the exchange, (5) per-rank step times."""
+    if reducer is None or not getattr(reducer, "active", False):
+        return {"mode": "none", "world": 1, "note": "single process, no gradient exchange (RSIS_FORCE_DIST=1 runs the collective path at world 1)"}
+    from rsis_amd import comm as _comm
+    from rsis_amd.train import EXCHANGE_CUTS, GraphedStep, exchange_plan
+    world = dist.get_world_size()
+    captured = gstep is not None and gstep.graph is not None
+    direct = captured and gstep.split and gstep.direct is not None
+    cuts = gstep.cuts if gstep is not None else EXCHANGE_CUTS
+    plan = exchange_plan(encoder, optims, cuts)
+    rep = {"mode": "direct-in-graph" if direct else ("cut-graphs" if captured else "eager-staged"),
+           "backend": dist.get_backend(), "world": world, "cuts": 0 if direct else cuts,
+           "rccl_direct": dict(_comm.LAST_STATUS),
+           "range_bytes": {k: int(sum(b.numel() * b.element_size() for b in v)) for k, v in plan.items()},
+           "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3), "all": [round(v, 3) for v in rank_ms]}}
+    try:
+        red = gstep._reduce if gstep is not None else (lambda b, _a=False: dist.all_reduce(b, op=dist.ReduceOp.SUM))
+        bufs = [b for k in ("dec", "trunk_hi", "rest") for b in plan[k]]
+        for b in bufs:
+            b.zero_()
+        fence()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        for b in bufs:
+            red(b)
+        e0.record()
+        for _ in range(reps):
+            for b in bufs:
+                red(b)
+        e1.record()
+        fence()
+        rep["allreduce_alone_ms"] = round(e0.elapsed_time(e1) / reps, 3)
+        nbytes = sum(rep["range_bytes"].values())
+        rep["allreduce_alone_busbw_gbs"] = round(2.0 * (world - 1) / world * nbytes / (e0.elapsed_time(e1) / reps) / 1e6, 1) if world > 1 else None
+    except Exception as ex:  # noqa: BLE001
+        rep["allreduce_alone_ms"] = "failed: %r" % (ex,)
+    if captured and not o.no_graph:
+        try:
+            if seg is not None and "exposed_allreduce" in seg and not direct:
+                rep["exposed_allreduce_ms_events"] = round(seg["exposed_allreduce"], 3)
+            gstep.release()
+            g2 = GraphedStep(a, encoder, decoder, crits, optims, None, warm=1)
+            while g2.graph is None and g2.failed is None:
+                g2(batch, t_run)
+            if g2.graph is None:
+                raise RuntimeError("capture failed: %s" % g2.failed)
+            for _ in range(3):
+                g2(batch, t_run)
+            n = max(5, o.steps // 3)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                g2(batch, t_run)
+            e1.record()
+            torch.cuda.synchronize()
+            ms0 = e0.elapsed_time(e1) / n
+            rep["step_ms_without_exchange"] = round(ms0, 3)
+            rep["exposed_allreduce_ms"] = round(max(rank_ms) - ms0, 3)
+            rep["exposed_note"] = ("max-over-ranks step time minus this rank's step time of the same captured iteration with the exchange off "
+                                   "(measured after the timed region); includes schedule overheads of the exchange (fork / join, cuts), not only wire time")
+            g2.release()
+        except Exception as ex:  # noqa: BLE001
+            rep["step_ms_without_exchange"] = "failed: %r" % (ex,)
+    note("exchange: %s" % json.dumps(rep))
+    return rep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -536,7 +625,7 @@ def main():
         return
     if o.roofline_only:
         assert torch.cuda.is_available(), "bench.py needs the GPU (there is no CPU path)"
-        print(json.dumps(_gate_roofline(o.batch, o.kernel_iters, o.imsize, o.dtype, o.T, product_only=o.product_only)))
+        print(json.dumps(_gate_roofline(o.batch, o.kernel_iters, (o.imsize, o.imsize_w or o.imsize), o.dtype, o.T, product_only=o.product_only)))
         return
 
     if o.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -571,8 +660,7 @@ def main():
         reducer.direct = make_direct_reducer(lambda m: print("[bench] rank %d: %s" % (rank, m), file=sys.stderr, flush=True) if rank == 0 else None)
     crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
     imw = o.imsize_w or o.imsize
-    if imw != o.imsize:
-        assert o.skip_roofline, "the roofline legs are defined on square inputs: pass --skip-roofline with --imsize-w"
+    geom = (o.imsize, imw)
     # 12 instances per image; with T > 12 every slot is an instance, so that all T steps run (train.py:87-92 stops after the
     # first step whose slot is empty in every image)
     batch = synthetic_batch(a.seed + 1000 * rank, o.batch, o.imsize, imw, a.gt_maxseqlen, max(12, min(o.T, a.gt_maxseqlen)), a.num_classes, "cuda")
@@ -613,20 +701,21 @@ def main():
 
     roof = roof_kernels = None
     if rank == 0 and not o.skip_roofline:
-        roof = _gate_roofline(o.batch, o.kernel_iters, o.imsize, o.dtype, o.T)
+        roof = _gate_roofline(o.batch, o.kernel_iters, geom, o.dtype, o.T)
         note("gate kernel roofline: executed %s, algorithmic %s, full-K %s TFLOP/s; %s %s of %s %s" % (
             roof["achieved_executed"], roof["achieved_algorithmic"], roof["full_k"]["achieved"], roof["bound"], roof["achieved"], roof["peak"], roof["unit"]))
-        roof_kernels = trunk_kernel_rooflines(o.batch, max(3, o.kernel_iters // 4), o.imsize, o.dtype)
+        roof_kernels = trunk_kernel_rooflines(o.batch, max(3, o.kernel_iters // 4), geom, o.dtype)
         note("roofline_kernels: %s" % "; ".join("%s %.1f TF/s" % (r["family"], r["tflops"]) for r in roof_kernels))
         if world == 1 and not o.skip_traffic:
             t0 = time.time()
-            traffic, detail = gate_kernel_traffic(o.batch, o.imsize, o.dtype)
+            traffic, detail = gate_kernel_traffic(o.batch, geom, o.dtype)
             roof["traffic"] = traffic
             if traffic is not None:
                 roof["traffic_unit"] = ("bytes per timestep (the gate launches of the 5 levels): 2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate "
                                         "passes; the x2 is the guide's gfx950 correction, re-measured for this kernel's dword LDS-DMA reads in "
                                         "profiles/r02_fetch_calibration.txt")
                 roof["traffic_vs_algorithmic"] = round(traffic / (roof["algorithmic_mbytes_per_timestep"] * 1e6), 3)
+                roof["traffic_vs_survey_minimal"] = round(traffic / (roof["survey_minimal_mbytes_per_timestep"] * 1e6), 3)
                 roof["traffic_detail"] = detail
             note("gate kernel HBM traffic: %s (%.0f s)" % (traffic if traffic is not None else detail, time.time() - t0))
     tw = time.time()
@@ -691,12 +780,15 @@ def main():
              "remaining range) %.2f | graph C (Adam + repack) %.2f"
              % (seg["cuts"], seg["replays"], " | ".join("%s %.2f" % (k, v) for k, v in seg.items() if k.startswith(("graph_A", "graph_B"))),
                 seg["exposed_allreduce"], seg["graph_C_adam_repack"]))
+    rank_ms = [1000.0 * dt / o.steps]
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        allt = [torch.zeros(1, device="cuda", dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allt, torch.tensor([dt], device="cuda", dtype=torch.float64))
+        rank_ms = [1000.0 * float(t.item()) / o.steps for t in allt]
+        dt = max(float(t.item()) for t in allt)                                   # MAX over ranks
     loss_val = float(losses[0])
     assert loss_val == loss_val, "loss is NaN"
+    exchange = exchange_report(a, encoder, decoder, crits, [enc_opt, dec_opt], reducer, gstep, seg, batch, t_run, rank_ms, o, fence, note)
 
     cpu, out, secondary = None, None, None
     if rank == 0:
@@ -736,13 +828,27 @@ def main():
             # BASELINE configs[4]'s per-GPU workload (Cityscapes geometry 512x1024, T=20, batch 8 per GPU, bf16), same harness, graph replay
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", "bf16", "--imsize", "512", "--imsize-w", "1024", "--batch", "8", "--T", "20",
-                                    "--steps", str(max(5, o.steps // 2)), "--warmup", str(o.warmup), "--skip-cpu", "--skip-secondary", "--skip-roofline"],
-                                   capture_output=True, text=True, timeout=600, env=dict(os.environ))
+                                    "--steps", str(max(5, o.steps // 2)), "--warmup", str(o.warmup), "--skip-cpu", "--skip-secondary",
+                                    "--kernel-iters", str(max(4, o.kernel_iters // 2))],
+                                   capture_output=True, text=True, timeout=900, env=dict(os.environ))
                 sj = json.loads(r.stdout.strip().splitlines()[-1])
                 sj["config"]["workload"] = sj["config"]["workload"].replace("configs[1]", "configs[4] per-GPU workload")
-                secondary.append({k: sj.get(k) for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config")})
+                secondary.append({k: sj.get(k) for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "roofline_kernels")})
             except Exception as ex:  # noqa: BLE001
                 secondary.append({"dtype": "bf16", "config": "configs[4]", "error": repr(ex)})
+            # the headline configuration once more with the collective path forced on at world size 1 (RSIS_FORCE_DIST=1: communicator,
+            # captured all-reduces, 1 / world scaling all run; the wire is a loop-back): what the exchange machinery costs per step
+            if os.environ.get("RSIS_FORCE_DIST", "") != "1":
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--batch", str(o.batch), "--imsize", str(o.imsize), "--T", str(o.T),
+                                        "--steps", str(max(10, o.steps // 2)), "--warmup", str(o.warmup), "--skip-cpu", "--skip-secondary", "--skip-roofline"],
+                                       capture_output=True, text=True, timeout=600,
+                                       env=dict(os.environ, RSIS_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())))
+                    sj = json.loads(r.stdout.strip().splitlines()[-1])
+                    sj["config"]["workload"] = sj["config"]["workload"].replace("configs[1]", "configs[1] with the gradient exchange forced on at world size 1")
+                    secondary.append({k: sj.get(k) for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "exchange")})
+                except Exception as ex:  # noqa: BLE001
+                    secondary.append({"dtype": "fp32", "config": "configs[1] + RSIS_FORCE_DIST=1", "error": repr(ex)})
             note("secondary (224x224): bf16 %s images/s, fp32 %s images/s" % (secondary[0].get("value"), secondary[1].get("value")))
         value = world * o.batch * o.steps / dt
         out = {"metric": "training images/sec at %dx%d, T=%d, batch=%d per GPU" % (o.imsize, imw, o.T, o.batch),
@@ -763,6 +869,7 @@ def main():
                                             if blk_trunk.ENABLED[0] else "fp32 NCHW everywhere (RSIS_BF16_STORAGE=0: bf16 operands only)")
         if seg is not None:
             out["config"]["exchange_ms_per_step"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in seg.items()}
+        out["exchange"] = exchange
     # RCCL prints a banner (version, library path) through C stdio, which on a pipe is flushed only at exit, i.e. AFTER anything
     # python printed: every rank flushes its C streams before the final barrier, rank 0 prints after it, so that the JSON line
     # is the last line of the job's (merged) stdout

@@ -46,6 +46,15 @@ def test_bench_two_ranks_one_json_line_graph_replay():
     assert ex["replays"] == 3 and ex["cuts"] == 2
     assert all(ex[k] >= 0 for k in ("graph_A_fwd_bptt", "graph_B1_trunk_bwd", "graph_B2_trunk_bwd", "exposed_allreduce", "graph_C_adam_repack"))
     assert "communicator size 2" in err and "split-graph schedule" in err
+    # the exchange explains itself in the JSON line (not only on stderr): schedule, why, bytes per range, the collectives alone, the
+    # same iteration without exchange, per-rank step times
+    xc = out["exchange"]
+    assert xc["mode"] == "cut-graphs" and xc["world"] == 2 and xc["cuts"] == 2 and xc["backend"] == "gloo", xc
+    assert xc["rccl_direct"]["mode"] == "cuts" and "gloo" in xc["rccl_direct"]["why"], xc["rccl_direct"]
+    rb = xc["range_bytes"]
+    assert set(rb) == {"dec", "trunk_hi", "rest"} and 150e6 < sum(rb.values()) < 200e6 and rb["trunk_hi"] > rb["dec"] > rb["rest"] > 0, rb
+    assert isinstance(xc["allreduce_alone_ms"], float) and isinstance(xc["step_ms_without_exchange"], float), xc
+    assert len(xc["rank_ms_per_step"]["all"]) == 2 and xc["rank_ms_per_step"]["max"] >= xc["rank_ms_per_step"]["min"] > 0
 
 
 def test_bench_two_ranks_eager_bucketed_exchange():
