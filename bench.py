@@ -788,6 +788,7 @@ def main():
         dt = max(float(t.item()) for t in allt)                                   # MAX over ranks
     loss_val = float(losses[0])
     assert loss_val == loss_val, "loss is NaN"
+    captured_launch = gstep is not None and gstep.graph is not None      # (exchange_report releases the captured graphs)
     exchange = exchange_report(a, encoder, decoder, crits, [enc_opt, dec_opt], reducer, gstep, seg, batch, t_run, rank_ms, o, fence, note)
 
     cpu, out, secondary = None, None, None
@@ -858,7 +859,7 @@ def main():
                "config": {"workload": "configs[1]: synthetic %dx%dx3, T=%d, batch=%d/GPU, ResNet-101 encoder + 5-scale ConvLSTM "
                                       "decoder, %s, fwd+match+3 losses+bwd+Adam (update_encoder on)" % (o.imsize, imw, o.T, o.batch, o.dtype),
                           "global_batch": world * o.batch, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5),
-                          "launch": "hipGraph replay of the captured iteration" if (gstep is not None and gstep.graph is not None)
+                          "launch": "hipGraph replay of the captured iteration" if captured_launch
                                     else "eager (one Python launch per kernel)"},
                "roofline": roof, "roofline_kernels": roof_kernels, "cpu_baseline": cpu, "secondary": secondary}
         if o.dtype != "fp32":

@@ -11,6 +11,7 @@ alone would be either meaningless or unmeetable by any fp32 implementation).
 bf16 bars: tests/test_gpu_bf16.py BF16_TOL.
 """
 import copy
+import os
 
 import numpy as np
 import pytest
