@@ -2,7 +2,7 @@
 # Regenerates the rocprofv3 summaries committed under profiles/ for one round (run on the GPU box: `gpurun -- bash tools/make_profiles.sh r03`).
 # Everything is written under gpurun_out/<tag>/ ; copy the *.txt / *.json you want judged into profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -56,6 +56,32 @@ for c in FETCH_SIZE WRITE_SIZE; do
   csvs="$csvs $(find $OUT/raw_st_$c -name '*counter_collection.csv' | head -1)"
 done
 python tools/step_traffic.py $csvs > $OUT/step_traffic_bf16_224.txt
+# ---- round 5: BASELINE configs[4]'s per-GPU workload (512x1024, T=20, batch 8, bf16): one replayed step, the roofline leg, its PMC bytes
+CFG4="--dtype bf16 --imsize 512 --imsize-w 1024 --batch 8 --T 20"
+db=$(prof step_cfg4 python bench.py $STEP $CFG4); python tools/prof_summary.py $db laststep > $OUT/bench_bf16_cfg4_step.txt
+db=$(prof roof_cfg4 python bench.py --roofline-only --product-only $CFG4)
+python tools/prof_by_grid.py $db "conv_blk_dec_group_kernel" > $OUT/roofline_leg_bf16_cfg4.txt
+python - $OUT/roof_cfg4.stdout >> $OUT/roofline_leg_bf16_cfg4.txt <<'PYEOF'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("# HIP events in the same (profiled) process: grouped launch %.4f ms per timestep; single launches %s; hoisted convs %.4f ms per iteration"
+      % (r["ms_per_timestep"], [(x["HxW"], x["ms_product"]) for x in r["per_scale"]], r["hoisted_convs_ms_per_iteration"]))
+PYEOF
+csvs=""
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $OUT/raw_pmc_cfg4_$c
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/raw_pmc_cfg4_$c -o pmc -- python bench.py --roofline-only --product-only --kernel-iters 4 $CFG4 > /dev/null 2>&1
+  csvs="$csvs $(find $OUT/raw_pmc_cfg4_$c -name '*counter_collection.csv' | head -1)"
+done
+python tools/pmc_summary.py "conv_blk_dec_group_kernel" $csvs > $OUT/gate_pmc_bf16_cfg4.txt
+# ---- round 5: MFMA-busy counters (their own pass, kernel-trace only) for the fp32 gate launch and the fp32 1x1 GEMM
+SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"
+rm -rf $OUT/raw_mfma_gate
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/raw_mfma_gate -o pmc -- python bench.py --roofline-only --product-only --kernel-iters 4 > /dev/null 2>&1
+python tools/pmc_summary.py "conv3x3_direct" $(find $OUT/raw_mfma_gate -name '*counter_collection.csv' | head -1) > $OUT/gate_mfma_busy_fp32.txt
+rm -rf $OUT/raw_mfma_gemm
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/raw_mfma_gemm -o pmc -- python tools/exp/gemm1x1_sweep.py --tiles 0 --iters 3 > /dev/null 2>&1
+python tools/pmc_summary.py "conv_igemm_kernel" $(find $OUT/raw_mfma_gemm -name '*counter_collection.csv' | head -1) > $OUT/gemm1x1_mfma_busy_fp32.txt
 # blocked bf16 conv against the fp32-storage bf16 conv on the trunk's shapes
 rm -rf $OUT/raw_*
 ls -la $OUT
