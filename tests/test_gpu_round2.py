@@ -322,6 +322,68 @@ def test_bf16_backward_against_an_independent_bf16_evaluation():
     assert not bad, "bf16 gradients further from fp32 than 2x an independent bf16 evaluation: %s" % bad[:6]
 
 
+def test_bf16_training_step_gradients_train_mode_batchnorm_well_conditioned():
+    """The step-level bf16 gradient check the filler-weight fixtures could not give (their train-mode BatchNorm chain has a condition
+    number of ~1e6): ONE runIter under `-dtype bf16` -- TRAIN-mode BatchNorm, so the blocked bf16 trunk, the blk skip
+    branches and the blk decoder all run, forward and backward -- at B = 8, 128 x 128, T = 3, hidden 128 with torch's DEFAULT initialisation
+    (well conditioned: activations O(1), no amplification through the 100 BatchNorms) and the mask loss only (no arg-max-routed
+    side-feature gradients).  Truth: the CPU oracle's iteration in float64 under the product's own assignment.  Bar per tensor, set by an
+    implementation-INDEPENDENT bf16 evaluation of the same graph (the oracle under torch's CPU bf16 autocast):
+    rel-L2(hip, f64) <= max(3 %, 2 x rel-L2(autocast, f64)); the loss within 1 % of the float64 loss."""
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import build_optimizers, runIter
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    from test_gpu_bf16 import BF16_TOL
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    B, S, T = 8, 128, 3
+    a = mk_args(maxseqlen=T, dtype="bf16", use_class_loss=False, use_stop_loss=False, optim="adam", optim_cnn="adam", lr=1e-3, lr_cnn=1e-6,
+                weight_decay=0.0, weight_decay_cnn=0.0)
+    a32 = mk_args(maxseqlen=T, use_class_loss=False, use_stop_loss=False)
+    torch.manual_seed(3)
+    oenc, odec = O.FeatureExtractor(a32), O.RSIS(a32)                     # torch default init
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    enc.load_state_dict(oenc.state_dict())
+    dec.load_state_dict(odec.state_dict())
+    batch = synthetic_batch(13, B, S, S, a.gt_maxseqlen, 12, a.num_classes, "cpu")
+    opts = list(build_optimizers(a, enc, dec))
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
+    losses, _outs, perms = runIter(a, enc, dec, *[t.cuda() for t in batch], crits, opts, mode="train", sync_losses=True, t_run=T, want_outs=False)
+    assign = perms[2].cpu().numpy()
+    hip = _grads_of(enc, dec)
+    hip.update({("enc." + k): p.grad.detach().cpu().clone() for k, p in enc.named_parameters() if k.startswith("base.") and not k.startswith("base.fc")})
+
+    def oracle_grads(e, d, b, ctx):
+        e.zero_grad()
+        d.zero_grad()
+        with ctx:
+            r = O.run_iter_forward(a32, e, d, *b, mode="train", assignment=assign)
+        r["loss"].backward()
+        out = {("dec." + k): p.grad.detach().double().clone() for k, p in d.named_parameters() if p.grad is not None}
+        out.update({("enc." + k): p.grad.detach().double().clone() for k, p in e.named_parameters() if p.grad is not None})
+        return float(r["loss"]), out
+    import contextlib
+    sd_bn = {k: v.clone() for k, v in oenc.state_dict().items() if "running_" in k or "num_batches" in k}
+    l16, g16 = oracle_grads(oenc, odec, batch, torch.autocast("cpu", dtype=torch.bfloat16))
+    oenc.load_state_dict(dict(oenc.state_dict(), **sd_bn))
+    e64, d64 = copy.deepcopy(oenc).double(), copy.deepcopy(odec).double()
+    b64 = tuple(t.double() if t.is_floating_point() else t for t in batch)
+    l64, g64 = oracle_grads(e64, d64, b64, contextlib.nullcontext())
+    assert abs(float(losses[0]) - l64) <= 0.01 * abs(l64), "bf16 loss %.5f vs float64 %.5f (autocast oracle %.5f)" % (float(losses[0]), l64, l16)
+    bad, rows = [], []
+    for k, ref in g64.items():
+        if k not in hip or float(ref.abs().max()) < 1e-12 or (k.startswith("enc.sk") and k.endswith("bias")):
+            continue                      # (a conv bias in front of a BatchNorm: zero gradient, both sides are noise)
+        e_hip, e_floor = _rel_l2(hip[k], ref), _rel_l2(g16[k], ref)
+        rows.append((e_hip / max(BF16_TOL["rel_l2"], 2.0 * e_floor), k, e_hip, e_floor))
+        if e_hip > max(BF16_TOL["rel_l2"], 2.0 * e_floor):
+            bad.append((k, round(e_hip, 4), round(e_floor, 4)))
+    print("bf16 train step: %d tensors, worst five (ratio to bar, name, hip, autocast floor): %s" % (len(rows), sorted(rows, reverse=True)[:5]))
+    assert len(rows) > 300
+    assert not bad, "bf16 gradients further from float64 than max(3 %%, 2 x an independent bf16 evaluation): %s" % bad[:8]
+
+
 _BENCH_ORACLE = {}
 _CONFIG_ORACLES = {}
 

@@ -193,3 +193,65 @@ def rle_numpy_decode_area(s):
         cnts.append(x)
         m += 1
     return int(sum(cnts[1::2]))
+
+
+def test_leaves_label_image_host_semantics():
+    """eval_leaves.py:105-120 restated (rsis_amd.eval_post.leaves_label_image; no device work): per-mask bytescale before the resize (so
+    the threshold is relative to the mask's own min / max), only timesteps whose stop probability exceeds -class_th paint, later
+    timesteps overwrite, timestep 0 paints label 0."""
+    import argparse
+    from rsis_amd import eval_post
+    a = argparse.Namespace(mask_th=0.5, class_th=0.5)
+    T, Hm, Wm, h, w = 4, 8, 8, 16, 24
+    m = np.zeros((T, Hm, Wm), np.float32)
+    m[0, :4, :4] = 0.9          # timestep 0: label 0 -> invisible
+    m[1, 2:6, 2:6] = 0.8
+    m[2, 4:, 4:] = 0.3          # max 0.3 < mask_th, but bytescale stretches it to 255: it DOES paint (the reference's quirk)
+    m[3, :, :] = 0.95           # would cover everything, but its stop probability is below class_th
+    stop = np.array([[0.9], [0.9], [0.9], [0.2]], np.float32)
+    lab = eval_post.leaves_label_image(a, torch.from_numpy(m), torch.from_numpy(stop), h, w)
+    assert lab.shape == (h, w) and lab.dtype == np.uint8
+    assert set(np.unique(lab)) == {0, 1, 2}
+    assert lab[h // 2 - 1, w // 2 - 2] == 1 and lab[h - 1, w - 1] == 2 and lab[1, 1] == 0
+    assert lab[h // 2 + 2, w // 2 + 3] == 2           # overlap of masks 1 and 2: the later timestep wins
+    # imresize = bytescale + PIL bilinear: a constant array maps to 0, a 0 / 1 array to 0 / 255
+    assert int(eval_post.imresize(np.full((4, 4), 0.7, np.float32), [8, 8]).max()) == 0
+    r = eval_post.imresize(np.array([[0, 1], [0, 1]], np.uint8) * np.uint8(255), [2, 8])
+    assert r.shape == (2, 8) and r[0, 0] == 0 and r[0, -1] == 255 and (np.diff(r[0].astype(int)) >= 0).all()
+
+
+@pytest.mark.gpu
+def test_cityscapes_and_leaves_writers(tmp_path):
+    """the on-disk outputs of eval_cityscapes.py:118-167 (one PNG of the largest connected component per (timestep, class), resized to
+    the image size, + `<sample>.txt` lines `<png> <cityscapes id> <class prob * objectness>`) and of eval_leaves.py:121-125 (label PNG
+    renamed rgb -> label) from test()-shaped outputs"""
+    import argparse
+    from PIL import Image
+    from rsis_amd import eval_post
+    a = argparse.Namespace(mask_th=0.5, class_th=0.5)
+    T, Hm, Wm, h, w, C = 3, 16, 32, 32, 64, 9
+    g = np.random.default_rng(5)
+    probs = np.zeros((T, Hm, Wm), np.float32)
+    probs[0, 2:10, 3:20] = 0.9
+    probs[0, 13:15, 28:31] = 0.8         # a second, smaller component: must not survive
+    probs[1, 5:7, 5:7] = 0.7
+    cls = g.random((T, C)).astype(np.float32)
+    stop = np.array([[0.9], [0.6], [0.1]], np.float32)
+    res = str(tmp_path / "city_results")
+    lines = eval_post.write_cityscapes_results(a, "frankfurt_000000_000294", torch.from_numpy(probs).cuda(), torch.from_numpy(cls),
+                                               torch.from_numpy(stop), h, w, res, "city_masks")
+    assert len(lines) == T * (C - 1)
+    txt = open(os.path.join(res, "frankfurt_000000_000294.txt")).read().splitlines()
+    assert len(txt) == len(lines)
+    name, cid, score = txt[0].split(" ")
+    assert name == "city_masks/frankfurt_000000_000294_0.png" and cid == "24" and abs(float(score) - cls[0, 1] * 0.9) < 1e-6
+    name, cid, score = txt[(C - 1) + 7].split(" ")
+    assert name.endswith("_%d.png" % (C - 1 + 7)) and cid == "33" and abs(float(score) - float(cls[1, 8]) * float(stop[1, 0])) < 1e-6
+    im = np.asarray(Image.open(os.path.join(res, "city_masks", "frankfurt_000000_000294_0.png")))
+    assert im.shape == (h, w) and im.dtype == np.uint8 and im[10, 20] == 255 and im[28, 59] == 0 and im[0, 0] == 0
+    empty = np.asarray(Image.open(os.path.join(res, "city_masks", "frankfurt_000000_000294_%d.png" % (2 * (C - 1)))))
+    assert empty.max() == 0                                              # timestep 2 has no pixel above the threshold
+    p = eval_post.write_leaves_result(a, "plant007_rgb", torch.from_numpy(probs).cuda(), torch.from_numpy(stop), h, w, str(tmp_path / "A1"))
+    assert p.endswith("plant007_label.png")
+    lab = np.asarray(Image.open(p))
+    assert lab.shape == (h, w) and set(np.unique(lab)) <= {0, 1} and lab[11, 11] == 1
