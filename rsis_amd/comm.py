@@ -166,15 +166,21 @@ def probe_direct(say=None, timeout=None):
     env.pop("TORCHELASTIC_RUN_ID", None)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-    child = subprocess.Popen([sys.executable, "-m", "rsis_amd.comm", "--probe"], env=env, cwd=root, stdout=subprocess.DEVNULL,
-                             stderr=subprocess.PIPE)
+    # (whatever goes wrong with the child on THIS rank -- it cannot be spawned, it dies, it never returns -- becomes rc != 0: every rank
+    #  still reaches the MIN all-reduce below, so the ranks cannot part ways here)
+    rc, err = -1, b""
     try:
-        _, err = child.communicate(timeout=timeout)
-        rc = child.returncode
-    except subprocess.TimeoutExpired:
-        child.kill()                                   # the exact PID this rank started
-        _, err = child.communicate()
-        rc = -9
+        child = subprocess.Popen([sys.executable, "-m", "rsis_amd.comm", "--probe"], env=env, cwd=root, stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.PIPE)
+        try:
+            _, err = child.communicate(timeout=timeout)
+            rc = child.returncode
+        except subprocess.TimeoutExpired:
+            child.kill()                                   # the exact PID this rank started
+            _, err = child.communicate()
+            rc = -9
+    except Exception as e:  # noqa: BLE001
+        err = repr(e).encode()
     ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if rc != 0:
