@@ -329,7 +329,12 @@ def test_bf16_training_step_gradients_train_mode_batchnorm_well_conditioned():
     (well conditioned: activations O(1), no amplification through the 100 BatchNorms) and the mask loss only (no arg-max-routed
     side-feature gradients).  Truth: the CPU oracle's iteration in float64 under the product's own assignment.  Bar per tensor, set by an
     implementation-INDEPENDENT bf16 evaluation of the same graph (the oracle under torch's CPU bf16 autocast):
-    rel-L2(hip, f64) <= max(3 %, 2 x rel-L2(autocast, f64)); the loss within 1 % of the float64 loss."""
+    rel-L2(hip, f64) <= max(3 %, 2 x rel-L2(autocast, f64)); the loss within 1 % of the float64 loss.
+    MEASURED (round 5, printed by the test): of 339 tensors only 14 are determined to 5 % by bf16 arithmetic at all (the decoder's and the
+    skip branches' -- there the HIP path is within 2.3 % of float64); for 313 the independent bf16 evaluation itself is > 50 % from float64
+    (median 127 %: the gradient of a randomly initialised 100-BatchNorm trunk is a sum of cancelling terms), and the HIP path sits at
+    <= 1.3 x that floor on every one of them.  So the step-level statement bf16 allows is "no further from the truth than bf16 arithmetic
+    itself", per tensor -- which is what is asserted; tighter per-kernel statements are in test_gpu_blk*.py (half a bf16 ulp per store)."""
     from oracle import rsis_oracle as O
     from rsis_amd.modules import FeatureExtractor, RSIS
     from rsis_amd.synthetic import synthetic_batch
@@ -665,8 +670,12 @@ def test_configs0_iteration_at_its_stated_size_matches_the_oracle(switches):
     assert (float((dec.fc_class.weight.detach() - head0).abs().max()) > 0) == switches[0]
 
 
-def test_train_py_runs_configs0_at_its_stated_size(tmp_path):
-    """`python -m rsis_amd.train` with configs[0]'s flag set at the stated size (256 x 256 via --resize, ResNet-101, hidden 128, T = 16,
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph-replay"])
+def test_train_py_runs_configs0_at_its_stated_size(tmp_path, graph):
+    """(graph-replay: the same run under `--graph` -- a REAL loader whose batches stop after different numbers of steps (3-9 leaves per
+    image), so train.py's cache of captured iterations (one hipGraph per (shapes, t_run, loss switches); four kept, least recently used
+    evicted) is exercised with more keys than it holds.)
+    `python -m rsis_amd.train` with configs[0]'s flag set at the stated size (256 x 256 via --resize, ResNet-101, hidden 128, T = 16,
     batch 2, `-class_loss_after -1`) for one epoch of a synthesised CVPPP A1 directory (96 training pairs = 48 iterations, the rest
     validation): runs on the device (the build has no CPU path: `--cpu` is refused, README), finite losses, checkpoint written."""
     import subprocess
@@ -678,12 +687,14 @@ def test_train_py_runs_configs0_at_its_stated_size(tmp_path):
     cmd = [sys.executable, "-m", "rsis_amd.train", "-model_name", "leaves_256", "-dataset", "leaves", "-leaves_dir", d, "-leaves_test_dir", d,
            "-num_classes", "2", "--resize", "-imsize", "256", "-maxseqlen", "16", "-gt_maxseqlen", "16", "-batch_size", "2", "-base_model", "resnet101",
            "-class_loss_after", "-1", "--log_term", "-max_epoch", "1", "-print_every", "12", "-models_root", models, "-num_workers", "2"]
-    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=1500)
+    r = subprocess.run(cmd + (["--graph"] if graph else []), cwd=root, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "Epoch 0:" in r.stdout and "nan" not in r.stdout.lower(), r.stdout[-1500:]
+    assert "capture failed" not in r.stdout + r.stderr, (r.stdout + r.stderr)[-1500:]
     assert os.path.exists(os.path.join(models, "leaves_256", "encoder.pt"))
-    r2 = subprocess.run(cmd + ["--cpu"], cwd=root, capture_output=True, text=True, timeout=600)
-    assert r2.returncode != 0 and "no CPU path" in (r2.stdout + r2.stderr)
+    if not graph:
+        r2 = subprocess.run(cmd + ["--cpu"], cwd=root, capture_output=True, text=True, timeout=600)
+        assert r2.returncode != 0 and "no CPU path" in (r2.stdout + r2.stderr)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
