@@ -380,12 +380,10 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgs p) {
   if constexpr (EPI == EPI_LSTM) {
     // the side feature of model.py:143 (as in conv3x3_direct.hip): one 64-bit atomic max per hidden channel and half wave
     if (p.side_key) {
+      unsigned long long kk[4];
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const unsigned long long k = rsis_key_max32(best[r4]);
-        const int jh = (co_base >> 2) + 2 * r4 + hi;
-        if (l31 == 0 && k != 0ull && jh < p.hid) atomicMax(p.side_key + (size_t)b0 * p.hid + jh, k);
-      }
+      for (int r4 = 0; r4 < 4; ++r4) kk[r4] = rsis_key_max32(best[r4]);
+      rsis_side_key_max4(p.side_key + (size_t)b0 * p.hid, (co_base >> 2) + hi, p.hid, kk, l31 == 0, tiles_x * tiles_y >= RSIS_SIDE_CHECK_TILES);
     }
   }
 #endif

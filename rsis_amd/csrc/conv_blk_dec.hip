@@ -295,12 +295,10 @@ __device__ __forceinline__ void bd_body(const BlkConvJob& p, const int bid, u32x
       __builtin_amdgcn_raw_buffer_store_b64(hc, r_h, (in && cbh < Cbh) ? (unsigned)(cbh * HW + osp) * 16u + 8u * hi : RSIS_OOB, 0, 0);
     }
     if (p.side_key) {
+      unsigned long long kk[4];
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const unsigned long long k = rsis_key_max32(best[r4]);
-        const int jh = 8 * cbh + 2 * r4 + hi;
-        if (l31 == 0 && k != 0ull && jh < hid) atomicMax(p.side_key + (size_t)b0 * hid + jh, k);
-      }
+      for (int r4 = 0; r4 < 4; ++r4) kk[r4] = rsis_key_max32(best[r4]);
+      rsis_side_key_max4(p.side_key + (size_t)b0 * hid, 8 * cbh + hi, hid, kk, l31 == 0, tiles_x * tiles_y >= RSIS_SIDE_CHECK_TILES);
     }
   }
 #endif
