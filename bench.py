@@ -139,12 +139,16 @@ def gate_kernel_roofline(B, iters, imsize, dtype="fp32", T=10, product_only=Fals
     # wavefront -- levels 0..4 at steps t+4..t, one timestep's worth of work -- as ONE rsis_convlstm_fwd_batch call ----
     from rsis_amd._lib import LstmJob
     jobs = (LstmJob * len(diag))()
+    keys = []
     for j, (dsrc, wd, G, c_prev, h, c, act, hid, H, W) in zip(jobs, diag):
         j.nsrc = len(dsrc)
         for k, s in enumerate(dsrc):
             j.src[k], j.Csrc[k] = s.data_ptr(), s.shape[1]
         (j.B, j.H, j.W, j.Wp, j.bias_packed, j.addend, j.c_prev, j.h_out, j.c_out, j.act_out, j.hid, j.ks, j.pad, j.tile, j.dtype) = (
             B, H, W, wd.data_ptr(), None, G.data_ptr(), c_prev.data_ptr(), h.data_ptr(), c.data_ptr(), act.data_ptr(), hid, 3, 1, 0, dt)
+        # (as the product launches it: the global max-pool of the side feature, model.py:143, folded into the epilogue as packed keys)
+        keys.append(torch.zeros(B, hid, dtype=torch.int64, device="cuda"))
+        j.side_key = keys[-1].data_ptr()
     ms_diag = _time_launch(lambda: check(L.rsis_convlstm_fwd_batch(jobs, len(diag), stream()), "rsis_convlstm_fwd_batch"), iters)
     singles_ms = tot["dyn_ms"]
     tot["dyn_ms"] = ms_diag
@@ -211,7 +215,8 @@ def gate_kernel_roofline_blk(B, iters, imsize, T=10):
         c_prev = torch.randn(B, hid, H, W, device="cuda")
         h, c = torch.empty((B, hid // 8, H, W, 8), **b16), torch.empty_like(c_prev)
         act = torch.empty((B, 4 * hid // 8, H, W, 8), **b16)
-        job = ops.blk_conv_job(srcs, wd, 4 * hid, addend=G, hid=hid, c_prev=c_prev, c_out=c, h_out=h, act_out=act)
+        key = torch.zeros(B, hid, dtype=torch.int64, device="cuda")          # (the side feature's max-pool keys, as the product launches it)
+        job = ops.blk_conv_job(srcs, wd, 4 * hid, addend=G, hid=hid, c_prev=c_prev, c_out=c, h_out=h, act_out=act, side_key=key)
         ms = _time_launch(lambda: ops.blk_conv3x3_batch([job]), iters)
         M = B * H * W
         fl = 2.0 * M * ((c_up + hid) * 9) * (4 * hid)
@@ -221,7 +226,7 @@ def gate_kernel_roofline_blk(B, iters, imsize, T=10):
                        "tflops_product": round(fl / ms / 1e9, 2), "gbs_product": round(byts / ms / 1e6, 1), "mbytes": round(byts / 1e6, 1),
                        "ms_hoist_per_iteration": round(ms_h, 4)})
         jobs.append(job)
-        keep.append((w, wh, wd, skip, G, srcs, c_prev, h, c, act))
+        keep.append((w, wh, wd, skip, G, srcs, c_prev, h, c, act, key))
         tot_bytes += byts
         tot_flops += fl
         singles_ms += ms
