@@ -31,18 +31,28 @@ __global__ __launch_bounds__(256) void softiou_sums_kernel(const float* __restri
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
-  for (long k = k0; k < k1; k += 8) {
-    f32x4 a = aone ? one4 : zero4, bv = bone ? one4 : zero4;
-    if (arow) {
-      const f32x4 v = *(gcf4_t)(pa + k);
+  // Loads are UNCONDITIONAL (rows beyond T / G read row 0 and are selected away) and four steps are requested before the first is used:
+  // `if (arow) v = load` compiled to branch + load + vmcnt(0) twice per 8-pixel step -- two dependent round trips per step, 120 us for a
+  // pass whose bytes need 50 (NOTES (32a)).
+  auto step = [&](const f32x4 va, const f32x4 vb) {
+    f32x4 a, bv;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a[e] = rsis_sigmoid(v[e]);
+    for (int e = 0; e < 4; ++e) {
+      a[e] = arow ? rsis_sigmoid(va[e]) : (aone ? 1.f : 0.f);
+      bv[e] = brow ? vb[e] : (bone ? 1.f : 0.f);
     }
-    if (brow) bv = *(gcf4_t)(pb + k);
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bv[e], acc, 0, 0, 0);
+  };
+  long k = k0;
+  for (; k + 32 <= k1; k += 32) {
+    f32x4 va[4], vb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { va[u] = *(gcf4_t)(pa + k + 8 * u); vb[u] = *(gcf4_t)(pb + k + 8 * u); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) step(va[u], vb[u]);
   }
+  for (; k < k1; k += 8) step(*(gcf4_t)(pa + k), *(gcf4_t)(pb + k));
   float* Sb = S + (size_t)b * (T + 1) * (G + 1);
   if (l31 <= G) {
 #pragma unroll
