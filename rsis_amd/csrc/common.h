@@ -136,6 +136,36 @@ __device__ __forceinline__ void rsis_side_key_max4(unsigned long long* row, int 
     if (lane_ok && k[r4] != 0ull && j0 + 2 * r4 < hid && k[r4] > cur[r4]) atomicMax(row + j0 + 2 * r4, k[r4]);
 }
 
+// ... and the form the gate kernels use since round 5: the half waves of a BLOCK first park their keys in LDS, the block combines them,
+// and ONE global atomic per hidden channel and block goes out -- 8 x fewer.  What it buys is set by the slot, not by the traffic: global
+// same-address atomics complete one after the other (~40-50 ns each), and with one per half wave the 112 x 112 level of a 224 x 224 batch
+// sent 448 to every slot -- 22 us on a launch of 24 (bf16), found when the bench's roofline leg started to launch with the keys as the
+// product does.  park: LDS, nwave x 8 slots of 8 bytes that nobody else touches any more (no initialisation needed: every half wave
+// writes its four slots, zeros included); EVERY thread of the block must call (it holds a barrier).  A wave covers the 8 hidden
+// channels wm * 8 .. + 7 (slot 2 r4 + hi); the WGN waves wm * WGN .. + WGN - 1 share them.
+__device__ __forceinline__ void rsis_side_key_block(unsigned long long* park, int wave, int WGM, int WGN, int hi, const unsigned long long* kk,
+                                                    bool lane_ok, unsigned long long* row, int jbase, int hid, bool check) {
+  if (lane_ok) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) park[wave * 8 + 2 * r4 + hi] = kk[r4];
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < WGM * 8) {
+    const int wm = t >> 3, c = t & 7;
+    unsigned long long k = 0ull;
+    for (int wn = 0; wn < WGN; ++wn) {
+      const unsigned long long v = park[(wm * WGN + wn) * 8 + c];
+      k = v > k ? v : k;
+    }
+    const int j = jbase + t;
+    if (k != 0ull && j < hid) {
+      const unsigned long long cur = check ? __hip_atomic_load(row + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      if (k > cur) atomicMax(row + j, k);
+    }
+  }
+}
+
 // Arguments of the split-K weight-gradient kernel (conv_wgrad.hip).
 struct WgradArgs {
   const float* dy;   // [B][CoutDy][Ho][Wo]   (for ConvLSTM: the gate pre-activation grads, interleaved rows)

@@ -435,7 +435,13 @@ __device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int
       unsigned long long kk[4];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) kk[r4] = rsis_key_max32(best[r4]);
-      rsis_side_key_max4(p.side_key + (size_t)b0 * p.hid, (co_base >> 2) + hi, p.hid, kk, l31 == 0, tiles_x * tiles_y >= RSIS_SIDE_CHECK_TILES);
+      if constexpr (KSP == 1)
+        // (parked in the staging buffers: dead since the barrier that ended the last chunk; no LDS of its own -- the 40 KB variants fit
+        //  four blocks on a CU exactly)
+        rsis_side_key_block((unsigned long long*)lds, wave, WGM, WGN, hi, kk, l31 == 0, p.side_key + (size_t)b0 * p.hid, (co_t * BM) >> 2, p.hid,
+                            tiles_x * tiles_y >= RSIS_SIDE_CHECK_TILES);
+      else      // (the waves of the second K half have left the kernel: no block barrier here)
+        rsis_side_key_max4(p.side_key + (size_t)b0 * p.hid, (co_base >> 2) + hi, p.hid, kk, l31 == 0, tiles_x * tiles_y >= RSIS_SIDE_CHECK_TILES);
     }
   }
 #endif

@@ -71,6 +71,7 @@ __device__ __forceinline__ void bd_body(const BlkConvJob& p, const int bid, u32x
 
   u32x4* const xs0 = lds;
   u32x4* const ws0 = lds + NR * XCP;
+  __shared__ unsigned long long skeys[4 * 8];       // EPI_LSTM: where the block's half waves park their side-feature keys (common.h)
 
   const int H = p.H, W = p.W, HW = H * W;
   const int ldw = p.ldw;
@@ -298,7 +299,8 @@ __device__ __forceinline__ void bd_body(const BlkConvJob& p, const int bid, u32x
       unsigned long long kk[4];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) kk[r4] = rsis_key_max32(best[r4]);
-      rsis_side_key_max4(p.side_key + (size_t)b0 * hid, 8 * cbh + hi, hid, kk, l31 == 0, tiles_x * tiles_y >= RSIS_SIDE_CHECK_TILES);
+      rsis_side_key_block(skeys, wave, WGM, WGN, hi, kk, l31 == 0, p.side_key + (size_t)b0 * hid, (co_t * BM) >> 2, hid,
+                          tiles_x * tiles_y >= RSIS_SIDE_CHECK_TILES);
     }
   }
 #endif
