@@ -217,7 +217,9 @@ def gate_kernel_roofline_blk(B, iters, imsize, T=10):
         act = torch.empty((B, 4 * hid // 8, H, W, 8), **b16)
         key = torch.zeros(B, hid, dtype=torch.int64, device="cuda")          # (the side feature's max-pool keys, as the product launches it)
         job = ops.blk_conv_job(srcs, wd, 4 * hid, addend=G, hid=hid, c_prev=c_prev, c_out=c, h_out=h, act_out=act, side_key=key)
-        ms = _time_launch(lambda: ops.blk_conv3x3_batch([job]), iters)
+        # (RSIS_BENCH_DIAG_ONLY=1, set for the PMC child passes: only the timestep's call is launched, so that every gate-kernel launch in
+        #  the counter file belongs to it -- the call may be one grid or, for very large jobs, several)
+        ms = 1e-9 if os.environ.get("RSIS_BENCH_DIAG_ONLY") == "1" else _time_launch(lambda: ops.blk_conv3x3_batch([job]), iters)
         M = B * H * W
         fl = 2.0 * M * ((c_up + hid) * 9) * (4 * hid)
         byts = 1.0 * M * (2 * (c_up + hid) + 2 * 4 * hid + 4 * hid + 2 * hid + 4 * hid + 2 * 4 * hid)
@@ -434,8 +436,8 @@ def gate_kernel_traffic(batch, imsize, dtype="fp32", timeout=150):
     if dtype != "fp32":
         from rsis_amd import decoder_seq
         blk = decoder_seq.BLK_ENABLED[0]
-        if blk:        # the roofline leg launches the group kernel six times: five single-job grids and the five-job grid (the largest)
-            name_re, n_shapes = GATE_BLK_RE, 6
+        if blk:        # the child launches only the timestep's call (RSIS_BENCH_DIAG_ONLY): one grid, or several when jobs go out alone
+            name_re, n_shapes = GATE_BLK_RE, 0
     import csv
     import shutil
     import statistics
@@ -443,7 +445,7 @@ def gate_kernel_traffic(batch, imsize, dtype="fp32", timeout=150):
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="rsis_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", RSIS_BENCH_DIAG_ONLY="1")
     per_counter = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -464,11 +466,8 @@ def gate_kernel_traffic(batch, imsize, dtype="fp32", timeout=150):
                     k = r["Kernel_Name"]
                     if r["Counter_Name"] == counter and name_re.search(k):
                         vals.setdefault((k, r["Grid_Size"]), []).append(float(r["Counter_Value"]))
-            if len(vals) != n_shapes:
+            if (n_shapes and len(vals) != n_shapes) or not vals:
                 return None, "expected %d gate-kernel launch shape(s) in the counter file, found %d" % (n_shapes, len(vals))
-            if blk:
-                big = max(vals, key=lambda kg: int(kg[1]))
-                vals = {big: vals[big]}
             per_counter[counter] = sum(statistics.median(v) for v in vals.values()) * 1024.0      # counters are in KiB
     except Exception as e:  # noqa: BLE001  (profiler missing / refused / timed out: the figure stays null)
         return None, "rocprofv3 pass failed: %r" % (e,)
