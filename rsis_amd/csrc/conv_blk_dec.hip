@@ -47,10 +47,12 @@ __device__ __forceinline__ float bd_lo(unsigned v) { return __uint_as_float(v <<
 __device__ __forceinline__ float bd_hi(unsigned v) { return __uint_as_float(v & 0xFFFF0000u); }
 __device__ __forceinline__ float bd_round(float v) { return bd_lo(bd_pack2(v, 0.f)); }      // the value a bf16 store keeps
 
-constexpr int bd_up256(int n) { return (n + 255) / 256 * 256; }
-// 16-byte cells of LDS one block of a tile variant needs: a ring of 3 stages of (activation patch + weight chunk)
+constexpr int bd_rows64(int n) { return (n + 63) / 64; }
+// 16-byte cells of LDS one block of a tile variant needs: a ring of NR stages of (activation patch + weight chunk), each padded to
+// whole 64-lane wave rows only (round 5: padded to 256-lane rows the 32-row variants needed 48 KB and three blocks fitted a CU; the
+// 1280-cell stage of the widest variant makes it 40 KB exactly: four)
 template <int BM, int TW, int TH, int NR>
-constexpr int bd_lds_cells() { return NR * (bd_up256(2 * (TH + 2) * (TW + 2)) + bd_up256(9 * 2 * BM)); }
+constexpr int bd_lds_cells() { return NR * 64 * (bd_rows64(2 * (TH + 2) * (TW + 2)) + bd_rows64(9 * 2 * BM)); }
 
 // The block program.  bid: the block's index inside its job.
 template <int BM, int TW, int TH, int EPI, int NR>
@@ -62,16 +64,14 @@ __device__ __forceinline__ void bd_body(const BlkConvJob& p, const int bid, u32x
   constexpr int TN = BN / WGN / 32;
   constexpr int PW = TW + 2, PH = TH + 2, IMS = PH * PW;
   constexpr int XC = NCB * IMS, WC = KK * NCB * BM;
-  constexpr int NXD = (XC + 255) / 256, NWD = (WC + 255) / 256;
-  constexpr int XCP = NXD * 256, WCP = NWD * 256;
-  constexpr int C_DMA = NXD + NWD;
+  // DMA at wave-row granularity: the stage is XR wave rows (64 cells) of activations followed by WR of weights; wave w issues rows w, w + 4, ...
+  // (a row is all-x or all-w: the descriptor is a wave-uniform choice), NI instructions per wave and chunk -- one fewer for the waves
+  // beyond TR % 4 (their `vmcnt` immediate follows)
+  constexpr int XR = bd_rows64(XC), WR = bd_rows64(WC), TR = XR + WR;
+  constexpr int NI = (TR + 3) / 4, STG = TR * 64;
   static_assert(TN >= 1 && BN % (WGN * 32) == 0 && WGM * WGN == 4, "tile");
-  static_assert(NR * (XCP + WCP) == bd_lds_cells<BM, TW, TH, NR>(), "LDS size helper out of sync");
-  static_assert(NR >= 2 && NR <= 3 && (NR - 2) * C_DMA < 64, "vmcnt is 6 bits");
-
-  u32x4* const xs0 = lds;
-  u32x4* const ws0 = lds + NR * XCP;
-  __shared__ unsigned long long skeys[4 * 8];       // EPI_LSTM: where the block's half waves park their side-feature keys (common.h)
+  static_assert(NR * STG == bd_lds_cells<BM, TW, TH, NR>(), "LDS size helper out of sync");
+  static_assert(NR >= 2 && NR <= 3 && (NR - 2) * NI < 64, "vmcnt is 6 bits");
 
   const int H = p.H, W = p.W, HW = H * W;
   const int ldw = p.ldw;
@@ -94,21 +94,23 @@ __device__ __forceinline__ void bd_body(const BlkConvJob& p, const int bid, u32x
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
 
-  unsigned xvo[NXD], wvo[NWD];
+  unsigned vo[NI];                 // byte offset of this lane's cell of its wave's i-th row (inside the x chunk or inside the weight chunk)
 #pragma unroll
-  for (int i = 0; i < NXD; ++i) {
-    const int e = tid + i * 256;
-    const int cb = e / IMS, rem = e - cb * IMS;
-    const int py = rem / PW, pxx = rem - py * PW;
-    const int gy = y0 + py - 1, gx = x0 + pxx - 1;
-    const bool ok = (e < XC) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
-    xvo[i] = ok ? (unsigned)(cb * HW + gy * W + gx) * 16u : RSIS_OOB;
+  for (int i = 0; i < NI; ++i) {
+    const int g = i * 4 + wave;
+    if (g < XR) {
+      const int e = g * 64 + lane;
+      const int cb = e / IMS, rem = e - cb * IMS;
+      const int py = rem / PW, pxx = rem - py * PW;
+      const int gy = y0 + py - 1, gx = x0 + pxx - 1;
+      const bool ok = (e < XC) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+      vo[i] = ok ? (unsigned)(cb * HW + gy * W + gx) * 16u : RSIS_OOB;
+    } else {
+      const int idx = (g - XR) * 64 + lane;
+      vo[i] = (g < TR && idx < WC) ? (unsigned)((idx / BM) * ldw + idx % BM) * 16u : RSIS_OOB;
+    }
   }
-#pragma unroll
-  for (int i = 0; i < NWD; ++i) {
-    const int idx = tid + i * 256;
-    wvo[i] = idx < WC ? (unsigned)((idx / BM) * ldw + idx % BM) * 16u : RSIS_OOB;
-  }
+  const bool full_rows = (TR % 4 == 0) || wave < (TR % 4);       // this wave issues NI (else NI - 1) DMA instructions per chunk
   const char* const wbase = (const char*)p.wp + (size_t)co_t * BM * 16;
 
   // chunk QG of the concatenated K axis = chunk cq of source s (the pack pads every source to whole 16-channel chunks)
@@ -125,14 +127,14 @@ __device__ __forceinline__ void bd_body(const BlkConvJob& p, const int bid, u32x
     const int cb0 = cq * NCB;                                                                                      \
     const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc(                                          \
         (void*)(sb + ((size_t)b0 * Cbs + cb0) * HW * 16), 0, min(NCB, Cbs - cb0) * HW * 16, 0x00020000);            \
-    u32x4* xd = xs0 + slot * XCP + wave * 64;                                                                      \
-    _Pragma("unroll") for (int i = 0; i < NXD; ++i)                                                                \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_vp_t)(xd + i * 256), 16, xvo[i], 0, 0, 0);                \
     const char* wrow = wbase + (size_t)(QG) * (KK * NCB) * ldw * 16;                                               \
     const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)wrow, 0, KK * NCB * ldw * 16, 0x00020000); \
-    u32x4* wd = ws0 + slot * WCP + wave * 64;                                                                      \
-    _Pragma("unroll") for (int i = 0; i < NWD; ++i)                                                                \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_, (lds_vp_t)(wd + i * 256), 16, wvo[i], 0, 0, 0);                \
+    u32x4* sd = lds + slot * STG + wave * 64;                                                                      \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                               \
+      const int g = i * 4 + wave;                                                                                  \
+      if (g < XR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_vp_t)(sd + i * 256), 16, vo[i], 0, 0, 0);     \
+      else if (g < TR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_, (lds_vp_t)(sd + i * 256), 16, vo[i], 0, 0, 0); \
+    }                                                                                                              \
   }
 
   int xoff[TN];
@@ -156,13 +158,13 @@ __device__ __forceinline__ void bd_body(const BlkConvJob& p, const int bid, u32x
 
   for (int t = 0; t < nq; ++t) {
     const int ahead = min(NR - 2, nq - 1 - t);
-    if (ahead == 1) { RSIS_VMCNT(C_DMA); }
+    if (ahead == 1) { if (full_rows) { RSIS_VMCNT(NI); } else { RSIS_VMCNT(NI - 1); } }
     else { RSIS_VMCNT(0); }
     __builtin_amdgcn_s_barrier();
     if (t + NR - 1 < nq) BD_ISSUE(t + NR - 1)
     {
-      const u32x4* Xs = xs0 + (t % NR) * XCP;
-      const u32x4* Ws = ws0 + (t % NR) * WCP + woff;
+      const u32x4* Xs = lds + (t % NR) * STG;
+      const u32x4* Ws = Xs + XR * 64 + woff;
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -299,7 +301,9 @@ __device__ __forceinline__ void bd_body(const BlkConvJob& p, const int bid, u32x
       unsigned long long kk[4];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) kk[r4] = rsis_key_max32(best[r4]);
-      rsis_side_key_block(skeys, wave, WGM, WGN, hi, kk, l31 == 0, p.side_key + (size_t)b0 * hid, (co_t * BM) >> 2, hid,
+      // (parked in the ring slot nobody reads any more: the last chunk sits in slot (nq - 1) % NR, slot nq % NR was last read before the
+      //  barrier every wave has passed and nothing was issued into it since -- no LDS of its own: 40 KB is four blocks per CU exactly)
+      rsis_side_key_block((unsigned long long*)(lds + (nq % NR) * STG), wave, WGM, WGN, hi, kk, l31 == 0, p.side_key + (size_t)b0 * hid, (co_t * BM) >> 2, hid,
                           tiles_x * tiles_y >= RSIS_SIDE_CHECK_TILES);
     }
   }
@@ -317,11 +321,12 @@ struct BlkConvGroup {
 static_assert(sizeof(BlkConvGroup) <= 4000, "kernel arguments are limited to 4 KB");
 constexpr int bd_max(int a, int b) { return a > b ? a : b; }
 
-// tile variants of the group kernel: 1 = 64 rows x 8x8 px (7 / 14-pixel maps: the decoder's coarse levels have >= 128 output rows),
-// 4 = 32 rows x 16x8, 5 = 32 rows x 32x8 (wide maps).  74 KB of LDS at most: two blocks per CU.
+// tile variants of the group kernel: 4 = 32 rows x 16x8 px, 5 = 32 rows x 32x8 px (wide maps).  40 KB of LDS: four blocks per CU.
+// (Until round 5 the 7 / 14-pixel levels ran a 64-row x 8x8 variant whose 18 wave rows of weights per stage set the kernel's LDS to
+//  48 KB -- three blocks per CU for EVERY job of the grid; they run variant 4 now: more, shorter blocks of a latency-bound job.)
 template <int EPI, int NR>
 __global__ __launch_bounds__(256) void conv_blk_dec_group_kernel(const BlkConvGroup g) {
-  constexpr int LMAX = bd_max(bd_lds_cells<64, 8, 8, NR>(), bd_max(bd_lds_cells<32, 16, 8, NR>(), bd_lds_cells<32, 32, 8, NR>()));
+  constexpr int LMAX = bd_max(bd_lds_cells<32, 16, 8, NR>(), bd_lds_cells<32, 32, 8, NR>());
   __shared__ __attribute__((aligned(16))) u32x4 lds[LMAX];
   const int b = blockIdx.x;
   int j = 0;
@@ -330,17 +335,15 @@ __global__ __launch_bounds__(256) void conv_blk_dec_group_kernel(const BlkConvGr
   const BlkConvJob& p = g.job[j];
   const int local = b - g.begin[j];
   switch (g.variant[j]) {
-    case 1: bd_body<64, 8, 8, EPI, NR>(p, local, lds); break;
     case 4: bd_body<32, 16, 8, EPI, NR>(p, local, lds); break;
     default: bd_body<32, 32, 8, EPI, NR>(p, local, lds); break;
   }
 }
 
 static int bd_pick_variant(const BlkConvJob& a, int force) {
-  if (force == 1 || force == 4 || force == 5) return force;
-  if (a.W <= 16) return a.Cout >= 64 ? 1 : 4;
-  if (a.W <= 32) return 4;
-  return 5;
+  if (force == 4 || force == 5) return force;
+  if (force == 1) return 4;            // (the retired 64-row variant: callers that still ask for it get the 16x8 tile)
+  return a.W <= 32 ? 4 : 5;
 }
 
 // n independent jobs with the same epilogue kind (epi: 0 plain, 1 LSTM) as grouped launches of <= RSIS_BD_MAXJ jobs, longest blocks first
@@ -366,7 +369,7 @@ int rsis_launch_conv_blk_dec(BlkConvJob* jobs, int n, int epi, const int* force_
       const int j = order[k];
       BlkConvJob a = jobs[j0 + j];
       const int v = var[j];
-      const int bm = v == 1 ? 64 : 32, tw = v == 5 ? 32 : (v == 4 ? 16 : 8);
+      const int bm = 32, tw = v == 5 ? 32 : 16;
       a.n_co_tiles = rsis_cdiv(a.Cout, bm);
       a.n_px_tiles = rsis_cdiv(a.W, tw) * rsis_cdiv(a.H, 8) * a.B;
       g.begin[k] = blocks;
