@@ -503,10 +503,13 @@ static bool bn_block_ok() {        // RSIS_BLK_BN_BLOCK=0: always the two-level 
   return ok;
 }
 static void bn_splits(int Cb, long N, int& S, long& per) {
-  // ~2048 blocks over the grid, at least 2048 cells per block (512 / 1024 measured: no better, NOTES (27)), at most 64 splits
+  // ~2048 blocks over the grid, at least `mincells` cells per block, at most 64 splits
+  // (at least 1024 cells per block: re-measured in round 5, after the apply kernels stopped adding the partial sums serially (NOTES (27)) --
+  //  2048: 12.10 / 12.54 ms per bf16 224^2 step on two boxes, 1024: 11.99 / 12.47, 512: 12.35; configs[4] geometry unchanged)
+  static const long mincells = getenv("RSIS_BLK_BN_MINCELLS") ? atol(getenv("RSIS_BLK_BN_MINCELLS")) : 1024;
   long s = 2048 / (Cb > 0 ? Cb : 1);
   if (s < 1) s = 1;
-  const long smax = (N + 2047) / 2048;
+  const long smax = (N + mincells - 1) / mincells;
   if (s > smax) s = smax;
   if (s > 64) s = 64;
   if (s < 1) s = 1;
