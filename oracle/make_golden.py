@@ -222,16 +222,144 @@ def round2_cases(O, filler, ref_model, ref_test, report):
     report.append((name + ".bytes", os.path.getsize(os.path.join(GOLD, name + ".npz"))))
 
 
+def round6_cases(O, filler, ref_model, ref_clstm, ref_test, report):
+    """Fixtures added in round 6 (VERDICT r5 "Missing 2" / SURVEY 8(c) last paragraph: logits O(1-5), saturated gates, T = 20).
+    `gates_gain` scales the ConvLSTM gate and conv_out weights of oracle/filler.py (2.0 in every earlier fixture):
+      e2e_256_hot : test() at 256x256, B=2, T=10 with gates_gain 6 -> |mask logit| reaches 5.5, half of all gate pre-activations
+                    are beyond |a| > 4 (sigmoid / tanh within 2 % of their asymptote); the share is stored per level.
+      e2e_256_T20 : the same geometry over T = 20 timesteps (the configs[4] sequence length) at gates_gain 4.
+      cell_hot    : ConvLSTMCell forward (t=0, t=1) + all gradients with inputs of scale 3 and gates_gain 6.
+    Every fixture also stores the float64 evaluation of the same graph: the reference arithmetic's own fp32 noise floor."""
+    a_ref, a_ora = mk_args(py2=True), mk_args()
+    renc, oenc = ref_model.FeatureExtractor(a_ref), O.FeatureExtractor(a_ora)
+    rdec, odec = ref_model.RSIS(a_ref), O.RSIS(a_ora)
+    for name, shape, T, sub, gain in (("e2e_256_hot", (2, 3, 256, 256), 10, 4, 6.0), ("e2e_256_T20", (2, 3, 256, 256), 20, 8, 4.0)):
+        for m in (renc, oenc):
+            filler.fill_module(m, seed=44)
+            m.eval()
+        for m in (rdec, odec):
+            filler.fill_module(m, seed=45, gates_gain=gain)
+            m.eval()
+        x = filler.tensor(44, name + ".x", shape)
+        a_ref.maxseqlen = a_ora.maxseqlen = T
+        logits, pre = [], [[] for _ in range(5)]
+        hooks = [rdec.register_forward_hook(lambda mod, inp, outp: logits.append(outp[0].detach().clone()))]
+        for i, cell in enumerate(rdec.clstm_list):
+            hooks.append(cell.Gates.register_forward_hook(lambda mod, inp, outp, _i=i: pre[_i].append(outp.detach().abs())))
+        with torch.no_grad():
+            rm, rc, rs = ref_test.test(a_ref, renc, rdec, x)
+        for h in hooks:
+            h.remove()
+        om, oc, os_ = O.test(a_ora, oenc, odec, x)
+        _ol, _, osl = O.test(a_ora, oenc, odec, x, return_logits=True)
+        report.append((name + ".masks", close(om, rm, 1e-5, name + ".masks")))
+        report.append((name + ".classes", close(oc, rc, 1e-5, name + ".classes")))
+        report.append((name + ".stops", close(os_, rs, 1e-5, name + ".stops")))
+        ref_logits = torch.cat(logits, 1)
+        with torch.no_grad():
+            feats = oenc(x)
+            hidden, ora_native = None, []
+            for _ in range(T):
+                m, _c, _s, hidden = odec(feats, hidden)
+                ora_native.append(m)
+        ora_native = torch.cat(ora_native, 1)
+        report.append((name + ".logits_native", close(ora_native, ref_logits, 5e-5, name + ".logits")))
+        e64, d64 = O.FeatureExtractor(a_ora).double(), O.RSIS(a_ora).double()
+        e64.load_state_dict(oenc.state_dict())
+        d64.load_state_dict(odec.state_dict())
+        e64.eval()
+        d64.eval()
+        with torch.no_grad():
+            f64 = e64(x.double())
+            hidden, nat64, stop64 = None, [], []
+            for _ in range(T):
+                m, _c, s_, hidden = d64(f64, hidden)
+                nat64.append(m)
+                stop64.append(s_)
+        nat64 = torch.cat(nat64, 1)
+        stop64 = torch.stack(stop64, 1)
+        floor = (ref_logits.double() - nat64).abs().max().item()
+        floor_stop = (osl.double().reshape(-1) - stop64.reshape(-1)).abs().max().item()
+        sat4 = np.array([float((torch.cat([q.flatten() for q in pre[i]]) > 4).float().mean()) for i in range(5)])
+        allp = torch.cat([q.flatten() for lv in pre for q in lv])
+        report.append((name + ".|logit|max", ref_logits.abs().max().item()))
+        report.append((name + ".logit_std", ref_logits.std().item()))
+        report.append((name + ".share_|logit|>3", float((ref_logits.abs() > 3).float().mean())))
+        report.append((name + ".share_gate_preact_|a|>4", float((allp > 4).float().mean())))
+        report.append((name + ".share_gate_preact_|a|>8", float((allp > 8).float().mean())))
+        report.append((name + ".fp32_floor_logits", floor))
+        report.append((name + ".fp32_floor_stop_logit", floor_stop))
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), shape=np.array(shape), T=np.array(T), sub=np.array(sub),
+                            gates_gain=np.array(gain),
+                            mask_logits_sub=npf(ref_logits[:, :, ::sub, ::sub]), mask_probs_sub=npf(rm[:, :, ::sub, ::sub]),
+                            classes=npf(rc), stops=npf(rs), stop_logits=npf(osl),
+                            mask_logits_sub_f64=npf(nat64[:, :, ::sub, ::sub]), stop_logits_f64=npf(stop64),
+                            logit_absmax=np.array(ref_logits.abs().max().item()), logit_std=np.array(ref_logits.std().item()),
+                            gate_sat4_per_level=sat4, gate_sat4=np.array(float((allp > 4).float().mean())),
+                            fp32_floor_logits=np.array(floor), fp32_floor_stop_logit=np.array(floor_stop))
+
+    # ---------------- cell_hot: saturated ConvLSTM cell, forward (None state, then with state) + every gradient ----------------
+    name, (B, Cin, hid, H, W), gain, xs = "cell_hot", (2, 40, 16, 12, 20), 6.0, 3.0
+    a = mk_args()
+    cells = {"ref": ref_clstm.ConvLSTMCell(a, Cin, hid, 3, 1), "ora": O.ConvLSTMCell(a, Cin, hid, 3, 1),
+             "f64": O.ConvLSTMCell(a, Cin, hid, 3, 1)}
+    for c in cells.values():
+        filler.fill_module(c, seed=12, gates_gain=gain)
+    cells["f64"].double()
+    out = {"shape": np.array([B, Cin, hid, H, W]), "gates_gain": np.array(gain), "x_scale": np.array(xs)}
+    res = {}
+    for tag, cell in cells.items():
+        dt = torch.float64 if tag == "f64" else torch.float32
+        x0 = filler.tensor(12, name + ".x0", (B, Cin, H, W), xs).to(dt).requires_grad_()
+        x1 = filler.tensor(12, name + ".x1", (B, Cin, H, W), xs).to(dt).requires_grad_()
+        gh = filler.tensor(12, name + ".gh", (B, hid, H, W)).to(dt)
+        gc = filler.tensor(12, name + ".gc", (B, hid, H, W)).to(dt)
+        pre = []
+        hk = cell.Gates.register_forward_hook(lambda mod, inp, outp: pre.append(outp.detach().abs()))
+        cell.zero_grad()
+        h0, c0 = cell(x0, None)
+        h1, c1 = cell(x1, (h0, c0))
+        hk.remove()
+        ((h1 * gh).sum() + (c1 * gc).sum()).backward()
+        res[tag] = dict(h0=h0, c0=c0, h1=h1, c1=c1, dx0=x0.grad.clone(), dx1=x1.grad.clone(),
+                        dW=cell.Gates.weight.grad.clone(), db=cell.Gates.bias.grad.clone())
+        if tag == "ref":
+            allp = torch.cat([q.flatten() for q in pre])
+            out["gate_sat4"] = np.array(float((allp > 4).float().mean()))
+            report.append((name + ".share_gate_preact_|a|>4", float(out["gate_sat4"])))
+            report.append((name + ".gate_preact_max", float(allp.max())))
+    for k in res["ref"]:
+        scale = max(1.0, float(res["ref"][k].abs().max()))
+        report.append((name + "." + k, close(res["ora"][k], res["ref"][k], 1e-5 * scale, name + "." + k)))
+        out[k] = npf(res["ref"][k])
+        out["f64." + k] = npf(res["f64"][k])
+        report.append((name + ".fp32_floor." + k, float((res["ref"][k].double() - res["f64"][k]).abs().max())))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+
+
 def main():
     from oracle import rsis_oracle as O
     from oracle import filler
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", default="all", choices=["all", "r1", "r2"],
-                    help="r1: the round-1 fixtures (REPORT.txt), r2: the fixtures added in round 2 (REPORT_r2.txt)")
+    ap.add_argument("--cases", default="all", choices=["all", "r1", "r2", "r6"],
+                    help="r1: the round-1 fixtures (REPORT.txt), r2: the fixtures added in round 2 (REPORT_r2.txt), "
+                         "r6: the hot / T=20 fixtures of round 6 (REPORT_r6.txt)")
     opt = ap.parse_args()
     ref_model, ref_clstm, ref_test, ref_hung, ref_obj = import_reference()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
+    if opt.cases in ("all", "r6"):
+        report = []
+        round6_cases(O, filler, ref_model, ref_clstm, ref_test, report)
+        w = max(len(k) for k, _ in report)
+        with open(os.path.join(GOLD, "REPORT_r6.txt"), "w") as f:
+            f.write("oracle vs imported reference (max abs err), dynamic range and fp32 noise floors of the hot / T=20 fixtures,\n"
+                    "generated by oracle/make_golden.py --cases r6\n")
+            for k, v in report:
+                f.write("%-*s %.3e\n" % (w, k, v))
+        print("round-6 fixtures written (%d checks)" % len(report))
+        if opt.cases == "r6":
+            return
     if opt.cases in ("all", "r2"):
         report = []
         round2_cases(O, filler, ref_model, ref_test, report)

@@ -16,7 +16,7 @@ def pytest_configure(config):
 # C-ABI entry point, the BASELINE geometries and the training step; then the bf16 twin) must not be hidden behind an auxiliary
 # test that happens to sort earlier alphabetically.  Modules not listed run after the parity suites and before the last group
 # (graph replay / multi-process tests, which exercise launch modes rather than arithmetic).
-_ORDER_FIRST = ["test_gpu_modules", "test_gpu_round2", "test_gpu_ops", "test_gpu_bf16", "test_gpu_bf16s", "test_maskpost", "test_targets",
+_ORDER_FIRST = ["test_gpu_modules", "test_gpu_hot", "test_gpu_round2", "test_gpu_ops", "test_gpu_bf16", "test_gpu_bf16s", "test_maskpost", "test_targets",
                 "test_augment", "test_leaves_loader"]
 _ORDER_LAST = ["test_gpu_determinism", "test_gpu_graph", "test_gpu_ddp", "test_gpu_bench"]
 
@@ -31,22 +31,27 @@ def _module_rank(item):
 
 
 def pytest_collection_modifyitems(config, items):
-    """`gpu` tests need a HIP device and the built library: skip (not fail) them elsewhere, so that a plain `pytest tests` on a
-    CPU box shows only real CPU-side regressions.  Also fixes the module run order (stable within a module), see _ORDER_FIRST."""
+    """`gpu` tests need a HIP device: on a box without one they are skipped, so that a plain `pytest tests` on a CPU box shows only
+    real CPU-side regressions.  On a box WITH a device a missing librsis_hip.so is a broken build, not a reason to skip: every `gpu`
+    test then FAILS ("green with skips" must not be possible).  Also fixes the module run order (stable within a
+    module), see _ORDER_FIRST."""
     import torch
     items.sort(key=_module_rank)
-    lib_path = os.path.join(ROOT, "rsis_amd", "lib", "librsis_hip.so")
-    why = None
+    lib_path = os.environ.get("RSIS_HIP_LIB") or os.path.join(ROOT, "rsis_amd", "lib", "librsis_hip.so")
     if not torch.cuda.is_available():
-        why = "no HIP GPU visible"
-    elif not os.path.exists(os.environ.get("RSIS_HIP_LIB") or lib_path):
-        why = "librsis_hip.so is not built"
-    if why is None:
-        return
-    skip = pytest.mark.skip(reason="gpu test: " + why)
-    for item in items:
-        if "gpu" in item.keywords:
-            item.add_marker(skip)
+        skip = pytest.mark.skip(reason="gpu test: no HIP GPU visible")
+        for item in items:
+            if "gpu" in item.keywords:
+                item.add_marker(skip)
+    elif not os.path.exists(lib_path):
+        config._rsis_missing_lib = lib_path
+
+
+def pytest_runtest_setup(item):
+    missing = getattr(item.config, "_rsis_missing_lib", None)
+    if missing and "gpu" in item.keywords:
+        pytest.fail("a HIP device is visible but %s is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(gpu tests fail, not skip, on a GPU box without the library)" % missing, pytrace=False)
 
 
 @pytest.fixture(scope="session")

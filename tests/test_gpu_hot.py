@@ -1,0 +1,146 @@
+"""GPU parity on the HOT fixtures of round 6 (SURVEY 8(c) last paragraph, VERDICT r5 "Missing 2"): the same reference path
+(src/test.py:16-50, src/modules/clstm.py:19-62) driven where it is hard --
+
+  e2e_256_hot : gate / conv_out weights x3 of the other fixtures: |mask logit| up to 5.5 (sigma 1.07), 48 % of ALL gate
+                pre-activations beyond |a| > 4 (93-98 % on the two coarsest levels, 30 % on the finest), B = 2, T = 10, 256x256;
+  e2e_256_T20 : T = 20 decoder steps (the configs[4] sequence length) at 256x256, weights x2: |logit| up to 3.3;
+  cell_hot    : one ConvLSTM cell, two steps, inputs of scale 3: 78 % of the pre-activations saturated, |a| up to 69; all gradients.
+
+Golden data = the unmodified reference's outputs (oracle/make_golden.py --cases r6; tests/golden/REPORT_r6.txt: oracle == reference
+bit for bit) AND the float64 evaluation of the same graph.  Bars, fixed before the kernels were run on these inputs:
+
+  * probabilities (mask, class, stop) and the raw stop logit: the flat north-star 1e-4 against the reference;
+  * mask logits against the reference: max(1e-4, 2 x floor), where floor = the reference's own max |fp32 - fp64| on the fixture
+    (1.0e-4 hot, 2.4e-4 T20: at these magnitudes the reference ITSELF is that far from the exact value, so two correct fp32
+    evaluations differ by up to twice that);
+  * mask logits against the float64 truth: max(1e-4, 1.5 x floor) -- the HIP path may not be materially further from the exact
+    result than the reference is;
+  * bf16: the bars of tests/test_gpu_bf16.py (3 % rel-L2, 10 % of max|ref|, 3e-2 on probabilities), unchanged.
+The measured figures are printed (pytest -s) and recorded in NOTES.md."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, gold, mk_args
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(g, dtype=None):
+    from oracle import filler
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    T, gain = int(g["T"]), float(g["gates_gain"])
+    a32 = mk_args(maxseqlen=T)
+    a = mk_args(maxseqlen=T, dtype=dtype) if dtype else a32
+    oenc = filler.fill_module(O.FeatureExtractor(a32), seed=44)
+    odec = filler.fill_module(O.RSIS(a32), seed=45, gates_gain=gain)
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    enc.load_state_dict(oenc.state_dict())
+    dec.load_state_dict(odec.state_dict())
+    return a, enc, dec
+
+
+@pytest.mark.parametrize("name", ["e2e_256_hot", "e2e_256_T20"])
+def test_e2e_hot_fp32(name):
+    from oracle import filler
+    from rsis_amd.test import test as hip_test
+    g = gold(name)
+    a, enc, dec = _models(g)
+    x = filler.tensor(44, name + ".x", tuple(int(v) for v in g["shape"])).cuda()
+    sub, floor = int(g["sub"]), float(g["fp32_floor_logits"])
+    masks, classes, stops = hip_test(a, enc, dec, x)
+    logits, _, stop_logits = hip_test(a, enc, dec, x, return_logits=True)
+    got = logits[:, :, ::sub, ::sub].double().cpu()
+    ref, f64 = torch.from_numpy(g["mask_logits_sub"]).double(), torch.from_numpy(g["mask_logits_sub_f64"]).double()
+    e_ref, e_64, r_64 = (got - ref).abs(), (got - f64).abs(), (ref - f64).abs()
+    print("\n%s: |logit|max %.2f, saturated gate share %.2f; mask logits: max|hip-ref| %.3e (%.1f %% of elements within 1e-4), "
+          "max|hip-f64| %.3e, the reference's own max|ref-f64| on the stored sub-sample %.3e (whole map %.3e)"
+          % (name, float(g["logit_absmax"]), float(g["gate_sat4"]), float(e_ref.max()), 100 * float((e_ref <= 1e-4).double().mean()),
+             float(e_64.max()), float(r_64.max()), floor))
+    assert_close(name + ".mask_logits vs reference", got, ref, max(1e-4, 2 * floor))
+    assert_close(name + ".mask_logits vs float64", got, f64, max(1e-4, 1.5 * floor))
+    assert_close(name + ".mask_probs", masks[:, :, ::sub, ::sub], g["mask_probs_sub"], 1e-4)
+    assert_close(name + ".classes", classes, g["classes"], 1e-4)
+    assert_close(name + ".stops", stops, g["stops"], 1e-4)
+    assert_close(name + ".stop_logits", stop_logits, g["stop_logits"], 1e-4)
+    assert "librsis_hip.so" in open("/proc/self/maps").read()
+
+
+def test_cell_hot_golden():
+    """clstm.py:19-62 with 78 % of the gate pre-activations saturated: h, c of both steps at 1e-4; gradients at the rule of
+    test_cell_golden (1e-4 of the tensor's scale + 1e-4 relative) widened by 3 x the reference's own |fp32 - fp64| of that tensor."""
+    from oracle import filler
+    from oracle import rsis_oracle as O
+    from rsis_amd.modules import ConvLSTMCell
+    name = "cell_hot"
+    g = gold(name)
+    B, Cin, hid, H, W = [int(v) for v in g["shape"]]
+    gain, xs = float(g["gates_gain"]), float(g["x_scale"])
+    ocell = filler.fill_module(O.ConvLSTMCell(mk_args(), Cin, hid, 3, 1), seed=12, gates_gain=gain)
+    cell = ConvLSTMCell(mk_args(), Cin, hid, 3, 1).cuda()
+    cell.load_state_dict(ocell.state_dict())
+    x0 = filler.tensor(12, name + ".x0", (B, Cin, H, W), xs).cuda().requires_grad_()
+    x1 = filler.tensor(12, name + ".x1", (B, Cin, H, W), xs).cuda().requires_grad_()
+    gh = filler.tensor(12, name + ".gh", (B, hid, H, W)).cuda()
+    gc = filler.tensor(12, name + ".gc", (B, hid, H, W)).cuda()
+    h0, c0 = cell(x0, None)
+    h1, c1 = cell(x1, (h0, c0))
+    ((h1 * gh).sum() + (c1 * gc).sum()).backward()
+    got = dict(h0=h0, c0=c0, h1=h1, c1=c1, dx0=x0.grad, dx1=x1.grad, dW=cell.Gates.weight.grad, db=cell.Gates.bias.grad)
+    for k, v in got.items():
+        ref, f64 = g[k], g["f64." + k]
+        floor = float(np.abs(ref.astype(np.float64) - f64).max())
+        err = float((v.detach().double().cpu() - torch.from_numpy(ref).double()).abs().max())
+        print("%s.%s: max|hip-ref| %.3e, reference's own |fp32-fp64| %.3e, |ref|max %.3g" % (name, k, err, floor, float(np.abs(ref).max())))
+        if k in ("h0", "c0", "h1", "c1"):
+            assert_close(name + "." + k, v, ref, 1e-4)
+        else:
+            assert_close(name + "." + k, v, ref, 1e-4 * max(1.0, float(np.abs(ref).max())) + 3 * floor, 1e-4)
+
+
+def test_e2e_hot_bf16():
+    """configs[2]-style bf16 inference on the hot fixture against the reference's fp32 golden.  What bf16 arithmetic can hold here was
+    measured with an implementation-INDEPENDENT bf16 evaluation first (the CPU oracle under torch's bf16 autocast, computed again in
+    this test): on the hot weights a bf16 rounding is amplified through 10 recurrent steps of saturating gates -- the autocast oracle is
+    2.8 % rel-L2 / max abs 1.33 (27 % of max|ref| 4.85) from the fp32 reference, growing 0.09 -> 1.33 over t = 0..9, with 2.4e-4 of the
+    elements beyond 10 % of max|ref| (on the cool e2e_256 fixture: 1.1 % / 0.020).  So the pointwise "10 % of max|ref|" bar of
+    test_gpu_bf16.py is not one bf16 can meet on this fixture, and the bar is stated as:
+      * mask logits rel-L2 < 3 % (unchanged);
+      * at most 1e-3 of the elements beyond 10 % of max|ref| (logits) / 3e-2 (mask probabilities);
+      * max abs error of logits and of probabilities <= 1.5 x the independent bf16 evaluation's;
+      * class / stop probabilities within 3e-2 (unchanged)."""
+    from oracle import filler
+    from oracle import rsis_oracle as O
+    from rsis_amd.test import test as hip_test
+    from test_gpu_bf16 import BF16_TOL, _rel_l2
+    name = "e2e_256_hot"
+    g = gold(name)
+    a, enc, dec = _models(g, dtype="bf16")
+    x = filler.tensor(44, name + ".x", tuple(int(v) for v in g["shape"]))
+    sub = int(g["sub"])
+    masks, classes, stops = hip_test(a, enc, dec, x.cuda())
+    logits, _, _sl = hip_test(a, enc, dec, x.cuda(), return_logits=True)
+    # the independent bf16 evaluation
+    a32 = mk_args(maxseqlen=int(g["T"]))
+    oenc = filler.fill_module(O.FeatureExtractor(a32), seed=44).eval()
+    odec = filler.fill_module(O.RSIS(a32), seed=45, gates_gain=float(g["gates_gain"])).eval()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ol, _oc, _os = O.test(a32, oenc, odec, x, return_logits=True)
+    ol = ol.float()[:, :, ::sub, ::sub].double()
+    ref = torch.from_numpy(g["mask_logits_sub"]).double()
+    refp = torch.from_numpy(g["mask_probs_sub"]).double()
+    got = logits[:, :, ::sub, ::sub].double().cpu()
+    gotp = masks[:, :, ::sub, ::sub].double().cpu()
+    e, ef = (got - ref).abs(), (ol - ref).abs()
+    ep, epf = (gotp - refp).abs(), (torch.sigmoid(ol) - refp).abs()
+    rel, big = _rel_l2(got, ref), BF16_TOL["decoder_logit"] * float(ref.abs().max())
+    print("\n%s bf16: mask logits rel-L2 %.3e (independent bf16 %.3e), max abs %.3e (independent %.3e) of max|ref| %.2f, share beyond "
+          "10 %% of max|ref| %.2e (independent %.2e); mask probs max abs %.3e (independent %.3e), share beyond 3e-2 %.2e"
+          % (name, rel, _rel_l2(ol, ref), float(e.max()), float(ef.max()), float(ref.abs().max()), float((e > big).double().mean()),
+             float((ef > big).double().mean()), float(ep.max()), float(epf.max()), float((ep > BF16_TOL["probs"]).double().mean())))
+    assert rel < BF16_TOL["rel_l2"], "mask logits rel L2 %.3e" % rel
+    assert float((e > big).double().mean()) <= 1e-3 and float((ep > BF16_TOL["probs"]).double().mean()) <= 1e-3
+    assert float(e.max()) <= 1.5 * float(ef.max()) and float(ep.max()) <= 1.5 * float(epf.max())
+    assert_close("hot.bf16.classes", classes, g["classes"], BF16_TOL["probs"])
+    assert_close("hot.bf16.stops", stops, g["stops"], BF16_TOL["probs"])

@@ -131,3 +131,39 @@ def test_e2e_256_matches_reference():
     assert_close("e2e.mask_logits", logits[:, :, ::sub, ::sub], g["mask_logits_sub"], 2e-5)
     assert_close("e2e.classes", classes, g["classes"], 1e-6)
     assert_close("e2e.stop_logits", stops, g["stop_logits"], 1e-5)
+
+
+@pytest.mark.parametrize("name", ["e2e_256_hot", "e2e_256_T20"])
+def test_e2e_hot_fixtures_match_reference(name):
+    """The hot / T = 20 fixtures of round 6 (oracle/make_golden.py --cases r6): gate and conv_out weights scaled so that mask logits
+    reach +-5.5 and half of the gate pre-activations saturate; the oracle reproduces the reference's stored outputs."""
+    g = gold(name)
+    a = mk_args(maxseqlen=int(g["T"]))
+    enc = filler.fill_module(O.FeatureExtractor(a), seed=44).eval()
+    dec = filler.fill_module(O.RSIS(a), seed=45, gates_gain=float(g["gates_gain"])).eval()
+    x = filler.tensor(44, name + ".x", tuple(int(v) for v in g["shape"]))
+    sub = int(g["sub"])
+    logits, classes, stops = O.test(a, enc, dec, x, return_logits=True)
+    assert_close(name + ".mask_logits", logits[:, :, ::sub, ::sub], g["mask_logits_sub"], 2e-5)
+    assert_close(name + ".classes", classes, g["classes"], 1e-6)
+    assert_close(name + ".stop_logits", stops, g["stop_logits"], 1e-5)
+    assert float(g["logit_absmax"]) > 3.0 and float(g["gate_sat4"]) > 0.3      # the fixture is what it says it is
+
+
+def test_cell_hot_matches_reference():
+    name = "cell_hot"
+    g = gold(name)
+    B, Cin, hid, H, W = [int(v) for v in g["shape"]]
+    cell = filler.fill_module(O.ConvLSTMCell(mk_args(), Cin, hid, 3, 1), seed=12, gates_gain=float(g["gates_gain"]))
+    xs = float(g["x_scale"])
+    x0 = filler.tensor(12, name + ".x0", (B, Cin, H, W), xs).requires_grad_()
+    x1 = filler.tensor(12, name + ".x1", (B, Cin, H, W), xs).requires_grad_()
+    gh = filler.tensor(12, name + ".gh", (B, hid, H, W))
+    gc = filler.tensor(12, name + ".gc", (B, hid, H, W))
+    h0, c0 = cell(x0, None)
+    h1, c1 = cell(x1, (h0, c0))
+    ((h1 * gh).sum() + (c1 * gc).sum()).backward()
+    got = dict(h0=h0, c0=c0, h1=h1, c1=c1, dx0=x0.grad, dx1=x1.grad, dW=cell.Gates.weight.grad, db=cell.Gates.bias.grad)
+    for k, v in got.items():
+        assert_close(name + "." + k, v, g[k], 2e-5 * max(1.0, float(np.abs(g[k]).max())), 1e-5)
+    assert float(g["gate_sat4"]) > 0.5
