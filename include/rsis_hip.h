@@ -491,11 +491,14 @@ int rsis_upconv_out_bwd(const float* dout, const void* h, int h_blk, const float
  * gradient buffers SUM-all-reduced over xGMI once per iteration).  A collective issued here is an ordinary operation of `stream`: it
  * can be captured into the hipGraph of the training iteration (torch.distributed's ProcessGroupNCCL cannot: its watchdog thread's
  * event queries abort a concurrent stream capture).  RCCL is resolved at run time (dlopen); RSIS_ERR_UNSUPPORTED if it is not there.
+ *   rsis_comm_available : RSIS_OK iff librccl resolves in this process (dlopen + symbols only: no bootstrap listener, no device work);
+ *                         what every rank calls to AGREE on the direct exchange before anything that can block inside RCCL;
  *   rsis_comm_unique_id : rank 0 fills id_out[128] (ncclUniqueId); the caller distributes it to the other ranks (any channel);
  *   rsis_comm_init      : collective over the `world` ranks, each on its own current HIP device; *comm receives the communicator;
  *   rsis_comm_size      : number of ranks of the communicator (-1 on error);
  *   rsis_comm_allreduce_sum_f32 : buf[n] <- sum over ranks, in place, enqueued on `stream`;
  *   rsis_comm_destroy, rsis_comm_last_error (text of the last RCCL failure of this process). ---- */
+int rsis_comm_available(void);
 int rsis_comm_unique_id(void* id_out);
 int rsis_comm_init(void** comm, int world, int rank, const void* id);
 int rsis_comm_size(void* comm);

@@ -140,6 +140,7 @@ SIGNATURES = {
     "rsis_upconv_out_bwd_blocks": (_i, [_i, _i, _i, _i]),
     "rsis_upconv_out_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsis_upconv_out_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsis_comm_available": (_i, []),
     "rsis_comm_unique_id": (_i, [_vp]),
     "rsis_comm_init": (_i, [_vpp, _i, _i, _vp]),
     "rsis_comm_size": (_i, [_vp]),

@@ -29,16 +29,23 @@ class DirectComm(object):
     def __init__(self):
         if not dist.is_initialized():
             raise RsisHipError("DirectComm needs torch.distributed for the rendezvous")
-        L = lib()
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.handle = None
-        # Agreement BEFORE anything that blocks inside RCCL: every rank resolves librccl and draws an id of its own (the
-        # call that loads the library; only rank 0's id is used), the outcome is MIN-reduced over the working torch.distributed
-        # group, and only a unanimous "loaded" goes on.  A rank that cannot load RCCL therefore fails everyone here, with the same
-        # sequence of torch.distributed collectives on every rank, instead of leaving the others inside ncclCommInitRank.
-        buf = ctypes.create_string_buffer(128)
-        rc = L.rsis_comm_unique_id(buf)
-        why = "" if rc == 0 else (L.rsis_comm_last_error() or b"").decode()
+        # Agreement BEFORE anything that blocks inside RCCL: every rank only RESOLVES librccl (rsis_comm_available:
+        # dlopen + symbols -- no bootstrap listener is started on ranks whose id would never be used), rank 0 alone draws the
+        # ncclUniqueId, and the outcome is MIN-reduced over the working torch.distributed group.  The whole local part sits in one
+        # try block: a rank that fails anywhere before the agreement (the library itself missing, RCCL not loadable, the id) still
+        # takes part in the SAME all_reduce with a 0, so the ranks' collective sequences cannot fall out of step.
+        buf, rc, why = ctypes.create_string_buffer(128), -1, ""
+        try:
+            L = lib()
+            rc = L.rsis_comm_available()
+            if rc == 0 and self.rank == 0:
+                rc = L.rsis_comm_unique_id(buf)
+            if rc != 0:
+                why = (L.rsis_comm_last_error() or b"").decode()
+        except Exception as e:  # noqa: BLE001
+            rc, why = -1, repr(e)
         if self.world > 1:
             ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -48,7 +55,8 @@ class DirectComm(object):
             dist.broadcast_object_list(box, src=0)          # reached by every rank or by none
             buf = ctypes.create_string_buffer(box[0], 128)
         elif rc != 0:
-            _check(rc, "rsis_comm_unique_id")
+            raise RsisHipError("RCCL is not available: " + why)
+        L = lib()
         self._id = buf
         handle = ctypes.c_void_p()
         _check(L.rsis_comm_init(ctypes.byref(handle), self.world, self.rank, self._id), "rsis_comm_init")
@@ -132,7 +140,8 @@ def _probe_child():
     sums.  It runs in a process of its own so that a collective that never returns can be killed from outside."""
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["RSIS_COMM_PROBE_PORT"], rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method="tcp://%s:%s" % (os.environ.get("RSIS_COMM_PROBE_ADDR", "127.0.0.1"),
+                                                                  os.environ["RSIS_COMM_PROBE_PORT"]), rank=rank, world_size=world)
     red = DirectReducer(DirectComm())
     x = torch.full((1 << 20,), float(rank + 1), device="cuda")
     red(x)
@@ -155,14 +164,24 @@ def probe_direct(say=None, timeout=None):
     import sys
     say = say or (lambda _m: None)
     timeout = PROBE_TIMEOUT if timeout is None else timeout
-    box = [None]
+    # Where the children meet: on ONE host, 127.0.0.1; when the ranks span hosts, the address the parents themselves
+    # rendezvoused over (MASTER_ADDR, i.e. rank 0's host) -- children on other hosts can never reach rank 0's loopback, which used to
+    # cost the full timeout and silently disable the direct exchange on every multi-node job.  The port is drawn by rank 0 from the
+    # kernel (bind to 0) and released just before the children start: the window in which another process could take it is the
+    # spawn time of one child; losing that race is a failed probe (cut schedule), never a hang.
+    hosts = [None] * dist.get_world_size()
+    dist.all_gather_object(hosts, socket.gethostname())
+    multi_host = len(set(hosts)) > 1
+    box = [None, None]
     if dist.get_rank() == 0:
+        addr = os.environ.get("MASTER_ADDR", socket.gethostname()) if multi_host else "127.0.0.1"
         with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            box[0] = so.getsockname()[1]
+            so.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            so.bind(("" if multi_host else "127.0.0.1", 0))
+            box = [addr, so.getsockname()[1]]
     dist.broadcast_object_list(box, src=0)
-    env = dict(os.environ, RSIS_COMM_PROBE_PORT=str(box[0]), RANK=str(dist.get_rank()), WORLD_SIZE=str(dist.get_world_size()),
-               LOCAL_RANK=str(torch.cuda.current_device()))
+    env = dict(os.environ, RSIS_COMM_PROBE_ADDR=str(box[0]), RSIS_COMM_PROBE_PORT=str(box[1]), RANK=str(dist.get_rank()),
+               WORLD_SIZE=str(dist.get_world_size()), LOCAL_RANK=str(torch.cuda.current_device()))
     env.pop("TORCHELASTIC_RUN_ID", None)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")

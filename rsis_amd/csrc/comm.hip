@@ -68,6 +68,8 @@ int fail(const char* what, int rc) {
 extern "C" {
 const char* rsis_comm_last_error(void) { return g_last_error; }
 
+int rsis_comm_available(void) { return load_rccl() ? RSIS_OK : RSIS_ERR_UNSUPPORTED; }
+
 int rsis_comm_unique_id(void* id_out) {
   if (!id_out) return RSIS_ERR_ARG;
   if (!load_rccl()) return RSIS_ERR_UNSUPPORTED;

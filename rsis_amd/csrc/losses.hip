@@ -86,7 +86,12 @@ __global__ __launch_bounds__(256) void softiou_bwd_kernel(const float* __restric
 }
 
 int rsis_l_softiou_sums(const float* logits, const float* y, float* S, int B, int T, int G, long N, hipStream_t st) {
+  if (B < 0 || T < 0 || G < 0 || N < 0) return RSIS_ERR_ARG;
+  if (B == 0) return RSIS_OK;
   if (rsis_zero_async(S, sizeof(float) * (size_t)B * (T + 1) * (G + 1), st) != RSIS_OK) return RSIS_ERR_LAUNCH;
+  // no prediction or no ground-truth slot: every sum is zero, and the kernel's unconditional loads of row 0 (lanes beyond T / G
+  // read it and discard the value) would touch a row that does not exist
+  if (T == 0 || G == 0 || N == 0) return RSIS_OK;
   // ~4 blocks per CU over the whole batch; each wave gets a multiple of 8 pixels
   int nsplit = (int)((1024 + B - 1) / B);
   long per_wave = (N + (long)nsplit * 4 - 1) / ((long)nsplit * 4);

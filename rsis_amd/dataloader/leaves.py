@@ -104,12 +104,15 @@ class LeavesDataset(object):
         return np.ascontiguousarray(im), np.ascontiguousarray(ins.astype(np.int32))
 
 
-def shard_batches(order, batch_size, rank=0, world=1):
+def shard_batches(order, batch_size, rank=0, world=1, drop_last=True):
     """Per-rank index lists of one epoch: the (already shuffled, identical on every rank) sample order is cut into GLOBAL batches of
     batch_size * world (the tail that does not fill one is dropped: drop_last=True, train.py:46-49) and rank r takes elements
     r, r + world, ... of each -- the ranks' shards of a step are disjoint and together are the reference's global batch."""
     gb = int(batch_size) * int(world)
-    return [order[i * gb:(i + 1) * gb][rank::world] for i in range(len(order) // gb)]
+    out = [order[i * gb:(i + 1) * gb][rank::world] for i in range(len(order) // gb)]
+    if not drop_last and len(order) % gb and int(world) == 1:       # evaluation (eval*.py: drop_last=False): the short last batch
+        out.append(order[len(order) // gb * gb:])
+    return out
 
 
 class DeviceLoader(object):
@@ -122,7 +125,8 @@ class DeviceLoader(object):
     len(dataset) // (batch_size * world) steps of the reference's global batch (train.py:46-49 under nn.DataParallel) and no
     sample is seen twice in a step; only the per-sample augmentation draws are rank-specific."""
 
-    def __init__(self, dataset, batch_size, shuffle=True, num_workers=4, seed=0, device="cuda", rank=0, world=1):
+    def __init__(self, dataset, batch_size, shuffle=True, num_workers=4, seed=0, device="cuda", rank=0, world=1, drop_last=True):
+        self.drop_last = bool(drop_last)
         if dataset.crop is False and batch_size != 1:
             raise ValueError("un-cropped samples have different sizes: batch_size must be 1")
         self.ds, self.bs, self.shuffle, self.device = dataset, int(batch_size), shuffle, device
@@ -136,7 +140,8 @@ class DeviceLoader(object):
         self._lock = threading.Lock()
 
     def __len__(self):
-        return len(self.ds) // (self.bs * self.world)                       # drop_last=True on the GLOBAL batch
+        n, gb = len(self.ds), self.bs * self.world                          # drop_last=True on the GLOBAL batch (training)
+        return n // gb + (1 if (not self.drop_last and self.world == 1 and n % gb) else 0)
 
     def steps_to_run(self, args, sw_mask):
         """early-stop rule of train.py:80-92 for this batch (one host sync; the batch is fresh, so nothing can be cached)"""
@@ -183,7 +188,7 @@ class DeviceLoader(object):
         order = list(range(len(self.ds)))
         if self.shuffle:
             self.order_rng.shuffle(order)
-        batches = shard_batches(order, self.bs, self.rank, self.world)
+        batches = shard_batches(order, self.bs, self.rank, self.world, self.drop_last)
         if not batches:
             return
         staged = self._stage(batches[0])

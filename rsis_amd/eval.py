@@ -33,6 +33,27 @@ def create_annotation(args, imname, pred_mask, class_id, score, classes, is_vali
             "score": score}
 
 
+def load_models(args):
+    """eval.py:229-246 (also eval_cityscapes.py:50-94, eval_leaves.py:45-89): the checkpoint of -model_name under -models_root ->
+    eval-mode encoder / decoder on the device, built from the LOADED args; args.num_classes / hidden_size follow the checkpoint.
+    Without a checkpoint directory the modules are randomly initialised (synthetic smoke runs), said on stderr."""
+    model_dir = os.path.join(args.models_root, args.model_name)
+    if os.path.exists(os.path.join(model_dir, "encoder.pt")):
+        encoder_dict, decoder_dict, _, _, load_args = load_checkpoint(args.model_name, args.use_gpu, root=args.models_root)
+        load_args.use_gpu = args.use_gpu
+        if getattr(args, "dtype", None):
+            load_args.dtype = args.dtype
+        encoder, decoder = FeatureExtractor(load_args), RSIS(load_args)
+        encoder_dict, decoder_dict = check_parallel(encoder_dict, decoder_dict)
+        encoder.load_state_dict(encoder_dict)
+        decoder.load_state_dict(decoder_dict)
+        args.num_classes, args.hidden_size = load_args.num_classes, load_args.hidden_size
+    else:
+        print("no checkpoint at %s: evaluating randomly initialised weights" % model_dir, file=sys.stderr)
+        encoder, decoder = FeatureExtractor(args), RSIS(args)
+    return encoder.cuda().eval(), decoder.cuda().eval()
+
+
 class Evaluate(object):
     def __init__(self, args):
         self.args = args
@@ -40,20 +61,7 @@ class Evaluate(object):
         if not getattr(args, "synthetic", False):
             raise Exception("only --synthetic inputs are wired in this build (the dataset readers of the reference's "
                             "src/dataloader are host-side I/O outside the hot path: SURVEY.md section 8)")
-        model_dir = os.path.join(args.models_root, args.model_name)
-        if os.path.exists(os.path.join(model_dir, "encoder.pt")):                     # eval.py:229-246
-            encoder_dict, decoder_dict, _, _, load_args = load_checkpoint(args.model_name, args.use_gpu, root=args.models_root)
-            load_args.use_gpu = args.use_gpu
-            self.encoder, self.decoder = FeatureExtractor(load_args), RSIS(load_args)
-            encoder_dict, decoder_dict = check_parallel(encoder_dict, decoder_dict)
-            self.encoder.load_state_dict(encoder_dict)
-            self.decoder.load_state_dict(decoder_dict)
-            self.args.num_classes, self.args.hidden_size = load_args.num_classes, load_args.hidden_size
-        else:
-            print("no checkpoint at %s: evaluating randomly initialised weights" % model_dir, file=sys.stderr)
-            self.encoder, self.decoder = FeatureExtractor(args), RSIS(args)
-        self.encoder.cuda().eval()
-        self.decoder.cuda().eval()
+        self.encoder, self.decoder = load_models(self.args)
         self.class_names = ["<eos>"] + ["class%d" % i for i in range(1, self.args.num_classes)]
         self.loader = SyntheticLoader(args, max(1, args.synthetic_batches // 4), args.seed + 7)
         self.sample_list = ["synthetic_%06d" % i for i in range(len(self.loader) * args.batch_size)]

@@ -701,9 +701,9 @@ def assign_min_cost(scores):
 
 
 def softiou_supported(out_masks, y_mask):
-    """the fused soft-IoU kernels cover T < 32 predictions, G < 32 ground-truth slots and N % 8 == 0 pixels"""
+    """the fused soft-IoU kernels cover 1 <= T < 32 predictions, 1 <= G < 32 ground-truth slots and N % 8 == 0 pixels"""
     return (out_masks.is_cuda and out_masks.dtype == torch.float32 and y_mask.dtype == torch.float32 and
-            out_masks.size(1) < 32 and y_mask.size(1) < 32 and out_masks.size(2) % 8 == 0)
+            1 <= out_masks.size(1) < 32 and 1 <= y_mask.size(1) < 32 and out_masks.size(2) >= 8 and out_masks.size(2) % 8 == 0)
 
 
 def softiou_sums(out_masks, y_mask):

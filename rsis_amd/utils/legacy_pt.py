@@ -26,7 +26,11 @@ MAGIC_NUMBER = 0x1950A86A20F9469CFC6C
 PROTOCOL_VERSION = 1001
 
 _DTYPES = {"FloatStorage": np.float32, "DoubleStorage": np.float64, "HalfStorage": np.float16, "LongStorage": np.int64,
-           "IntStorage": np.int32, "ShortStorage": np.int16, "CharStorage": np.int8, "ByteStorage": np.uint8}
+           "IntStorage": np.int32, "ShortStorage": np.int16, "CharStorage": np.int8, "ByteStorage": np.uint8,
+           # storages torch gained after the reference's 0.2 but still writes into the pre-zip container (a bf16 checkpoint of this
+           # build saved with _use_new_zipfile_serialization=False): bf16 is read as 16-bit words and re-viewed, bool as bytes
+           "BFloat16Storage": np.int16, "BoolStorage": np.bool_}
+_VIEW_AS = {"BFloat16Storage": torch.bfloat16}
 
 
 def is_legacy_file(path):
@@ -46,7 +50,8 @@ class _StorageRef(object):
     def __init__(self, stype, key, location, numel, view):
         if not isinstance(stype, _StorageType) or stype.name not in _DTYPES:
             raise pickle.UnpicklingError("legacy checkpoint: unknown storage type %r" % (stype,))
-        self.dtype, self.key, self.location, self.numel = _DTYPES[stype.name], str(key), location, int(numel)
+        self.dtype, self.key, self.location, self.numel = np.dtype(_DTYPES[stype.name]), str(key), location, int(numel)
+        self.view_as = _VIEW_AS.get(stype.name)
         self.offset = 0
         if view is not None:             # (view_key, offset, view_size): a storage that is a window of a larger root storage
             self.offset = int(view[1])
@@ -78,7 +83,8 @@ def _ordered_dict(*args):
     return OrderedDict(*args)
 
 
-_TENSOR_NAMES = {"FloatTensor", "DoubleTensor", "HalfTensor", "LongTensor", "IntTensor", "ShortTensor", "CharTensor", "ByteTensor"}
+_TENSOR_NAMES = {"FloatTensor", "DoubleTensor", "HalfTensor", "LongTensor", "IntTensor", "ShortTensor", "CharTensor", "ByteTensor",
+                 "BFloat16Tensor", "BoolTensor"}
 
 
 class _Unpickler(pickle.Unpickler):
@@ -135,7 +141,8 @@ def _materialise(obj, roots):
         if start < 0 or any(s < 0 for s in stride) or start + span > base.size:
             raise pickle.UnpicklingError("legacy checkpoint: tensor reaches outside its storage")
         t = torch.from_numpy(base)
-        return torch.as_strided(t, size, stride, start).clone() if size else t[start].clone()
+        t = torch.as_strided(t, size, stride, start).clone() if size else t[start].clone()
+        return t.view(ref.view_as) if ref.view_as is not None else t
     if isinstance(obj, OrderedDict):
         return OrderedDict((k, _materialise(v, roots)) for k, v in obj.items())
     if isinstance(obj, dict):

@@ -143,8 +143,11 @@ def load_checkpoint(model_name, use_gpu=True, root="../models"):
     """reference utils/utils.py:97-111.  The four .pt files are tensor dictionaries: files in torch's current zip format (this build's
     own checkpoints, anything saved by torch >= 1.6) are read with weights_only=True; files in the pre-zip container the REFERENCE's
     torch 0.2 wrote (python-2 protocol-2 pickles, `torch.cuda.FloatTensor` objects) go through rsis_amd.utils.legacy_pt, a closed-list
-    reader that needs neither the GPU they were saved from nor code execution.  Tensors come back on the CPU (`load_state_dict`
-    copies them to wherever the modules live; `use_gpu` is accepted for signature compatibility).  args.pkl (python 2 wrote it with
+    reader that needs neither the GPU they were saved from nor code execution.
+    CONTRACT (differs from the reference, whose `torch.load` restores tensors to the device they were saved from): EVERY tensor of the
+    four dictionaries, optimizer state included, comes back ON THE CPU whatever `use_gpu` says -- the argument is accepted for
+    signature compatibility only.  `load_state_dict` / `FlatGroup.copy_` copy them to wherever the modules live; a caller that uses
+    the returned tensors directly must move them itself (`.cuda()`).  args.pkl (python 2 wrote it with
     protocol 0) goes through an allow-listed unpickler, `latin1` for its str payloads."""
     from . import legacy_pt
     d = os.path.join(root, model_name)

@@ -241,3 +241,17 @@ def test_legacy_reader_refuses_code_and_truncation(tmp_path):
         raise AssertionError("out-of-storage tensor accepted")
     except pickle.UnpicklingError:
         pass
+
+
+def test_legacy_reader_reads_bf16_and_bool_storages(tmp_path):
+    """a pre-zip container written by a CURRENT torch (`_use_new_zipfile_serialization=False`) may hold BFloat16Storage /
+    BoolStorage, which torch 0.2 did not have: bf16 is read as 16-bit words and re-viewed, bool as bytes; views and strides as before."""
+    from rsis_amd.utils import legacy_pt
+    d = {"w": torch.randn(3, 4).bfloat16(), "m": torch.tensor([True, False, True]), "v": torch.randn(8).bfloat16()[2:6],
+         "t": torch.arange(6.0).reshape(2, 3).t()}
+    p = str(tmp_path / "x.pt")
+    torch.save(d, p, _use_new_zipfile_serialization=False)
+    assert legacy_pt.is_legacy_file(p)
+    got = legacy_pt.load(p)
+    for k, v in d.items():
+        assert got[k].dtype == v.dtype and got[k].device.type == "cpu" and torch.equal(got[k], v), k

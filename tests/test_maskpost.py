@@ -255,3 +255,52 @@ def test_cityscapes_and_leaves_writers(tmp_path):
     assert p.endswith("plant007_label.png")
     lab = np.asarray(Image.open(p))
     assert lab.shape == (h, w) and set(np.unique(lab)) <= {0, 1} and lab[11, 11] == 1
+
+
+@pytest.mark.gpu
+def test_eval_leaves_and_eval_cityscapes_drivers(tmp_path):
+    """The two dataset evaluation scripts end to end (reference src/eval_leaves.py:91-125, src/eval_cityscapes.py:96-174; ADVICE r5:
+    the writers had no caller): a checkpoint written by save_checkpoint is loaded, test() runs over the split, result files appear in
+    the reference's layout.  eval_leaves over the 5-image val split of a synthesised CVPPP directory with batch 2 (so the last batch
+    is ONE image: the reference would index past it); one label image is re-derived from test() by hand and must be identical."""
+    import numpy as np
+    from PIL import Image
+    from rsis_amd.args import get_parser
+    from rsis_amd.dataloader.leaves import synthesize_leaves_dir
+    from rsis_amd.eval_post import leaves_label_image
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.test import test as hip_test
+    from rsis_amd.utils.utils import save_checkpoint
+    from rsis_amd import eval_cityscapes, eval_leaves
+    d = synthesize_leaves_dir(str(tmp_path / "A1"), n=101, size=(80, 96), seed=5)
+    models = str(tmp_path / "models")
+    a = get_parser().parse_args(["-model_name", "lv", "-dataset", "leaves", "-leaves_dir", d, "-leaves_test_dir", d, "-eval_split", "val",
+                                 "-batch_size", "2", "-maxseqlen", "4", "-gt_maxseqlen", "6", "-num_classes", "2", "-imsize", "64",
+                                 "--resize", "-hidden_size", "32", "-num_workers", "2", "-class_th", "0.0", "-models_root", models])
+    torch.manual_seed(3)
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    a.epoch_resume, a.best_val_loss = 0, 0.0
+    save_checkpoint(a, enc, dec, torch.optim.Adam(enc.parameters()), torch.optim.Adam(dec.parameters()), root=models)
+    ev = eval_leaves.Evaluate(a)
+    assert len(ev.sample_list) == 5 and len(ev.loader) == 3
+    written = ev.create_figures()
+    assert len(written) == 5 and all(p.endswith("_label.png") and os.path.exists(p) for p in written)
+    assert os.path.dirname(written[0]) == os.path.join(models, "lv", "lv_results", "A1")
+    img = np.asarray(Image.open(written[0]))
+    assert img.shape == (80, 96) and img.dtype == np.uint8 and img.max() <= 3
+    # by hand: the first val batch through test(), the first image's label map
+    x = next(iter(ev.loader))[0]
+    masks, _c, stops = hip_test(a, ev.encoder, ev.decoder, x)
+    want = leaves_label_image(a, masks[0].view(4, 64, 64), stops[0], 80, 96)
+    assert (img == want).all()
+
+    c = get_parser().parse_args(["--synthetic", "-model_name", "cs", "-batch_size", "2", "-maxseqlen", "3", "-hidden_size", "32",
+                                 "-synthetic_batches", "4", "-num_classes", "9", "-imsize", "64", "-models_root", models])
+    n = eval_cityscapes.Evaluate(c).create_figures()
+    assert n == 2 * 3 * 8                                      # images x timesteps x foreground classes
+    res = os.path.join(models, "cs", "cs_results")
+    lines = open(os.path.join(res, "synthetic_000000.txt")).read().splitlines()
+    assert len(lines) == 24
+    png, cid, score = lines[0].split(" ")
+    assert int(cid) == 24 and 0.0 <= float(score) <= 1.0
+    assert np.asarray(Image.open(os.path.join(res, png))).shape == (128, 128)     # the "original" size: twice the input
