@@ -34,6 +34,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# what a register-only v_mfma_f32_32x32x2_f32 loop SUSTAINS on these boxes (tools/exp/clock_probe.hip, profiles/r05_r: 0.875 of nominal;
+# power management holds the block clock near 2.1 GHz): reported beside `peak` as `peak_sustained` / `frac_of_sustained`, never instead of it
+PEAK_F32_MFMA_SUSTAINED_TFLOPS = 137.6
 # ConvLSTM gate GEMMs at config 2: (x segments, hid, H=W)
 GATE_LAYERS = [([128], 128, 8), ([128, 128], 64, 16), ([64, 64], 32, 32), ([32, 32], 16, 64), ([16, 16], 8, 128)]
 
@@ -177,7 +180,10 @@ def gate_kernel_roofline(B, iters, imsize, dtype="fp32", T=10, product_only=Fals
     if dtype == "fp32":
         out.update({"bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4), "frac_algorithmic": round(algorithmic / PEAK_F32_MFMA_TFLOPS, 4),
-                    "frac_full_k": round(full / PEAK_F32_MFMA_TFLOPS, 4)})
+                    "frac_full_k": round(full / PEAK_F32_MFMA_TFLOPS, 4),
+                    "peak_sustained": PEAK_F32_MFMA_SUSTAINED_TFLOPS, "frac_of_sustained": round(executed / PEAK_F32_MFMA_SUSTAINED_TFLOPS, 4),
+                    "peak_sustained_note": "what a register-only v_mfma_f32_32x32x2_f32 loop holds on these boxes (profiles/r05_r); "
+                                           "`frac` is against the guide's nominal `peak`"})
     else:
         gbs = tot["bytes"] / tot["dyn_ms"] / 1e6
         out.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
@@ -256,8 +262,11 @@ TRUNK_SHAPES = [(256, 256, 3, 16, 22), (256, 1024, 1, 16, 23), (1024, 256, 1, 16
                 (2048, 512, 1, 8, 2), (2048, 128, 3, 8, 1), (1024, 128, 3, 16, 1), (64, 16, 3, 128, 1)]
 
 
-def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
-    """roofline_kernels: the four kernel families that hold most of the step next to the gate kernel -- the 1x1 GEMM (forward and
+def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32", inference=False):
+    """inference=True: the FORWARD launches as test() issues them -- fp32: rsis_conv2d_fwd on its inference path (segmented
+    accumulation, no split-K); bf16: rsis_blk_conv2d_bn_eval (the eval-mode BatchNorm (+ ReLU) folded into the conv's epilogue) --
+    two families, conv1x1 / conv3x3 forward.  Otherwise --
+    roofline_kernels: the four kernel families that hold most of the step next to the gate kernel -- the 1x1 GEMM (forward and
     data gradient), the direct 3x3 conv with the plain epilogue (forward and data gradient), and the tiled weight gradients (3x3,
     1x1) -- on the stride-1 layer shapes of the ResNet-101 trunk and the skip convs, weighted by how many layers have each shape."""
     from rsis_amd import ops
@@ -278,6 +287,17 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
             wp, wd = pack.fwd(w), pack.dgrad(w)
             ob, dxb, dW = torch.empty_like(yb), torch.empty_like(xb), torch.zeros_like(w)
             fl = 2.0 * B * hh * ww * cin * ks * ks * cout
+            if inference:
+                g_, b_, m_, v_ = (torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda"), torch.randn(cout, device="cuda"),
+                                  torch.rand(cout, device="cuda") + 0.5)
+                ms_f = _time_launch(lambda: check(L.rsis_blk_conv2d_bn_eval(ptr(xb), B, cin, hh, ww, ptr(wp), cout, ks, None, ptr(g_), ptr(b_), ptr(m_),
+                                                                            ptr(v_), 1e-5, 1, 0, ptr(ob), 0, stream()), "blk fwd + bn eval"), iters)
+                f = fam.setdefault("conv%dx%d fwd (eval)" % (ks, ks), {"flops": 0.0, "ms": 0.0, "bytes": 0.0, "launches": 0})
+                f["flops"] += fl * count
+                f["ms"] += ms_f * count
+                f["bytes"] += 2.0 * B * hh * ww * (cin + cout) * count
+                f["launches"] += count
+                continue
             ms_f = _time_launch(lambda: check(L.rsis_blk_conv2d(ptr(xb), B, cin, hh, ww, ptr(wp), cout, ks, None, ptr(ob), 0, stream()), "blk fwd"), iters)
             ms_d = _time_launch(lambda: check(L.rsis_blk_conv2d(ptr(yb), B, cout, hh, ww, ptr(wd), cin, ks, None, ptr(dxb), 0, stream()), "blk dgrad"), iters)
             ms_w = _time_launch(lambda: check(L.rsis_conv2d_wgrad(ptr(yb), ptr(xb), ptr(dW), B, cin, hh, ww, cout, hh, ww, ks, 1, pad, cin, 0, 0,
@@ -298,8 +318,16 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
         dx, dW = torch.empty_like(x), torch.zeros_like(w)
         pa, ia, pd = ptr_array([x]), int_array([cin]), ptr_array([dx])
         fl = 2.0 * B * hh * ww * cin * ks * ks * cout
-        ms_f = _time_launch(lambda: check(L.rsis_conv2d_fwd(pa, ia, 1, B, hh, ww, ptr(wp), cout, ks, 1, pad, None, None, ptr(y), hh, ww, 0, dt,
-                                                            stream()), "fwd"), iters)
+        # tile 100 = a TRAINING call (split-K allowed, one accumulation chain); tile 0 = the inference / parity path (segmented sums)
+        ms_f = _time_launch(lambda: check(L.rsis_conv2d_fwd(pa, ia, 1, B, hh, ww, ptr(wp), cout, ks, 1, pad, None, None, ptr(y), hh, ww,
+                                                            0 if inference else 100, dt, stream()), "fwd"), iters)
+        if inference:
+            f = fam.setdefault("conv%dx%d fwd (eval)" % (ks, ks), {"flops": 0.0, "ms": 0.0, "bytes": 0.0, "launches": 0})
+            f["flops"] += fl * count
+            f["ms"] += ms_f * count
+            f["bytes"] += 4.0 * B * hh * ww * (cin + cout) * count
+            f["launches"] += count
+            continue
         ms_d = _time_launch(lambda: check(L.rsis_conv2d_dgrad(ptr(y), B, cout, hh, ww, ptr(wd), cin, ks, 1, pad, pd, ia, 1, hh, ww, None, 0, dt,
                                                               stream()), "dgrad"), iters)
         ms_w = _time_launch(lambda: check(L.rsis_conv2d_wgrad(ptr(y), ptr(x), ptr(dW), B, cin, hh, ww, cout, hh, ww, ks, 1, pad, cin, 0, 0, dt,
@@ -314,7 +342,7 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
     # the weight gradients as the training step launches them: parked during backward, flushed in ONE rsis_conv2d_wgrad_batch call
     # (grouped launches over all layers of a tile configuration); per family = all layers of that kernel size in one call
     from rsis_amd._lib import WgradJob
-    for ksz in (3, 1):
+    for ksz in (() if inference else (3, 1)):
         jobs, keep, fl, by = [], [], 0.0, 0.0
         for si, (cin, cout, ks, hw, count) in enumerate(TRUNK_SHAPES):
             if ks != ksz:
@@ -349,7 +377,12 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
                               else "wgrad1_bf16_group_kernel (rsis_conv2d_wgrad_batch)"),
             "conv3x3 wgrad": ("conv_wgrad_tiled_group_kernel<..., 3, ...> (rsis_conv2d_wgrad_batch)",
                               "wgrad3_tr_group_kernel (trunk, blk operands: LDS-DMA + ds_read_b64_tr_b16) + wgrad3_bf16_group_kernel (skip convs, fp32 operands)"
-                              if blk_on else "wgrad3_bf16_group_kernel (rsis_conv2d_wgrad_batch)")}
+                              if blk_on else "wgrad3_bf16_group_kernel (rsis_conv2d_wgrad_batch)"),
+            "conv1x1 fwd (eval)": ("conv_igemm_kernel<..., V4> (inference path)",
+                                   "conv_blk_kernel<1, ...> + eval BatchNorm (+ ReLU) epilogue (rsis_blk_conv2d_bn_eval)" if blk_on else "conv_bf16_kernel<1, ...>"),
+            "conv3x3 fwd (eval)": ("conv3x3_direct_kernel<..., EPI_PLAIN, FLUSH> (segmented accumulation)",
+                                   "conv_blk_kernel<3, ...> + eval BatchNorm (+ ReLU) epilogue (trunk) + conv_bf16_kernel<3, ...> (skip convs)"
+                                   if blk_on else "conv_bf16_kernel<3, ...>")}
     out = []
     for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
         tf = f["flops"] / f["ms"] / 1e9
@@ -358,7 +391,8 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
              "ms_per_step": round(f["ms"], 3), "avg_us": round(1e3 * f["ms"] / f["launches"] * (2 if "fwd" in name else 1), 1),
              "tflops": round(tf, 1)}
         if dtype == "fp32":
-            r.update({"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)})
+            r.update({"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                      "peak_sustained": PEAK_F32_MFMA_SUSTAINED_TFLOPS, "frac_of_sustained": round(tf / PEAK_F32_MFMA_SUSTAINED_TFLOPS, 4)})
         else:
             # bf16: the family is priced against the roof its arithmetic intensity (algorithmic FLOP per activation byte) puts it under --
             # the 3x3 convs of the trunk sit right of the ridge (2500 TFLOP/s / 8 TB/s = 312 FLOP/B), the 1x1 ones left of it
@@ -371,6 +405,64 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32"):
                 r.update({"bound": "hbm", "peak": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4)})
         out.append(r)
     return out
+
+
+# forward GFLOP per image of the whole model (trunk + skip convs + T x (gates + conv_out)), for the inference record
+MODEL_FWD_GFLOP = {(256, 256): (20.374 + 2.416, 1.6704), (224, 224): (15.599 + 1.850, 1.2789), (512, 1024): (162.991 + 19.327, 13.363)}
+
+
+def inference_record(o):
+    """`bench.py --inference`: test() (reference src/test.py:16-50 -- eval-mode encoder once, T decoder steps, masks resized to the input,
+    sigmoid; the caller of reference src/eval.py:262) on a resident synthetic batch, as a replayed hipGraph (rsis_amd.test.GraphedTest), timed
+    like the training line: W untimed calls (the capture among them), then EXACTLY K replays between synchronisations, HIP events per
+    replay.  One JSON line; `value` = images / s of whole batches through test()."""
+    from rsis_amd.modules import FeatureExtractor, RSIS
+    from rsis_amd.test import GraphedTest
+    assert torch.cuda.is_available(), "bench.py needs the GPU (there is no CPU path)"
+    imw = o.imsize_w or o.imsize
+    a = bench_args(o.batch, o.imsize, o.T, o.dtype)
+    torch.manual_seed(a.seed)
+    enc, dec = FeatureExtractor(a).cuda().eval(), RSIS(a).cuda().eval()
+    x = torch.randn(o.batch, 3, o.imsize, imw, device="cuda")
+    run = GraphedTest(a, enc, dec)
+    for _ in range(max(o.warmup, 4)):
+        run(x)
+    assert run.graph is not None, "test() was not captured"
+    t_end = time.time() + 1.5                      # settle (clock ramp), untimed
+    while time.time() < t_end:
+        run(x)
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(o.steps + 1)]
+    t0 = time.time()
+    evs[0].record()
+    for i in range(o.steps):
+        run(x)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(o.steps))
+    masks = run.outs[0]
+    assert tuple(masks.shape[:2]) == (o.batch, o.T) and bool(torch.isfinite(masks).all())
+    ms = 1000.0 * dt / o.steps
+    out = {"metric": "inference images/sec at %dx%d, T=%d, batch=%d" % (o.imsize, imw, o.T, o.batch), "value": round(o.batch * o.steps / dt, 1),
+           "unit": "images/s", "n_gpus": 1, "steps": o.steps, "warmup": o.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32" if o.dtype == "fp32" else "bf16", "data": "synthetic",
+           "config": {"workload": "test() of reference src/test.py:16-50 (eval-mode ResNet-101 encoder once, %d decoder timesteps over the 5-scale "
+                                  "ConvLSTM pyramid, masks resized to %dx%d, sigmoid), batch %d, %s; a 'step' = one batch through test()"
+                                  % (o.T, o.imsize, imw, o.batch, o.dtype),
+                      "launch": "hipGraph replay of the captured test() (rsis_amd.test.GraphedTest)",
+                      "event_ms_per_batch": {"median": round(per[len(per) // 2], 3), "min": round(per[0], 3), "max": round(per[-1], 3)}}}
+    g = MODEL_FWD_GFLOP.get((o.imsize, imw))
+    if g is not None:
+        gf = (g[0] + o.T * g[1]) * o.batch
+        tf = gf / ms
+        peak = PEAK_F32_MFMA_TFLOPS if o.dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        out["model_flops"] = {"algorithmic_gflop_per_batch": round(gf, 1), "tflops": round(tf, 1), "peak": peak, "frac": round(tf / peak, 4),
+                              "note": "whole-model forward FLOPs (SURVEY Appendix A, full-K gates) / time of a batch: a throughput figure, "
+                                      "not a kernel roofline (the per-family ones are in roofline_kernels)"}
+    if not o.skip_roofline:
+        out["roofline_kernels"] = trunk_kernel_rooflines(o.batch, max(3, o.kernel_iters // 4), (o.imsize, imw), o.dtype, inference=True)
+    print(json.dumps(out))
 
 
 def cpu_baseline(imsize, T, budget_s=25.0):
@@ -620,6 +712,7 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--product-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--skip-secondary", action="store_true", help="do not run the bf16 224x224 leg (BASELINE configs[2]) after the headline run")
+    ap.add_argument("--inference", action="store_true", help="time test() (reference src/test.py:16-50) instead of the training iteration")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the gate-kernel roofline leg and print its object (for `rocprofv3 --kernel-trace --stats`: the "
                          "profile then holds exactly the launches the `roofline` figure is computed from)")
@@ -630,6 +723,10 @@ def main():
     if o.roofline_only:
         assert torch.cuda.is_available(), "bench.py needs the GPU (there is no CPU path)"
         print(json.dumps(_gate_roofline(o.batch, o.kernel_iters, (o.imsize, o.imsize_w or o.imsize), o.dtype, o.T, product_only=o.product_only)))
+        return
+
+    if o.inference:
+        inference_record(o)
         return
 
     if o.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -854,6 +951,28 @@ def main():
                     secondary.append({k: sj.get(k) for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "exchange")})
                 except Exception as ex:  # noqa: BLE001
                     secondary.append({"dtype": "fp32", "config": "configs[1] + RSIS_FORCE_DIST=1", "error": repr(ex)})
+                # ... and the CUT schedule (RSIS_EXCHANGE=cuts: graphs A | B1 | B2 | C with torch.distributed collectives between them -- the
+                # fallback whenever the direct communicator is not available) next to it, so that both schedules are driver-timed every round
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--batch", str(o.batch), "--imsize", str(o.imsize), "--T", str(o.T),
+                                        "--steps", str(max(10, o.steps // 2)), "--warmup", str(o.warmup), "--skip-cpu", "--skip-secondary", "--skip-roofline"],
+                                       capture_output=True, text=True, timeout=600,
+                                       env=dict(os.environ, RSIS_FORCE_DIST="1", RSIS_EXCHANGE="cuts", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())))
+                    sj = json.loads(r.stdout.strip().splitlines()[-1])
+                    sj["config"]["workload"] = sj["config"]["workload"].replace(
+                        "configs[1]", "configs[1] with the gradient exchange forced on at world size 1, CUT schedule (RSIS_EXCHANGE=cuts)")
+                    secondary.append({k: sj.get(k) for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "exchange")})
+                except Exception as ex:  # noqa: BLE001
+                    secondary.append({"dtype": "fp32", "config": "configs[1] + RSIS_FORCE_DIST=1 + RSIS_EXCHANGE=cuts", "error": repr(ex)})
+            # inference: test() (reference src/test.py:16-50, the caller of src/eval.py:262) at the headline geometry in fp32 and at configs[2]'s in bf16
+            for extra in (["--imsize", str(o.imsize), "--dtype", "fp32"], ["--imsize", "224", "--dtype", "bf16"]):
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--inference", "--batch", str(o.batch), "--T", str(o.T), "--steps",
+                                        str(o.steps), "--warmup", str(o.warmup), "--kernel-iters", str(o.kernel_iters)] + extra,
+                                       capture_output=True, text=True, timeout=600, env=dict(os.environ))
+                    secondary.append(json.loads(r.stdout.strip().splitlines()[-1]))
+                except Exception as ex:  # noqa: BLE001
+                    secondary.append({"metric": "inference images/sec", "config": " ".join(extra), "error": repr(ex)})
             note("secondary (224x224): bf16 %s images/s, fp32 %s images/s" % (secondary[0].get("value"), secondary[1].get("value")))
         value = world * o.batch * o.steps / dt
         out = {"metric": "training images/sec at %dx%d, T=%d, batch=%d per GPU" % (o.imsize, imw, o.T, o.batch),
@@ -875,6 +994,12 @@ def main():
         if seg is not None:
             out["config"]["exchange_ms_per_step"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in seg.items()}
         out["exchange"] = exchange
+        # never a line whose exchange ran over another number of ranks than it is labelled with
+        rd = (exchange or {}).get("rccl_direct") or {}
+        if (exchange or {}).get("mode") not in (None, "none"):
+            assert exchange.get("world") == o.gpus == world, "exchange over %s ranks in a --gpus %d run" % (exchange.get("world"), o.gpus)
+            if rd.get("mode") == "direct":
+                assert rd.get("world") == o.gpus, "direct RCCL communicator of %s ranks in a --gpus %d run" % (rd.get("world"), o.gpus)
     # RCCL prints a banner (version, library path) through C stdio, which on a pipe is flushed only at exit, i.e. AFTER anything
     # python printed: every rank flushes its C streams before the final barrier, rank 0 prints after it, so that the JSON line
     # is the last line of the job's (merged) stdout

@@ -116,8 +116,36 @@ def _worker_real_layout(rank, world, port, q):
     gscale = red.finish()
     dist.all_reduce = orig
     flat = torch.cat([g_dec.flat_g, g_enc.flat_g])
-    want = torch.cat([(coef[id(p)] * 0 if id(p) in skip_ids else coef[id(p)] / (rank + 1) * 3.0).reshape(-1) for p in g_dec.params + g_enc.params])
-    q.put((rank, float((flat - want).abs().max()), gscale, len(red.buckets), n_from_hooks, len(fired), sizes[:3], g_dec.state_key().count(False)))
+    rank_sum = world * (world + 1) / 2.0                      # sum over the ranks of (rank + 1)
+    want = torch.cat([(coef[id(p)] * 0 if id(p) in skip_ids else coef[id(p)] / (rank + 1) * rank_sum).reshape(-1) for p in g_dec.params + g_enc.params])
+    res = (rank, float((flat - want).abs().max()), gscale, len(red.buckets), n_from_hooks, len(fired), sizes[:3], g_dec.state_key().count(False))
+    if world > 2:
+        # ... and the STAGED exchange of the split backward (train.exchange_plan + StagedExchange: what GraphedStep's cut schedule and the
+        # eager staged path run) over the same flat buffers, with the collectives of torch.distributed: each range reduced exactly once,
+        # in stage order, asynchronous ones waited for; the result equals the rank sum element for element
+        from rsis_amd.train import StagedExchange, exchange_plan
+
+        class _Opt(object):                                    # exchange_plan only reads .group of FlatAdam instances
+            pass
+        from rsis_amd.optim import FlatAdam
+        eo, do = FlatAdam.__new__(FlatAdam), FlatAdam.__new__(FlatAdam)
+        eo.group, do.group = g_enc, g_dec
+        pattern = torch.cat([torch.arange(g.flat_g.numel(), dtype=torch.float32) % 251 for g in (g_dec, g_enc)])
+        g_dec.flat_g.copy_(pattern[:g_dec.flat_g.numel()] * (rank + 1))
+        g_enc.flat_g.copy_(pattern[g_dec.flat_g.numel():] * (rank + 1))
+        plan = exchange_plan(enc, [eo, do], 2)
+        calls = []
+
+        def reduce(buf, async_op):
+            calls.append((buf.numel(), bool(async_op)))
+            return dist.all_reduce(buf, async_op=True) if async_op else dist.all_reduce(buf)
+        ex = StagedExchange(plan, reduce)
+        ex("dec")
+        ex("trunk_hi")
+        ex.finish()
+        got = torch.cat([g_dec.flat_g, g_enc.flat_g])
+        res = res + (float((got - pattern * rank_sum).abs().max()), calls, [sum(t.numel() for t in plan[k]) for k in ("dec", "trunk_hi", "rest")])
+    q.put(res)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -139,6 +167,30 @@ def test_bucketed_allreduce_real_parameter_layout_world2_gloo():
         assert n_hooks == nb - 1                                 # all but the bucket holding fc_stop were launched from hooks
         assert sizes[0] <= (16 << 20) // 8 + (8 << 20)           # graduated first buckets (1/8, 1/2, full) of a group
         assert inactive == 2                                     # fc_stop.weight / .bias: skipped by the Adam step
+
+
+def test_bucketed_allreduce_and_staged_exchange_real_parameter_layout_world8_gloo():
+    """The 8-rank shape of BASELINE configs[3] / [4]: eight gloo ranks, each with the product's real parameter
+    layout (ResNet-101 trunk group, decoder + skip group), (1) the bucketed all-reduce driven by autograd hooks and (2) the three-range
+    staged exchange of the split backward.  Exact sums (small integers), every bucket / range reduced exactly once on every rank."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_real_layout, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for rank, err, gscale, nb, n_hooks, n_all, sizes, inactive, err2, calls, range_elems in res:
+        assert err == 0.0 and gscale == 1.0 / world
+        assert nb >= 12 and n_all == nb and n_hooks == nb - 1 and inactive == 2
+        assert err2 == 0.0
+        assert [a for _n, a in calls] == [True, True, False]          # dec and layers 3-4 asynchronous at their cuts, the rest at the end
+        assert [n for n, _a in calls] == range_elems and range_elems[1] > 0.9 * (range_elems[1] + range_elems[2])
+    assert len({tuple(r[10]) for r in res}) == 1                       # the same three ranges on every rank
 
 
 def test_flatgroup_views_and_zero_grad():
