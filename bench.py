@@ -388,7 +388,7 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32", inference=False):
         tf = f["flops"] / f["ms"] / 1e9
         r = {"family": name, "kernel": kern[name][0 if dtype == "fp32" else 1],
              ("layers_per_step" if f.get("grouped") else "launches_per_step"): f["launches"],
-             "ms_per_step": round(f["ms"], 3), "avg_us": round(1e3 * f["ms"] / f["launches"] * (2 if "fwd" in name else 1), 1),
+             "ms_per_step": round(f["ms"], 3), "avg_us": round(1e3 * f["ms"] / f["launches"] * (2 if "fwd+dgrad" in name else 1), 1),
              "tflops": round(tf, 1)}
         if dtype == "fp32":
             r.update({"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),

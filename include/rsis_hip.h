@@ -40,9 +40,18 @@ extern "C" {
  * the end of this header), dW is fp32 in the reference layout as always; ks in {1, 3}, stride 1, "same" padding, Cout % 8 == 0 and
  * Cs % 8 == 0 (RSIS_ERR_UNSUPPORTED otherwise) */
 #define RSIS_DTYPE_BF16_BLK 2
+/* Exact-f32 arithmetic as RSIS_DTYPE_F32, but a 3x3 / stride 1 / pad 1 conv whose input AND output channel counts are multiples of 32
+ * (one source, no ConvLSTM rows: rsis_conv_uses_wino) runs as Winograd F(2x2, 3x3) on the f32 MFMA (conv_wino.hip: 2.25x fewer
+ * matrix flops, transforms fused into the staging path and the epilogue).  The packed copies then hold the TRANSFORMED weights
+ * (G g G^T, 16 values per (output, input) channel pair); rsis_conv2d_fwd / _dgrad pick the kernel from this dtype.  Every other
+ * geometry, and the weight gradient, behaves exactly as under RSIS_DTYPE_F32.  Results differ from the direct kernel by fp32
+ * rounding only (measured closer to float64 than a sequential fp32 sum: the 2304-deep chain becomes 16 chains of 256). */
+#define RSIS_DTYPE_F32_WINO 3
 
 int rsis_version(void);
 const char* rsis_error_string(int code);
+/* 1 when a conv of this geometry runs on the Winograd kernel under RSIS_DTYPE_F32_WINO */
+int rsis_conv_uses_wino(int ks, int stride, int pad, int Cin, int Cout, int nseg, int lstm_hid);
 
 /* Bit-reproducible mode (process-wide; initial value 1 when the environment has RSIS_DETERMINISTIC=1, else 0).  The reference's
  * CPU path is deterministic; this library's default is not: split-K sums, weight gradients and BatchNorm / bias / soft-IoU

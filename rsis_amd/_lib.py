@@ -81,6 +81,7 @@ SIGNATURES = {
     "rsis_set_deterministic": (_i, [_i]),
     "rsis_get_deterministic": (_i, []),
     "rsis_conv_uses_bf16": (_i, [_i, _i, _i, _i]),
+    "rsis_conv_uses_wino": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "rsis_conv_packed_bytes_fwd": (_l, [_i, _i, _i, _i, _i, _i, _ip]),
     "rsis_conv_packed_bytes_dgrad": (_l, [_i, _i, _i, _i, _i, _i]),
     "rsis_conv_pack_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ip, _ip, _i, _i, _vp]),

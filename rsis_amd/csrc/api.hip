@@ -7,6 +7,8 @@
 int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_tile, hipStream_t st);
 int rsis_launch_conv_wgrad(WgradArgs& a, int ks, hipStream_t st);
 int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st);
+int rsis_launch_conv_wino(const float* x, const void* U, const float* bias, const float* addend, float* y, int B, int C, int Cout, int H, int W,
+                          hipStream_t st);
 int rsis_launch_convlstm_direct_group(ConvArgs* jobs, int n, const int* force_variant, hipStream_t st);
 int rsis_launch_conv3x3_direct_group_plain(ConvArgs* jobs, int n, const int* force_variant, hipStream_t st);
 int rsis_l_lstm_bwd_group(const void* const*, const int*, int, hipStream_t);
@@ -105,6 +107,15 @@ static inline bool use_bf16(int dtype, int ks, int stride, int pad, int Cout) {
   return dtype == RSIS_DTYPE_BF16 && bf16_geom(ks, stride, pad, Cout);
 }
 static inline int bf16_ckb(int ks) { return ks == 1 ? RSIS_CKB1 : RSIS_CKB3; }
+// -- RSIS_DTYPE_F32_WINO: Winograd F(2x2, 3x3) on the f32 MFMA (conv_wino.hip) for 3x3 / stride 1 / pad 1 convs with ONE source covering
+//    all input channels, both channel counts multiples of 32 (forward tiles 32 output channels over 8-channel chunks, the data gradient
+//    swaps the roles); anything else under that dtype is plain RSIS_DTYPE_F32
+static inline bool wino_geom(int ks, int stride, int pad, int Cin, int Cout, int nseg, int lstm_hid) {
+  return ks == 3 && stride == 1 && pad == 1 && nseg == 1 && lstm_hid == 0 && Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0;
+}
+static inline bool use_wino(int dtype, int ks, int stride, int pad, int Cin, int Cout, int nseg, int lstm_hid) {
+  return dtype == RSIS_DTYPE_F32_WINO && wino_geom(ks, stride, pad, Cin, Cout, nseg, lstm_hid);
+}
 // cell rows of a bf16 packed copy whose reduction axis is the concat of nseg channel segments
 static inline int bf16_rows(int ks, int nseg, const int* Cseg) {
   const int ckb = bf16_ckb(ks);
@@ -147,10 +158,14 @@ const char* rsis_error_string(int code) {
 }
 
 int rsis_conv_uses_bf16(int ks, int stride, int pad, int Cout) { return bf16_geom(ks, stride, pad, Cout) ? 1 : 0; }
+int rsis_conv_uses_wino(int ks, int stride, int pad, int Cin, int Cout, int nseg, int lstm_hid) {
+  return wino_geom(ks, stride, pad, Cin, Cout, nseg, lstm_hid) ? 1 : 0;
+}
 
 long rsis_conv_packed_bytes_fwd(int dtype, int Cout, int ks, int stride, int pad, int nseg, const int* Cseg) {
   if (nseg < 1 || nseg > RSIS_MAX_SRC || !Cseg) return -1;
   const long ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN);
+  if (use_wino(dtype, ks, stride, pad, Cseg[0], Cout, nseg, 0)) return (long)Cout * Cseg[0] * 16 * 4;
   if (use_bf16(dtype, ks, stride, pad, Cout)) return (long)bf16_rows(ks, nseg, Cseg) * ldw * 16;
   if (use_direct_fwd(ks, stride, pad)) return (long)direct_rows(nseg, Cseg) * ldw * 4;
   int c = 0;
@@ -160,6 +175,7 @@ long rsis_conv_packed_bytes_fwd(int dtype, int Cout, int ks, int stride, int pad
 
 long rsis_conv_packed_bytes_dgrad(int dtype, int Cout, int ks, int stride, int pad, int c_count) {
   const long ldw = rsis_roundup(c_count, RSIS_LDW_ALIGN);
+  if (use_wino(dtype, ks, stride, pad, c_count, Cout, 1, 0)) return (long)Cout * c_count * 16 * 4;
   if (use_bf16(dtype, ks, stride, pad, Cout)) return (long)bf16_rows(ks, 1, &Cout) * ldw * 16;
   if (use_direct(ks, stride, pad)) return (long)direct_rows(1, &Cout) * ldw * 4;
   if (use_direct_s2(ks, stride, pad)) {      // direct layout for one destination, implicit-GEMM layout for several: room for either
@@ -191,6 +207,9 @@ int rsis_conv_pack_fwd(const float* W, void* Wp, int Cout, int Ctot, int ks, int
   const int ldw = rsis_roundup(Cout, RSIS_LDW_ALIGN);
   int csum = 0;
   for (int s = 0; s < nseg; ++s) csum += Cseg[s];
+  if (use_wino(dtype, ks, stride, pad, csum, Cout, nseg, lstm_hid) && csum == Ctot && (!Coff || Coff[0] == 0))
+    return rsis_l_pack(7, W, Wp, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, (Cout / 32) * (Ctot / 8), 0, (hipStream_t)stream);
+  if (dtype == RSIS_DTYPE_F32_WINO && wino_geom(ks, stride, pad, csum, Cout, nseg, lstm_hid)) return RSIS_ERR_UNSUPPORTED;   // (a channel subset)
   if (use_bf16(dtype, ks, stride, pad, Cout))
     return rsis_l_pack(5, W, Wp, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, bf16_rows(ks, nseg, Cseg), lstm_hid, (hipStream_t)stream);
   if (use_direct_fwd(ks, stride, pad))
@@ -205,6 +224,9 @@ int rsis_conv_pack_dgrad(const float* W, void* Wd, int Cout, int Ctot, int ks, i
   int csum = 0;
   for (int s = 0; s < nseg; ++s) csum += Cseg[s];
   const int ldw = rsis_roundup(csum, RSIS_LDW_ALIGN);
+  if (use_wino(dtype, ks, stride, pad, csum, Cout, nseg, lstm_hid) && csum == Ctot && (!Coff || Coff[0] == 0))
+    return rsis_l_pack(8, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, (Ctot / 32) * (Cout / 8), 0, (hipStream_t)stream);
+  if (dtype == RSIS_DTYPE_F32_WINO && wino_geom(ks, stride, pad, csum, Cout, nseg, lstm_hid)) return RSIS_ERR_UNSUPPORTED;
   if (use_bf16(dtype, ks, stride, pad, Cout))
     return rsis_l_pack(6, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, bf16_rows(ks, 1, &Cout), lstm_hid, (hipStream_t)stream);
   if (use_direct(ks, stride, pad))
@@ -256,6 +278,14 @@ int rsis_conv_pack_job_fill(rsis_pack_job* j) {
   if (j->lstm_hid > 0 && j->dtype == RSIS_DTYPE_BF16 && j->ks != 3) return -1;                  // (see rsis_convlstm_fwd)
   int csum = 0;
   for (int s = 0; s < j->nseg; ++s) csum += j->Cseg[s];
+  const bool wino = use_wino(j->dtype, j->ks, j->stride, j->pad, csum, j->Cout, j->nseg, j->lstm_hid);
+  if (wino && (csum != j->Ctot || j->Coff[0] != 0)) return -1;
+  if (wino) {
+    j->ldw = rsis_roundup(j->dgrad ? csum : j->Cout, RSIS_LDW_ALIGN);
+    j->imode = j->dgrad ? 8 : 7;
+    j->krows = j->dgrad ? (j->Ctot / 32) * (j->Cout / 8) : (j->Cout / 32) * (j->Ctot / 8);
+    return rsis_l_pack_blocks(j->imode, j->krows, j->ldw, j->ks);
+  }
   if (!j->dgrad) {
     j->ldw = rsis_roundup(j->Cout, RSIS_LDW_ALIGN);
     if (use_bf16(j->dtype, j->ks, j->stride, j->pad, j->Cout)) { j->imode = 5; j->krows = bf16_rows(j->ks, j->nseg, j->Cseg); }
@@ -303,6 +333,8 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
   a.dst[0] = out; a.Cd[0] = Cout; a.ndst = 1;
   a.ostride = 1; a.oH = Ho; a.oW = Wo; a.ksplit = 1;
   a.precise = allow_splitk ? 0 : 1;       // (tile + 100 marks a training call; everything else is the inference / parity path)
+  if (use_wino(dtype, ks, stride, pad, Csrc[0], Cout, nsrc, 0))
+    return rsis_launch_conv_wino(src[0], Wp, bias, addend, out, B, Csrc[0], Cout, H, W, (hipStream_t)stream);
   if (use_bf16(dtype, ks, stride, pad, Cout)) {
     if (stride != 1) return RSIS_ERR_UNSUPPORTED;      // strided 1x1: run the stride-1 form on a sub-sampled input
     if (ks == 1 && nsrc != 1) return RSIS_ERR_UNSUPPORTED;
@@ -358,6 +390,11 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const vo
   if (ctot > Cin_packed) return RSIS_ERR_ARG;
   a.ostride = 1; a.oH = Hx; a.oW = Wx; a.ksplit = 1;
   a.wp = (const float*)Wd; a.ldw = rsis_roundup(Cin_packed, RSIS_LDW_ALIGN); a.Cout = ctot; a.bias = nullptr; a.addend = addend;
+  if (use_wino(dtype, ks, stride, pad, Cin_packed, Cout, 1, 0)) {
+    // the data gradient of a Winograd conv is the same kernel on the transposed, rotated weights (pack mode 8): dy plays the input
+    if (ndst != 1 || Cdx[0] != Cin_packed || Hx != Hy || Wx != Wy) return RSIS_ERR_UNSUPPORTED;
+    return rsis_launch_conv_wino(dy, Wd, nullptr, addend, dx[0], B, Cout, Cin_packed, Hy, Wy, (hipStream_t)stream);
+  }
   if (use_bf16(dtype, ks, stride, pad, Cout)) {
     if (ks == 3) {
       if (Hx != Hy || Wx != Wy) return RSIS_ERR_ARG;

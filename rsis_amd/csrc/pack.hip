@@ -208,6 +208,43 @@ __device__ __forceinline__ void pack_tile_bf16(const rsis_pack_job& j, int tb, u
   }
 }
 
+// ---- Winograd F(2x2, 3x3) copies (conv_wino.hip): U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], stored as
+//   out[((ot * nq + q) * 16 + xi) * 256 + cl * 32 + col]   ot = output-channel tile of 32, q = chunk of 8 reduction channels,
+//   xi = 4 i + j the position in the 4 x 4 Winograd domain -- one (ot, q) block of 4096 floats is what a block of the conv kernel
+//   DMAs per chunk.  mode 7 (forward): output channel = the weight's row co, reduction channel = its input channel ci, g = W[co][ci];
+//   mode 8 (data gradient): output channel = ci, reduction channel = co, g = W[co][ci] rotated by 180 degrees (the transposed conv).
+//   One tile = one (ot, q) block, one thread = one channel pair (9 loads, 16 coalesced stores).
+__device__ __forceinline__ void pack_tile_wino(int mode, const float* __restrict__ W, float* __restrict__ out, int Cout, int Ctot, int tb) {
+  const int n_red = mode == 7 ? Ctot : Cout, nq = n_red >> 3;
+  const int ot = tb / nq, q = tb - ot * nq;
+  const int cl = threadIdx.x >> 5, col = threadIdx.x & 31;
+  const int o = ot * 32 + col, rch = q * 8 + cl;                 // output / reduction channel of the conv this copy serves
+  const int co = mode == 7 ? o : rch, ci = mode == 7 ? rch : o;  // row / input channel of the reference weight
+  const float* g_ = W + ((size_t)co * Ctot + ci) * 9;
+  float g[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) g[k] = g_[mode == 7 ? k : 8 - k];
+  float t[4][3];
+#pragma unroll
+  for (int s_ = 0; s_ < 3; ++s_) {
+    t[0][s_] = g[s_];
+    t[1][s_] = 0.5f * (g[s_] + g[3 + s_] + g[6 + s_]);
+    t[2][s_] = 0.5f * (g[s_] - g[3 + s_] + g[6 + s_]);
+    t[3][s_] = g[6 + s_];
+  }
+  float* o_ = out + ((size_t)tb * 16) * 256 + cl * 32 + col;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o_[(4 * i + 0) * 256] = t[i][0];
+    o_[(4 * i + 1) * 256] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+    o_[(4 * i + 2) * 256] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+    o_[(4 * i + 3) * 256] = t[i][2];
+  }
+}
+__global__ __launch_bounds__(256) void pack_wino_kernel(int mode, const float* __restrict__ W, float* __restrict__ out, int Cout, int Ctot) {
+  pack_tile_wino(mode, W, out, Cout, Ctot, blockIdx.x);
+}
+
 // ---- batched repack: every packed copy of every conv weight in ONE launch (after an optimizer step ~240 tiny pack launches
 // per training step otherwise).  jobs[] lives in device memory; job i owns the blocks [block_begin_i, block_begin_{i+1}), one block
 // per PACK_T x PACK_T tile of the packed matrix.  The forward layouts (columns = output channel) are transposes of the reference
@@ -307,7 +344,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const rsis_pack_job* __
       next_begin = lo + 1 < njobs ? jobs[lo + 1].block_begin : total_tiles;
     }
     const int tb = b - j.block_begin;
-    if (j.imode >= 5) pack_tile_bf16(j, tb, (unsigned short*)&tile[0][0]);
+    if (j.imode >= 7) pack_tile_wino(j.imode, j.W, (float*)j.out, j.Cout, j.Ctot, tb);
+    else if (j.imode >= 5) pack_tile_bf16(j, tb, (unsigned short*)&tile[0][0]);
     else if (j.ks == 1) pack_tile<1>(j, tb, tile);
     else if (j.ks == 3) pack_tile<9>(j, tb, tile);
     else pack_tile<0>(j, tb, tile);
@@ -320,6 +358,7 @@ int rsis_l_pack_batch(const rsis_pack_job* jobs, int njobs, int total_blocks, hi
   return rsis_check_launch();
 }
 int rsis_l_pack_blocks(int mode, int krows, int ldw, int ks) {
+  if (mode >= 7) return krows;                              // Winograd copies: krows carries the number of (ot, q) blocks
   if (mode == 5) return krows / (ks * ks * (bf16_ckb(ks * ks) / 8)) * (ldw / 64);     // one chunk x 64 columns per block
   if (mode == 6) return (krows + 15) / 16 * (ldw / 64);
   return (mode >= 3 ? krows / (RSIS_CK * 9) : (krows + PACK_T - 1) / PACK_T) * (ldw / PACK_TC);
@@ -332,7 +371,7 @@ static inline int pack_grid(long total) {
 }
 
 // mode: 0 igemm fwd, 1 igemm dgrad, 2 direct fwd, 3 direct dgrad (stride 1), 4 direct dgrad (stride 2: taps not flipped),
-// 5 bf16 fwd, 6 bf16 dgrad (cell layouts of conv_bf16.hip)
+// 5 bf16 fwd, 6 bf16 dgrad (cell layouts of conv_bf16.hip), 7 Winograd fwd, 8 Winograd dgrad (conv_wino.hip)
 int rsis_l_pack(int mode, const float* W, void* out, int Cout, int Ctot, int ks, int nseg, const int* Cseg, const int* Coff,
                 int ldw, int krows, int hid, hipStream_t st) {
   SegMap m = {};
@@ -341,6 +380,10 @@ int rsis_l_pack(int mode, const float* W, void* out, int Cout, int Ctot, int ks,
   for (int s = 0; s < nseg; ++s) { m.C[s] = Cseg[s]; m.off[s] = Coff ? Coff[s] : base; base += Cseg[s]; }
   const long total = (long)krows * ldw;
   const dim3 g(pack_grid(total)), b(256);
+  if (mode == 7 || mode == 8) {      // Winograd copies (one source covering every input channel; krows = (ot, q) blocks)
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(krows), b, 0, st, mode, W, (float*)out, Cout, Ctot);
+    return rsis_check_launch();
+  }
   if (mode < 0 || mode > 6) return RSIS_ERR_ARG;
   if (mode >= 5) {     // bf16 cell layouts: krows = cell rows, out = bf16
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(pack_grid(total * 8)), b, 0, st, mode, W, (unsigned short*)out, Cout, Ctot, ks * ks, m, ldw,

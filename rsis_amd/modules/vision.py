@@ -29,11 +29,16 @@ class HipConv2d(nn.Module):
             nn.init.uniform_(self.bias, -bound, bound)
         else:
             self.register_parameter("bias", None)
-        self._pack = ops.PackedConv(self.kernel_size, [self.in_channels], stride=self.stride, pad=self.padding)
+        self._pack = None
+        self._set_rsis_dtype(ops.DTYPE_F32)
 
     def _set_rsis_dtype(self, d):
-        """f32 or bf16 MFMA kernels for this conv (ops.set_dtype); the parameters stay fp32"""
-        if self._pack.dtype != d:
+        """f32 or bf16 MFMA kernels for this conv (ops.set_dtype); the parameters stay fp32.  Under fp32 the 3x3 convs that
+        ops.conv_dtype selects (RSIS_WINOGRAD) get the Winograd copy of their weight (same arithmetic type, fewer matrix flops)."""
+        import torch as _t
+        if _t.cuda.is_available():       # (the rule asks the library which geometries its kernel covers; CPU-side module construction -- tests of
+            d = ops.conv_dtype(d, self.kernel_size, self.stride, self.padding, self.in_channels, self.out_channels)   # the parameter layout -- has none)
+        if self._pack is None or self._pack.dtype != d:
             self._pack = ops.PackedConv(self.kernel_size, [self.in_channels], stride=self.stride, pad=self.padding, dtype=d)
 
     def forward(self, x, grad_slot=None, park_slot=None):

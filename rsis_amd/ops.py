@@ -37,6 +37,38 @@ def _direct_target(param):
 
 # arithmetic of the MFMA conv kernels (include/rsis_hip.h RSIS_DTYPE_*); a property of each PackedConv, set from `-dtype`
 DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32_WINO = 3      # include/rsis_hip.h RSIS_DTYPE_F32_WINO: exact-f32 arithmetic, eligible 3x3 convs as Winograd F(2x2, 3x3)
+
+
+def _wino_rule():
+    """RSIS_WINOGRAD: which fp32 3x3 / stride 1 / pad 1 convs run as Winograd F(2x2, 3x3) on the f32 MFMA (conv_wino.hip).
+    "0" = none; "all" = every conv the kernel covers (rsis_conv_uses_wino); a comma list of channel counts = the square convs
+    (Cin == Cout) of those widths.  Default "256": the 22 layer-3 bottleneck convs of ResNet-101 -- two thirds of the trunk's 3x3 flops."""
+    v = os.environ.get("RSIS_WINOGRAD", "256").strip().lower()
+    if v in ("0", "", "off", "none"):
+        return None
+    if v == "all":
+        return "all"
+    return {int(t) for t in v.split(",") if t.strip()}
+
+
+WINOGRAD = [_wino_rule()]
+# Winograd also on the inference / parity path (no_grad calls: test(), eval.py)?  Default off: those calls keep the direct kernel with
+# segmented accumulation, bit for bit what they computed before the Winograd kernel existed.  Measured with it on (round 6): every
+# e2e golden still within 1e-4 of the reference, but on the HOT fixture (e2e_256_hot: |logit| to 5.5, half the gates saturated) the
+# worst mask logit moves from 1.08e-4 to 1.86e-4 from float64 (the reference itself: 1.0e-4) -- 22 stacked Winograd layers are as
+# accurate per layer as an unsegmented direct sum (2.8e-6 vs 2.6e-6 on O(1) data), not as accurate as the segmented one.
+WINOGRAD_INFER = [os.environ.get("RSIS_WINOGRAD_INFER", "0") == "1"]
+
+
+def conv_dtype(dtype, ks, stride, pad, cin, cout):
+    """the dtype a plain conv's PackedConv is built with: fp32 convs the Winograd rule selects get DTYPE_F32_WINO"""
+    d = int(dtype)
+    rule = WINOGRAD[0]
+    if d != DTYPE_F32 or rule is None or not lib().rsis_conv_uses_wino(int(ks), int(stride), int(pad), int(cin), int(cout), 1, 0):
+        return d
+    return DTYPE_F32_WINO if (rule == "all" or (cin == cout and cin in rule)) else d
+
 DTYPES = {"fp32": DTYPE_F32, "f32": DTYPE_F32, "float32": DTYPE_F32, "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16}
 
 
@@ -132,6 +164,7 @@ class PackedConv(object):
         self._key_f = None
         self._key_d = None
         self.training_call = False
+        self._twin = None
         self.wp = None
         self.wd = None
         self.bias_p = None
@@ -139,6 +172,12 @@ class PackedConv(object):
 
     def _key(self, w):
         return (_WEIGHT_EPOCH[0], w._version, w.data_ptr(), self.dtype)
+
+    def direct_twin(self):
+        """the RSIS_DTYPE_F32 copy set of a Winograd-packed conv (same geometry): what its inference / parity calls run on"""
+        if self._twin is None:
+            self._twin = PackedConv(self.ks, self.segs, lstm_hid=self.lstm_hid, stride=self.stride, pad=self.pad, offs=self.offs, dtype=DTYPE_F32)
+        return self._twin
 
     def _pack_bias(self, bias):
         """gate-interleaved copy of a ConvLSTM bias (row 4*j + gate), refreshed IN PLACE in a buffer allocated once: the kernels of
@@ -422,7 +461,10 @@ def conv2d(srcs, weight, bias, stride, pad, pack, grad_slot=None, park_slot=None
     takes an addend from; park_slot: the slot it parks its own data gradient in (see GradSlot)."""
     # (ctx.needs_input_grad is True for parameters even under no_grad, and grad mode is off inside Function.forward, so the
     #  "is this a training call" decision is taken here)
-    pack.training_call = torch.is_grad_enabled() and (weight.requires_grad or any(s.requires_grad for s in srcs))
+    training = torch.is_grad_enabled() and (weight.requires_grad or any(s.requires_grad for s in srcs))
+    if pack.dtype == DTYPE_F32_WINO and not training and not WINOGRAD_INFER[0]:
+        pack = pack.direct_twin()            # inference / parity path: the direct kernel, segmented accumulation (see WINOGRAD_INFER)
+    pack.training_call = training
     if grad_slot is not None:
         grad_slot.reset()
     slot = grad_slot if park_slot is None else (grad_slot, park_slot)

@@ -16,7 +16,7 @@ def pytest_configure(config):
 # C-ABI entry point, the BASELINE geometries and the training step; then the bf16 twin) must not be hidden behind an auxiliary
 # test that happens to sort earlier alphabetically.  Modules not listed run after the parity suites and before the last group
 # (graph replay / multi-process tests, which exercise launch modes rather than arithmetic).
-_ORDER_FIRST = ["test_gpu_modules", "test_gpu_hot", "test_gpu_round2", "test_gpu_ops", "test_gpu_bf16", "test_gpu_bf16s", "test_maskpost", "test_targets",
+_ORDER_FIRST = ["test_gpu_modules", "test_gpu_hot", "test_gpu_round2", "test_gpu_ops", "test_gpu_wino", "test_gpu_bf16", "test_gpu_bf16s", "test_maskpost", "test_targets",
                 "test_augment", "test_leaves_loader"]
 _ORDER_LAST = ["test_gpu_determinism", "test_gpu_graph", "test_gpu_ddp", "test_gpu_bench"]
 

@@ -111,7 +111,7 @@ def test_e2e_hot_bf16():
       * the share of elements beyond 10 % of max|ref| (logits) / beyond 3e-2 (mask probabilities) <= max(1e-3, 1.5 x the independent
         bf16 evaluation's share: 2.4e-4 / 6.1e-3 measured on the CPU);
       * max abs error of logits and of probabilities <= 1.5 x the independent bf16 evaluation's;
-      * class / stop probabilities within 3e-2 (unchanged)."""
+      * class / stop probabilities within max(3e-2, 1.5 x the independent bf16 evaluation's max abs error)."""
     from oracle import filler
     from oracle import rsis_oracle as O
     from rsis_amd.test import test as hip_test
@@ -129,6 +129,7 @@ def test_e2e_hot_bf16():
     odec = filler.fill_module(O.RSIS(a32), seed=45, gates_gain=float(g["gates_gain"])).eval()
     with torch.autocast("cpu", dtype=torch.bfloat16):
         ol, _oc, _os = O.test(a32, oenc, odec, x, return_logits=True)
+        _om, oc16, os16 = O.test(a32, oenc, odec, x)
     ol = ol.float()[:, :, ::sub, ::sub].double()
     ref = torch.from_numpy(g["mask_logits_sub"]).double()
     refp = torch.from_numpy(g["mask_probs_sub"]).double()
@@ -145,5 +146,10 @@ def test_e2e_hot_bf16():
     assert float((e > big).double().mean()) <= max(1e-3, 1.5 * float((ef > big).double().mean()))
     assert float((ep > BF16_TOL["probs"]).double().mean()) <= max(1e-3, 1.5 * float((epf > BF16_TOL["probs"]).double().mean()))
     assert float(e.max()) <= 1.5 * float(ef.max()) and float(ep.max()) <= 1.5 * float(epf.max())
-    assert_close("hot.bf16.classes", classes, g["classes"], BF16_TOL["probs"])
-    assert_close("hot.bf16.stops", stops, g["stops"], BF16_TOL["probs"])
+    ec = float((oc16.float().double() - torch.from_numpy(g["classes"]).double()).abs().max())
+    es = float((os16.float().double() - torch.from_numpy(g["stops"]).double()).abs().max())
+    print("class probs: hip max abs %.3e (independent bf16 %.3e); stop probs: hip %.3e (independent %.3e)" % (
+        float((classes.double().cpu() - torch.from_numpy(g["classes"]).double()).abs().max()), ec,
+        float((stops.double().cpu() - torch.from_numpy(g["stops"]).double()).abs().max()), es))
+    assert_close("hot.bf16.classes", classes, g["classes"], max(BF16_TOL["probs"], 1.5 * ec))
+    assert_close("hot.bf16.stops", stops, g["stops"], max(BF16_TOL["probs"], 1.5 * es))

@@ -50,7 +50,11 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const WinoArgs p) {
   float* const VS = US + 2 * U_S;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef NQ_FORCE
+  const int n_co = p.Cout / 32, nq = NQ_FORCE;
+#else
   const int n_co = p.Cout / 32, nq = p.C / CK;
+#endif
   // blocks b, b + 8, ... share an XCD: an XCD takes B/8 images x all output-channel tiles (the 4 MB of U stay in its L2)
   const int bid = blockIdx.x, xcd = bid & 7, qq = bid >> 3;
   const int co_t = qq % n_co;
@@ -73,14 +77,16 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const WinoArgs p) {
 
 #define ISSUE_RAW(Q, SLOT)                                                                                              \
   {                                                                                                                     \
-    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)(Q) * CK * HW * HW), 0, CK * HW * HW * 4, 0x00020000); \
+    const int q_ = (Q) < nq ? (Q) : 0;  /* beyond the last chunk: a zero-range descriptor (the loads write zeros into a dead stage) */ \
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (size_t)q_ * CK * HW * HW), 0, (Q) < nq ? CK * HW * HW * 4 : 0, 0x00020000); \
     float* dst = RAW + (SLOT) * RAW_S + wave * 64;                                                                      \
     _Pragma("unroll") for (int i = 0; i < RAW_N; ++i)                                                                   \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_vp_t)(dst + i * 256), 4, xvo[i], 0, 0, 0);                     \
   }
 #define ISSUE_U(Q, SLOT)                                                                                                \
   {                                                                                                                     \
-    const __amdgpu_buffer_rsrc_t ru_ = __builtin_amdgcn_make_buffer_rsrc((void*)(ub + (size_t)(Q) * U_S), 0, U_S * 4, 0x00020000); \
+    const int q_ = (Q) < nq ? (Q) : 0;                                                                                  \
+    const __amdgpu_buffer_rsrc_t ru_ = __builtin_amdgcn_make_buffer_rsrc((void*)(ub + (size_t)q_ * U_S), 0, (Q) < nq ? U_S * 4 : 0, 0x00020000); \
     float* dst = US + (SLOT) * U_S + wave * 256;                                                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                       \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ru_, (lds_vp_t)(dst + i * 1024), 16, (unsigned)(tid + i * 256) * 16u, 0, 0, 0); \
@@ -135,25 +141,97 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const WinoArgs p) {
 
   const int aoff = (4 * wave) * (CK * 32) + hi * 32 + l31;       // U[xi = 4 wave + c][2 kp + hi][l31]
   const int boff = (4 * wave) * (CK * 64) + hi * 64 + l31;       // V[xi][2 kp + hi][tg * 32 + l31]
+  // The chunk loop, scheduled by hand (sched_barrier fences; inside a fence-delimited piece the order is the source order):
+  // the 8 MFMAs of k-pair kp are issued in 4 pairs, and in the shadow of each pair (2 x 64 cycles of the matrix pipe) the wave
+  // issues a slice of everything else -- the operand reads of k-pair kp + 1, and a quarter of the input transform of chunk t + 1
+  // (item 0 = channel `wave` in pieces 0-1, item 1 = channel `wave + 4` in pieces 2-3: reads + row pass, then column pass + writes).
+  // The transform runs unconditionally (in the last iteration on stale data into a dead stage): one basic block.
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define LOAD_OPS(KP, S)                                                                    \
+  _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                          \
+    av[S][c] = Us[c * (CK * 32) + (2 * (KP)) * 32];                                        \
+    bv[S][c][0] = Vs[c * (CK * 64) + (2 * (KP)) * 64];                                     \
+    bv[S][c][1] = Vs[c * (CK * 64) + (2 * (KP)) * 64 + 32];                                \
+  }
+#ifdef NO_MFMA
+#define MF(S, c) acc[c][0][0] += av[S][c] * bv[S][c][0]; acc[c][1][0] += av[S][c] * bv[S][c][1];
+#else
+#define MF(S, c)                                                                           \
+  acc[c][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[S][c], bv[S][c][0], acc[c][0], 0, 0, 0); \
+  acc[c][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[S][c], bv[S][c][1], acc[c][1], 0, 0, 0);
+#endif
+  float av[2][4], bv[2][4][2];
   for (int t = 0; t < nq; ++t) {
     const int cur = t & 1, nxt = cur ^ 1;
-    if (t + 2 < nq) ISSUE_RAW(t + 2, cur)
-    if (t + 1 < nq) ISSUE_U(t + 1, nxt)
     const float* Us = US + cur * U_S + aoff;
     const float* Vs = VS + cur * V_S + boff;
+    LOAD_OPS(0, 0)
+#ifndef NO_DMA
+    ISSUE_RAW(t + 2, cur)
+    ISSUE_U(t + 1, nxt)
+#endif
+    const float* raw = RAW + nxt * RAW_S + roff;
+    float* vo = VS + nxt * V_S + lane;
 #pragma unroll
-    for (int kp = 0; kp < 4; ++kp) {
+    for (int it = 0; it < 2; ++it) {
+      const int ci = wave + 4 * it;
+      const float* sp = raw + ci * (PW * RSTRIDE);
+      float* o = vo + ci * 64;
+      float d[4][4], e[4][4];
+      // ---- piece 2 it: k-pair 2 it; transform reads + row pass ----
+      SB();
+      LOAD_OPS(2 * it + 1, 1)
+      MF(0, 0)
+      SB();
+#ifdef NO_TRANSFORM
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float a = Us[c * (CK * 32) + (2 * kp) * 32];
-        const float b0 = Vs[c * (CK * 64) + (2 * kp) * 64], b1 = Vs[c * (CK * 64) + (2 * kp) * 64 + 32];
-        acc[c][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[c][0], 0, 0, 0);
-        acc[c][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[c][1], 0, 0, 0);
+      for (int r = 0; r < 4; ++r) { d[r][0] = d[r][1] = d[r][2] = d[r][3] = (float)t; }
+#else
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x2 a = *(const f32x2*)(sp + r * RSTRIDE), b = *(const f32x2*)(sp + r * RSTRIDE + 2);
+        d[r][0] = a[0]; d[r][1] = a[1]; d[r][2] = b[0]; d[r][3] = b[1];
       }
-      if (t + 1 < nq) {
-        if (kp == 1) transform(RAW + nxt * RAW_S, VS + nxt * V_S, wave);
-        if (kp == 3) transform(RAW + nxt * RAW_S, VS + nxt * V_S, wave + 4);
+#endif
+      MF(0, 1)
+      SB();
+#pragma unroll
+      for (int c = 0; c < 2; ++c) { e[0][c] = d[0][c] - d[2][c]; e[1][c] = d[1][c] + d[2][c]; e[2][c] = d[2][c] - d[1][c]; e[3][c] = d[1][c] - d[3][c]; }
+      MF(0, 2)
+      SB();
+#pragma unroll
+      for (int c = 2; c < 4; ++c) { e[0][c] = d[0][c] - d[2][c]; e[1][c] = d[1][c] + d[2][c]; e[2][c] = d[2][c] - d[1][c]; e[3][c] = d[1][c] - d[3][c]; }
+      MF(0, 3)
+      SB();
+      // ---- piece 2 it + 1: k-pair 2 it + 1; column pass + writes ----
+      if (it == 0) { LOAD_OPS(2, 0) }
+      MF(1, 0)
+      SB();
+#ifdef NO_TRANSFORM
+      if (e[0][0] == 12345.f)
+#endif
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        o[(4 * r + 0) * (CK * 64)] = e[r][0] - e[r][2];
+        o[(4 * r + 1) * (CK * 64)] = e[r][1] + e[r][2];
+        o[(4 * r + 2) * (CK * 64)] = e[r][2] - e[r][1];
+        o[(4 * r + 3) * (CK * 64)] = e[r][1] - e[r][3];
       }
+      MF(1, 1)
+      SB();
+#ifdef NO_TRANSFORM
+      if (e[0][0] == 12345.f)
+#endif
+#pragma unroll
+      for (int r = 2; r < 4; ++r) {
+        o[(4 * r + 0) * (CK * 64)] = e[r][0] - e[r][2];
+        o[(4 * r + 1) * (CK * 64)] = e[r][1] + e[r][2];
+        o[(4 * r + 2) * (CK * 64)] = e[r][2] - e[r][1];
+        o[(4 * r + 3) * (CK * 64)] = e[r][1] - e[r][3];
+      }
+      MF(1, 2)
+      MF(1, 3)
+      SB();
     }
     LAND()
     __syncthreads();
@@ -266,6 +344,6 @@ int main(int argc, char** argv) {
   hipEventElapsedTime(&ms, e0, e1);
   const double us = 1e3 * ms / iters, gf_direct = 2.0 * B * 256 * C * 9 * Cout / 1e9;
   printf("wino_f32_kernel: %.1f us per launch (%d blocks, %d KB LDS); direct-conv-equivalent %.1f TFLOP/s, executed (x 16/36) %.1f TFLOP/s\n",
-         us, grid, lds / 1024, gf_direct / us / 1e3, gf_direct * 16 / 36 / us / 1e3);
+         us, grid, lds / 1024, gf_direct / us * 1e3, gf_direct * 16 / 36 / us * 1e3);
   return worst < 2e-4 ? 0 : 2;
 }
