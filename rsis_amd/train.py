@@ -749,7 +749,13 @@ def trainIters(args):
                         #  captures instead of re-capturing on every change; a resident synthetic batch only ever has one)
                         cache = graphs.setdefault("cache", {})
                         if key not in cache:
-                            while len(cache) >= 4:                 # evict the least recently USED capture (dicts keep insertion order)
+                            # Policy (round 6, measured with tools/graph_cache_bench.py): a loader whose batches stop at different steps
+                            # produces at most `maxseqlen` values of t_run per mode, so keeping maxseqlen + 1 captures means every key is
+                            # captured ONCE and replayed from then on -- with the four kept until round 5 a CVPPP-like set (3-9 leaves per
+                            # image, 7+ keys) re-captured continually (2 eager steps + a capture each time).  The captures share one graph
+                            # memory pool; what a key costs is its static input copies (the GT masks: B x gt_maxseqlen x H x W floats).
+                            keep = max(4, int(args.maxseqlen) + 1)
+                            while len(cache) >= keep:              # evict the least recently USED capture (dicts keep insertion order)
                                 cache.pop(next(iter(cache))).release()
                             # the captures never replay concurrently and their results are cloned at once: ONE graph memory pool for all
                             # of them (a private pool each held a full step's activations per key)
