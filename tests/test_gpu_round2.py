@@ -808,3 +808,26 @@ def test_ragged_targets_match_the_oracle():
         assert want == want, k + ": the oracle's value is NaN"
         assert_close(k, got, want, 1e-4, 1e-4)      # (train-mode BN over 64 samples per channel at the deepest level: 4e-5 relative on the class loss)
     assert (perms[1].cpu().numpy() == r["y_class_perm"].numpy()).all()
+
+
+def test_bf16_training_tracks_fp32_over_200_iterations():
+    """bf16 TRAINING quality (reference src/train.py:159-187): 200 iterations at BASELINE configs[2]'s geometry (224 x 224,
+    T = 10, batch 32, all three losses, both Adam optimizers) under fp32 and bf16 from identical initial weights (torch's default
+    initialisation) and an identical stream of 16 synthetic batches -- tools/bf16_training_quality.py.  Bands, per window of 20 iterations:
+    total loss within 6 %, soft-IoU loss (1 - matched soft IoU, train.py:167) within 8 % of the fp32 run; both runs bring the loss down by
+    more than 30 %.  Measured (round 6, profiles/r06_bf16_training_curve.txt): 4.3 % / 6.4 % at the worst window, loss 1.380 -> 0.843 (fp32)
+    and 1.381 -> 0.855 (bf16); an fp32 run from weights perturbed by one part in a million drifts from the fp32 run by a comparable
+    amount over the same iterations (the control row of that file) -- the bands are the resolution of the comparison, not a bf16 bias."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bf16_training_quality as Q
+    curves = Q.run(200)
+    bd = Q.bands(curves)
+    print("loss windows rel:", ["%.4f" % v for v in bd["loss"]["rel"]], "soft-IoU:", ["%.4f" % v for v in bd["soft_iou_loss"]["rel"]])
+    for dt in ("fp32", "bf16"):
+        tot = curves[dt][0]
+        assert all(v == v and abs(v) < 1e3 for v in tot)
+        assert sum(tot[-20:]) / 20 < 0.7 * tot[0], (dt, tot[0], tot[-20:])
+    assert max(bd["loss"]["rel"]) <= 0.06, bd["loss"]["rel"]
+    assert max(bd["soft_iou_loss"]["rel"]) <= 0.08, bd["soft_iou_loss"]["rel"]

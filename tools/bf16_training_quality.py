@@ -15,7 +15,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 
-def run(iters=200, B=32, S=224, T=10, n_batches=16, seed=0, log=None):
+def run(iters=200, B=32, S=224, T=10, n_batches=16, seed=0, log=None, control=False):
+    """control=True adds a third curve: fp32 again from the same weights perturbed by ONE PART IN A MILLION (w * (1 + 1e-6 n), n ~ N(0, 1)) --
+    how far two fp32 trajectories of this chaotic system drift apart over the same iterations, i.e. the resolution of the comparison."""
     import bench
     from rsis_amd.modules import FeatureExtractor, RSIS
     from rsis_amd.synthetic import synthetic_batch
@@ -24,14 +26,19 @@ def run(iters=200, B=32, S=224, T=10, n_batches=16, seed=0, log=None):
     batches = [synthetic_batch(100 + i, B, S, S, 20, 12, 21, "cuda") for i in range(n_batches)]
     init = None
     curves = {}
-    for dtype in ("fp32", "bf16"):
-        a = bench.bench_args(B, S, T, dtype)
+    for dtype in ("fp32", "bf16") + (("fp32_perturbed",) if control else ()):
+        a = bench.bench_args(B, S, T, dtype.split("_")[0])
         torch.manual_seed(seed)
         enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
         if init is None:
             init = ({k: v.clone() for k, v in enc.state_dict().items()}, {k: v.clone() for k, v in dec.state_dict().items()})
         enc.load_state_dict(init[0])
         dec.load_state_dict(init[1])
+        if dtype == "fp32_perturbed":
+            gen = torch.Generator(device="cuda").manual_seed(7)
+            with torch.no_grad():
+                for q in list(enc.parameters()) + list(dec.parameters()):
+                    q.mul_(1.0 + 1e-6 * torch.randn(q.shape, device="cuda", generator=gen))
         opts = list(build_optimizers(a, enc, dec))
         crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(0.5)]
         t_run = steps_to_run(a, batches[0][3])
@@ -52,11 +59,11 @@ def run(iters=200, B=32, S=224, T=10, n_batches=16, seed=0, log=None):
     return curves
 
 
-def bands(curves, window=20):
+def bands(curves, window=20, other="bf16"):
     """the statements the test asserts: windowed means (20 iterations) of the two curves, relative distance per window"""
     out = {}
     for name, idx in (("loss", 0), ("soft_iou_loss", 1)):
-        f, b = curves["fp32"][idx], curves["bf16"][idx]
+        f, b = curves["fp32"][idx], curves[other][idx]
         n = len(f) // window
         wf = [sum(f[i * window:(i + 1) * window]) / window for i in range(n)]
         wb = [sum(b[i * window:(i + 1) * window]) / window for i in range(n)]
@@ -75,13 +82,17 @@ def main():
         print(m, flush=True)
         lines.append(m)
     log("# bf16 vs fp32 training, configs[2] geometry (224x224, T=10, B=32), %d iterations, identical initial weights and batches" % o.iters)
-    curves = run(o.iters, log=log)
+    curves = run(o.iters, log=log, control=True)
     bd = bands(curves)
     for name, d in bd.items():
         log("%s, means over windows of 20 iterations:" % name)
         log("  fp32 " + " ".join("%.4f" % v for v in d["fp32"]))
         log("  bf16 " + " ".join("%.4f" % v for v in d["bf16"]))
         log("  |bf16 - fp32| / fp32 " + " ".join("%.4f" % v for v in d["rel"]) + "   (max %.4f)" % max(d["rel"]))
+    bc = bands(curves, other="fp32_perturbed")
+    for name, d in bc.items():
+        log("CONTROL %s: fp32 from weights perturbed by 1e-6 relative, |perturbed - fp32| / fp32 per window " % name
+            + " ".join("%.4f" % v for v in d["rel"]) + "   (max %.4f)" % max(d["rel"]))
     log("per-iteration loss, every 10th: fp32 " + " ".join("%.3f" % v for v in curves["fp32"][0][::10]))
     log("per-iteration loss, every 10th: bf16 " + " ".join("%.3f" % v for v in curves["bf16"][0][::10]))
     if o.out:

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--epochs", type=int, default=4)
+    ap.add_argument("--epochs", type=int, default=8)
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--imsize", type=int, default=256)
     o = ap.parse_args()
@@ -43,9 +43,10 @@ def main():
             assert p.returncode == 0, "train.py failed in %s mode" % mode
             n_img = 96 // o.batch * o.batch
             per = [marks[0] - t0] + [b - a for a, b in zip(marks, marks[1:])]      # (each span also holds the 8-image validation pass before it)
-            print("%-5s batch %d: epoch wall times %s s -> images/s %s (epoch 0 includes start-up%s)" % (
+            rest = sorted(per[1:])
+            print("%-5s batch %d: epoch wall times %s s -> images/s %s (epoch 0 includes start-up%s); MEDIAN of epochs >= 1: %.1f images/s" % (
                 mode, o.batch, " ".join("%.1f" % v for v in per), " ".join("%.1f" % (n_img / v) for v in per),
-                " and every capture" if mode == "graph" else ""), flush=True)
+                " and every capture" if mode == "graph" else "", n_img / rest[len(rest) // 2]), flush=True)
 
 
 if __name__ == "__main__":
