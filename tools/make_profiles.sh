@@ -2,7 +2,7 @@
 # Regenerates the rocprofv3 summaries committed under profiles/ for one round (run on the GPU box: `gpurun -- bash tools/make_profiles.sh r03`).
 # Everything is written under gpurun_out/<tag>/ ; copy the *.txt / *.json you want judged into profiles/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -82,6 +82,18 @@ python tools/pmc_summary.py "conv3x3_direct" $(find $OUT/raw_mfma_gate -name '*c
 rm -rf $OUT/raw_mfma_gemm
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/raw_mfma_gemm -o pmc -- python tools/exp/gemm1x1_sweep.py --tiles 0 --iters 3 > /dev/null 2>&1
 python tools/pmc_summary.py "conv_igemm_kernel" $(find $OUT/raw_mfma_gemm -name '*counter_collection.csv' | head -1) > $OUT/gemm1x1_mfma_busy_fp32.txt
+# ---- round 6: inference (test() as a replayed graph) fp32 256^2 and bf16 224^2: one step each; the Winograd kernel: per-shape A/B table and
+# its MFMA-busy counters (own pass)
+INF="--inference --steps 3 --warmup 4 --skip-roofline"
+db=$(prof inf_fp32 python bench.py $INF);                          python tools/prof_summary.py $db lastperiod > $OUT/inference_fp32_step.txt
+db=$(prof inf_bf16 python bench.py $INF --dtype bf16 --imsize 224); python tools/prof_summary.py $db lastperiod > $OUT/inference_bf16_224_step.txt
+python tools/wino_bench.py --iters 30 > $OUT/wino_per_shape.txt 2>&1
+rm -rf $OUT/raw_mfma_wino
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/raw_mfma_wino -o pmc -- python tools/wino_bench.py --iters 3 --only-wino > /dev/null 2>&1
+python tools/pmc_summary.py "conv_wino_f32_kernel" $(find $OUT/raw_mfma_wino -name '*counter_collection.csv' | head -1) > $OUT/wino_mfma_busy_fp32.txt
+rm -rf $OUT/raw_lds_wino
+rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_BUSY_CU_CYCLES SQ_WAVES --output-format csv -d $OUT/raw_lds_wino -o pmc -- python tools/wino_bench.py --iters 3 --only-wino > /dev/null 2>&1
+python tools/pmc_summary.py "conv_wino_f32_kernel" $(find $OUT/raw_lds_wino -name '*counter_collection.csv' | head -1) > $OUT/wino_lds_counters_fp32.txt
 # blocked bf16 conv against the fp32-storage bf16 conv on the trunk's shapes
 rm -rf $OUT/raw_*
 ls -la $OUT

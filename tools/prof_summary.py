@@ -18,14 +18,21 @@ def short(name):
 
 def main():
     path = sys.argv[1]
-    last = len(sys.argv) > 2 and sys.argv[2] == "laststep"
+    last = len(sys.argv) > 2 and sys.argv[2] in ("laststep", "lastperiod")
     steps = float(sys.argv[2]) if len(sys.argv) > 2 and not last else None
     rows = []
     if last:
         cur = sqlite3.connect(path).cursor()
         ks = list(cur.execute("select name,start,end from kernels order by start"))
-        ad = [i for i, k in enumerate(ks) if "adam_kernel" in k[0]]
-        seg = ks[ad[-4] + 1: ad[-2] + 1]
+        if sys.argv[2] == "lastperiod":
+            # `lastperiod` (a run that ends with replays of ONE captured graph and has no optimizer step to delimit it: bench.py --inference):
+            # the shortest L >= 50 with names[-L:] == names[-2L:-L] -- the kernels of the last replay
+            names = [k[0] for k in ks]
+            L = next(L for L in range(50, len(names) // 2) if names[-L:] == names[-2 * L:-L])
+            seg = ks[-L:]
+        else:
+            ad = [i for i, k in enumerate(ks) if "adam_kernel" in k[0]]
+            seg = ks[ad[-4] + 1: ad[-2] + 1]
         agg = {}
         for n, s0, e0 in seg:
             a = agg.setdefault(short(n), [0, 0.0])
@@ -33,7 +40,7 @@ def main():
             a[1] += (e0 - s0) / 1e6
         tot = sum(a[1] for a in agg.values())
         rows = [(n, a[0], a[1], 1e3 * a[1] / a[0], 100.0 * a[1] / tot) for n, a in agg.items()]
-        print("# one training step: %d kernel launches, first start to last end %.3f ms" % (len(seg), (seg[-1][2] - seg[0][1]) / 1e6))
+        print("# one %s: %d kernel launches, first start to last end %.3f ms" % ("replay of the captured graph" if sys.argv[2] == "lastperiod" else "training step", len(seg), (seg[-1][2] - seg[0][1]) / 1e6))
     elif path.endswith(".db"):
         cur = sqlite3.connect(path).cursor()
         for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
