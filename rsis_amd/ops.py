@@ -43,8 +43,10 @@ DTYPE_F32_WINO = 3      # include/rsis_hip.h RSIS_DTYPE_F32_WINO: exact-f32 arit
 def _wino_rule():
     """RSIS_WINOGRAD: which fp32 3x3 / stride 1 / pad 1 convs run as Winograd F(2x2, 3x3) on the f32 MFMA (conv_wino.hip).
     "0" = none; "all" = every conv the kernel covers (rsis_conv_uses_wino); a comma list of channel counts = the square convs
-    (Cin == Cout) of those widths.  Default "256": the 22 layer-3 bottleneck convs of ResNet-101 -- two thirds of the trunk's 3x3 flops."""
-    v = os.environ.get("RSIS_WINOGRAD", "256").strip().lower()
+    (Cin == Cout) of those widths.  Default "64,128,256": the stride-1 bottleneck convs of ResNet-101 layers 1-3 (3 + 3 + 22 convs; per shape,
+    tools/wino_bench.py: 256 @16^2 90 -> 56 us, 128 @32^2 78 -> 56, 64 @64^2 75 -> 68; NOT layer 4: 512 @8^2 fills a quarter of the
+    64-tile block, 98 -> 176 us)."""
+    v = os.environ.get("RSIS_WINOGRAD", "64,128,256").strip().lower()
     if v in ("0", "", "off", "none"):
         return None
     if v == "all":
