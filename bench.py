@@ -312,7 +312,13 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32", inference=False):
             continue
         x = torch.randn(B, cin, hh, ww, device="cuda")
         w = torch.randn(cout, cin, ks, ks, device="cuda") / (ks * cin ** 0.5)
-        pack = ops.PackedConv(ks, [cin], stride=1, pad=pad, dtype=dt)
+        # the copy flavour the product's module builds for this conv: training calls of the layer 1-3 bottleneck convs run the Winograd
+        # kernel (ops.conv_dtype, RSIS_WINOGRAD); the skip convs have a bias and their own module, inference calls keep the direct kernel
+        cdt = dt
+        if not inference and si < N_TRUNK_SHAPES:
+            cdt = ops.conv_dtype(dt, ks, 1, pad, cin, cout)
+        wino = cdt == ops.DTYPE_F32_WINO
+        pack = ops.PackedConv(ks, [cin], stride=1, pad=pad, dtype=cdt)
         wp, wd = pack.fwd(w), pack.dgrad(w)
         y = torch.empty(B, cout, hh, ww, device="cuda")
         dx, dW = torch.empty_like(x), torch.zeros_like(w)
@@ -320,7 +326,7 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32", inference=False):
         fl = 2.0 * B * hh * ww * cin * ks * ks * cout
         # tile 100 = a TRAINING call (split-K allowed, one accumulation chain); tile 0 = the inference / parity path (segmented sums)
         ms_f = _time_launch(lambda: check(L.rsis_conv2d_fwd(pa, ia, 1, B, hh, ww, ptr(wp), cout, ks, 1, pad, None, None, ptr(y), hh, ww,
-                                                            0 if inference else 100, dt, stream()), "fwd"), iters)
+                                                            0 if inference else 100, cdt, stream()), "fwd"), iters)
         if inference:
             f = fam.setdefault("conv%dx%d fwd (eval)" % (ks, ks), {"flops": 0.0, "ms": 0.0, "bytes": 0.0, "launches": 0})
             f["flops"] += fl * count
@@ -328,12 +334,12 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32", inference=False):
             f["bytes"] += 4.0 * B * hh * ww * (cin + cout) * count
             f["launches"] += count
             continue
-        ms_d = _time_launch(lambda: check(L.rsis_conv2d_dgrad(ptr(y), B, cout, hh, ww, ptr(wd), cin, ks, 1, pad, pd, ia, 1, hh, ww, None, 0, dt,
+        ms_d = _time_launch(lambda: check(L.rsis_conv2d_dgrad(ptr(y), B, cout, hh, ww, ptr(wd), cin, ks, 1, pad, pd, ia, 1, hh, ww, None, 0, cdt,
                                                               stream()), "dgrad"), iters)
         ms_w = _time_launch(lambda: check(L.rsis_conv2d_wgrad(ptr(y), ptr(x), ptr(dW), B, cin, hh, ww, cout, hh, ww, ks, 1, pad, cin, 0, 0, dt,
                                                               stream()), "wgrad"), iters)
         act_bytes = 4.0 * B * hh * ww * (cin + cout)
-        for name, ms, n in (("conv%dx%d fwd+dgrad" % (ks, ks), ms_f + ms_d, 2), ("conv%dx%d wgrad" % (ks, ks), ms_w, 1)):
+        for name, ms, n in (("conv%dx%d fwd+dgrad%s" % (ks, ks, " (winograd)" if wino else ""), ms_f + ms_d, 2), ("conv%dx%d wgrad" % (ks, ks), ms_w, 1)):
             f = fam.setdefault(name, {"flops": 0.0, "ms": 0.0, "bytes": 0.0, "launches": 0})
             f["flops"] += n * fl * count
             f["ms"] += ms * count
@@ -378,6 +384,7 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32", inference=False):
             "conv3x3 wgrad": ("conv_wgrad_tiled_group_kernel<..., 3, ...> (rsis_conv2d_wgrad_batch)",
                               "wgrad3_tr_group_kernel (trunk, blk operands: LDS-DMA + ds_read_b64_tr_b16) + wgrad3_bf16_group_kernel (skip convs, fp32 operands)"
                               if blk_on else "wgrad3_bf16_group_kernel (rsis_conv2d_wgrad_batch)"),
+            "conv3x3 fwd+dgrad (winograd)": ("conv_wino_f32_kernel (Winograd F(2x2,3x3), training calls of the layer 1-3 bottleneck convs)",) * 2,
             "conv1x1 fwd (eval)": ("conv_igemm_kernel<..., V4> (inference path)",
                                    "conv_blk_kernel<1, ...> + eval BatchNorm (+ ReLU) epilogue (rsis_blk_conv2d_bn_eval)" if blk_on else "conv_bf16_kernel<1, ...>"),
             "conv3x3 fwd (eval)": ("conv3x3_direct_kernel<..., EPI_PLAIN, FLUSH> (segmented accumulation)",
@@ -390,7 +397,15 @@ def trunk_kernel_rooflines(B, iters, imsize, dtype="fp32", inference=False):
              ("layers_per_step" if f.get("grouped") else "launches_per_step"): f["launches"],
              "ms_per_step": round(f["ms"], 3), "avg_us": round(1e3 * f["ms"] / f["launches"] * (2 if "fwd+dgrad" in name else 1), 1),
              "tflops": round(tf, 1)}
-        if dtype == "fp32":
+        if dtype == "fp32" and "winograd" in name:
+            # `tflops` is the DIRECT-EQUIVALENT rate (2 M K N of the convolution / time: what the throughput metric sees); the kernel executes
+            # 16/36 of those flops on the matrix cores, and `frac` is EXECUTED / peak -- a roofline fraction, never above 1
+            ex = tf * 16.0 / 36.0
+            r.update({"tflops_executed": round(ex, 1), "bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(ex / PEAK_F32_MFMA_TFLOPS, 4),
+                      "frac_algorithmic": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "peak_sustained": PEAK_F32_MFMA_SUSTAINED_TFLOPS,
+                      "frac_of_sustained": round(ex / PEAK_F32_MFMA_SUSTAINED_TFLOPS, 4),
+                      "note": "Winograd F(2x2,3x3): 2.25x fewer matrix flops than the direct form; bound in practice by the LDS (profiles/r06 wino counters)"})
+        elif dtype == "fp32":
             r.update({"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
                       "peak_sustained": PEAK_F32_MFMA_SUSTAINED_TFLOPS, "frac_of_sustained": round(tf / PEAK_F32_MFMA_SUSTAINED_TFLOPS, 4)})
         else:

@@ -815,9 +815,10 @@ def test_bf16_training_tracks_fp32_over_200_iterations():
     T = 10, batch 32, all three losses, both Adam optimizers) under fp32 and bf16 from identical initial weights (torch's default
     initialisation) and an identical stream of 16 synthetic batches -- tools/bf16_training_quality.py.  Bands, per window of 20 iterations:
     total loss within 6 %, soft-IoU loss (1 - matched soft IoU, train.py:167) within 8 % of the fp32 run; both runs bring the loss down by
-    more than 30 %.  Measured (round 6, profiles/r06_bf16_training_curve.txt): 4.3 % / 6.4 % at the worst window, loss 1.380 -> 0.843 (fp32)
-    and 1.381 -> 0.855 (bf16); an fp32 run from weights perturbed by one part in a million drifts from the fp32 run by a comparable
-    amount over the same iterations (the control row of that file) -- the bands are the resolution of the comparison, not a bf16 bias."""
+    more than 30 %.  Measured (round 6, two runs; profiles/r06_bf16_training_curve.txt): worst window 3.5-4.3 % (total) / 3.9-6.4 % (soft IoU),
+    loss 1.380 -> 0.843 (fp32) and 1.381 -> 0.855 (bf16) in one run, equal final windows in the other (no sign preference).  The CONTROL row of
+    that file -- fp32 again from weights perturbed by one part in a million -- drifts 1.1 % / 1.7 % from the fp32 run over the same iterations:
+    the bf16 run deviates 2-4 x more than two fp32 trajectories do, inside bands a few times that drift."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))

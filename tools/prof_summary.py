@@ -27,9 +27,16 @@ def main():
         if sys.argv[2] == "lastperiod":
             # `lastperiod` (a run that ends with replays of ONE captured graph and has no optimizer step to delimit it: bench.py --inference):
             # the shortest L >= 50 with names[-L:] == names[-2L:-L] -- the kernels of the last replay
-            names = [k[0] for k in ks]
-            L = next(L for L in range(50, len(names) // 2) if names[-L:] == names[-2 * L:-L])
-            seg = ks[-L:]
+            # (a few kernels may follow the last replay -- the caller's finiteness check: up to 40 trailing launches are skipped)
+            names, seg = [k[0] for k in ks], None
+            for tail in range(0, 41):
+                nm = names[:len(names) - tail]
+                L = next((L for L in range(50, len(nm) // 2) if nm[-L:] == nm[-2 * L:-L]), None)
+                if L is not None:
+                    seg = ks[len(nm) - L:len(nm)]
+                    break
+            if seg is None:
+                raise SystemExit("no repeating launch sequence found at the end of the trace")
         else:
             ad = [i for i, k in enumerate(ks) if "adam_kernel" in k[0]]
             seg = ks[ad[-4] + 1: ad[-2] + 1]
