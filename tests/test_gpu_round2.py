@@ -815,7 +815,7 @@ def test_bf16_training_tracks_fp32_over_200_iterations():
     T = 10, batch 32, all three losses, both Adam optimizers) under fp32 and bf16 from identical initial weights (torch's default
     initialisation) and an identical stream of 16 synthetic batches -- tools/bf16_training_quality.py.  Bands, per window of 20 iterations:
     total loss within 6 %, soft-IoU loss (1 - matched soft IoU, train.py:167) within 8 % of the fp32 run; both runs bring the loss down by
-    more than 30 %.  Measured (round 6, two runs; profiles/r06_bf16_training_curve.txt): worst window 3.5-4.3 % (total) / 3.9-6.4 % (soft IoU),
+    more than 30 %.  Measured (round 6, three runs; profiles/r06_q_bf16_training_curve.txt): worst window 2.6-4.3 % (total) / 3.9-6.4 % (soft IoU),
     loss 1.380 -> 0.843 (fp32) and 1.381 -> 0.855 (bf16) in one run, equal final windows in the other (no sign preference).  The CONTROL row of
     that file -- fp32 again from weights perturbed by one part in a million -- drifts 1.1 % / 1.7 % from the fp32 run over the same iterations:
     the bf16 run deviates 2-4 x more than two fp32 trajectories do, inside bands a few times that drift."""
