@@ -828,6 +828,7 @@ def test_bf16_training_tracks_fp32_over_200_iterations():
     curves = Q.run(200)
     bd = Q.bands(curves)
     print("loss windows rel:", ["%.4f" % v for v in bd["loss"]["rel"]], "soft-IoU:", ["%.4f" % v for v in bd["soft_iou_loss"]["rel"]])
+    print("last three windows, fp32 vs bf16 (total loss):", ["%.4f / %.4f" % (x, y) for x, y in zip(bd["loss"]["fp32"][-3:], bd["loss"]["bf16"][-3:])])
     for dt in ("fp32", "bf16"):
         tot = curves[dt][0]
         assert all(v == v and abs(v) < 1e3 for v in tot)
