@@ -9,6 +9,8 @@ int rsis_launch_conv_wgrad(WgradArgs& a, int ks, hipStream_t st);
 int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st);
 int rsis_launch_conv_wino(const float* x, const void* U, const float* bias, const float* addend, float* y, int B, int C, int Cout, int H, int W,
                           hipStream_t st);
+int rsis_launch_conv_wino_group(int n, const float* const* x, const void* const* U, float* const* y, float* const* y1, const int* B, const int* C,
+                                const int* Cout, const int* C0, const int* H, const int* W, hipStream_t st);
 int rsis_launch_convlstm_direct_group(ConvArgs* jobs, int n, const int* force_variant, hipStream_t st);
 int rsis_launch_conv3x3_direct_group_plain(ConvArgs* jobs, int n, const int* force_variant, hipStream_t st);
 int rsis_l_lstm_bwd_group(const void* const*, const int*, int, hipStream_t);
@@ -113,6 +115,11 @@ static inline int bf16_ckb(int ks) { return ks == 1 ? RSIS_CKB1 : RSIS_CKB3; }
 static inline bool wino_geom(int ks, int stride, int pad, int Cin, int Cout, int nseg, int lstm_hid) {
   return ks == 3 && stride == 1 && pad == 1 && nseg == 1 && lstm_hid == 0 && Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0;
 }
+// the DATA GRADIENT also covers convs whose input is a concat of segments and whose rows are ConvLSTM gate rows (the gate convs of the
+// decoder: d(up) | dh_prev): the kernel's output channels are the concat (a multiple of 32), its reduction the rows (a multiple of 8)
+static inline bool wino_geom_dgrad(int ks, int stride, int pad, int Cin, int Cout) {
+  return ks == 3 && stride == 1 && pad == 1 && Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0;
+}
 static inline bool use_wino(int dtype, int ks, int stride, int pad, int Cin, int Cout, int nseg, int lstm_hid) {
   return dtype == RSIS_DTYPE_F32_WINO && wino_geom(ks, stride, pad, Cin, Cout, nseg, lstm_hid);
 }
@@ -175,7 +182,7 @@ long rsis_conv_packed_bytes_fwd(int dtype, int Cout, int ks, int stride, int pad
 
 long rsis_conv_packed_bytes_dgrad(int dtype, int Cout, int ks, int stride, int pad, int c_count) {
   const long ldw = rsis_roundup(c_count, RSIS_LDW_ALIGN);
-  if (use_wino(dtype, ks, stride, pad, c_count, Cout, 1, 0)) return (long)Cout * c_count * 16 * 4;
+  if (dtype == RSIS_DTYPE_F32_WINO && wino_geom_dgrad(ks, stride, pad, c_count, Cout)) return (long)Cout * c_count * 16 * 4;
   if (use_bf16(dtype, ks, stride, pad, Cout)) return (long)bf16_rows(ks, 1, &Cout) * ldw * 16;
   if (use_direct(ks, stride, pad)) return (long)direct_rows(1, &Cout) * ldw * 4;
   if (use_direct_s2(ks, stride, pad)) {      // direct layout for one destination, implicit-GEMM layout for several: room for either
@@ -224,9 +231,8 @@ int rsis_conv_pack_dgrad(const float* W, void* Wd, int Cout, int Ctot, int ks, i
   int csum = 0;
   for (int s = 0; s < nseg; ++s) csum += Cseg[s];
   const int ldw = rsis_roundup(csum, RSIS_LDW_ALIGN);
-  if (use_wino(dtype, ks, stride, pad, csum, Cout, nseg, lstm_hid) && csum == Ctot && (!Coff || Coff[0] == 0))
-    return rsis_l_pack(8, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, (Ctot / 32) * (Cout / 8), 0, (hipStream_t)stream);
-  if (dtype == RSIS_DTYPE_F32_WINO && wino_geom(ks, stride, pad, csum, Cout, nseg, lstm_hid)) return RSIS_ERR_UNSUPPORTED;
+  if (dtype == RSIS_DTYPE_F32_WINO && wino_geom_dgrad(ks, stride, pad, csum, Cout))
+    return rsis_l_pack(8, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, (csum / 32) * (Cout / 8), lstm_hid, (hipStream_t)stream);
   if (use_bf16(dtype, ks, stride, pad, Cout))
     return rsis_l_pack(6, W, Wd, Cout, Ctot, ks, nseg, Cseg, Coff, ldw, bf16_rows(ks, 1, &Cout), lstm_hid, (hipStream_t)stream);
   if (use_direct(ks, stride, pad))
@@ -278,12 +284,13 @@ int rsis_conv_pack_job_fill(rsis_pack_job* j) {
   if (j->lstm_hid > 0 && j->dtype == RSIS_DTYPE_BF16 && j->ks != 3) return -1;                  // (see rsis_convlstm_fwd)
   int csum = 0;
   for (int s = 0; s < j->nseg; ++s) csum += j->Cseg[s];
-  const bool wino = use_wino(j->dtype, j->ks, j->stride, j->pad, csum, j->Cout, j->nseg, j->lstm_hid);
-  if (wino && (csum != j->Ctot || j->Coff[0] != 0)) return -1;
+  const bool wino = j->dgrad ? (j->dtype == RSIS_DTYPE_F32_WINO && wino_geom_dgrad(j->ks, j->stride, j->pad, csum, j->Cout))
+                             : use_wino(j->dtype, j->ks, j->stride, j->pad, csum, j->Cout, j->nseg, j->lstm_hid);
+  if (wino && !j->dgrad && (csum != j->Ctot || j->Coff[0] != 0)) return -1;
   if (wino) {
     j->ldw = rsis_roundup(j->dgrad ? csum : j->Cout, RSIS_LDW_ALIGN);
     j->imode = j->dgrad ? 8 : 7;
-    j->krows = j->dgrad ? (j->Ctot / 32) * (j->Cout / 8) : (j->Cout / 32) * (j->Ctot / 8);
+    j->krows = j->dgrad ? (csum / 32) * (j->Cout / 8) : (j->Cout / 32) * (csum / 8);
     return rsis_l_pack_blocks(j->imode, j->krows, j->ldw, j->ks);
   }
   if (!j->dgrad) {
@@ -390,10 +397,14 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const vo
   if (ctot > Cin_packed) return RSIS_ERR_ARG;
   a.ostride = 1; a.oH = Hx; a.oW = Wx; a.ksplit = 1;
   a.wp = (const float*)Wd; a.ldw = rsis_roundup(Cin_packed, RSIS_LDW_ALIGN); a.Cout = ctot; a.bias = nullptr; a.addend = addend;
-  if (use_wino(dtype, ks, stride, pad, Cin_packed, Cout, 1, 0)) {
-    // the data gradient of a Winograd conv is the same kernel on the transposed, rotated weights (pack mode 8): dy plays the input
-    if (ndst != 1 || Cdx[0] != Cin_packed || Hx != Hy || Wx != Wy) return RSIS_ERR_UNSUPPORTED;
-    return rsis_launch_conv_wino(dy, Wd, nullptr, addend, dx[0], B, Cout, Cin_packed, Hy, Wy, (hipStream_t)stream);
+  if (dtype == RSIS_DTYPE_F32_WINO && wino_geom_dgrad(ks, stride, pad, Cin_packed, Cout)) {
+    // the data gradient of a Winograd conv is the same kernel on the transposed, rotated weights (pack mode 8): dy plays the input.
+    // One destination (any leading multiple of 32 channels of the concat) or two splitting it at a multiple of 32.
+    if (ndst > 2 || ctot % 32 != 0 || Cdx[0] % 32 != 0 || Hx != Hy || Wx != Wy || (ndst == 2 && addend)) return RSIS_ERR_UNSUPPORTED;
+    if (ndst == 1) return rsis_launch_conv_wino(dy, Wd, nullptr, addend, dx[0], B, Cout, ctot, Hy, Wy, (hipStream_t)stream);
+    const float* xs[1] = {dy}; const void* us[1] = {Wd}; float* y0[1] = {dx[0]}; float* y1[1] = {dx[1]};
+    const int b1[1] = {B}, c1[1] = {Cout}, co1[1] = {ctot}, c01[1] = {Cdx[0]}, h1[1] = {Hy}, w1[1] = {Wy};
+    return rsis_launch_conv_wino_group(1, xs, us, y0, y1, b1, c1, co1, c01, h1, w1, (hipStream_t)stream);
   }
   if (use_bf16(dtype, ks, stride, pad, Cout)) {
     if (ks == 3) {
@@ -916,11 +927,22 @@ int rsis_conv2d_dgrad_batch(const rsis_dgrad_job* jobs, int njobs, void* stream)
   if (!jobs || njobs < 1 || njobs > 64) return RSIS_ERR_ARG;
   ConvArgs grp[64];
   int force[64], ng = 0, rc = RSIS_OK;
+  // jobs whose packed copy is a Winograd one (RSIS_DTYPE_F32_WINO: the decoder levels with >= 32-channel sources on >= 16-pixel maps) go
+  // into grouped Winograd launches of up to 4 jobs; the rest as before
+  const float* wx[4]; const void* wu[4]; float* wy0[4]; float* wy1[4];
+  int wb[4], wc[4], wco[4], wc0[4], wh[4], ww[4], nw = 0;
   for (int j = 0; j < njobs && rc == RSIS_OK; ++j) {
     const rsis_dgrad_job& q = jobs[j];
     if (!q.dy || !q.Wd || q.ndst < 1 || q.ndst > RSIS_MAX_SRC) return RSIS_ERR_ARG;
     int ctot = 0;
     for (int i = 0; i < q.ndst; ++i) { if (!q.dx[i] || q.Cdx[i] < 1) return RSIS_ERR_ARG; ctot += q.Cdx[i]; }
+    if (q.dtype == RSIS_DTYPE_F32_WINO && wino_geom_dgrad(q.ks, q.stride, q.pad, q.Cin_packed, q.Cout) && !q.addend && q.ndst <= 2 &&
+        ctot % 32 == 0 && q.Cdx[0] % 32 == 0 && q.Hx == q.Hy && q.Wx == q.Wy) {
+      wx[nw] = q.dy; wu[nw] = q.Wd; wy0[nw] = q.dx[0]; wy1[nw] = q.ndst == 2 ? q.dx[1] : nullptr;
+      wb[nw] = q.B; wc[nw] = q.Cout; wco[nw] = ctot; wc0[nw] = q.Cdx[0]; wh[nw] = q.Hy; ww[nw] = q.Wy;
+      if (++nw == 4) { rc = rsis_launch_conv_wino_group(nw, wx, wu, wy0, wy1, wb, wc, wco, wc0, wh, ww, (hipStream_t)stream); nw = 0; }
+      continue;
+    }
     // grouped: the exact-f32 direct kernel (3x3 / stride 1 / pad 1, no addend) with 32-bit epilogue addressing; everything else -- and
     // every job in the deterministic mode, where launches stay as the single-call path issues them -- through rsis_conv2d_dgrad
     const bool groupable = q.dtype == RSIS_DTYPE_F32 && use_direct(q.ks, q.stride, q.pad) && !q.addend && q.Hx == q.Hy && q.Wx == q.Wy &&
@@ -943,6 +965,7 @@ int rsis_conv2d_dgrad_batch(const rsis_dgrad_job* jobs, int njobs, void* stream)
     a.wp = (const float*)q.Wd; a.ldw = rsis_roundup(q.Cin_packed, RSIS_LDW_ALIGN); a.Cout = ctot; a.bias = nullptr; a.addend = nullptr;
     force[ng] = direct_variant(q.tile); grp[ng++] = a;
   }
+  if (rc == RSIS_OK && nw > 0) rc = rsis_launch_conv_wino_group(nw, wx, wu, wy0, wy1, wb, wc, wco, wc0, wh, ww, (hipStream_t)stream);
   if (rc == RSIS_OK && ng == 1) rc = rsis_launch_conv3x3_direct(grp[0], 0, force[0], (hipStream_t)stream);
   else if (rc == RSIS_OK && ng > 1) rc = rsis_launch_conv3x3_direct_group_plain(grp, ng, force, (hipStream_t)stream);
   return rc;

@@ -19,6 +19,9 @@
 #include <type_traits>
 
 enum { EPI_PLAIN = 0, EPI_LSTM = 1 };
+#ifndef RSIS_GEMM_NST_DEFAULT
+#define RSIS_GEMM_NST_DEFAULT 2
+#endif
 
 typedef const float __attribute__((address_space(1)))* gcf_t;   // explicit global pointers: global_load, never flat_load
 typedef const char __attribute__((address_space(1)))* gcc_t;
@@ -30,7 +33,10 @@ typedef const f32x4 __attribute__((address_space(1)))* gcf4_t;
 // tiles are lane-linear images of what the threads fetch, so there are no staging registers, no ds_write pass and no
 // per-lane predicates (pixels beyond the tensor get an out-of-range offset, which the descriptor turns into zeros).
 typedef __attribute__((address_space(3))) void* lds_vp_t;
-template <int BM, int BN, int BK, int WGM, int WGN, int KS, bool DGRAD, int EPI, bool V4>
+// NST (V4 only): depth of the LDS-DMA ring.  NST = 3 keeps two K-tiles in flight and waits with a COUNTED vmcnt + a bare s_barrier --
+// `__syncthreads()` carries a fence that hipcc turns into s_waitcnt vmcnt(0), which drains the ring at every K-tile (what made the
+// ring-depth experiment of round 5, NOTES (41), a no-op with extra LDS; found with the Winograd kernel in round 6).
+template <int BM, int BN, int BK, int WGM, int WGN, int KS, bool DGRAD, int EPI, bool V4, int NST = 2>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; the buffer-resource builtins do not exist there)
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -48,9 +54,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int BV_LOADS = V4 ? BK / BV_ROWS : 1;
   typedef typename std::conditional<(KK > 32), unsigned long long, unsigned>::type mask_t;
 
-  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (BM + BN)];
-  float* const As0 = lds;                 // [2][BK][BM]
-  float* const Bs0 = lds + 2 * BK * BM;   // [2][BK][BN]
+  static_assert(NST == 2 || V4, "deeper rings: the LDS-DMA path only");
+  __shared__ __attribute__((aligned(16))) float lds[NST * BK * (BM + BN)];
+  float* const As0 = lds;                   // [NST][BK][BM]
+  float* const Bs0 = lds + NST * BK * BM;   // [NST][BK][BN]
 
   // ---- scalar copies of the arguments (no dynamic indexing of the by-value struct: that would spill it to scratch) ----
   const gcc_t src0 = (gcc_t)p.src[0], src1 = (gcc_t)p.src[1], src2 = (gcc_t)p.src[2];
@@ -195,6 +202,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     }                                                                                                              \
   }
 
+  if constexpr (V4 && NST > 2) {
+    // ---- ring of NST stages: tile t + NST - 1 is issued while tile t computes; one barrier per tile, at the top ----
+    constexpr int C_DMA = BV_LOADS + A_LOADS;          // DMA instructions per wave and K-tile (A_F4 % 256 == 0 for every V4 tile shape)
+    static_assert(A_F4 % 256 == 0 && (NST - 2) * C_DMA < 64, "vmcnt bookkeeping");
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i)
+      if (i < ntiles) RSIS_DMA_TILE(i, i)
+    int slot = 0;
+    for (int t = 0; t < ntiles; ++t) {
+      const int ahead = min(NST - 2, ntiles - 1 - t);  // younger tiles of this wave's DMA that may still be in flight
+      if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * C_DMA) & 15) | (((2 * C_DMA) >> 4) << 14));
+      else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (C_DMA & 15) | ((C_DMA >> 4) << 14));
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_barrier();                     // every wave's share of tile t is in LDS; the stage of tile t - 1 is free
+      const int nslot = slot == 0 ? NST - 1 : slot - 1; // (t + NST - 1) % NST
+      if (t + NST - 1 < ntiles) RSIS_DMA_TILE(t + NST - 1, nslot)
+      const float* As = As0 + slot * BK * BM + wm * TM * 32 + l31;
+      const float* Bs = Bs0 + slot * BK * BN + wn * TN * 32 + l31;
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const int krow = kk * 2 + hi;
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = As[krow * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bs[krow * BN + j * 32];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      slot = slot + 1 == NST ? 0 : slot + 1;
+    }
+  } else {
   // ---- software pipeline: global->regs for tile t+1 overlaps MFMA on tile t; one barrier per tile ----
   if (ntiles > 0) {
     if constexpr (V4) {
@@ -238,6 +280,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       if (more) RSIS_STORE_TILE(cur ^ 1)
     }
     __syncthreads();
+  }
   }
 #undef RSIS_LOAD_TILE
 #undef RSIS_STORE_TILE
@@ -377,6 +420,11 @@ static int launch_cfg(ConvArgs& a, hipStream_t st) {
   if constexpr (KS == 1 && !DGRAD && EPI == EPI_PLAIN) {
     if (a.stride == 1 && a.pad == 0 && a.nsrc == 1 && (a.H * a.W) % 4 == 0 && a.C[0] % BK == 0 &&
         (long)a.B * a.C[0] * a.H * a.W * 4 < (1L << 31)) {
+      if constexpr (BM == 64 && BN == 64 && BK == 32) {      // the trunk's 1x1 GEMM tile: ring depth by RSIS_GEMM_NST (2, 3 or 4)
+        static const int nst = getenv("RSIS_GEMM_NST") ? atoi(getenv("RSIS_GEMM_NST")) : RSIS_GEMM_NST_DEFAULT;
+        if (nst == 3) { hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, KS, DGRAD, EPI, true, 3>), dim3(grid), dim3(256), 0, st, a); return rsis_check_launch(); }
+        if (nst == 4) { hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, KS, DGRAD, EPI, true, 4>), dim3(grid), dim3(256), 0, st, a); return rsis_check_launch(); }
+      }
       hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, KS, DGRAD, EPI, true>), dim3(grid), dim3(256), 0, st, a);
       return rsis_check_launch();
     }

@@ -49,17 +49,30 @@ constexpr int DMA_PER_ITER = RAW_N + U_N;
 struct WinoArgs {
   const float* x;        // [B][C][H][W]
   const float* U;        // [Cout/32][C/8][16][8][32]  (pack.hip modes 7 / 8)
-  float* y;              // [B][Cout][H][W]
+  float* y;              // [B][C0][H][W]: output channels [0, C0)
+  float* y1;             // [B][Cout - C0][H][W]: output channels [C0, Cout) (the second destination of a split data gradient) or null
   const float* bias;     // [Cout] or null
-  const float* addend;   // [B][Cout][H][W] or null
-  int B, C, Cout, H, W;
+  const float* addend;   // [B][Cout][H][W] or null (single destination only)
+  int B, C, Cout, C0, H, W;
   int ry, rx;            // regions per image
   int n_regions;         // B * ry * rx
 };
+// grouped launch: up to 4 independent convs in one grid (the gate data gradients of the levels of one reverse wavefront diagonal that
+// take the Winograd kernel); jobs by value in the kernel arguments, block b belongs to the last job whose begin <= b
+#define WINO_MAXJ 4
+struct WinoGroup {
+  int n;
+  int begin[WINO_MAXJ + 1];
+  WinoArgs job[WINO_MAXJ];
+};
 }  // namespace
 
-__global__ __launch_bounds__(WNT) void conv_wino_f32_kernel(const WinoArgs p) {
+__global__ __launch_bounds__(WNT) void conv_wino_f32_kernel(const WinoGroup g) {
 #if __HIP_DEVICE_COMPILE__
+  int jb = 0;
+#pragma unroll
+  for (int k = 1; k < WINO_MAXJ; ++k) jb += (k < g.n && g.begin[k] <= (int)blockIdx.x) ? 1 : 0;
+  const WinoArgs& p = g.job[jb];
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const RAW = lds;
   float* const US = lds + WRING * RAW_S;
@@ -70,7 +83,7 @@ __global__ __launch_bounds__(WNT) void conv_wino_f32_kernel(const WinoArgs p) {
   const int H = p.H, W = p.W, HW = H * W;
   // blocks b, b + 8, ... share an XCD: an XCD owns a contiguous range of regions x every output-channel tile, so the packed
   // weights (Cout x C x 64 bytes: 4 MB for 256 -> 256) are fetched into its L2 once and a region's input stays there for its n_co blocks
-  const int bid = blockIdx.x, xcd = bid & 7, qq = bid >> 3;
+  const int bid = (int)blockIdx.x - g.begin[jb], xcd = bid & 7, qq = bid >> 3;
   const int co_t = qq % n_co;
   const int reg = xcd * ((p.n_regions + 7) >> 3) + qq / n_co;
   if (reg >= p.n_regions) return;
@@ -212,11 +225,14 @@ __global__ __launch_bounds__(WNT) void conv_wino_f32_kernel(const WinoArgs p) {
   // P0 = m0, P1 = -m0 - m1 to T[r][j] = (M A)[r][j]; then Y[0][j] = T0j + T1j + T2j, Y[1][j] = T1j - T2j - T3j.  The 8 waves park
   // P0 / P1 of one 32-tile group in LDS (64 KB: the V stages), wave w' finishes accumulator rows 2 w', 2 w' + 1; two rounds. ----
   float* Ps = VS;                                              // [w][j][r][lane]: 8 * 2 * 16 * 64 floats = 64 KB
-  const int Cout = p.Cout;
+  // destination of this block's 32 output channels (C0 is a multiple of 32: the choice is uniform over the block)
+  const bool second = co_t * 32 >= p.C0;
+  const int Cout = second ? p.Cout - p.C0 : p.C0;          // channels of the destination tensor
+  const int cbase = second ? co_t * 32 - p.C0 : co_t * 32; // this block's first channel inside it
   const unsigned span = (unsigned)((size_t)p.B * Cout * HW * 4);
-  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, span, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? p.y1 : p.y), 0, span, 0x00020000);
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.addend ? p.addend : p.y), 0, p.addend ? span : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : (const void*)p.y), 0, p.bias ? Cout * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : (const void*)p.y), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
   float bvv[2];
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(WNT) void conv_wino_f32_kernel(const WinoArgs p) {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       const int r = 2 * wave + rr;
-      const int co = co_t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * hi;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -272,22 +288,53 @@ __global__ __launch_bounds__(WNT) void conv_wino_f32_kernel(const WinoArgs p) {
 #endif
 }
 
-// x [B][C][H][W] -> y [B][Cout][H][W] (+ bias, + addend); U: the Winograd packed copy.  C % 8 == 0, Cout % 32 == 0.
-int rsis_launch_conv_wino(const float* x, const void* U, const float* bias, const float* addend, float* y, int B, int C, int Cout,
-                          int H, int W, hipStream_t st) {
+static int wino_fill(WinoArgs& a, const float* x, const void* U, const float* bias, const float* addend, float* y, float* y1, int B, int C,
+                     int Cout, int C0, int H, int W) {
   if (!x || !U || !y || B < 1 || H < 1 || W < 1 || C < WCK || C % WCK != 0 || Cout < 32 || Cout % 32 != 0) return RSIS_ERR_ARG;
+  if (C0 < 32 || C0 > Cout || C0 % 32 != 0 || (C0 < Cout && (!y1 || addend))) return RSIS_ERR_ARG;
   if ((size_t)B * Cout * H * W * 4 >= (1ull << 31) || (size_t)WCK * H * W * 4 >= (1ull << 31)) return RSIS_ERR_UNSUPPORTED;
+  a.x = x; a.U = (const float*)U; a.y = y; a.y1 = y1; a.bias = bias; a.addend = addend;
+  a.B = B; a.C = C; a.Cout = Cout; a.C0 = C0; a.H = H; a.W = W;
+  a.ry = rsis_cdiv(H, WRG); a.rx = rsis_cdiv(W, WRG);
+  a.n_regions = B * a.ry * a.rx;
+  return RSIS_OK;
+}
+static int wino_launch(WinoGroup& g, int blocks, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv_wino_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * 4) != hipSuccess) return RSIS_ERR_LAUNCH;
     attr_set = true;
   }
-  WinoArgs a;
-  a.x = x; a.U = (const float*)U; a.y = y; a.bias = bias; a.addend = addend;
-  a.B = B; a.C = C; a.Cout = Cout; a.H = H; a.W = W;
-  a.ry = rsis_cdiv(H, WRG); a.rx = rsis_cdiv(W, WRG);
-  a.n_regions = B * a.ry * a.rx;
-  const int grid = 8 * (Cout / 32) * rsis_cdiv(a.n_regions, 8);
-  hipLaunchKernelGGL(conv_wino_f32_kernel, dim3(grid), dim3(WNT), LDS_FLOATS * 4, st, a);
+  hipLaunchKernelGGL(conv_wino_f32_kernel, dim3(blocks), dim3(WNT), LDS_FLOATS * 4, st, g);
   return rsis_check_launch();
+}
+
+// x [B][C][H][W] -> y [B][Cout][H][W] (+ bias, + addend); U: the Winograd packed copy.  C % 8 == 0, Cout % 32 == 0.
+int rsis_launch_conv_wino(const float* x, const void* U, const float* bias, const float* addend, float* y, int B, int C, int Cout,
+                          int H, int W, hipStream_t st) {
+  WinoGroup g = {};
+  const int rc = wino_fill(g.job[0], x, U, bias, addend, y, nullptr, B, C, Cout, Cout, H, W);
+  if (rc) return rc;
+  g.n = 1;
+  const int blocks = 8 * (Cout / 32) * rsis_cdiv(g.job[0].n_regions, 8);
+  for (int k = 1; k <= WINO_MAXJ; ++k) g.begin[k] = blocks;
+  return wino_launch(g, blocks, st);
+}
+
+// n <= WINO_MAXJ independent convs in one grid, each with up to two destinations splitting its output channels at C0[j] (a multiple
+// of 32): the gate data gradients d(up) | dh_prev of one reverse wavefront diagonal (rsis_conv2d_dgrad_batch)
+int rsis_launch_conv_wino_group(int n, const float* const* x, const void* const* U, float* const* y, float* const* y1, const int* B, const int* C,
+                                const int* Cout, const int* C0, const int* H, const int* W, hipStream_t st) {
+  if (n < 1 || n > WINO_MAXJ) return RSIS_ERR_ARG;
+  WinoGroup g = {};
+  g.n = n;
+  int blocks = 0;
+  for (int j = 0; j < n; ++j) {
+    const int rc = wino_fill(g.job[j], x[j], U[j], nullptr, nullptr, y[j], y1[j], B[j], C[j], Cout[j], C0[j], H[j], W[j]);
+    if (rc) return rc;
+    g.begin[j] = blocks;
+    blocks += 8 * (Cout[j] / 32) * rsis_cdiv(g.job[j].n_regions, 8);
+  }
+  for (int k = n; k <= WINO_MAXJ; ++k) g.begin[k] = blocks;
+  return wino_launch(g, blocks, st);
 }

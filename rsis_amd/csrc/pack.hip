@@ -212,18 +212,29 @@ __device__ __forceinline__ void pack_tile_bf16(const rsis_pack_job& j, int tb, u
 //   out[((ot * nq + q) * 16 + xi) * 256 + cl * 32 + col]   ot = output-channel tile of 32, q = chunk of 8 reduction channels,
 //   xi = 4 i + j the position in the 4 x 4 Winograd domain -- one (ot, q) block of 4096 floats is what a block of the conv kernel
 //   DMAs per chunk.  mode 7 (forward): output channel = the weight's row co, reduction channel = its input channel ci, g = W[co][ci];
-//   mode 8 (data gradient): output channel = ci, reduction channel = co, g = W[co][ci] rotated by 180 degrees (the transposed conv).
+//   mode 8 (data gradient): output channel = ci, reduction channel = co, g = W[co][ci] rotated by 180 degrees (the transposed conv);
+//   here the output channels may be the concat of up to 3 channel segments and the rows gate-interleaved (the ConvLSTM gate convs).
 //   One tile = one (ot, q) block, one thread = one channel pair (9 loads, 16 coalesced stores).
-__device__ __forceinline__ void pack_tile_wino(int mode, const float* __restrict__ W, float* __restrict__ out, int Cout, int Ctot, int tb) {
-  const int n_red = mode == 7 ? Ctot : Cout, nq = n_red >> 3;
+__device__ __forceinline__ void pack_tile_wino(int mode, const float* __restrict__ W, float* __restrict__ out, int Cout, int Ctot, int tb,
+                                               const SegMap& m, int hid) {
+  // channel maps as in the other layouts: the conv's input channels are the CONCAT of the segments (index cg -> weight input channel
+  // seg_channel), its rows may be gate-interleaved ConvLSTM rows (packed row co_p -> weight row ref_row): the gate convs' data gradient
+  int csum = 0;
+#pragma unroll
+  for (int s_ = 0; s_ < 3; ++s_) csum += s_ < m.n ? m.C[s_] : 0;
+  const int n_red = mode == 7 ? csum : Cout, nq = n_red >> 3;
   const int ot = tb / nq, q = tb - ot * nq;
   const int cl = threadIdx.x >> 5, col = threadIdx.x & 31;
   const int o = ot * 32 + col, rch = q * 8 + cl;                 // output / reduction channel of the conv this copy serves
-  const int co = mode == 7 ? o : rch, ci = mode == 7 ? rch : o;  // row / input channel of the reference weight
-  const float* g_ = W + ((size_t)co * Ctot + ci) * 9;
+  const int cop = mode == 7 ? o : rch, cg = mode == 7 ? rch : o; // packed row / concat index
+  const int ci = seg_channel(m, cg);
+  const bool ok = ci >= 0 && cop < Cout;
+  const float* g_ = W + ((size_t)ref_row(ok ? cop : 0, hid) * Ctot + (ok ? ci : 0)) * 9;
   float g[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) g[k] = g_[mode == 7 ? k : 8 - k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) g[k] = ok ? g[k] : 0.f;
   float t[4][3];
 #pragma unroll
   for (int s_ = 0; s_ < 3; ++s_) {
@@ -241,8 +252,9 @@ __device__ __forceinline__ void pack_tile_wino(int mode, const float* __restrict
     o_[(4 * i + 3) * 256] = t[i][2];
   }
 }
-__global__ __launch_bounds__(256) void pack_wino_kernel(int mode, const float* __restrict__ W, float* __restrict__ out, int Cout, int Ctot) {
-  pack_tile_wino(mode, W, out, Cout, Ctot, blockIdx.x);
+__global__ __launch_bounds__(256) void pack_wino_kernel(int mode, const float* __restrict__ W, float* __restrict__ out, int Cout, int Ctot, SegMap m,
+                                                        int hid) {
+  pack_tile_wino(mode, W, out, Cout, Ctot, blockIdx.x, m, hid);
 }
 
 // ---- batched repack: every packed copy of every conv weight in ONE launch (after an optimizer step ~240 tiny pack launches
@@ -344,7 +356,13 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const rsis_pack_job* __
       next_begin = lo + 1 < njobs ? jobs[lo + 1].block_begin : total_tiles;
     }
     const int tb = b - j.block_begin;
-    if (j.imode >= 7) pack_tile_wino(j.imode, j.W, (float*)j.out, j.Cout, j.Ctot, tb);
+    if (j.imode >= 7) {
+      SegMap wm;
+      wm.n = j.nseg;
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) { wm.C[s_] = j.Cseg[s_]; wm.off[s_] = j.Coff[s_]; }
+      pack_tile_wino(j.imode, j.W, (float*)j.out, j.Cout, j.Ctot, tb, wm, j.lstm_hid);
+    }
     else if (j.imode >= 5) pack_tile_bf16(j, tb, (unsigned short*)&tile[0][0]);
     else if (j.ks == 1) pack_tile<1>(j, tb, tile);
     else if (j.ks == 3) pack_tile<9>(j, tb, tile);
@@ -381,7 +399,7 @@ int rsis_l_pack(int mode, const float* W, void* out, int Cout, int Ctot, int ks,
   const long total = (long)krows * ldw;
   const dim3 g(pack_grid(total)), b(256);
   if (mode == 7 || mode == 8) {      // Winograd copies (one source covering every input channel; krows = (ot, q) blocks)
-    hipLaunchKernelGGL(pack_wino_kernel, dim3(krows), b, 0, st, mode, W, (float*)out, Cout, Ctot);
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(krows), b, 0, st, mode, W, (float*)out, Cout, Ctot, m, hid);
     return rsis_check_launch();
   }
   if (mode < 0 || mode > 6) return RSIS_ERR_ARG;

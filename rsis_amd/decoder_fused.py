@@ -104,6 +104,22 @@ def _packs(cell, c_up, c_skip):
     return cell._packs[key]
 
 
+def dyn_dgrad_pack(cell, c_up, c_skip, H, W):
+    """The copy set the gate conv's DATA GRADIENT (d(up) | dh_prev, explicit BPTT of decoder_seq) reads: under fp32, on levels whose
+    sources are 32-channel multiples and whose map holds at least 12 x 12 pixels, a Winograd F(2x2, 3x3) copy (ops.DTYPE_F32_WINO,
+    RSIS_WINOGRAD_GATES, default on: the 16 x 16 and 32 x 32 levels at 256 x 256 input, hidden 128) -- otherwise the dynamic pack itself.
+    The forward keeps the direct kernel with the fused LSTM epilogue on every level."""
+    _hoist, dyn = _packs(cell, c_up, c_skip)
+    hid = cell.hidden_size
+    if (dyn.dtype != ops.DTYPE_F32 or not ops.WINOGRAD_GATES[0] or cell.kernel_size != 3 or cell.padding != 1 or min(H, W) < 12
+            or (c_up + hid) % 32 or c_up % 32 or c_up == 0 or (4 * hid) % 32):
+        return dyn
+    key = ("fused-dgrad-wino", c_up, c_skip)
+    if key not in cell._packs:
+        cell._packs[key] = ops.PackedConv(3, list(dyn.segs), lstm_hid=hid, stride=1, pad=1, offs=list(dyn.offs), dtype=ops.DTYPE_F32_WINO)
+    return cell._packs[key]
+
+
 class _HoistFn(torch.autograd.Function):
     """G = conv(skip, W[:, skip channels]) + b on gate-interleaved rows (once per iteration)."""
 

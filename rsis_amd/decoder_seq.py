@@ -343,7 +343,8 @@ class _DecoderSeqFn(torch.autograd.Function):
         DHP = [torch.empty((B, lv.hid, lv.H, lv.W), **f32) for lv in levels]                 # ... through the recurrence, from step t + 1
         DC = [[torch.empty((B, lv.hid, lv.H, lv.W), **f32) for _ in range(2)] for lv in levels]
         DUP = [torch.empty((B, lv.c_up, lv.H, lv.W), **f32) if lv.c_up > 0 else None for lv in levels]
-        wds = [lv.dyn.dgrad(gates_w[i]) for i, lv in enumerate(levels)]
+        dpk = [decoder_fused.dyn_dgrad_pack(lv.cell, lv.c_up, lv.c_skip, lv.H, lv.W) for lv in levels]
+        wds = [dpk[i].dgrad(gates_w[i]) for i, lv in enumerate(levels)]
         # the last level's hidden states receive their gradient from conv_out only (no level above): all T steps in one launch
         DH_last = torch.empty((T, B, last.hid, last.H, last.W), **f32)
         if upc:
@@ -394,7 +395,7 @@ class _DecoderSeqFn(torch.autograd.Function):
                     dxs = ([DUP[i]] if lv.c_up > 0 else []) + ([DHP[i]] if t > 0 else [])
                     (j.dy, j.B, j.Cout, j.Hy, j.Wy, j.Wd, j.Cin_packed, j.ks, j.stride, j.pad, j.ndst, j.Hx, j.Wx, j.addend, j.tile, j.dtype) = (
                         ptr(DA[i][t]), B, 4 * lv.hid, lv.H, lv.W, ptr(wds[i]), lv.dyn.cin, 3, 1, 1, len(dxs), lv.H, lv.W, None, ops.FORCE_TILE[0],
-                        lv.dyn.dtype)
+                        dpk[i].dtype)
                     for k, x in enumerate(dxs):
                         j.dx[k], j.Cdx[k] = x.data_ptr(), x.shape[1]
                 check(L.rsis_conv2d_dgrad_batch(dg, len(dgc), stream()), "rsis_conv2d_dgrad_batch")

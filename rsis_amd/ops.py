@@ -61,6 +61,8 @@ WINOGRAD = [_wino_rule()]
 # worst mask logit moves from 1.08e-4 to 1.86e-4 from float64 (the reference itself: 1.0e-4) -- 22 stacked Winograd layers are as
 # accurate per layer as an unsegmented direct sum (2.8e-6 vs 2.6e-6 on O(1) data), not as accurate as the segmented one.
 WINOGRAD_INFER = [os.environ.get("RSIS_WINOGRAD_INFER", "0") == "1"]
+# the decoder's gate data gradients (training only) on the Winograd kernel where the level qualifies (decoder_fused.dyn_dgrad_pack)
+WINOGRAD_GATES = [os.environ.get("RSIS_WINOGRAD_GATES", "1") != "0" and os.environ.get("RSIS_WINOGRAD", "x").strip().lower() not in ("0", "off", "none")]
 
 
 def conv_dtype(dtype, ks, stride, pad, cin, cout):

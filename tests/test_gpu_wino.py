@@ -134,3 +134,49 @@ def test_inference_calls_of_a_winograd_conv_run_the_direct_kernel():
         assert not torch.equal(a, c) and float((a - c).abs().max()) < 2e-5
     finally:
         ops.WINOGRAD_INFER[0] = prev
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 64, 16, 16, True), (2, 64, 32, 32, 32, True), (3, 128, 64, 14, 18, False), (2, 64, 32, 20, 12, True)])
+def test_winograd_gate_data_gradient_two_destinations(shape):
+    """The decoder's gate data gradient (d(up) | dh_prev of reference clstm.py:43-47, explicit BPTT) through the Winograd kernel: the pack
+    of the DYNAMIC channels of a ConvLSTM Gates weight (two channel segments with offsets, gate-interleaved rows: pack mode 8 with a
+    segment map), two destinations splitting the output channels, grouped with a second job in one launch (rsis_conv2d_dgrad_batch) --
+    against float64 and against the direct kernel's packed copy on the same inputs.  with_h = False: the t = 0 form (d(up) only)."""
+    from rsis_amd import _lib, ops
+    from rsis_amd._lib import check, lib, ptr, stream
+    B, c_up, hid, H, W, with_h = shape
+    c_skip = c_up
+    L = lib()
+    Ctot = c_up + c_skip + hid
+    w = _rng_t(31, (4 * hid, Ctot, 3, 3), 1.0 / np.sqrt(9 * Ctot)).cuda()
+    da = _rng_t(32, (B, 4 * hid, H, W)).cuda()            # gate-interleaved rows: row 4 j + gate
+    segs, offs = [c_up, hid], [0, c_up + c_skip]
+    res = {}
+    for tag, dt in (("direct", ops.DTYPE_F32), ("wino", ops.DTYPE_F32_WINO)):
+        pack = ops.PackedConv(3, segs, lstm_hid=hid, stride=1, pad=1, offs=offs, dtype=dt)
+        wd = pack.dgrad(w)
+        dup, dhp = torch.full((B, c_up, H, W), 7.0, device="cuda"), torch.full((B, hid, H, W), 7.0, device="cuda")
+        dxs = [dup] + ([dhp] if with_h else [])
+        jobs = (_lib.DgradJob * 2)()
+        for j in jobs:       # the same job twice (second copy into scratch): exercises the grouped launch
+            (j.dy, j.B, j.Cout, j.Hy, j.Wy, j.Wd, j.Cin_packed, j.ks, j.stride, j.pad, j.ndst, j.Hx, j.Wx, j.addend, j.tile, j.dtype) = (
+                ptr(da), B, 4 * hid, H, W, ptr(wd), pack.cin, 3, 1, 1, len(dxs), H, W, None, 0, dt)
+        scratch = [torch.empty_like(x) for x in dxs]
+        for k, x in enumerate(dxs):
+            jobs[0].dx[k], jobs[0].Cdx[k] = x.data_ptr(), x.shape[1]
+            jobs[1].dx[k], jobs[1].Cdx[k] = scratch[k].data_ptr(), x.shape[1]
+        check(L.rsis_conv2d_dgrad_batch(jobs, 2, stream()), "rsis_conv2d_dgrad_batch")
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(dxs, scratch))
+        res[tag] = [x.double().cpu() for x in dxs]
+    # float64: the reference-layout weight has rows [i | f | o | g] x hid; interleaved row 4 j + gate <- reference row gate * hid + j
+    perm = torch.arange(4 * hid).view(4, hid).t().reshape(-1)
+    da_ref = torch.empty_like(da)
+    da_ref[:, perm] = da                                   # da in reference row order
+    full = F.conv_transpose2d(da_ref.double().cpu(), w.double().cpu(), stride=1, padding=1)      # gradient of all Ctot input channels
+    want = [full[:, :c_up]] + ([full[:, c_up + c_skip:]] if with_h else [])
+    for k, ref in enumerate(want):
+        e_d, e_w = float((res["direct"][k] - ref).abs().max()), float((res["wino"][k] - ref).abs().max())
+        print("dst %d: |direct - f64| %.3e, |winograd - f64| %.3e" % (k, e_d, e_w))
+        assert_close("winograd dst %d" % k, res["wino"][k], ref, 2e-6 * np.sqrt(9 * 4 * hid) + 1e-6, 2e-6)
+        assert e_w <= 2 * e_d + 1e-6
