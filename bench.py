@@ -522,7 +522,7 @@ def cpu_baseline(imsize, T, budget_s=25.0):
 # the fused ConvLSTM gate kernel in a profiler's kernel-name column: template arguments <BM, TW, TH, NI, EPI, KSP, NWV>, EPI == 1 is
 # the fused LSTM epilogue (tests/test_abi.py checks the pattern against the symbols of the built library)
 REAL_STDOUT = 1
-GATE_KERNEL_RE = re.compile(r"conv3x3_direct_kernel<\d+, \d+, \d+, \d+, 1, \d+, \d+(, (true|false))?>")
+GATE_KERNEL_RE = re.compile(r"conv3x3_direct_kernel<\d+, \d+, \d+, \d+, 1, \d+, \d+(, (true|false))*>")
 # ... and the grouped launch of one wavefront diagonal (rsis_convlstm_fwd_batch): template arguments <EPI, FLUSH> (FLUSH: the segmented-
 # accumulation instantiation of inference / deep-K calls, not what a training step launches)
 GATE_GROUP_RE = re.compile(r"conv3x3_direct_group_kernel<1(, false)?>")

@@ -325,9 +325,12 @@ static int fill_sources(ConvArgs& a, const float* const* src, const int* Csrc, i
   return RSIS_OK;
 }
 
-int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp, int Cout,
-                    int ks, int stride, int pad, const float* bias, const float* addend, float* out, int Ho, int Wo,
-                    int tile, int dtype, void* stream) {
+// the eval-mode BatchNorm folded into the epilogue (rsis_conv2d_fwd_bn_eval), or null
+struct BnEval { const float* gamma; const float* beta; const float* mean; const float* var; float eps; int relu; };
+
+static int conv2d_fwd_impl(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp, int Cout,
+                           int ks, int stride, int pad, const float* bias, const float* addend, float* out, int Ho, int Wo,
+                           int tile, int dtype, void* stream, const BnEval* bn) {
   const bool allow_splitk = tile >= 100;     // tile + 100: the caller accepts a split-K (atomic, order-nondeterministic) sum
   tile %= 100;
   ConvArgs a = {};
@@ -340,6 +343,14 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
   a.dst[0] = out; a.Cd[0] = Cout; a.ndst = 1;
   a.ostride = 1; a.oH = Ho; a.oW = Wo; a.ksplit = 1;
   a.precise = allow_splitk ? 0 : 1;       // (tile + 100 marks a training call; everything else is the inference / parity path)
+  if (bn) {
+    // the fp32 single-destination epilogues of conv_igemm.hip / conv3x3_direct.hip only (inference calls): everything else is
+    // refused BEFORE anything is launched, and the caller runs the conv and the BatchNorm as two launches
+    if (!bn->gamma || !bn->beta || !bn->mean || !bn->var) return RSIS_ERR_ARG;
+    if (allow_splitk || dtype != RSIS_DTYPE_F32 || Cout % 4 != 0 || (size_t)B * Cout * Ho * Wo * 4 >= (1ull << 31)) return RSIS_ERR_UNSUPPORTED;
+    if (use_direct(ks, stride, pad) && Cout == 1) return RSIS_ERR_UNSUPPORTED;
+    a.ep_gamma = bn->gamma; a.ep_beta = bn->beta; a.ep_mean = bn->mean; a.ep_var = bn->var; a.ep_eps = bn->eps; a.ep_relu = bn->relu ? 1 : 0;
+  }
   if (use_wino(dtype, ks, stride, pad, Csrc[0], Cout, nsrc, 0))
     return rsis_launch_conv_wino(src[0], Wp, bias, addend, out, B, Csrc[0], Cout, H, W, (hipStream_t)stream);
   if (use_bf16(dtype, ks, stride, pad, Cout)) {
@@ -375,6 +386,20 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
   if (use_direct_f2(ks, stride, pad))        // 3x3 / stride 2 forward: the direct kernel on a (2T+1)^2 patch (EPI_F2 = 3)
     return rsis_launch_conv3x3_direct(a, 3, direct_variant(tile), (hipStream_t)stream);
   return rsis_launch_conv_igemm(a, ks, false, 0, tile, (hipStream_t)stream);
+}
+
+int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp, int Cout,
+                    int ks, int stride, int pad, const float* bias, const float* addend, float* out, int Ho, int Wo,
+                    int tile, int dtype, void* stream) {
+  return conv2d_fwd_impl(src, Csrc, nsrc, B, H, W, Wp, Cout, ks, stride, pad, bias, addend, out, Ho, Wo, tile, dtype, stream, nullptr);
+}
+
+int rsis_conv2d_fwd_bn_eval(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp, int Cout,
+                            int ks, int stride, int pad, const float* bias, const float* addend, const float* gamma, const float* beta,
+                            const float* running_mean, const float* running_var, float eps, int relu, float* out, int Ho, int Wo,
+                            int tile, void* stream) {
+  const BnEval bn = {gamma, beta, running_mean, running_var, eps, relu};
+  return conv2d_fwd_impl(src, Csrc, nsrc, B, H, W, Wp, Cout, ks, stride, pad, bias, addend, out, Ho, Wo, tile % 100, RSIS_DTYPE_F32, stream, &bn);
 }
 
 int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const void* Wd, int Cin_packed, int ks, int stride,

@@ -34,6 +34,18 @@ int rsis_deterministic();
 static inline int rsis_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int rsis_roundup(int a, int b) { return ((a + b - 1) / b) * b; }
 
+// Eval-mode BatchNorm (reference: nn.BatchNorm2d in eval(), model.py:50-54 and the torchvision trunk) as a per-channel affine map.
+// ONE definition for the stand-alone launch (pointwise.hip: bn_apply_kernel) and for the conv epilogues that fold it in at inference
+// (conv_igemm.hip / conv3x3_direct.hip, ConvArgs::ep_*): both produce the same bits by construction.
+__device__ __forceinline__ void rsis_bn_affine(float rstd, float gamma, float beta, float mean, float& sc, float& sh) {
+  sc = rstd * gamma;
+  sh = __builtin_fmaf(-mean, sc, beta);
+}
+__device__ __forceinline__ float rsis_bn_eval_rstd(float var, float eps) { return 1.0f / sqrtf(var + eps); }
+__device__ __forceinline__ float rsis_bn_apply(float v, float sc, float sh, float r, int relu) {
+  const float t = __builtin_fmaf(v, sc, sh) + r;
+  return relu ? fmaxf(t, 0.f) : t;
+}
 __device__ __forceinline__ float rsis_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 // The same two functions on the hardware's transcendental units (v_exp_f32, v_rcp_f32: ~1 ulp each), for the bf16 (blk) decoder
 // kernels: 4 / 5 instructions instead of ~25 (expf + an IEEE division) / ~35 (tanhf).  The ConvLSTM cell of the 112 x 112 level has
@@ -69,7 +81,8 @@ struct ConvArgs {
   int Cout;                        // real number of output rows
   const float* bias;               // [Cout] (packed row order) or null
   const float* addend;             // optional, same layout as dst[0] (single destination only)
-  // conv_blk.hip only (inference): the eval-mode BatchNorm behind the conv in its epilogue -- y = relu?(v * sc + sh (+ addend)) with
+  // inference: the eval-mode BatchNorm behind the conv in its epilogue (conv_blk.hip; fp32: the single-destination epilogues of
+  // conv_igemm.hip / conv3x3_direct.hip, rsis_conv2d_fwd_bn_eval, where ep_round is unused: fp32 has no intermediate rounding) -- y = relu?(v * sc + sh (+ addend)) with
   // sc = gamma * rsqrtf(var + eps), sh = beta - mean * sc, v = the product rounded to bf16 first (ep_round: the bits of the separate
   // BatchNorm launch) or kept in fp32 (one rounding in all).  ep_gamma == null: none.
   const float* ep_gamma; const float* ep_beta; const float* ep_mean; const float* ep_var;

@@ -59,7 +59,7 @@ constexpr int direct_lds_floats() {
 
 // The block program.  bid: the block's index inside its launch (or inside its job of a grouped launch); kz / ksplit: its slice of
 // the channel chunks (grid split-K); lds: the block's LDS, direct_lds_floats<...>() floats.
-template <int BM, int TW, int TH, int NI, int EPI, int KSP = 1, int NWV = 4, bool FLUSH = false>
+template <int BM, int TW, int TH, int NI, int EPI, int KSP = 1, int NWV = 4, bool FLUSH = false, bool BNE = false>
 __device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int bid, const int kz, const int ksplit, float* const lds) {
 #if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; the buffer-resource builtins do not exist there)
   constexpr int BN = TW * TH * NI;
@@ -251,6 +251,19 @@ __device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int
       for (int r = 0; r < 16; ++r) acc[j][r] += tot[j][r];
   }
 
+  if constexpr (BNE) {
+    // inference, eval-mode BatchNorm folded into the epilogue (rsis_conv2d_fwd_bn_eval): the block's BM (scale, shift) pairs, computed
+    // once by its first BM threads into the tail of the (now dead) weight stage -- the epilogue reads them back as float4s, so the fold
+    // holds no registers across the tiles (as 2 x 16 registers per lane it took the 32-row variants from 92 to 140 VGPRs)
+    float* tab = lds + direct_lds_floats<BM, TW, TH, NI, EPI, NWV>() - 2 * BM;
+    if (tid < BM) {
+      const int row = co_t * BM + tid;
+      float sc = 0.f, sh = 0.f;
+      if (row < p.Cout) rsis_bn_affine(rsis_bn_eval_rstd(p.ep_var[row], p.ep_eps), p.ep_gamma[row], p.ep_beta[row], p.ep_mean[row], sc, sh);
+      tab[tid] = sc; tab[BM + tid] = sh;
+    }
+    if constexpr (KSP == 1) __syncthreads();      // (KSP > 1: the barrier of the reduction below)
+  }
   if constexpr (KSP > 1) {
     // sum the K-halves: waves with wk > 0 park their accumulators in LDS (the staging buffers are dead after the last barrier)
     float* red = lds + ((wm * WGN + wn) * TN) * 16 * 64;
@@ -328,6 +341,21 @@ __device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int
             const int k = (r & 3) + 8 * (r >> 2);
             av[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, k < rows_left ? vo + k * rowb : 0x7FFFFFF0u, 0, 0));
           }
+        }
+        if constexpr (BNE) {
+          // inference: y = relu?(bn_eval(conv + bias) + addend) -- the arithmetic of bn_apply_kernel (common.h: rsis_bn_apply)
+          const float* tab = lds + direct_lds_floats<BM, TW, TH, NI, EPI, NWV>() - 2 * BM + wm * 32 + 4 * hi;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(tab + 8 * g), h4 = *reinterpret_cast<const f32x4*>(tab + BM + 8 * g);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int r = 4 * g + kk, k = kk + 8 * g;
+              const float v = rsis_bn_apply(acc[j][r] + bv[r], s4[kk], h4[kk], addend ? av[r] : 0.f, p.ep_relu);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, k < rows_left ? vo + k * rowb : 0x7FFFFFF0u, 0, 0);
+            }
+          }
+          continue;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -447,10 +475,10 @@ __device__ __forceinline__ void conv3x3_direct_body(const ConvArgs& p, const int
 #endif
 }
 
-template <int BM, int TW, int TH, int NI, int EPI, int KSP = 1, int NWV = 4, bool FLUSH = false>
+template <int BM, int TW, int TH, int NI, int EPI, int KSP = 1, int NWV = 4, bool FLUSH = false, bool BNE = false>
 __global__ __launch_bounds__(NWV * 64) void conv3x3_direct_kernel(const ConvArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[direct_lds_floats<BM, TW, TH, NI, EPI, NWV>()];
-  conv3x3_direct_body<BM, TW, TH, NI, EPI, KSP, NWV, FLUSH>(p, blockIdx.x, blockIdx.y, gridDim.y, lds);
+  conv3x3_direct_body<BM, TW, TH, NI, EPI, KSP, NWV, FLUSH, BNE>(p, blockIdx.x, blockIdx.y, gridDim.y, lds);
 }
 
 // ---- grouped launch: several INDEPENDENT convs in ONE grid (rsis_convlstm_fwd_batch: the ConvLSTM levels of one diagonal of the
@@ -505,6 +533,17 @@ static int launch_direct_cfg(ConvArgs& a, hipStream_t st) {
       if (ksplit > nq / 8) ksplit = nq / 8;
       if (ksplit > 16) ksplit = 16;
       if (ksplit < 1) ksplit = 1;
+    }
+  }
+  if (a.ep_gamma) {
+    // inference with the eval-mode BatchNorm folded into the epilogue (rsis_conv2d_fwd_bn_eval): the BNE instantiations -- segmented
+    // accumulation whatever the depth on the 256-thread variants (no segment boundary is crossed below RSIS_ACC_FLUSH chunks: same bits)
+    if constexpr (EPI == EPI_PLAIN) {
+      if (ksplit != 1 || a.ndst != 1 || a.Cout % 4 != 0 || (size_t)a.B * a.Cout * a.H * a.W * 4 >= (1ull << 31)) return RSIS_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL((conv3x3_direct_kernel<BM, TW, TH, NI, EPI, KSP, NWV, NWV == 4, true>), dim3(grid, 1), dim3(NWV * 64), 0, st, a);
+      return rsis_check_launch();
+    } else {
+      return RSIS_ERR_UNSUPPORTED;       // (nothing launched: the caller runs conv and BatchNorm as two launches)
     }
   }
   if constexpr ((EPI == EPI_PLAIN || EPI == EPI_LSTM) && NWV == 4) {

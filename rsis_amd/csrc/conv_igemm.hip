@@ -18,7 +18,7 @@
 #include "common.h"
 #include <type_traits>
 
-enum { EPI_PLAIN = 0, EPI_LSTM = 1 };
+enum { EPI_PLAIN = 0, EPI_LSTM = 1, EPI_BN = 2 };     // EPI_BN: EPI_PLAIN + the folded eval-mode BatchNorm (inference; its own instantiations)
 #ifndef RSIS_GEMM_NST_DEFAULT
 #define RSIS_GEMM_NST_DEFAULT 2
 #endif
@@ -286,10 +286,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #undef RSIS_STORE_TILE
 #undef RSIS_DMA_TILE
 
+  if constexpr (EPI == EPI_BN) {
+    // the block's BM (scale, shift) pairs of the folded eval-mode BatchNorm, once, into the operand stages (dead: the K loop ends on a
+    // barrier) -- registers instead (2 x 16 per lane) took this tile from 92 to 132 VGPRs
+    if (tid < BM) {
+      const int row = co_t * BM + tid;
+      float sc = 0.f, sh = 0.f;
+      if (row < p.Cout) rsis_bn_affine(rsis_bn_eval_rstd(p.ep_var[row], p.ep_eps), p.ep_gamma[row], p.ep_beta[row], p.ep_mean[row], sc, sh);
+      lds[tid] = sc; lds[BM + tid] = sh;
+    }
+    __syncthreads();
+  }
   // ---- epilogue ----
   const int co_base = co_t * BM + wm * TM * 32;
   const gcf_t bias = (gcf_t)p.bias, addend = (gcf_t)p.addend;
-  if (EPI == EPI_PLAIN) {
+  if (EPI == EPI_PLAIN || EPI == EPI_BN) {
     const gf_t d0 = (gf_t)p.dst[0], d1 = (gf_t)p.dst[1], d2 = (gf_t)p.dst[2];
     const int Cd0 = p.Cd[0], Cd1 = p.Cd[1], Cd2 = p.Cd[2], Cout = p.Cout;
     const int e1 = Cd0, e2 = Cd0 + Cd1;
@@ -321,6 +332,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
               const int k = (r & 3) + 8 * (r >> 2);
               av[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, k < rows_left ? vo + k * rowb : 0x7FFFFFF0u, 0, 0));
             }
+          }
+          if constexpr (EPI == EPI_BN) {
+            // inference: y = relu?(bn_eval(conv + bias) + addend) -- the arithmetic of bn_apply_kernel (common.h: rsis_bn_apply); the
+            // block's (scale, shift) table sits in the dead operand stages (filled below the K loop)
+            const float* tab = lds + wm * TM * 32 + i * 32 + 4 * hi;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 s4 = *reinterpret_cast<const f32x4*>(tab + 8 * g), h4 = *reinterpret_cast<const f32x4*>(tab + BM + 8 * g);
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk) {
+                const int r = 4 * g + kk, k = kk + 8 * g;
+                float v = acc[i][j][r];
+                if (bias) v += k < rows_left ? bias[row0 + k] : 0.f;
+                v = rsis_bn_apply(v, s4[kk], h4[kk], addend ? av[r] : 0.f, p.ep_relu);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, k < rows_left ? vo + k * rowb : 0x7FFFFFF0u, 0, 0);
+              }
+            }
+            continue;
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -417,10 +446,10 @@ static int launch_cfg(ConvArgs& a, hipStream_t st) {
   a.n_co_tiles = rsis_cdiv(a.Cout, BM);
   a.n_px_tiles = rsis_cdiv(Npx, BN);
   const int grid = a.n_co_tiles * 8 * rsis_cdiv(a.n_px_tiles, 8);
-  if constexpr (KS == 1 && !DGRAD && EPI == EPI_PLAIN) {
+  if constexpr (KS == 1 && !DGRAD && (EPI == EPI_PLAIN || EPI == EPI_BN)) {
     if (a.stride == 1 && a.pad == 0 && a.nsrc == 1 && (a.H * a.W) % 4 == 0 && a.C[0] % BK == 0 &&
         (long)a.B * a.C[0] * a.H * a.W * 4 < (1L << 31)) {
-      if constexpr (BM == 64 && BN == 64 && BK == 32) {      // the trunk's 1x1 GEMM tile: ring depth by RSIS_GEMM_NST (2, 3 or 4)
+      if constexpr (BM == 64 && BN == 64 && BK == 32 && EPI == EPI_PLAIN) {      // the trunk's 1x1 GEMM tile: ring depth by RSIS_GEMM_NST (2, 3 or 4)
         static const int nst = getenv("RSIS_GEMM_NST") ? atoi(getenv("RSIS_GEMM_NST")) : RSIS_GEMM_NST_DEFAULT;
         if (nst == 3) { hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, KS, DGRAD, EPI, true, 3>), dim3(grid), dim3(256), 0, st, a); return rsis_check_launch(); }
         if (nst == 4) { hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, KS, DGRAD, EPI, true, 4>), dim3(grid), dim3(256), 0, st, a); return rsis_check_launch(); }
@@ -471,6 +500,14 @@ int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_t
     if (dgrad) return RSIS_ERR_UNSUPPORTED;
     if (ks == 3) return launch_ks<3, false, EPI_LSTM>(a, st, force_tile);
     if (ks == 1) return launch_ks<1, false, EPI_LSTM>(a, st, force_tile);
+    return RSIS_ERR_UNSUPPORTED;
+  }
+  if (a.ep_gamma) {
+    // rsis_conv2d_fwd_bn_eval: the 1x1 GEMMs of the trunk (64 x 64 tile) and the 7x7 stem (64 x 128), single destination
+    if (dgrad || epi != EPI_PLAIN || a.ndst != 1 || a.Cout <= 32 || a.Cout % 4 != 0 || (size_t)a.B * a.Cout * a.oH * a.oW * 4 >= (1ull << 31))
+      return RSIS_ERR_UNSUPPORTED;       // (nothing launched)
+    if (ks == 1) return launch_cfg<64, 64, 32, 2, 2, 1, false, EPI_BN>(a, st);
+    if (ks == 7 && a.Cout <= 64) return launch_cfg<64, 128, 32, 2, 2, 7, false, EPI_BN>(a, st);
     return RSIS_ERR_UNSUPPORTED;
   }
   if (!dgrad) {

@@ -507,24 +507,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
   } else {
     mean = run_mean[c];
-    rstd = 1.0f / sqrtf(run_var[c] + eps);
+    rstd = rsis_bn_eval_rstd(run_var[c], eps);
   }
-  const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
+  float sc, sh;
+  rsis_bn_affine(rstd, gamma[c], beta[c], mean, sc, sh);
   if ((HW & 3) == 0) {
     BN_FOREACH(4, {
       f32x4 v = *reinterpret_cast<const f32x4*>(x + idx);
       f32x4 r = {0.f, 0.f, 0.f, 0.f};
       if (res) r = *reinterpret_cast<const f32x4*>(res + idx);
-      for (int k = 0; k < 4; ++k) { float t = v[k] * sc + sh + r[k]; v[k] = relu ? fmaxf(t, 0.f) : t; }
+      for (int k = 0; k < 4; ++k) v[k] = rsis_bn_apply(v[k], sc, sh, r[k], relu);
       *reinterpret_cast<f32x4*>(y + idx) = v;
     })
   } else {
-    BN_FOREACH(1, {
-      float v = x[idx] * sc + sh;
-      if (res) v += res[idx];
-      if (relu) v = fmaxf(v, 0.f);
-      y[idx] = v;
-    })
+    BN_FOREACH(1, { y[idx] = rsis_bn_apply(x[idx], sc, sh, res ? res[idx] : 0.f, relu); })
   }
 }
 

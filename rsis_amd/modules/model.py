@@ -14,7 +14,7 @@ import os
 from .. import decoder_fused, decoder_seq, ops
 from ..utils.utils import get_skip_dims
 from .clstm import ConvLSTMCell
-from .vision import HipBatchNorm2d, HipConv2d, ResNet101
+from .vision import HipBatchNorm2d, HipConv2d, ResNet101, conv_bn
 
 
 class FeatureExtractor(nn.Module):
@@ -91,11 +91,11 @@ class FeatureExtractor(nn.Module):
             s5, s4, s3, s2 = blk_trunk.skips_forward([(self.sk5, self.bn5), (self.sk4, self.bn4), (self.sk3, self.bn3), (self.sk2, self.bn2)],
                                                      [x5, x4, x3, x2])
             return s5, s4, s3, s2, self.bn1(self.sk1(x1))
-        x5_skip = self.bn5(self.sk5(x5))             # model.py:59-63 (BN, no ReLU)
-        x4_skip = self.bn4(self.sk4(x4))
-        x3_skip = self.bn3(self.sk3(x3))
-        x2_skip = self.bn2(self.sk2(x2))
-        x1_skip = self.bn1(self.sk1(x1))
+        x5_skip = conv_bn(self.sk5, self.bn5, x5)    # model.py:59-63 (BN, no ReLU)
+        x4_skip = conv_bn(self.sk4, self.bn4, x4)
+        x3_skip = conv_bn(self.sk3, self.bn3, x3)
+        x2_skip = conv_bn(self.sk2, self.bn2, x2)
+        x1_skip = conv_bn(self.sk1, self.bn1, x1)
         return x5_skip, x4_skip, x3_skip, x2_skip, x1_skip
 
     def backward_trunk(self, between=None):

@@ -85,6 +85,18 @@ class HipBatchNorm2d(nn.Module):
                              eps=self.eps, momentum=self.momentum, arena=arena if self.training else None, res_slot=res_slot)
 
 
+def conv_bn(conv, bn, x, relu=False, res=None):
+    """act(bn(conv(x)) + res).  A call that records no autograd graph with the BatchNorm in eval mode (test() / eval.py) runs as ONE
+    launch -- the BatchNorm, the residual add and the ReLU in the conv's epilogue (ops.conv2d_bn_eval) -- where the library has that
+    epilogue; every other call is the two modules."""
+    if not bn.training and not torch.is_grad_enabled() and x.is_cuda:
+        y = ops.conv2d_bn_eval(x, conv.weight, conv.bias, conv.stride, conv.padding, conv._pack, bn.weight, bn.bias, bn.running_mean,
+                               bn.running_var, bn.eps, relu=relu, res=res)
+        if y is not None:
+            return y
+    return bn(conv(x), res=res, relu=relu)
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -104,6 +116,11 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         # In training x has two consumers inside the block (conv1 and the identity branch / downsample conv); instead of
         # letting autograd add their gradients, the second one is handed to conv1's data-gradient kernel (ops.GradSlot).
+        if not self.training and not torch.is_grad_enabled():          # inference: each conv + BatchNorm (+ residual) (+ ReLU) one launch
+            out = conv_bn(self.conv1, self.bn1, x, relu=True)
+            out = conv_bn(self.conv2, self.bn2, out, relu=True)
+            residual = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
+            return conv_bn(self.conv3, self.bn3, out, relu=True, res=residual)
         hand = self.training and torch.is_grad_enabled() and x.requires_grad
         slot = self._slot if hand else None
         out = self.bn1(self.conv1(x, grad_slot=slot), relu=True)
@@ -152,7 +169,7 @@ class ResNet101(nn.Module):
     def forward(self, x, blk_out=False):
         """blk_out (internal fast path of FeatureExtractor.forward(blk_skips=True)): under -dtype bf16 return x5..x2 as the blk tensors
         the trunk computes in, without the converters to fp32 NCHW"""
-        x1 = self.bn1(self.conv1(x), relu=True)   # vision.py:12-14 (x1 is the post-ReLU stem)
+        x1 = conv_bn(self.conv1, self.bn1, x, relu=True)   # vision.py:12-14 (x1 is the post-ReLU stem)
         hand = self.training and torch.is_grad_enabled() and x1.requires_grad
         x = ops.maxpool3x3s2(x1, grad_slot=self._slot_x1 if hand else None)   # :15
         if blk_trunk.usable(self, x):

@@ -475,6 +475,48 @@ def conv2d(srcs, weight, bias, stride, pad, pack, grad_slot=None, park_slot=None
     return _Conv2dFn.apply(pack, int(stride), int(pad), len(srcs), slot, *srcs, weight, bias)
 
 
+# Inference: the eval-mode BatchNorm behind a conv (+ residual add) (+ ReLU) in the conv's epilogue (rsis_conv2d_fwd_bn_eval) -- bit for bit
+# the two launches, without the BatchNorm's read + write of the activation.  RSIS_EVAL_FOLD=0 keeps the separate launches (A/B switch).
+EVAL_FOLD = [os.environ.get("RSIS_EVAL_FOLD", "1") != "0"]
+_ERR_UNSUPPORTED = 3
+
+
+def conv2d_bn_eval(x, weight, bias, stride, pad, pack, gamma, beta, running_mean, running_var, eps, relu=False, res=None):
+    """relu?(bn_eval(conv(x) + bias) + res) as ONE launch, for calls that record no autograd graph (test() / eval.py); returns None when the
+    library has no folded epilogue for this conv (3x3 / stride 2, Winograd-only geometry, ...) -- the caller then runs conv and BatchNorm."""
+    if not EVAL_FOLD[0] or torch.is_grad_enabled() or pack.dtype not in (DTYPE_F32, DTYPE_F32_WINO):
+        return None
+    if pack.dtype == DTYPE_F32_WINO:
+        pack = pack.direct_twin()                # the inference path of a Winograd conv is the direct kernel (see conv2d)
+    x = _contig(x)
+    res = _contig(res) if res is not None else None
+    require_cuda_f32(x, weight, bias, res, gamma, beta, running_mean, running_var)
+    L = lib()
+    B, Cin, H, W = x.shape
+    Cout, ks = weight.shape[0], weight.shape[2]
+    Ho, Wo = _conv_out_size(H, ks, stride, pad), _conv_out_size(W, ks, stride, pad)
+    if pack.stride != stride or pack.pad != pad:
+        raise _lib.RsisHipError("PackedConv was built for stride %d pad %d, used with %d/%d" % (pack.stride, pack.pad, stride, pad))
+    if Cout % 4 != 0 or (ks == 3 and stride != 1):
+        return None
+    pack.training_call = False
+    wp = pack.fwd(weight)
+    stride_k = stride
+    if ks == 1 and stride > 1 and pad == 0:      # the strided 1x1 convs run the stride-1 GEMM on a sub-sampled copy (see _Conv2dFn)
+        sub = torch.empty((B, Cin, Ho, Wo), dtype=torch.float32, device=x.device)
+        check(L.rsis_subsample2d(ptr(x), ptr(sub), B * Cin, H, W, stride, stream()), "rsis_subsample2d")
+        x, H, W, stride_k = sub, Ho, Wo, 1
+    out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    assert res is None or tuple(res.shape) == tuple(out.shape)
+    rc = L.rsis_conv2d_fwd_bn_eval(ptr_array([x]), int_array([Cin]), 1, B, H, W, ptr(wp), Cout, ks, stride_k, pad,
+                                   ptr(bias.detach() if bias is not None else None), ptr(res), ptr(gamma.detach()), ptr(beta.detach()),
+                                   ptr(running_mean), ptr(running_var), float(eps), 1 if relu else 0, ptr(out), Ho, Wo, FORCE_TILE[0], stream())
+    if rc == _ERR_UNSUPPORTED:
+        return None
+    check(rc, "rsis_conv2d_fwd_bn_eval")
+    return out
+
+
 class _ConvLSTMFn(torch.autograd.Function):
     """ConvLSTMCell.forward (reference clstm.py:19-62) as one fused kernel; returns (h, c)."""
 
