@@ -8,7 +8,7 @@ int rsis_launch_conv_igemm(ConvArgs& a, int ks, bool dgrad, int epi, int force_t
 int rsis_launch_conv_wgrad(WgradArgs& a, int ks, hipStream_t st);
 int rsis_launch_conv3x3_direct(ConvArgs& a, int epi, int force_variant, hipStream_t st);
 int rsis_launch_conv_wino(const float* x, const void* U, const float* bias, const float* addend, float* y, int B, int C, int Cout, int H, int W,
-                          hipStream_t st);
+                          hipStream_t st, int precise);
 int rsis_launch_conv_wino_group(int n, const float* const* x, const void* const* U, float* const* y, float* const* y1, const int* B, const int* C,
                                 const int* Cout, const int* C0, const int* H, const int* W, hipStream_t st);
 int rsis_launch_convlstm_direct_group(ConvArgs* jobs, int n, const int* force_variant, hipStream_t st);
@@ -352,7 +352,7 @@ static int conv2d_fwd_impl(const float* const* src, const int* Csrc, int nsrc, i
     a.ep_gamma = bn->gamma; a.ep_beta = bn->beta; a.ep_mean = bn->mean; a.ep_var = bn->var; a.ep_eps = bn->eps; a.ep_relu = bn->relu ? 1 : 0;
   }
   if (use_wino(dtype, ks, stride, pad, Csrc[0], Cout, nsrc, 0))
-    return rsis_launch_conv_wino(src[0], Wp, bias, addend, out, B, Csrc[0], Cout, H, W, (hipStream_t)stream);
+    return rsis_launch_conv_wino(src[0], Wp, bias, addend, out, B, Csrc[0], Cout, H, W, (hipStream_t)stream, a.precise);
   if (use_bf16(dtype, ks, stride, pad, Cout)) {
     if (stride != 1) return RSIS_ERR_UNSUPPORTED;      // strided 1x1: run the stride-1 form on a sub-sampled input
     if (ks == 1 && nsrc != 1) return RSIS_ERR_UNSUPPORTED;
@@ -426,7 +426,7 @@ int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const vo
     // the data gradient of a Winograd conv is the same kernel on the transposed, rotated weights (pack mode 8): dy plays the input.
     // One destination (any leading multiple of 32 channels of the concat) or two splitting it at a multiple of 32.
     if (ndst > 2 || ctot % 32 != 0 || Cdx[0] % 32 != 0 || Hx != Hy || Wx != Wy || (ndst == 2 && addend)) return RSIS_ERR_UNSUPPORTED;
-    if (ndst == 1) return rsis_launch_conv_wino(dy, Wd, nullptr, addend, dx[0], B, Cout, ctot, Hy, Wy, (hipStream_t)stream);
+    if (ndst == 1) return rsis_launch_conv_wino(dy, Wd, nullptr, addend, dx[0], B, Cout, ctot, Hy, Wy, (hipStream_t)stream, 0);
     const float* xs[1] = {dy}; const void* us[1] = {Wd}; float* y0[1] = {dx[0]}; float* y1[1] = {dx[1]};
     const int b1[1] = {B}, c1[1] = {Cout}, co1[1] = {ctot}, c01[1] = {Cdx[0]}, h1[1] = {Hy}, w1[1] = {Wy};
     return rsis_launch_conv_wino_group(1, xs, us, y0, y1, b1, c1, co1, c01, h1, w1, (hipStream_t)stream);

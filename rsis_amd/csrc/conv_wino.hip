@@ -67,6 +67,10 @@ struct WinoGroup {
 };
 }  // namespace
 
+// FLUSH (inference calls): every WINO_FLUSH chunks (32 input channels) the MFMA accumulators are added to a second register set and cleared --
+// the segmented accumulation of conv3x3_direct.hip (its NOTES (13) / round-4 reason: an MFMA accumulates its k-steps as ONE chain).
+#define WINO_FLUSH 4
+template <bool FLUSH>
 __global__ __launch_bounds__(WNT) void conv_wino_f32_kernel(const WinoGroup g) {
 #if __HIP_DEVICE_COMPILE__
   int jb = 0;
@@ -186,7 +190,26 @@ __global__ __launch_bounds__(WNT) void conv_wino_f32_kernel(const WinoGroup g) {
   acc[c][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[S][c], bv[S][c][1], acc[c][1], 0, 0, 0);
   float av[2][2], bv[2][2][2];
   int s3 = 0;                                   // t % WRING
+  f32x16 tot[FLUSH ? 2 : 1][FLUSH ? 2 : 1];
+  if constexpr (FLUSH) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[c][j][r] = 0.f;
+  }
   for (int t = 0; t < nq; ++t) {
+    if constexpr (FLUSH) {
+      if (t > 0 && (t & (WINO_FLUSH - 1)) == 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { tot[c][j][r] += acc[c][j][r]; acc[c][j][r] = 0.f; }
+      }
+    }
     const int cur = t & 1, nxt = cur ^ 1;
     const int s3n = s3 + 1 == WRING ? 0 : s3 + 1;                  // (t + 1) % 3
     const int s3p = s3n + 1 == WRING ? 0 : s3n + 1;                // (t + 2) % 3
@@ -220,6 +243,14 @@ __global__ __launch_bounds__(WNT) void conv_wino_f32_kernel(const WinoGroup g) {
   }
   WINO_WAIT_VM(0)      // (the zero-range tail loads still write LDS: they must have landed before the stages are reused below)
   __builtin_amdgcn_s_barrier();
+  if constexpr (FLUSH) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][j][r] += tot[c][j][r];
+  }
 
   // ---- output transform.  Row part in registers: with m_c = M[r][2 h + c], half 0 contributes P0 = m0 + m1, P1 = m1 and half 1
   // P0 = m0, P1 = -m0 - m1 to T[r][j] = (M A)[r][j]; then Y[0][j] = T0j + T1j + T2j, Y[1][j] = T1j - T2j - T3j.  The 8 waves park
@@ -299,26 +330,28 @@ static int wino_fill(WinoArgs& a, const float* x, const void* U, const float* bi
   a.n_regions = B * a.ry * a.rx;
   return RSIS_OK;
 }
-static int wino_launch(WinoGroup& g, int blocks, hipStream_t st) {
+static int wino_launch(WinoGroup& g, int blocks, hipStream_t st, bool flush = false) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_wino_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * 4) != hipSuccess) return RSIS_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)conv_wino_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * 4) != hipSuccess) return RSIS_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)conv_wino_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * 4) != hipSuccess) return RSIS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_wino_f32_kernel, dim3(blocks), dim3(WNT), LDS_FLOATS * 4, st, g);
+  if (flush) hipLaunchKernelGGL(conv_wino_f32_kernel<true>, dim3(blocks), dim3(WNT), LDS_FLOATS * 4, st, g);
+  else hipLaunchKernelGGL(conv_wino_f32_kernel<false>, dim3(blocks), dim3(WNT), LDS_FLOATS * 4, st, g);
   return rsis_check_launch();
 }
 
 // x [B][C][H][W] -> y [B][Cout][H][W] (+ bias, + addend); U: the Winograd packed copy.  C % 8 == 0, Cout % 32 == 0.
 int rsis_launch_conv_wino(const float* x, const void* U, const float* bias, const float* addend, float* y, int B, int C, int Cout,
-                          int H, int W, hipStream_t st) {
+                          int H, int W, hipStream_t st, int precise) {
   WinoGroup g = {};
   const int rc = wino_fill(g.job[0], x, U, bias, addend, y, nullptr, B, C, Cout, Cout, H, W);
   if (rc) return rc;
   g.n = 1;
   const int blocks = 8 * (Cout / 32) * rsis_cdiv(g.job[0].n_regions, 8);
   for (int k = 1; k <= WINO_MAXJ; ++k) g.begin[k] = blocks;
-  return wino_launch(g, blocks, st);
+  return wino_launch(g, blocks, st, precise != 0);
 }
 
 // n <= WINO_MAXJ independent convs in one grid, each with up to two destinations splitting its output channels at C0[j] (a multiple

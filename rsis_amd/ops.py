@@ -487,6 +487,8 @@ def conv2d_bn_eval(x, weight, bias, stride, pad, pack, gamma, beta, running_mean
     if not EVAL_FOLD[0] or torch.is_grad_enabled() or pack.dtype not in (DTYPE_F32, DTYPE_F32_WINO):
         return None
     if pack.dtype == DTYPE_F32_WINO:
+        if WINOGRAD_INFER[0]:
+            return None                          # opted into Winograd for inference: that kernel has no folded epilogue
         pack = pack.direct_twin()                # the inference path of a Winograd conv is the direct kernel (see conv2d)
     x = _contig(x)
     res = _contig(res) if res is not None else None
