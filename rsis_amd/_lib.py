@@ -89,7 +89,7 @@ SIGNATURES = {
     "rsis_conv_pack_job_fill": (_i, [ctypes.POINTER(PackJob)]),
     "rsis_conv_pack_batch": (_i, [_vp, _i, _i, _vp]),
     "rsis_conv2d_fwd": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "rsis_conv2d_fwd_bn_eval": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _i, _i, _vp]),
+    "rsis_conv2d_fwd_bn_eval": (_i, [_vpp, _ip, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _i, _i, _i, _vp]),
     "rsis_conv2d_dgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vpp, _ip, _i, _i, _i, _vp, _i, _i, _vp]),
     "rsis_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsis_conv2d_wgrad_batch": (_i, [ctypes.POINTER(WgradJob), _i, _vp]),

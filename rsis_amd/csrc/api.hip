@@ -347,7 +347,9 @@ static int conv2d_fwd_impl(const float* const* src, const int* Csrc, int nsrc, i
     // the fp32 single-destination epilogues of conv_igemm.hip / conv3x3_direct.hip only (inference calls): everything else is
     // refused BEFORE anything is launched, and the caller runs the conv and the BatchNorm as two launches
     if (!bn->gamma || !bn->beta || !bn->mean || !bn->var) return RSIS_ERR_ARG;
-    if (allow_splitk || dtype != RSIS_DTYPE_F32 || Cout % 4 != 0 || (size_t)B * Cout * Ho * Wo * 4 >= (1ull << 31)) return RSIS_ERR_UNSUPPORTED;
+    // (a conv of a bf16 model that the library runs on the fp32 kernels anyway -- the 7x7 stem -- is covered: same packed layout)
+    if (allow_splitk || Cout % 4 != 0 || (size_t)B * Cout * Ho * Wo * 4 >= (1ull << 31)) return RSIS_ERR_UNSUPPORTED;
+    if (dtype != RSIS_DTYPE_F32 && (dtype != RSIS_DTYPE_BF16 || use_bf16(dtype, ks, stride, pad, Cout))) return RSIS_ERR_UNSUPPORTED;
     if (use_direct(ks, stride, pad) && Cout == 1) return RSIS_ERR_UNSUPPORTED;
     a.ep_gamma = bn->gamma; a.ep_beta = bn->beta; a.ep_mean = bn->mean; a.ep_var = bn->var; a.ep_eps = bn->eps; a.ep_relu = bn->relu ? 1 : 0;
   }
@@ -397,9 +399,9 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
 int rsis_conv2d_fwd_bn_eval(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp, int Cout,
                             int ks, int stride, int pad, const float* bias, const float* addend, const float* gamma, const float* beta,
                             const float* running_mean, const float* running_var, float eps, int relu, float* out, int Ho, int Wo,
-                            int tile, void* stream) {
+                            int tile, int dtype, void* stream) {
   const BnEval bn = {gamma, beta, running_mean, running_var, eps, relu};
-  return conv2d_fwd_impl(src, Csrc, nsrc, B, H, W, Wp, Cout, ks, stride, pad, bias, addend, out, Ho, Wo, tile % 100, RSIS_DTYPE_F32, stream, &bn);
+  return conv2d_fwd_impl(src, Csrc, nsrc, B, H, W, Wp, Cout, ks, stride, pad, bias, addend, out, Ho, Wo, tile % 100, dtype, stream, &bn);
 }
 
 int rsis_conv2d_dgrad(const float* dy, int B, int Cout, int Hy, int Wy, const void* Wd, int Cin_packed, int ks, int stride,

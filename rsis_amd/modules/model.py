@@ -90,7 +90,7 @@ class FeatureExtractor(nn.Module):
             from .. import blk_trunk
             s5, s4, s3, s2 = blk_trunk.skips_forward([(self.sk5, self.bn5), (self.sk4, self.bn4), (self.sk3, self.bn3), (self.sk2, self.bn2)],
                                                      [x5, x4, x3, x2])
-            return s5, s4, s3, s2, self.bn1(self.sk1(x1))
+            return s5, s4, s3, s2, conv_bn(self.sk1, self.bn1, x1)
         x5_skip = conv_bn(self.sk5, self.bn5, x5)    # model.py:59-63 (BN, no ReLU)
         x4_skip = conv_bn(self.sk4, self.bn4, x4)
         x3_skip = conv_bn(self.sk3, self.bn3, x3)

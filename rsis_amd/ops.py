@@ -484,8 +484,8 @@ _ERR_UNSUPPORTED = 3
 def conv2d_bn_eval(x, weight, bias, stride, pad, pack, gamma, beta, running_mean, running_var, eps, relu=False, res=None):
     """relu?(bn_eval(conv(x) + bias) + res) as ONE launch, for calls that record no autograd graph (test() / eval.py); returns None when the
     library has no folded epilogue for this conv (3x3 / stride 2, Winograd-only geometry, ...) -- the caller then runs conv and BatchNorm."""
-    if not EVAL_FOLD[0] or torch.is_grad_enabled() or pack.dtype not in (DTYPE_F32, DTYPE_F32_WINO):
-        return None
+    if not EVAL_FOLD[0] or torch.is_grad_enabled() or pack.dtype not in (DTYPE_F32, DTYPE_F32_WINO, DTYPE_BF16):
+        return None                              # (a bf16 pack: only the convs the library runs on the fp32 kernels anyway -- it decides)
     if pack.dtype == DTYPE_F32_WINO:
         if WINOGRAD_INFER[0]:
             return None                          # opted into Winograd for inference: that kernel has no folded epilogue
@@ -512,7 +512,7 @@ def conv2d_bn_eval(x, weight, bias, stride, pad, pack, gamma, beta, running_mean
     assert res is None or tuple(res.shape) == tuple(out.shape)
     rc = L.rsis_conv2d_fwd_bn_eval(ptr_array([x]), int_array([Cin]), 1, B, H, W, ptr(wp), Cout, ks, stride_k, pad,
                                    ptr(bias.detach() if bias is not None else None), ptr(res), ptr(gamma.detach()), ptr(beta.detach()),
-                                   ptr(running_mean), ptr(running_var), float(eps), 1 if relu else 0, ptr(out), Ho, Wo, FORCE_TILE[0], stream())
+                                   ptr(running_mean), ptr(running_var), float(eps), 1 if relu else 0, ptr(out), Ho, Wo, FORCE_TILE[0], pack.dtype, stream())
     if rc == _ERR_UNSUPPORTED:
         return None
     check(rc, "rsis_conv2d_fwd_bn_eval")

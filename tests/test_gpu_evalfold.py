@@ -100,11 +100,11 @@ def test_library_refuses_before_launching():
     out = torch.full((2, 64, 16, 16), 7.0, device="cuda")
     v = torch.ones(64, device="cuda")
     rc = lib().rsis_conv2d_fwd_bn_eval(ptr_array([x]), int_array([64]), 1, 2, 32, 32, ptr(pack.fwd(w)), 64, 3, 2, 1, None, None, ptr(v), ptr(v),
-                                       ptr(v), ptr(v), 1e-5, 1, ptr(out), 16, 16, 0, stream())
+                                       ptr(v), ptr(v), 1e-5, 1, ptr(out), 16, 16, 0, 0, stream())
     torch.cuda.synchronize()
     assert rc == 3 and bool((out == 7.0).all())
     rc = lib().rsis_conv2d_fwd_bn_eval(ptr_array([x]), int_array([64]), 1, 2, 32, 32, ptr(pack.fwd(w)), 64, 3, 2, 1, None, None, None, ptr(v),
-                                       ptr(v), ptr(v), 1e-5, 1, ptr(out), 16, 16, 0, stream())
+                                       ptr(v), ptr(v), 1e-5, 1, ptr(out), 16, 16, 0, 0, stream())
     assert rc not in (0, 3)        # a missing BatchNorm array is an argument error
 
 
@@ -172,3 +172,23 @@ def test_test_entry_point_fold_is_bit_identical_and_launches_less():
     for p, q in zip(o1, o0):
         assert torch.equal(p, q)
     assert n_plain == 109 and n_fold == 3, (n_plain, n_fold)     # 104 trunk + 5 skip BatchNorms; the three 3x3 / stride-2 convs keep theirs
+
+
+def test_bf16_model_stem_folds_too():
+    """under -dtype bf16 the 7x7 stem (and any conv the library runs on the fp32 kernels anyway) takes the folded epilogue: the library, not
+    the binding, decides; a conv that the bf16 kernels run is refused"""
+    from rsis_amd import ops
+    from rsis_amd.modules.vision import HipConv2d, conv_bn
+    torch.manual_seed(5)
+    conv = HipConv2d(3, 64, 7, stride=2, padding=3, bias=False).cuda().eval()
+    conv._set_rsis_dtype(ops.DTYPE_BF16)
+    bn = _bn(64, 11)
+    x = torch.randn(2, 3, 96, 96, device="cuda")
+    with torch.no_grad():
+        one = ops.conv2d_bn_eval(x, conv.weight, None, 2, 3, conv._pack, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu=True)
+        assert one is not None and torch.equal(one, bn(conv(x), relu=True)) and torch.equal(conv_bn(conv, bn, x, relu=True), one)
+    c3 = HipConv2d(64, 64, 3, padding=1, bias=False).cuda().eval()
+    c3._set_rsis_dtype(ops.DTYPE_BF16)
+    xx = torch.randn(2, 64, 16, 16, device="cuda")
+    with torch.no_grad():
+        assert ops.conv2d_bn_eval(xx, c3.weight, None, 1, 1, c3._pack, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps) is None
