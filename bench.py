@@ -727,6 +727,9 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--product-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--skip-secondary", action="store_true", help="do not run the bf16 224x224 leg (BASELINE configs[2]) after the headline run")
+    ap.add_argument("--encoder-frozen", action="store_true", help="update_encoder off -- the reference's state until -finetune_after epochs have passed "
+                    "(args.py:39-45): rsis_amd then does not compute the trunk's backward at all (FeatureExtractor.trunk_grad); a SECONDARY record, "
+                    "never the headline line")
     ap.add_argument("--inference", action="store_true", help="time test() (reference src/test.py:16-50) instead of the training iteration")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the gate-kernel roofline leg and print its object (for `rocprofv3 --kernel-trace --stats`: the "
@@ -763,6 +766,8 @@ def main():
     check_world(o.gpus)                  # never a mislabelled line: --gpus N runs N ranks on N devices or exits non-zero
     rank, local_rank, world = init_distributed()
     a = bench_args(o.batch, o.imsize, o.T, o.dtype)
+    if o.encoder_frozen:
+        a.update_encoder = False
     torch.manual_seed(a.seed)
     encoder, decoder = FeatureExtractor(a).cuda(), RSIS(a).cuda()
     if world > 1 or os.environ.get("RSIS_FORCE_DIST", "") == "1":
@@ -1037,6 +1042,15 @@ def main():
                     secondary.append({k: sj.get(k) for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "exchange")})
                 except Exception as ex:  # noqa: BLE001
                     secondary.append({"dtype": "fp32", "config": "configs[1] + RSIS_FORCE_DIST=1 + RSIS_EXCHANGE=cuts", "error": repr(ex)})
+            # update_encoder off (the reference's training state until -finetune_after epochs: args.py:39-45), headline geometry
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--encoder-frozen", "--batch", str(o.batch), "--imsize", str(o.imsize), "--T", str(o.T),
+                                    "--steps", str(o.steps), "--warmup", str(o.warmup), "--skip-cpu", "--skip-secondary", "--skip-roofline"],
+                                   capture_output=True, text=True, timeout=600, env=dict(os.environ))
+                sj = json.loads(r.stdout.strip().splitlines()[-1])
+                secondary.append({k: sj.get(k) for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config")})
+            except Exception as ex:  # noqa: BLE001
+                secondary.append({"metric": "training images/sec", "config": "--encoder-frozen", "error": repr(ex)})
             # inference: test() (reference src/test.py:16-50, the caller of src/eval.py:262) at the headline geometry in fp32 and at configs[2]'s in bf16
             for extra in (["--imsize", str(o.imsize), "--dtype", "fp32"], ["--imsize", "224", "--dtype", "bf16"]):
                 try:
@@ -1053,7 +1067,9 @@ def main():
                "ms_per_step": round(1000.0 * dt / o.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if o.dtype == "fp32" else "bf16", "data": "synthetic",
                "config": {"workload": "configs[1]: synthetic %dx%dx3, T=%d, batch=%d/GPU, ResNet-101 encoder + 5-scale ConvLSTM "
-                                      "decoder, %s, fwd+match+3 losses+bwd+Adam (update_encoder on)" % (o.imsize, imw, o.T, o.batch, o.dtype),
+                                      "decoder, %s, fwd+match+3 losses+bwd+Adam (%s)" % (o.imsize, imw, o.T, o.batch, o.dtype,
+                                      "update_encoder OFF: the reference's state before -finetune_after; trunk forward in train mode, no trunk backward, "
+                                      "decoder + skip-branch update" if o.encoder_frozen else "update_encoder on"),
                           "global_batch": world * o.batch, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5),
                           "launch": "hipGraph replay of the captured iteration" if captured_launch
                                     else "eager (one Python launch per kernel)"},

@@ -17,6 +17,10 @@ from .clstm import ConvLSTMCell
 from .vision import HipBatchNorm2d, HipConv2d, ResNet101, conv_bn
 
 
+# RSIS_FROZEN_TRUNK_BACKWARD=1: compute (and discard) the trunk's backward while the encoder is not being updated, as the reference does
+FROZEN_TRUNK = [os.environ.get("RSIS_FROZEN_TRUNK_BACKWARD", "0") != "1"]
+
+
 class FeatureExtractor(nn.Module):
     """Returns base network to extract visual features from image (reference model.py:15-70)."""
 
@@ -47,6 +51,12 @@ class FeatureExtractor(nn.Module):
         # so that the decoder-group gradients are final (and can travel) before the trunk's backward starts
         self.split_backward = 0          # 0 off, 1 cut at the skip convs, 2 also in front of layer3 (ResNet101.cut_layer3)
         self._cut = None
+        # trunk_grad = False (train.runIter sets it from args.update_encoder): a training forward whose trunk gradients nobody will use.
+        # The reference back-propagates through the ResNet on every iteration and only skips enc_opt.step() (train.py:184-187; the skip
+        # convs / BatchNorms belong to the decoder's optimizer, utils.py:get_skip_params) -- until `-finetune_after` epochs have passed
+        # (20 in scripts/train_cityscapes.sh) the trunk's backward is computed and thrown away.  With trunk_grad False the trunk runs
+        # under no_grad (train-mode BatchNorm, running statistics updated as before) and the backward ends at the skip convs.
+        self.trunk_grad = True
         ops.set_dtype(self, getattr(args, "dtype", "fp32"))      # `-dtype bf16`: bf16-operand MFMA kernels where they exist
 
     def _arm_bn_arena(self, device):
@@ -70,11 +80,17 @@ class FeatureExtractor(nn.Module):
             self._arm_bn_arena(x.device)
         # (the second cut is armed only on the path that records the first one below: a semseg / raw caller, or one outside a training
         #  iteration, gets the uncut graph and a plain loss.backward() reaches every layer)
-        self.base.cut_layer3 = int(self.split_backward) >= 2 and not (semseg or raw) and self.training and torch.is_grad_enabled()
+        frozen = self.training and torch.is_grad_enabled() and not self.trunk_grad and not (semseg or raw) and FROZEN_TRUNK[0]
+        self.base.cut_layer3 = int(self.split_backward) >= 2 and not (semseg or raw) and self.training and torch.is_grad_enabled() and not frozen
         self.base._cut3 = None
         self._cut = None
         blk_skips = bool(blk_skips) and not (semseg or raw) and (self.training or not torch.is_grad_enabled()) and self.kernel_size == 3
-        x5, x4, x3, x2, x1 = self.base(x, blk_out=True) if blk_skips else self.base(x)            # model.py:57
+        prev_tf, ops.TRAINING_FORWARD[0] = ops.TRAINING_FORWARD[0], frozen or ops.TRAINING_FORWARD[0]
+        try:
+            with torch.set_grad_enabled(torch.is_grad_enabled() and not frozen):
+                x5, x4, x3, x2, x1 = self.base(x, blk_out=True) if blk_skips else self.base(x)            # model.py:57
+        finally:
+            ops.TRAINING_FORWARD[0] = prev_tf
         if semseg:
             return x5
         if raw:

@@ -60,6 +60,10 @@ WINOGRAD = [_wino_rule()]
 # e2e golden still within 1e-4 of the reference, but on the HOT fixture (e2e_256_hot: |logit| to 5.5, half the gates saturated) the
 # worst mask logit moves from 1.08e-4 to 1.86e-4 from float64 (the reference itself: 1.0e-4) -- 22 stacked Winograd layers are as
 # accurate per layer as an unsegmented direct sum (2.8e-6 vs 2.6e-6 on O(1) data), not as accurate as the segmented one.
+# set by FeatureExtractor.forward around a TRAINING forward that runs under no_grad (the frozen trunk: modules/model.py trunk_grad): the
+# convs then take the kernels of a training call (Winograd where the rule says so, split-K allowed) -- the same arithmetic as the
+# iteration that does back-propagate through them -- instead of the inference / parity instantiations
+TRAINING_FORWARD = [False]
 WINOGRAD_INFER = [os.environ.get("RSIS_WINOGRAD_INFER", "0") == "1"]
 # the decoder's gate data gradients (training only) on the Winograd kernel where the level qualifies (decoder_fused.dyn_dgrad_pack)
 WINOGRAD_GATES = [os.environ.get("RSIS_WINOGRAD_GATES", "1") != "0" and os.environ.get("RSIS_WINOGRAD", "x").strip().lower() not in ("0", "off", "none")]
@@ -465,7 +469,7 @@ def conv2d(srcs, weight, bias, stride, pad, pack, grad_slot=None, park_slot=None
     takes an addend from; park_slot: the slot it parks its own data gradient in (see GradSlot)."""
     # (ctx.needs_input_grad is True for parameters even under no_grad, and grad mode is off inside Function.forward, so the
     #  "is this a training call" decision is taken here)
-    training = torch.is_grad_enabled() and (weight.requires_grad or any(s.requires_grad for s in srcs))
+    training = (torch.is_grad_enabled() and (weight.requires_grad or any(s.requires_grad for s in srcs))) or TRAINING_FORWARD[0]
     if pack.dtype == DTYPE_F32_WINO and not training and not WINOGRAD_INFER[0]:
         pack = pack.direct_twin()            # inference / parity path: the direct kernel, segmented accumulation (see WINOGRAD_INFER)
     pack.training_call = training

@@ -119,6 +119,10 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
                                             (lambda b, a: dist.all_reduce(b, op=dist.ReduceOp.SUM, group=reducer.pg, async_op=a)))
     encoder.train(train)                                             # train.py:71-76
     decoder.train(train)
+    if hasattr(encoder, "trunk_grad"):
+        # the trunk's gradients are used by enc_opt.step() only (train.py:186-187): while the encoder is not being updated its backward is
+        # not computed at all (FeatureExtractor.trunk_grad; RSIS_FROZEN_TRUNK_BACKWARD=1 restores the reference's compute-and-discard)
+        encoder.trunk_grad = bool(args.update_encoder)
     y_mask = y_mask.float()
     sw_mask = sw_mask.float()
     sw_class = sw_class.float()

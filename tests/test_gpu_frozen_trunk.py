@@ -1,0 +1,101 @@
+"""update_encoder = False (the reference's state until `-finetune_after` epochs have passed: args.py:39-45, scripts/train_cityscapes.sh: 20
+epochs): the reference back-propagates through the ResNet trunk on every iteration and then skips enc_opt.step() (src/train.py:184-187) -- the
+trunk's backward is computed and thrown away.  rsis_amd does not compute it (FeatureExtractor.trunk_grad, set by train.runIter; the skip
+convs and their BatchNorms belong to the decoder's optimizer -- utils.py:get_skip_params -- and keep their gradients).
+
+Everything a user of the reference can observe must be unchanged: losses, outputs, the matching, every parameter after the optimizer step
+(trunk untouched, decoder + skip branch updated), the train-mode BatchNorm running statistics of the trunk.  Checked against the SAME
+iteration with RSIS_FROZEN_TRUNK_BACKWARD=1 (the reference's compute-and-discard), in the library's bit-reproducible mode: equal bits."""
+import pytest
+import torch
+
+from helpers import mk_args
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(seed=3, B=4, hw=96, T=3):
+    from rsis_amd.modules import RSIS, FeatureExtractor
+    from rsis_amd.synthetic import synthetic_batch
+    from rsis_amd.train import build_optimizers, steps_to_run
+    from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
+    a = mk_args(hidden_size=32, maxseqlen=T, gt_maxseqlen=T + 1, update_encoder=False, lr=1e-3, lr_cnn=1e-4, weight_decay=1e-6, weight_decay_cnn=1e-6,
+                seed=seed, optim="adam", optim_cnn="adam")
+    torch.manual_seed(seed)
+    enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
+    opts = build_optimizers(a, enc, dec)
+    crits = [softIoULoss(), MaskedNLLLoss(None), MaskedBCELoss(a.stop_balance_weight)]
+    batch = synthetic_batch(seed, B, hw, hw, a.gt_maxseqlen, T, a.num_classes, "cuda")
+    return a, enc, dec, opts, crits, batch, steps_to_run(a, batch[3])
+
+
+def _run(frozen, iters=3, graph=False):
+    from rsis_amd import ops
+    from rsis_amd.modules import model as M
+    from rsis_amd.train import GraphedStep, runIter
+    prev_f, prev_d = M.FROZEN_TRUNK[0], ops.is_deterministic()
+    M.FROZEN_TRUNK[0] = frozen
+    ops.set_deterministic(True)
+    try:
+        a, enc, dec, opts, crits, batch, t_run = _setup()
+        trunk0 = [p.detach().clone() for p in enc.base.parameters()]
+        losses = []
+        g = GraphedStep(a, enc, dec, crits, opts, None, warm=1) if graph else None
+        for _ in range(iters):
+            if g is not None:
+                out = g(batch, t_run)
+                losses.append([float(v) for v in out[0]])
+            else:
+                out = runIter(a, enc, dec, *batch, crits, opts, mode="train", sync_losses=True, t_run=t_run, want_outs=False)
+                losses.append([float(v) for v in out[0]])
+        torch.cuda.synchronize()
+        if g is not None:
+            assert g.graph is not None, "capture failed: %s" % g.failed
+        state = {"losses": losses,
+                 "dec": [p.detach().clone() for p in dec.parameters()],
+                 "skip": [p.detach().clone() for k, p in enc.named_parameters() if not k.startswith("base.")],
+                 "trunk": [p.detach().clone() for p in enc.base.parameters()], "trunk0": trunk0,
+                 "stats": [b.detach().clone() for k, b in enc.named_buffers() if "running_" in k]}
+        if g is not None:
+            g.release()
+        return state
+    finally:
+        M.FROZEN_TRUNK[0] = prev_f
+        ops.set_deterministic(prev_d)
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph-replay"])
+def test_frozen_trunk_iteration_equals_compute_and_discard(graph):
+    ours, ref = _run(True, graph=graph), _run(False, graph=graph)
+    assert ours["losses"] == ref["losses"], (ours["losses"], ref["losses"])
+    assert ours["losses"][0][0] != ours["losses"][-1][0]                       # the decoder did learn something
+    for k in ("dec", "skip", "stats"):
+        assert len(ours[k]) == len(ref[k]) and all(torch.equal(p, q) for p, q in zip(ours[k], ref[k])), k
+    for st in (ours, ref):                                                       # nobody touches the trunk's weights while update_encoder is off
+        assert all(torch.equal(p, q) for p, q in zip(st["trunk"], st["trunk0"]))
+    assert any(not torch.equal(p, q) for p, q in zip(ours["stats"], _fresh_stats()))     # train-mode BatchNorm kept updating its running statistics
+
+
+def _fresh_stats():
+    _a, enc, _dec, _o, _c, _b, _t = _setup()
+    return [b.detach().clone() for k, b in enc.named_buffers() if "running_" in k]
+
+
+def test_frozen_trunk_records_no_trunk_graph_and_switches_back_on():
+    """the trunk's features carry no autograd history while update_encoder is off; when the flag flips (train.py:313-318) the next iteration
+    back-propagates through the trunk again and the encoder's parameters move"""
+    from rsis_amd.train import runIter
+    a, enc, dec, opts, crits, batch, t_run = _setup()
+    runIter(a, enc, dec, *batch, crits, opts, mode="train", sync_losses=False, t_run=t_run, want_outs=False)
+    assert enc.trunk_grad is False
+    enc.train()
+    with torch.enable_grad():
+        feats = enc(batch[0])
+    assert all(f.requires_grad for f in feats)                                    # the skip branch is still differentiable ...
+    x5 = enc.base(batch[0])[0]
+    assert x5.requires_grad                                                       # (a direct call of the trunk is untouched)
+    p0 = next(enc.base.layer4.parameters()).detach().clone()
+    a.update_encoder = True
+    runIter(a, enc, dec, *batch, crits, opts, mode="train", sync_losses=False, t_run=t_run, want_outs=False)
+    assert enc.trunk_grad is True
+    assert not torch.equal(next(enc.base.layer4.parameters()).detach(), p0)
