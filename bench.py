@@ -647,7 +647,7 @@ def exchange_report(a, encoder, decoder, crits, optims, reducer, gstep, seg, bat
     captured = gstep is not None and gstep.graph is not None
     direct = captured and gstep.split and gstep.direct is not None
     cuts = gstep.cuts if gstep is not None else EXCHANGE_CUTS
-    plan = exchange_plan(encoder, optims, cuts)
+    plan = exchange_plan(encoder, optims, cuts, bool(a.update_encoder))
     rep = {"mode": "direct-in-graph" if direct else ("cut-graphs" if captured else "eager-staged"),
            "backend": dist.get_backend(), "world": world, "cuts": 0 if direct else cuts,
            "rccl_direct": dict(_comm.LAST_STATUS),

@@ -115,7 +115,7 @@ def runIter(args, encoder, decoder, x, y_mask, y_class, sw_mask, sw_class, crits
         restore = (encoder.split_backward, reducer.hooks_enabled)      # (not sticky: a later forward + backward outside runIter gets the uncut graph)
         encoder.split_backward, reducer.hooks_enabled = EXCHANGE_CUTS, False
         direct = getattr(reducer, "direct", None)          # RCCL bound directly (rsis_amd/comm.py) when it could be built
-        between = exchange = StagedExchange(exchange_plan(encoder, optims, EXCHANGE_CUTS), direct if direct is not None else
+        between = exchange = StagedExchange(exchange_plan(encoder, optims, EXCHANGE_CUTS, bool(args.update_encoder)), direct if direct is not None else
                                             (lambda b, a: dist.all_reduce(b, op=dist.ReduceOp.SUM, group=reducer.pg, async_op=a)))
     encoder.train(train)                                             # train.py:71-76
     decoder.train(train)
@@ -349,13 +349,17 @@ class StagedExchange(object):
             self.reduce(b, False)
 
 
-def exchange_plan(encoder, optims, cuts):
+def exchange_plan(encoder, optims, cuts, update_encoder=True):
     """flat-gradient ranges that are final after each stage of a split backward (encoder.split_backward = cuts):
     {"dec": [...], "trunk_hi": [...], "rest": [...]} -- "dec" when BPTT and the skip convs are done, "trunk_hi" when trunk layers
-    4-3 are, "rest" at the end.  optims = [enc_opt, dec_opt] (FlatAdam)."""
+    4-3 are, "rest" at the end.  optims = [enc_opt, dec_opt] (FlatAdam).  update_encoder False (every rank has the same args): the
+    trunk's gradients are neither computed (FeatureExtractor.trunk_grad) nor applied (train.py:186-187), so its 178 MB do not travel."""
     groups = [o.group for o in optims if isinstance(o, FlatAdam)]
     enc_g = optims[0].group
     dec = [g.flat_g for g in groups if g is not enc_g]
+    from .modules import model as _model
+    if not update_encoder and _model.FROZEN_TRUNK[0] and hasattr(encoder, "trunk_grad"):
+        return {"dec": dec, "trunk_hi": [], "rest": []}
     if cuts <= 0:
         return {"dec": [], "trunk_hi": [], "rest": dec + [enc_g.flat_g]}
     if cuts == 1:
@@ -439,7 +443,7 @@ class GraphedStep(object):
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.reducer.pg, async_op=async_op)
 
     def _plan(self):
-        return exchange_plan(self.encoder, self.optims, self.cuts)
+        return exchange_plan(self.encoder, self.optims, self.cuts, bool(self.args.update_encoder))
 
     def __call__(self, batch, t_run):
         if self.graphs is None and self.failed is None and self.n_eager >= self.warm:
