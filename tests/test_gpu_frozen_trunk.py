@@ -14,13 +14,13 @@ from helpers import mk_args
 pytestmark = pytest.mark.gpu
 
 
-def _setup(seed=3, B=4, hw=96, T=3):
+def _setup(seed=3, B=4, hw=96, T=3, dtype="fp32"):
     from rsis_amd.modules import RSIS, FeatureExtractor
     from rsis_amd.synthetic import synthetic_batch
     from rsis_amd.train import build_optimizers, steps_to_run
     from rsis_amd.utils.objectives import MaskedBCELoss, MaskedNLLLoss, softIoULoss
     a = mk_args(hidden_size=32, maxseqlen=T, gt_maxseqlen=T + 1, update_encoder=False, lr=1e-3, lr_cnn=1e-4, weight_decay=1e-6, weight_decay_cnn=1e-6,
-                seed=seed, optim="adam", optim_cnn="adam")
+                seed=seed, optim="adam", optim_cnn="adam", dtype=dtype)
     torch.manual_seed(seed)
     enc, dec = FeatureExtractor(a).cuda(), RSIS(a).cuda()
     opts = build_optimizers(a, enc, dec)
@@ -29,7 +29,7 @@ def _setup(seed=3, B=4, hw=96, T=3):
     return a, enc, dec, opts, crits, batch, steps_to_run(a, batch[3])
 
 
-def _run(frozen, iters=3, graph=False):
+def _run(frozen, iters=3, graph=False, dtype="fp32"):
     from rsis_amd import ops
     from rsis_amd.modules import model as M
     from rsis_amd.train import GraphedStep, runIter
@@ -37,7 +37,7 @@ def _run(frozen, iters=3, graph=False):
     M.FROZEN_TRUNK[0] = frozen
     ops.set_deterministic(True)
     try:
-        a, enc, dec, opts, crits, batch, t_run = _setup()
+        a, enc, dec, opts, crits, batch, t_run = _setup(dtype=dtype)
         trunk0 = [p.detach().clone() for p in enc.base.parameters()]
         losses = []
         g = GraphedStep(a, enc, dec, crits, opts, None, warm=1) if graph else None
@@ -99,3 +99,13 @@ def test_frozen_trunk_records_no_trunk_graph_and_switches_back_on():
     runIter(a, enc, dec, *batch, crits, opts, mode="train", sync_losses=False, t_run=t_run, want_outs=False)
     assert enc.trunk_grad is True
     assert not torch.equal(next(enc.base.layer4.parameters()).detach(), p0)
+
+
+def test_frozen_trunk_bf16():
+    """the same switch under -dtype bf16 (channel-blocked bf16 trunk, blk decoder): the iteration runs, the decoder learns, the trunk's weights
+    stay, and the losses follow the compute-and-discard iteration (bf16 kernels: same arithmetic, so equal in the deterministic mode too)"""
+    ours, ref = _run(True, dtype="bf16"), _run(False, dtype="bf16")
+    for lo, lr in zip(ours["losses"], ref["losses"]):
+        assert all(abs(x - y) <= 1e-3 * max(1.0, abs(y)) for x, y in zip(lo, lr)), (ours["losses"], ref["losses"])
+    assert all(torch.equal(p, q) for p, q in zip(ours["trunk"], ours["trunk0"]))
+    assert any(not torch.equal(p, q) for p, q in zip(ours["dec"], _setup(dtype="bf16")[2].parameters()))
