@@ -95,9 +95,8 @@ int rsis_conv2d_fwd(const float* const* src, const int* Csrc, int nsrc, int B, i
  *   out = relu?( (conv + bias - running_mean) / sqrt(running_var + eps) * gamma + beta  (+ addend) )
  * -- bit for bit what rsis_conv2d_fwd followed by rsis_bn_fwd(train = 0) writes (one shared definition of the arithmetic), without the
  * BatchNorm launch and its read + write of the activation.  fp32 kernels (dtype RSIS_DTYPE_F32, or a RSIS_DTYPE_BF16 pack of a conv the
- * library runs on the fp32 kernels anyway: the 7x7 stem), one destination, Cout % 4 == 0, no split-K; the 3x3 /
- * stride-2 forward and conv_out are not covered: RSIS_ERR_UNSUPPORTED is returned BEFORE anything is launched and the caller runs the
- * two launches. */
+ * library runs on the fp32 kernels anyway: the 7x7 stem), one destination, Cout % 4 == 0, no split-K (conv_out is not
+ * covered): otherwise RSIS_ERR_UNSUPPORTED is returned BEFORE anything is launched and the caller runs the two launches. */
 int rsis_conv2d_fwd_bn_eval(const float* const* src, const int* Csrc, int nsrc, int B, int H, int W, const void* Wp, int Cout,
                             int ks, int stride, int pad, const float* bias, const float* addend, const float* gamma, const float* beta,
                             const float* running_mean, const float* running_var, float eps, int relu, float* out, int Ho, int Wo,

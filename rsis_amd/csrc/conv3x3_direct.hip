@@ -538,9 +538,9 @@ static int launch_direct_cfg(ConvArgs& a, hipStream_t st) {
   if (a.ep_gamma) {
     // inference with the eval-mode BatchNorm folded into the epilogue (rsis_conv2d_fwd_bn_eval): the BNE instantiations -- segmented
     // accumulation whatever the depth on the 256-thread variants (no segment boundary is crossed below RSIS_ACC_FLUSH chunks: same bits)
-    if constexpr (EPI == EPI_PLAIN) {
+    if constexpr (EPI == EPI_PLAIN || EPI == EPI_F2) {     // (EPI_F2, the stride-2 forward: no segmented instantiation, as its plain calls)
       if (ksplit != 1 || a.ndst != 1 || a.Cout % 4 != 0 || (size_t)a.B * a.Cout * a.H * a.W * 4 >= (1ull << 31)) return RSIS_ERR_UNSUPPORTED;
-      hipLaunchKernelGGL((conv3x3_direct_kernel<BM, TW, TH, NI, EPI, KSP, NWV, NWV == 4, true>), dim3(grid, 1), dim3(NWV * 64), 0, st, a);
+      hipLaunchKernelGGL((conv3x3_direct_kernel<BM, TW, TH, NI, EPI, KSP, NWV, NWV == 4 && EPI == EPI_PLAIN, true>), dim3(grid, 1), dim3(NWV * 64), 0, st, a);
       return rsis_check_launch();
     } else {
       return RSIS_ERR_UNSUPPORTED;       // (nothing launched: the caller runs conv and BatchNorm as two launches)

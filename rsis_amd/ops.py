@@ -503,7 +503,7 @@ def conv2d_bn_eval(x, weight, bias, stride, pad, pack, gamma, beta, running_mean
     Ho, Wo = _conv_out_size(H, ks, stride, pad), _conv_out_size(W, ks, stride, pad)
     if pack.stride != stride or pack.pad != pad:
         raise _lib.RsisHipError("PackedConv was built for stride %d pad %d, used with %d/%d" % (pack.stride, pack.pad, stride, pad))
-    if Cout % 4 != 0 or (ks == 3 and stride != 1):
+    if Cout % 4 != 0:
         return None
     pack.training_call = False
     wp = pack.fwd(weight)

@@ -44,6 +44,9 @@ CASES = [
     (256, 32, 3, 1, 64, 64, True, False, False),           # sk2
     (64, 16, 3, 1, 128, 128, True, False, False),          # sk1: 16 output channels
     (3, 64, 7, 2, 128, 128, False, True, False),           # the stem
+    (128, 128, 3, 2, 64, 64, False, True, False),          # 3x3 / stride 2 (conv2 of the first block of layers 2-4): 16 x 8 output tile
+    (512, 512, 3, 2, 16, 16, False, True, False),          # ... 8 x 8 output tile, 64 rows
+    (64, 64, 3, 2, 31, 29, False, True, False),            # ... odd map
     (24, 40, 3, 1, 20, 12, True, True, True),              # odd channel counts (3 chunks, a row tail), ragged map, everything on
 ]
 
@@ -72,17 +75,18 @@ def test_fold_equals_the_two_launches(case):
 
 
 def test_uncovered_convs_fall_back():
-    """3x3 / stride 2 has no folded epilogue: the library refuses before launching, conv_bn runs the two modules; so does any call that
-    records an autograd graph or meets a BatchNorm in training mode"""
+    """a conv without a folded epilogue (output channels not a multiple of 4: conv_out) is refused before anything is launched and conv_bn runs the
+    two modules; so does any call that records an autograd graph or meets a BatchNorm in training mode"""
     from rsis_amd import ops
     from rsis_amd.modules.vision import HipConv2d, conv_bn
     torch.manual_seed(0)
-    conv = HipConv2d(64, 64, 3, stride=2, padding=1, bias=False).cuda().eval()
-    bn = _bn(64, 3)
+    conv = HipConv2d(64, 6, 3, padding=1, bias=True).cuda().eval()
+    bn = _bn(6, 3)
     x = torch.randn(2, 64, 32, 32, device="cuda")
     with torch.no_grad():
-        assert ops.conv2d_bn_eval(x, conv.weight, None, 2, 1, conv._pack, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps) is None
+        assert ops.conv2d_bn_eval(x, conv.weight, conv.bias, 1, 1, conv._pack, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps) is None
         assert torch.equal(conv_bn(conv, bn, x, relu=True), bn(conv(x), relu=True))
+    bn = _bn(64, 4)
     conv1 = HipConv2d(64, 64, 1, bias=False).cuda()
     assert ops.conv2d_bn_eval(x, conv1.weight, None, 1, 0, conv1._pack, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps) is None   # grad mode
     y = conv_bn(conv1, bn, x.requires_grad_(True), relu=True)
@@ -91,20 +95,20 @@ def test_uncovered_convs_fall_back():
 
 
 def test_library_refuses_before_launching():
-    """rsis_conv2d_fwd_bn_eval on a geometry without the epilogue returns RSIS_ERR_UNSUPPORTED and leaves the output untouched"""
+    """rsis_conv2d_fwd_bn_eval on a conv without the epilogue (6 output channels) returns RSIS_ERR_UNSUPPORTED and leaves the output untouched"""
     from rsis_amd import ops
     from rsis_amd._lib import int_array, lib, ptr, ptr_array, stream
     x = torch.randn(2, 64, 32, 32, device="cuda")
-    w = torch.randn(64, 64, 3, 3, device="cuda")
-    pack = ops.PackedConv(3, [64], stride=2, pad=1)
-    out = torch.full((2, 64, 16, 16), 7.0, device="cuda")
-    v = torch.ones(64, device="cuda")
-    rc = lib().rsis_conv2d_fwd_bn_eval(ptr_array([x]), int_array([64]), 1, 2, 32, 32, ptr(pack.fwd(w)), 64, 3, 2, 1, None, None, ptr(v), ptr(v),
-                                       ptr(v), ptr(v), 1e-5, 1, ptr(out), 16, 16, 0, 0, stream())
+    w = torch.randn(6, 64, 3, 3, device="cuda")
+    pack = ops.PackedConv(3, [64], stride=1, pad=1)
+    out = torch.full((2, 6, 32, 32), 7.0, device="cuda")
+    v = torch.ones(6, device="cuda")
+    rc = lib().rsis_conv2d_fwd_bn_eval(ptr_array([x]), int_array([64]), 1, 2, 32, 32, ptr(pack.fwd(w)), 6, 3, 1, 1, None, None, ptr(v), ptr(v),
+                                       ptr(v), ptr(v), 1e-5, 1, ptr(out), 32, 32, 0, 0, stream())
     torch.cuda.synchronize()
     assert rc == 3 and bool((out == 7.0).all())
-    rc = lib().rsis_conv2d_fwd_bn_eval(ptr_array([x]), int_array([64]), 1, 2, 32, 32, ptr(pack.fwd(w)), 64, 3, 2, 1, None, None, None, ptr(v),
-                                       ptr(v), ptr(v), 1e-5, 1, ptr(out), 16, 16, 0, 0, stream())
+    rc = lib().rsis_conv2d_fwd_bn_eval(ptr_array([x]), int_array([64]), 1, 2, 32, 32, ptr(pack.fwd(w)), 6, 3, 1, 1, None, None, None, ptr(v),
+                                       ptr(v), ptr(v), 1e-5, 1, ptr(out), 32, 32, 0, 0, stream())
     assert rc not in (0, 3)        # a missing BatchNorm array is an argument error
 
 
@@ -171,7 +175,7 @@ def test_test_entry_point_fold_is_bit_identical_and_launches_less():
         ops.EVAL_FOLD[0] = old
     for p, q in zip(o1, o0):
         assert torch.equal(p, q)
-    assert n_plain == 109 and n_fold == 3, (n_plain, n_fold)     # 104 trunk + 5 skip BatchNorms; the three 3x3 / stride-2 convs keep theirs
+    assert n_plain == 109 and n_fold == 0, (n_plain, n_fold)     # 104 trunk + 5 skip BatchNorms: every one of them in a conv epilogue
 
 
 def test_bf16_model_stem_folds_too():
