@@ -793,7 +793,9 @@ def trainIters(args):
                               % (batch_idx, m["total"], m["class"], m["iou"], m["stop"], te,
                                  args.print_every * x.size(0) * world / max(te, 1e-9)))
                     start = time.time()
-            m = {k: float(torch.stack(v).mean()) for k, v in epoch_losses[split].items()}
+            # (a split without a single batch -- a validation set smaller than one batch -- gives nan means, as np.mean([]) does in the
+            #  reference, train.py:403-405: no checkpoint is saved on it, the epoch goes on)
+            m = {k: (float(torch.stack(v).mean()) if v else float("nan")) for k, v in epoch_losses[split].items()}
             if world > 1:                                                 # epoch means over all ranks
                 tv = torch.tensor([m["total"], m["iou"], m["stop"], m["class"]], device="cuda")
                 dist.all_reduce(tv)

@@ -109,3 +109,27 @@ def test_frozen_trunk_bf16():
         assert all(abs(x - y) <= 1e-3 * max(1.0, abs(y)) for x, y in zip(lo, lr)), (ours["losses"], ref["losses"])
     assert all(torch.equal(p, q) for p, q in zip(ours["trunk"], ours["trunk0"]))
     assert any(not torch.equal(p, q) for p, q in zip(ours["dec"], _setup(dtype="bf16")[2].parameters()))
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph-replay"])
+def test_train_py_switches_from_frozen_to_finetuning(tmp_path, graph):
+    """`python -m rsis_amd.train -finetune_after 1` on a synthesised CVPPP A1 directory: epoch 0 runs with update_encoder off (no trunk backward),
+    epoch 1 flips the flag (train.py:313-318) and the trunk trains -- through the CLI, eager and `--graph` (a second capture key)."""
+    import os
+    import subprocess
+    import sys
+    from rsis_amd.dataloader.leaves import synthesize_leaves_dir
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = synthesize_leaves_dir(str(tmp_path / "A1"), n=104, size=(150, 140), seed=6)
+    models = str(tmp_path / "models")
+    cmd = [sys.executable, "-m", "rsis_amd.train", "-model_name", "ft", "-dataset", "leaves", "-leaves_dir", d, "-leaves_test_dir", d,
+           "-num_classes", "2", "--resize", "-imsize", "128", "-maxseqlen", "6", "-gt_maxseqlen", "10", "-batch_size", "4", "-base_model", "resnet101",
+           "-hidden_size", "32", "-class_loss_after", "-1", "-finetune_after", "1", "--log_term", "-max_epoch", "2", "-print_every", "4",
+           "-models_root", models, "-num_workers", "2"]
+    r = subprocess.run(cmd + (["--graph"] if graph else []), cwd=root, capture_output=True, text=True, timeout=1200)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert "Epoch 0:" in r.stdout and "Epoch 1:" in r.stdout and "nan" not in r.stdout.lower(), r.stdout[-2000:]
+    assert "capture failed" not in out, out[-1500:]
+    i0, i1, sw = r.stdout.find("Epoch 0:"), r.stdout.find("Epoch 1:"), r.stdout.find("Starting to update encoder")     # train.py:315
+    assert 0 <= i0 < sw < i1, r.stdout[-2000:]       # epoch 0 ran frozen, the switch is announced, epoch 1 trains the trunk
