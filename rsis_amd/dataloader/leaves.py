@@ -54,6 +54,8 @@ class LeavesDataset(object):
         else:
             self.image_files = sorted(glob.glob(os.path.join(args.leaves_test_dir, "*_rgb.png")))
             self.gt_files = []
+        self._cache, self._cache_bytes = {}, 0
+        self._cache_limit = int(float(os.environ.get("RSIS_LOADER_CACHE_MB", "1024")) * (1 << 20))
 
     def get_classes(self):
         return self.classes
@@ -77,8 +79,23 @@ class LeavesDataset(object):
         fake = np.array(img)[:, :, 0]
         return img, fake, fake
 
-    def host_item(self, index, rng):
-        """everything of dataset.py:47-62 that is decoding / index arithmetic: -> (uint8 image (3, S, S), int32 instance map (S, S))"""
+    def _decoded(self, index):
+        """the deterministic part of host_item -- PNG decode, the bilinear resize of the image, the nearest zoom of the instance map -- kept
+        after its first evaluation: the reference re-decodes every file in every epoch (dataset.py:47-54), which at CVPPP's 128 images
+        is 7-15 ms of host time per image for the same bytes, and made `train.py` on this loader host-bound (NOTES (54): 62 images/s at
+        batch 2).  Bounded by RSIS_LOADER_CACHE_MB (default 1024; 0 = off): A1 at 256 x 256 is 58 MB.  The random part (flip, crop) works
+        on views and copies, never on the cached arrays."""
+        hit = self._cache.get(index)
+        if hit is not None:
+            return hit
+        item = self._decode(index)
+        nbytes = item[0].nbytes + item[1].nbytes
+        if self._cache_bytes + nbytes <= self._cache_limit:
+            self._cache[index] = item
+            self._cache_bytes += nbytes
+        return item
+
+    def _decode(self, index):
         from PIL import Image
         from scipy.ndimage import zoom
         img, ins, _seg = self.get_raw_sample(index)
@@ -94,6 +111,13 @@ class LeavesDataset(object):
         im = np.asarray(img, dtype=np.uint8).transpose(2, 0, 1)             # (3, h, w)
         h, w = im.shape[1:]
         ins = zoom(ins, [float(h) / ins.shape[0], float(w) / ins.shape[1]], mode="nearest", order=0)   # dataset_utils.py:133-140
+        return np.ascontiguousarray(im), np.ascontiguousarray(ins)
+
+    def host_item(self, index, rng):
+        """everything of dataset.py:47-62 that is decoding / index arithmetic: -> (uint8 image (3, S, S), int32 instance map (S, S))"""
+        im, ins = self._decoded(index)
+        S = self.imsize
+        h, w = im.shape[1:]
         if self.flip and rng.random() < 0.5:                                # dataset_utils.py:51-55
             im, ins = im[:, :, ::-1], ins[:, ::-1]
         if self.crop:                                                       # transforms.py:15-21 random_crop (centred range)
@@ -138,6 +162,7 @@ class DeviceLoader(object):
         self.mean = torch.tensor(MEAN, device=device).view(1, 3, 1, 1)
         self.std = torch.tensor(STD, device=device).view(1, 3, 1, 1)
         self._lock = threading.Lock()
+        self._pins = {}
 
     def __len__(self):
         n, gb = len(self.ds), self.bs * self.world                          # drop_last=True on the GLOBAL batch (training)
@@ -148,28 +173,50 @@ class DeviceLoader(object):
         from ..train import steps_to_run
         return steps_to_run(args, sw_mask)
 
-    def _stage(self, idxs):
+    def _pinned(self, slot, n, S):
+        """two sets of pinned staging buffers, reused: `torch.empty(...).pin_memory()` per batch is a hipHostMalloc + first-touch page faults
+        -- 1.9 of the 2.15 ms a batch of two CACHED samples took to stage (tools/exp/stage_bench.py), more than the GPU needs for a tenth
+        of its step.  A set is refilled only after the host-to-device copy that last read it has completed (event)."""
+        key = (slot & 1, n, tuple(S))
+        ent = self._pins.get(key)
+        if ent is None:
+            ent = [torch.empty((n, 3) + tuple(S), dtype=torch.uint8).pin_memory(), torch.empty((n,) + tuple(S), dtype=torch.int32).pin_memory(), None]
+            ent += [ent[0].numpy(), ent[1].numpy()]            # (filled through numpy: a torch CPU copy_ of 200 KB costs ~1 ms of thread-pool wake-up)
+            self._pins[key] = ent
+        if ent[2] is not None:
+            ent[2].synchronize()
+            ent[2] = None
+        return ent
+
+    def _stage(self, idxs, slot=0):
         """decode one batch into pinned buffers (host side only)"""
         seeds = [self.rng.getrandbits(32) for _ in idxs]
-        items = list(self.pool.map(lambda a: self.ds.host_item(a[0], random.Random(a[1])), zip(idxs, seeds)))
+        work = list(zip(idxs, seeds))
+        if all(i in self.ds._cache for i in idxs):             # cache hits are index arithmetic: not worth a hand-over to the pool
+            items = [self.ds.host_item(i, random.Random(sd)) for i, sd in work]
+        else:
+            items = list(self.pool.map(lambda a: self.ds.host_item(a[0], random.Random(a[1])), work))
         S = items[0][0].shape[1:]
-        img = torch.empty((len(items), 3) + S, dtype=torch.uint8).pin_memory()
-        ins = torch.empty((len(items),) + S, dtype=torch.int32).pin_memory()
+        ent = self._pinned(slot, len(items), S)
+        img, ins = ent[0], ent[1]
         for i, (a, b) in enumerate(items):
-            img[i].copy_(torch.from_numpy(a))
-            ins[i].copy_(torch.from_numpy(b))
+            np.copyto(ent[3][i], a)
+            np.copyto(ent[4][i], b)
         mats = None
         if self.ds.augmentation_transform is not None:                      # one matrix per sample, drawn as the reference draws them
             with self._lock:
                 mats = torch.stack([self.ds.augmentation_transform.matrix(S[0], S[1]) for _ in items])
-        return img, ins, mats
+        return img, ins, mats, ent
 
     def _to_device(self, staged):
-        img, ins, mats = staged
+        img, ins, mats, ent = staged
         st = self.copy_stream
         with torch.cuda.stream(st):
             x = img.to(self.device, non_blocking=True)
             m = ins.to(self.device, non_blocking=True)
+            if ent is not None:                 # the staging set may be refilled once these two copies have run
+                ent[2] = torch.cuda.Event()
+                ent[2].record(st)
         cur = torch.cuda.current_stream()
         cur.wait_stream(st)
         x.record_stream(cur)                # allocated on the copy stream, consumed on this one: keep the caching allocator from
@@ -191,11 +238,11 @@ class DeviceLoader(object):
         batches = shard_batches(order, self.bs, self.rank, self.world, self.drop_last)
         if not batches:
             return
-        staged = self._stage(batches[0])
+        staged = self._stage(batches[0], 0)
         for k in range(len(batches)):
             fut, box = None, []
             if k + 1 < len(batches):                                        # decode the next batch while this one trains
-                fut = threading.Thread(target=lambda kk=k + 1, out=box: out.append(self._stage(batches[kk])))
+                fut = threading.Thread(target=lambda kk=k + 1, out=box: out.append(self._stage(batches[kk], kk)))
                 fut.start()
             yield self._to_device(staged)
             if fut is not None:

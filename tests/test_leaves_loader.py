@@ -38,6 +38,36 @@ def test_leaves_dataset_host_side(tmp_path):
     assert im2.shape == (3, 48, 48) and m2.shape == (48, 48)
 
 
+def test_decoded_samples_are_cached_and_never_mutated(tmp_path, monkeypatch):
+    """the deterministic part of a sample (decode + resizes) is kept after its first evaluation: later draws (flip, crop) give exactly what an
+    uncached dataset gives, the cached arrays stay untouched, and RSIS_LOADER_CACHE_MB bounds / disables the cache"""
+    from rsis_amd.dataloader.leaves import LeavesDataset, synthesize_leaves_dir
+    import random
+    d = synthesize_leaves_dir(str(tmp_path / "A1"), n=100, size=(120, 136), seed=2)
+    cached = LeavesDataset(_args(d), split="train", imsize=64, augment=True)
+    monkeypatch.setenv("RSIS_LOADER_CACHE_MB", "0")
+    plain = LeavesDataset(_args(d), split="train", imsize=64, augment=True)
+    assert plain._cache_limit == 0
+    first = [cached.host_item(i, random.Random(100 + i)) for i in range(6)]
+    snap = {i: (a.copy(), b.copy()) for i, (a, b) in cached._cache.items()}
+    assert len(snap) == 6 and cached._cache_bytes == sum(a.nbytes + b.nbytes for a, b in snap.values())
+    for rep in range(3):                                       # other random draws on cache hits
+        for i in range(6):
+            got, want = cached.host_item(i, random.Random(7 * rep + i)), plain.host_item(i, random.Random(7 * rep + i))
+            assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+            got[0][...] = 0                                     # the caller owns what it gets ...
+    for i, (a, b) in cached._cache.items():                    # ... the cache is what was decoded
+        assert (a == snap[i][0]).all() and (b == snap[i][1]).all()
+    again = [cached.host_item(i, random.Random(100 + i)) for i in range(6)]
+    assert all((p[0] == q[0]).all() and (p[1] == q[1]).all() for p, q in zip(first, again))
+    assert not plain._cache
+    monkeypatch.setenv("RSIS_LOADER_CACHE_MB", "0.03")          # 31 KB: room for one 64-pixel sample (3 x 64 x 72 + 64 x 72 bytes), not two
+    small = LeavesDataset(_args(d), split="train", imsize=64)
+    for i in range(4):
+        small.host_item(i, random.Random(i))
+    assert len(small._cache) == 1 and small._cache_bytes <= small._cache_limit
+
+
 @pytest.mark.gpu
 def test_device_loader_targets_equal_reference_sequence_from_masks(tmp_path):
     """without augmentation the device batch must be exactly batch_to_var(sequence_from_masks(host maps)) and the normalised image"""
