@@ -487,7 +487,8 @@ _ERR_UNSUPPORTED = 3
 
 def conv2d_bn_eval(x, weight, bias, stride, pad, pack, gamma, beta, running_mean, running_var, eps, relu=False, res=None):
     """relu?(bn_eval(conv(x) + bias) + res) as ONE launch, for calls that record no autograd graph (test() / eval.py); returns None when the
-    library has no folded epilogue for this conv (3x3 / stride 2, Winograd-only geometry, ...) -- the caller then runs conv and BatchNorm."""
+    library has no folded epilogue for this conv (conv_out, output channels not a multiple of 4, a conv the bf16 kernels run, ...) -- the caller
+    then runs conv and BatchNorm."""
     if not EVAL_FOLD[0] or torch.is_grad_enabled() or pack.dtype not in (DTYPE_F32, DTYPE_F32_WINO, DTYPE_BF16):
         return None                              # (a bf16 pack: only the convs the library runs on the fp32 kernels anyway -- it decides)
     if pack.dtype == DTYPE_F32_WINO:
